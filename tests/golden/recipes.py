@@ -1,0 +1,28 @@
+"""Seeded input recipes shared by tests/golden/make_golden.py (which feeds them to the REFERENCE)
+and by the parity tests (which feed them to the oracle and to the HIP path).  Pure torch; no
+reference import.  Large inputs are regenerated from these recipes instead of being stored."""
+import torch
+
+
+def e2e_inputs(seed: int, D: int):
+    g = torch.Generator().manual_seed(seed + 1)
+    nc = torch.randn(D, generator=g) * 0.1
+    test_feats = torch.randn(1, 1, 512 * 2, D, generator=g) * 0.3
+    g2 = torch.Generator().manual_seed(seed + 2)
+    frames = torch.randn(1, 512, 3, 32, 32, generator=g2)
+    g3 = torch.Generator().manual_seed(seed + 3)
+    labels = torch.tensor([2, 11, 7, 7])
+    train_feats = torch.randn(4, 1, 512, D, generator=g3) * 0.3
+    g4 = torch.Generator().manual_seed(seed + 4)
+    mask = torch.bernoulli(torch.ones(4, 32) * 0.3, generator=g4)
+    # guarantee >= 3 surviving segments per video so that top-k is tie-free
+    for r in range(4):
+        if mask[r].sum() < 3:
+            mask[r, :3] = 1
+    return dict(nc=nc, test_feats=test_feats, frames=frames, labels=labels,
+                train_feats=train_feats, mask=mask)
+
+
+def vit_frames(seed: int, n: int, res: int):
+    g = torch.Generator().manual_seed(seed + 100)
+    return torch.randn(n, 3, res, res, generator=g)
