@@ -1,0 +1,146 @@
+"""ctypes binding of libacx (include/acx.h).  The library is the product's only compute path: if it
+cannot be loaded the package raises, it never falls back to PyTorch ops or to the oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import _build
+
+c_void_p, c_int32, c_int64, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+ACX_F32, ACX_BF16 = 0, 1
+PREC_F32, PREC_BF16 = 0, 1
+ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
+AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE = 0, 1, 2
+NORM_LAYER, NORM_CHAN = 0, 1
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("C", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldw", c_int32), ("ldc", c_int32),
+        ("a_dtype", c_int32), ("c_dtype", c_int32), ("prec", c_int32),
+        ("bias", c_void_p), ("act", c_int32),
+        ("residual", c_void_p), ("ldr", c_int32),
+        ("a_sub", c_void_p),
+        ("amap", c_int32), ("gn", c_int32), ("gl", c_int32), ("cin", c_int32), ("seg", c_int32),
+        ("pos0", c_void_p), ("pos1", c_void_p),
+    ]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "ln1_w", "ln1_b", "ln2_w", "ln2_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
+        "fc_w", "fc_b", "proj_w", "proj_b",
+        "in_proj_w_bf16", "out_proj_w_bf16", "fc_w_bf16", "proj_w_bf16")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [
+        ("conv1_w", c_void_p), ("conv1_w_bf16", c_void_p),
+        ("class_embedding", c_void_p), ("positional_embedding", c_void_p),
+        ("ln_pre_w", c_void_p), ("ln_pre_b", c_void_p), ("ln_post_w", c_void_p), ("ln_post_b", c_void_p),
+        ("proj_t", c_void_p), ("proj_t_bf16", c_void_p),
+        ("blocks", C.POINTER(BlockWeights)),
+    ]
+
+
+class VitDesc(C.Structure):
+    _fields_ = [(n, c_int32) for n in ("resolution", "patch", "width", "layers", "heads", "embed_dim", "prec")]
+
+
+_SIGS = {
+    "acx_version": (C.c_int, []),
+    "acx_create": (C.c_int, [C.POINTER(c_void_p), C.c_int]),
+    "acx_destroy": (None, [c_void_p]),
+    "acx_last_error": (C.c_char_p, [c_void_p]),
+    "acx_gemm": (C.c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
+    "acx_layernorm": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                c_int64, c_int32, c_float, c_int32, c_void_p]),
+    "acx_attention": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                c_int32, c_void_p]),
+    "acx_vit_patches": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_vit_embed": (C.c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
+    "acx_vit_workspace_bytes": (c_size_t, [C.POINTER(VitDesc), c_int32]),
+    "acx_vit_encode": (C.c_int, [c_void_p, C.POINTER(VitDesc), C.POINTER(VitWeights), c_void_p, c_int32, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+    "acx_transformer_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "acx_transformer_forward": (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                          c_int32, C.POINTER(BlockWeights), c_void_p, c_size_t, c_void_p]),
+    "acx_text_directions": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_selector_project": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                       c_void_p]),
+    "acx_bn_stats": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acx_selector_bn": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
+                                  c_float, c_void_p]),
+    "acx_axial_attention": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                      c_int32, c_void_p]),
+    "acx_cls_head": (C.c_int, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_class_probs": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "acx_prompt_embed": (C.c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_void_p]),
+    "acx_gather_rows": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "acx_add_bcast": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "acx_concat_features": (C.c_int, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_cast_bf16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "acx_colsum": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+}
+
+# entry points added by later translation units register themselves here (name -> signature)
+EXTRA_SIGS: dict = {}
+
+_lock = threading.Lock()
+_lib = None
+_ctxs: dict = {}
+
+
+class AcxError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    return sorted(set(_SIGS) | set(EXTRA_SIGS))
+
+
+def lib() -> C.CDLL:
+    """Loads (building if the in-tree binary is missing or stale and hipcc is present) libacx.so."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            path = _build.LIB
+            if not os.path.exists(path) or (_build._stale() and os.path.exists(_build.HIPCC)):
+                path = _build.build(verbose=False)
+            try:
+                L = C.CDLL(path)
+            except OSError as e:
+                raise AcxError(f"libacx.so could not be loaded from {path}: {e}. There is no fallback path: "
+                               f"build it with `python -m anomalyclip_amd._build`.") from e
+            for name, (res, args) in {**_SIGS, **EXTRA_SIGS}.items():
+                try:
+                    fn = getattr(L, name)
+                except AttributeError as e:
+                    raise AcxError(f"libacx.so does not export {name}") from e
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+        return _lib
+
+
+def ctx(device: int = 0) -> int:
+    """One acx context per device."""
+    L = lib()
+    with _lock:
+        if device not in _ctxs:
+            h = c_void_p()
+            rc = L.acx_create(C.byref(h), device)
+            if rc != 0:
+                raise AcxError(f"acx_create({device}) failed [{rc}]: {L.acx_last_error(None).decode()}")
+            _ctxs[device] = h.value
+        return _ctxs[device]
+
+
+def check(rc: int, handle) -> None:
+    if rc != 0:
+        raise AcxError(f"libacx error {rc}: {lib().acx_last_error(handle).decode()}")

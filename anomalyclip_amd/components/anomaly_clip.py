@@ -1,0 +1,158 @@
+"""AnomalyCLIP model assembly -- drop-in for the reference's
+`src.models.components.anomaly_clip.AnomalyCLIP` (anomaly_clip.py:17-233): same constructor keys
+(configs/model/anomaly_clip_*.yaml `net:` block), same attributes the LightningModule reaches into
+(`image_encoder`, `text_encoder.text_projection`, `token_embedding`, `selector_model`,
+`temporal_model`, `prompt_learner`, `embedding_dim`), same `forward` signature and return tuples.
+
+Differences forced by the environment, not by design:
+  * no `clip.load` (network download + TorchScript patching, SURVEY.md section 2 "out of scope"):
+    the CLIP geometry is given by `arch` and weights arrive through `load_state_dict`
+    (a Lightning `.ckpt`'s `state_dict` with the `net.` prefix stripped, or
+    anomalyclip_amd.init_weights for synthetic runs);
+  * no BPE tokenizer: `tokenized_prompts` is looked up in anomalyclip_amd/data/prompts.json by
+    class names (the three label files of the reference) or passed explicitly.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..init_weights import ClipGeometry, VIT_B16, TINY
+from .clip_vit import VisionTransformer
+from .coop import PromptLearner
+from .selector_model import SelectorModel
+from .temporal_model import TemporalModel
+from .text_encoder import TextEncoder
+
+_ARCH = {"ViT-B/16": VIT_B16, "tiny": TINY}
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "prompts.json")
+
+
+def _read_classnames(labels_file: str):
+    import csv
+    with open(labels_file) as f:
+        rows = list(csv.reader(f))[1:]
+    return sorted(r[1] for r in rows if len(r) >= 2)          # anomaly_clip.py:69-70
+
+
+def lookup_prompts(classnames=None, key: Optional[str] = None):
+    with open(_DATA) as f:
+        table = json.load(f)
+    if key is not None:
+        return table[key]
+    for v in table.values():
+        if v["classnames"] == list(classnames):
+            return v
+    raise ValueError("no pre-tokenised prompts for these class names: pass tokenized_prompts= (from the reference's "
+                     "clip.tokenize of 'X X X X X X X X <name>.')")
+
+
+class _TokenEmbedding(nn.Module):
+    def __init__(self, vocab: int, width: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(vocab, width).normal_(std=0.02))
+
+
+class AnomalyCLIP(nn.Module):
+    def __init__(self, **kwargs):
+        super().__init__()
+        g = kwargs.get
+        self.arch = g("arch", "ViT-B/16")
+        self.labels_file = g("labels_file")
+        self.emb_size, self.depth, self.heads, self.dim_heads = g("emb_size"), g("depth"), g("heads"), g("dim_heads")
+        self.num_segments, self.seg_length = g("num_segments"), g("seg_length")
+        self.concat_features = bool(g("concat_features"))
+        self.normal_id, self.stride = g("normal_id"), g("stride", 1)
+        self.load_from_features = g("load_from_features", True)
+        self.select_idx_dropout_topk = g("select_idx_dropout_topk")
+        self.select_idx_dropout_bottomk = g("select_idx_dropout_bottomk")
+        self.ncrops, self.num_topk, self.num_bottomk = g("ncrops", 1), g("num_topk"), g("num_bottomk")
+        self.precision = g("precision", "f32")          # "f32": exact-f32 MFMA (parity path); "bf16": bf16 MFMA
+        geom = g("clip_geometry") or _ARCH[self.arch]
+        if isinstance(geom, dict):
+            geom = ClipGeometry(**geom)
+        self.geometry = geom
+
+        classnames = g("classnames")
+        tokenized = g("tokenized_prompts")
+        if classnames is None:
+            if self.labels_file and os.path.isfile(self.labels_file):
+                classnames = _read_classnames(self.labels_file)
+            else:
+                classnames = lookup_prompts(key=g("labels_key", "ucf"))["classnames"]
+        if tokenized is None:
+            tokenized = torch.tensor(lookup_prompts(classnames)["tokenized_prompts"], dtype=torch.int32)
+        self.classnames = classnames
+
+        self.embedding_dim = geom.transformer_width                      # anomaly_clip.py:72
+        self.token_embedding = _TokenEmbedding(geom.vocab_size, geom.transformer_width)
+        n_ctx = g("n_ctx", 8)
+        self.prompt_learner = PromptLearner(len(classnames), n_ctx, geom.transformer_width, tokenized,
+                                            self.token_embedding.weight.detach(), bool(g("shared_context", False)))
+        self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+        self.register_buffer("eot_index", tokenized.argmax(dim=-1).to(torch.int64), persistent=False)
+        self.text_encoder = TextEncoder(geom.context_length, geom.transformer_width, geom.transformer_heads,
+                                        geom.transformer_layers, geom.embed_dim, self.precision)
+        self.image_encoder = VisionTransformer(geom.image_resolution, geom.vision_patch_size, geom.vision_width,
+                                               geom.vision_layers, geom.vision_heads, geom.embed_dim,
+                                               precision=self.precision, chunk=g("vit_chunk", 256))
+        self.selector_model = SelectorModel(classnames, self.normal_id, nn.Parameter(torch.tensor(2.6592601)),
+                                            self.num_segments, self.seg_length, self.select_idx_dropout_topk,
+                                            self.select_idx_dropout_bottomk, self.num_topk, self.num_bottomk)
+        additional = len(classnames) - 1
+        input_size = self.embedding_dim + additional * int(self.concat_features)     # anomaly_clip.py:92-93
+        self.temporal_model = TemporalModel(input_size, self.emb_size, 1, self.heads, self.dim_heads, self.depth,
+                                            self.num_segments, self.seg_length)
+        self.cache_text_features = bool(g("cache_text_features", False))
+        self._text_cache = None
+
+    # ------------------------------------------------------------------------------------------
+    def get_text_features(self) -> torch.Tensor:
+        """anomaly_clip.py:217-221 (prompt assembly + positional add fused into one kernel)."""
+        from . import functional as Fn
+        if torch.is_grad_enabled() and (self.prompt_learner.ctx.requires_grad or self.text_encoder.text_projection.requires_grad):
+            return Fn.text_features_train(self)
+        if self.cache_text_features and self._text_cache is not None:
+            return self._text_cache
+        x = self.prompt_learner(self.text_encoder.positional_embedding)
+        tf = self.text_encoder.encode(x, self.eot_index)
+        if self.cache_text_features:
+            self._text_cache = tf
+        return tf
+
+    def get_temporal_model_input(self, image_features, similarity, ncentroid):
+        """anomaly_clip.py:223-233; returns (features, a_sub): the re-centring is either folded into
+        the concat kernel or deferred to the projection GEMM's A staging."""
+        x = image_features.reshape(-1, image_features.shape[-1]).contiguous()
+        if self.concat_features:
+            Kp = self.temporal_model.prepared()["Kp"]
+            return ops.concat_features(similarity.contiguous(), x, ncentroid, Kp), None
+        return x, ncentroid
+
+    def forward(self, image_features, labels, ncentroid, segment_size=1, test_mode=False):
+        dev = image_features.device
+        ncentroid = ncentroid.to(dev, torch.float32).contiguous()
+        segment_size = int(segment_size)
+        if test_mode:
+            if not self.load_from_features:
+                b, t, c, h, w = image_features.size()
+                f = self.image_encoder(image_features.view(-1, c, h, w))                # anomaly_clip.py:119-123
+                # "(b ncrops n s l) d -> b ncrops (n s l) d" is a pure view
+                image_features = f.view(b, self.ncrops, -1, f.shape[-1])
+            b, ncrops, t, d = image_features.shape
+            x = image_features.reshape(-1, t, d).contiguous().float()
+            text_features = self.get_text_features()
+            similarity = self.selector_model(x, text_features, labels, ncentroid, True)
+            feats, a_sub = self.get_temporal_model_input(x, similarity, ncentroid)
+            scores = self.temporal_model(feats, segment_size, True, a_sub=a_sub)
+            if self.stride != 1:                                                         # anomaly_clip.py:149-150
+                similarity = similarity.repeat_interleave(self.stride, dim=0)
+                scores = scores.repeat_interleave(self.stride, dim=0)
+            return similarity, scores.view(-1)
+        from . import functional as Fn
+        return Fn.anomaly_clip_train_forward(self, image_features, labels, ncentroid)

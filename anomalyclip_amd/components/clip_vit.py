@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's CLIP transformer modules (clip/model.py:174-290): same
+module tree and parameter names (so reference / Lightning checkpoints load with load_state_dict),
+but `forward` hands raw device pointers to libacx instead of calling torch ops.
+
+Reference mapping
+    LayerNorm                 clip/model.py:174-180
+    ResidualAttentionBlock    clip/model.py:188-217
+    Transformer               clip/model.py:220-230
+    VisionTransformer         clip/model.py:233-290
+The CLIP image encoder is frozen in AnomalyCLIP (anomaly_clip_module.py:68-69), so only a forward
+exists for it (no autograd through the ViT).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import ops
+
+PRECISIONS = {"f32": L.PREC_F32, "bf16": L.PREC_BF16}
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, width: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(width))
+        self.bias = nn.Parameter(torch.zeros(width))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        shp = x.shape
+        return ops.layernorm(x.reshape(-1, shp[-1]).contiguous(), self.weight, self.bias).view(shp)
+
+
+class _Linear(nn.Module):
+    """Parameter holder with nn.Linear's names (weight [out,in], bias [out])."""
+
+    def __init__(self, fin: int, fout: int, bias: bool = True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.zeros(fout)) if bias else None
+        nn.init.normal_(self.weight, std=fin ** -0.5)
+
+
+class _MHA(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names."""
+
+    def __init__(self, width: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.out_proj = _Linear(width, width)
+        nn.init.normal_(self.in_proj_weight, std=width ** -0.5)
+
+
+class _MLP(nn.Module):
+    def __init__(self, width: int):
+        super().__init__()
+        self.c_fc = _Linear(width, 4 * width)
+        self.c_proj = _Linear(4 * width, width)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, width: int, heads: int):
+        super().__init__()
+        self.attn = _MHA(width)
+        self.ln_1 = LayerNorm(width)
+        self.mlp = _MLP(width)
+        self.ln_2 = LayerNorm(width)
+
+
+class Transformer(nn.Module):
+    """Holds `resblocks`; executes through acx_transformer_forward (in place on a [rows, W] f32 buffer)."""
+
+    def __init__(self, width: int, layers: int, heads: int, causal: bool = False):
+        super().__init__()
+        if width != heads * 64:
+            raise ValueError("libacx attention kernels are built for head dim 64 (every CLIP ViT/text tower)")
+        self.width, self.layers, self.heads, self.causal = width, layers, heads, causal
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads) for _ in range(layers)])
+        self._cache = None
+
+    # -- weight table handed to the C ABI (host array of device pointers), rebuilt when parameters change
+    def _key(self, prec):
+        return (prec,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def block_table(self, prec: int):
+        key = self._key(prec)
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1]
+        arr = (L.BlockWeights * self.layers)()
+        keep: List[torch.Tensor] = []
+        for i, b in enumerate(self.resblocks):
+            w = arr[i]
+            w.ln1_w, w.ln1_b = b.ln_1.weight.data_ptr(), b.ln_1.bias.data_ptr()
+            w.ln2_w, w.ln2_b = b.ln_2.weight.data_ptr(), b.ln_2.bias.data_ptr()
+            w.in_proj_w, w.in_proj_b = b.attn.in_proj_weight.data_ptr(), b.attn.in_proj_bias.data_ptr()
+            w.out_proj_w, w.out_proj_b = b.attn.out_proj.weight.data_ptr(), b.attn.out_proj.bias.data_ptr()
+            w.fc_w, w.fc_b = b.mlp.c_fc.weight.data_ptr(), b.mlp.c_fc.bias.data_ptr()
+            w.proj_w, w.proj_b = b.mlp.c_proj.weight.data_ptr(), b.mlp.c_proj.bias.data_ptr()
+            if prec == L.PREC_BF16:
+                for name, p in (("in_proj_w_bf16", b.attn.in_proj_weight), ("out_proj_w_bf16", b.attn.out_proj.weight),
+                                ("fc_w_bf16", b.mlp.c_fc.weight), ("proj_w_bf16", b.mlp.c_proj.weight)):
+                    t = ops.cast_bf16(p.detach())
+                    keep.append(t)
+                    setattr(w, name, t.data_ptr())
+        self._cache = (key, (arr, keep))
+        return self._cache[1]
+
+    def forward_(self, x: torch.Tensor, batch: int, seq: int, prec: int = L.PREC_F32) -> torch.Tensor:
+        """In-place forward on x [batch*seq, W] (f32, contiguous)."""
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.shape == (batch * seq, self.width)
+        lib = L.lib()
+        nbytes = lib.acx_transformer_workspace_bytes(self.width, batch * seq)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        arr, _keep = self.block_table(prec)
+        h = ops._h(x)
+        L.check(lib.acx_transformer_forward(h, x.data_ptr(), batch, seq, self.width, self.heads, self.layers,
+                                            int(self.causal), prec, arr, ws.data_ptr(), nbytes, ops._stream()), h)
+        return x
+
+
+class _Conv(nn.Module):
+    def __init__(self, width: int, patch: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(width, 3, patch, patch))
+        nn.init.normal_(self.weight, std=(3 * patch * patch) ** -0.5)
+
+
+class VisionTransformer(nn.Module):
+    """CLIP ViT image encoder; `forward(frames[F,3,R,R]) -> [F, output_dim]` runs acx_vit_encode in
+    chunks of `chunk` frames (workspace is allocated once per chunk size and reused)."""
+
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int,
+                 output_dim: int, precision: str = "f32", chunk: int = 256):
+        super().__init__()
+        self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
+        self.width, self.layers, self.heads = width, layers, heads
+        self.conv1 = _Conv(width, patch_size)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self.precision = precision
+        self.chunk = chunk
+        self._wcache = None
+        self._ws: Optional[torch.Tensor] = None
+
+    def _weights(self, prec: int):
+        key = (prec,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._wcache is not None and self._wcache[0] == key:
+            return self._wcache[1]
+        keep = []
+        w = L.VitWeights()
+        conv = self.conv1.weight.detach().reshape(self.width, -1).contiguous()
+        proj_t = self.proj.detach().t().contiguous()
+        keep += [conv, proj_t]
+        w.conv1_w, w.proj_t = conv.data_ptr(), proj_t.data_ptr()
+        if prec == L.PREC_BF16:
+            cb, pb = ops.cast_bf16(conv), ops.cast_bf16(proj_t)
+            keep += [cb, pb]
+            w.conv1_w_bf16, w.proj_t_bf16 = cb.data_ptr(), pb.data_ptr()
+        w.class_embedding = self.class_embedding.data_ptr()
+        w.positional_embedding = self.positional_embedding.data_ptr()
+        w.ln_pre_w, w.ln_pre_b = self.ln_pre.weight.data_ptr(), self.ln_pre.bias.data_ptr()
+        w.ln_post_w, w.ln_post_b = self.ln_post.weight.data_ptr(), self.ln_post.bias.data_ptr()
+        arr, keep2 = self.transformer.block_table(prec)
+        w.blocks = C.cast(arr, C.POINTER(L.BlockWeights))
+        keep += [arr, keep2]
+        self._wcache = (key, (w, keep))
+        return self._wcache[1]
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == x.shape[3] == self.input_resolution
+        x = x.contiguous().float()
+        prec = PRECISIONS[self.precision]
+        lib = L.lib()
+        d = L.VitDesc(self.input_resolution, self.patch_size, self.width, self.layers, self.heads, self.output_dim, prec)
+        w, _keep = self._weights(prec)
+        F = x.shape[0]
+        out = torch.empty(F, self.output_dim, dtype=torch.float32, device=x.device)
+        chunk = min(self.chunk, F)
+        nbytes = lib.acx_vit_workspace_bytes(C.byref(d), chunk)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        h = ops._h(x)
+        s = ops._stream()
+        for f0 in range(0, F, chunk):
+            n = min(chunk, F - f0)
+            L.check(lib.acx_vit_encode(h, C.byref(d), C.byref(w), x[f0:f0 + n].data_ptr(), n, out[f0:f0 + n].data_ptr(),
+                                       self._ws.data_ptr(), self._ws.numel(), s), h)
+        return out

@@ -1,0 +1,185 @@
+"""TemporalModel (reference temporal_model.py:8-77) with the axial transformer of the un-vendored
+`axial_attention` dependency re-implemented on libacx kernels.
+
+PARITY NOTE: the arithmetic of `AxialImageTransformer` lives in an UNPINNED PyPI package whose
+source is not part of the reference checkout; this module follows the restatement in
+oracle/axial_attention_restated.py.  Parity for this row is "unpinned".
+The parameter tree keeps upstream's names (`axial_attn.pos_emb.param_{0,1}`,
+`axial_attn.layers.blocks.{i}.{f,g}.net...`) so a reference checkpoint's keys line up.
+
+Data layout: tokens are kept channels-LAST, rows ordered (tile, n, l) with E contiguous -- every
+per-token op (LayerNorm, Linear) is a row op, the two axial attentions only differ in the row
+stride between sequence elements, and the 3x3 convolutions over the (N=32, L=16) grid become
+implicit GEMMs whose A rows are shifted token rows (acx_gemm AMAP_CONV3X3).  The reference's
+test-mode re-tiling "(b n s l) d -> (b s) n l d" is folded into the projection GEMM's row gather
+and undone by the classifier kernel's scatter.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import ops
+from .classification_head import ClassificationHead
+from .clip_vit import LayerNorm, _Linear
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, dim, heads, dim_heads):
+        super().__init__()
+        hidden = heads * dim_heads
+        self.to_q = _Linear(dim, hidden, bias=False)
+        self.to_kv = _Linear(dim, 2 * hidden, bias=False)
+        self.to_out = _Linear(hidden, dim)
+
+
+class _PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = LayerNorm(dim)
+
+
+class _Holder(nn.Module):
+    """`PermuteToFrom` / `Deterministic` wrappers of upstream: only their attribute names matter."""
+
+    def __init__(self, name: str, child: nn.Module):
+        super().__init__()
+        setattr(self, name, child)
+
+
+class _ChanLayerNorm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+        self.b = nn.Parameter(torch.zeros(1, dim, 1, 1))
+
+
+class _Conv3x3(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3).normal_(std=(9 * cin) ** -0.5))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+def _ff(dim):
+    return nn.ModuleList([_ChanLayerNorm(dim), _Conv3x3(dim, 4 * dim), nn.Identity(), _Conv3x3(4 * dim, dim)])
+
+
+class _Block(nn.Module):
+    def __init__(self, f, g):
+        super().__init__()
+        self.f = _Holder("net", f)
+        self.g = _Holder("net", g)
+
+
+class _PosEmb(nn.Module):
+    def __init__(self, dim, n, l):
+        super().__init__()
+        self.param_0 = nn.Parameter(torch.randn(1, dim, n, 1))
+        self.param_1 = nn.Parameter(torch.randn(1, dim, 1, l))
+
+
+class AxialImageTransformer(nn.Module):
+    def __init__(self, dim, depth, heads, dim_heads, num_segments, seg_length):
+        super().__init__()
+        self.dim, self.depth, self.heads = dim, depth, heads
+        self.e = dim_heads if dim_heads else dim // heads
+        self.pos_emb = _PosEmb(dim, num_segments, seg_length)
+        blocks = []
+        for _ in range(depth):
+            attn = [_Holder("fn", _PreNorm(dim, _SelfAttention(dim, heads, self.e))) for _ in range(2)]
+            blocks.append(_Block(attn[0], attn[1]))
+            blocks.append(_Block(_ff(dim), _ff(dim)))
+        self.layers = _Holder("blocks", nn.ModuleList(blocks))
+
+
+class TemporalModel(nn.Module):
+    def __init__(self, input_size: int, emb_size: int, output_size: int, heads: int, dim_heads: Optional[int],
+                 depth: int, num_segments: int, seg_length: int):
+        super().__init__()
+        self.input_size, self.emb_size, self.output_size = input_size, emb_size, output_size
+        self.heads, self.dim_heads, self.depth = heads, dim_heads, depth
+        self.num_segments, self.seg_length = num_segments, seg_length
+        self.projection = _Linear(input_size, emb_size)
+        self.axial_attn = AxialImageTransformer(emb_size, depth, heads, dim_heads, num_segments, seg_length)
+        self.classifier = ClassificationHead(emb_size, output_size)
+        self._prep = None
+
+    # ---- derived weight layouts for the kernels (cached; rebuilt when a parameter changes)
+    def prepared(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._prep is not None and self._prep[0] == key:
+            return self._prep[1]
+        with torch.no_grad():
+            P = {}
+            K = self.input_size
+            Kp = (K + 31) // 32 * 32
+            w = self.projection.weight.detach()
+            if Kp != K:
+                w = torch.cat([w, w.new_zeros(w.shape[0], Kp - K)], dim=1)
+            P["proj_w"], P["Kp"] = w.contiguous(), Kp
+            pe = self.axial_attn.pos_emb
+            P["pos0"] = pe.param_0.detach()[0, :, :, 0].t().contiguous()   # [N, E]
+            P["pos1"] = pe.param_1.detach()[0, :, 0, :].t().contiguous()   # [L, E]
+            blks = self.axial_attn.layers.blocks
+            for d in range(self.depth):
+                for fg in ("f", "g"):
+                    sa = getattr(blks[2 * d], fg).net.fn.fn
+                    P[f"qkv_w{d}{fg}"] = torch.cat([sa.to_q.weight.detach(), sa.to_kv.weight.detach()], 0).contiguous()
+                    ff = getattr(blks[2 * d + 1], fg).net
+                    # conv weight [Cout, Cin, 3, 3] -> [Cout, tap=kh*3+kw, Cin]  (K = 9*Cin, tap-major)
+                    P[f"c1_w{d}{fg}"] = ff[1].weight.detach().permute(0, 2, 3, 1).reshape(ff[1].weight.shape[0], -1).contiguous()
+                    P[f"c2_w{d}{fg}"] = ff[3].weight.detach().permute(0, 2, 3, 1).reshape(ff[3].weight.shape[0], -1).contiguous()
+                    P[f"g{d}{fg}"] = ff[0].g.detach().reshape(-1).contiguous()
+                    P[f"b{d}{fg}"] = ff[0].b.detach().reshape(-1).contiguous()
+        self._prep = (key, P)
+        return P
+
+    def _attn(self, x_in, resid, d, fg, tiles, axis, P):
+        N, Lg, E = self.num_segments, self.seg_length, self.emb_size
+        pn = getattr(self.axial_attn.layers.blocks[2 * d], fg).net.fn
+        h = ops.layernorm(x_in, pn.norm.weight, pn.norm.bias)
+        qkv = ops.gemm(h, P[f"qkv_w{d}{fg}"])
+        o = ops.axial_attention(qkv, tiles, N, Lg, self.heads, self.axial_attn.e, axis)
+        return ops.gemm(o, pn.fn.to_out.weight, bias=pn.fn.to_out.bias, residual=resid)
+
+    def _ff(self, x_in, resid, d, fg, P):
+        N, Lg, E = self.num_segments, self.seg_length, self.emb_size
+        ff = getattr(self.axial_attn.layers.blocks[2 * d + 1], fg).net
+        h = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN)
+        u = ops.gemm(h, P[f"c1_w{d}{fg}"], bias=ff[1].bias, act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
+        return ops.gemm(u, P[f"c2_w{d}{fg}"], bias=ff[3].bias, residual=resid, amap=L.AMAP_CONV3X3, gn=N, gl=Lg,
+                        cin=4 * E)
+
+    def forward(self, features: torch.Tensor, segment_size: int, test_mode: bool,
+                a_sub: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """features [rows, input_size] -> scores [rows, 1] (temporal_model.py:42-77).  `a_sub` fuses the
+        caller's re-centring (anomaly_clip.py:143,201) into the projection GEMM's A staging."""
+        from . import functional as Fn
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return Fn.temporal_train(self, features, a_sub)
+        P = self.prepared()
+        N, Lg, E = self.num_segments, self.seg_length, self.emb_size
+        x = features.reshape(-1, features.shape[-1])
+        rows = x.shape[0]
+        if x.shape[1] != P["Kp"]:
+            raise ValueError("pad the temporal input to prepared()['Kp'] columns (ops.concat_features does)")
+        x = x.contiguous()
+        tiles = rows // (N * Lg)
+        seg = segment_size if test_mode else 0
+        x0 = ops.gemm(x, P["proj_w"], bias=self.projection.bias, a_sub=a_sub,
+                      amap=L.AMAP_TESTTILE if test_mode else L.AMAP_IDENTITY, gn=N, gl=Lg, seg=max(seg, 1),
+                      pos0=P["pos0"], pos1=P["pos1"])
+        x1 = x2 = x0
+        for d in range(self.depth):
+            y1 = self._attn(x2, x1, d, "f", tiles, 0, P)      # long-term: along the N segments
+            y2 = self._attn(y1, x2, d, "g", tiles, 1, P)      # short-term: along the L frames
+            x1 = self._ff(y2, y1, d, "f", P)
+            x2 = self._ff(x1, y2, d, "g", P)
+        c = self.classifier
+        s = ops.cls_head(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight, c.linear.bias, N, Lg, seg)
+        return s.view(-1, 1)

@@ -1,0 +1,173 @@
+// libacx context management and the whole-encoder drivers (host code only: they sequence the
+// kernels of acx_gemm / acx_norm / acx_attn / acx_head on the caller's stream; no allocation,
+// no synchronisation, safe to capture in a hipGraph).
+#include "acx_internal.h"
+
+#include <new>
+
+thread_local char acx_tls_err[512] = {0};
+
+extern "C" int acx_version(void) { return ACX_VERSION; }
+
+extern "C" int acx_create(acx_ctx** out, int device) {
+  if (!out) return acx_fail(nullptr, ACX_E_BADARG, "acx_create: null out%s");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || device < 0 || device >= n) {
+    snprintf(acx_tls_err, 512, "acx_create: device %d not available (%s, %d devices)", device,
+             e == hipSuccess ? "ok" : hipGetErrorString(e), n);
+    return ACX_E_HIP;
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    snprintf(acx_tls_err, 512, "acx_create: hipGetDeviceProperties: %s", hipGetErrorString(e));
+    return ACX_E_HIP;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    snprintf(acx_tls_err, 512, "acx_create: libacx is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
+    return ACX_E_UNSUPPORTED;
+  }
+  acx_ctx* c = new (std::nothrow) acx_ctx;
+  if (!c) return acx_fail(nullptr, ACX_E_HIP, "acx_create: out of host memory%s");
+  c->device = device;
+  c->err[0] = 0;
+  *out = c;
+  return ACX_OK;
+}
+
+extern "C" void acx_destroy(acx_ctx* ctx) { delete ctx; }
+
+extern "C" const char* acx_last_error(acx_ctx* ctx) { return ctx ? ctx->err : acx_tls_err; }
+
+namespace {
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct TfWs {   // transformer scratch carved from the caller's workspace
+  char *h, *qkv, *att, *mlp;
+  size_t total;
+};
+
+TfWs carve_tf(char* base, int64_t rows, int W) {
+  TfWs w;
+  size_t off = 0;
+  w.h = base + off;   off += al((size_t)rows * W * 4);
+  w.qkv = base + off; off += al((size_t)rows * 3 * W * 4);
+  w.att = base + off; off += al((size_t)rows * W * 4);
+  w.mlp = base + off; off += al((size_t)rows * 4 * W * 4);
+  w.total = off;
+  return w;
+}
+
+int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
+           void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
+           hipStream_t s) {
+  acx_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.A = A; d.C = C;
+  d.W = prec == ACX_PREC_BF16 ? Wb : (const void*)Wf;
+  if (!d.W) return acx_fail(ctx, ACX_E_BADARG, "driver: missing %s weight copy for the requested precision",
+                            prec == ACX_PREC_BF16 ? "bf16" : "f32");
+  d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc;
+  d.a_dtype = a_dtype; d.c_dtype = c_dtype; d.prec = prec;
+  d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldc;
+  return acx_gemm(ctx, &d, s);
+}
+
+int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int heads, int layers, int causal, int prec,
+                       const acx_block_weights* blk, const TfWs& ws, hipStream_t s) {
+  const int64_t rows = (int64_t)batch * L;
+  const int hdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
+  int rc;
+  for (int l = 0; l < layers; ++l) {
+    const acx_block_weights& b = blk[l];
+    // x = x + attn(ln_1(x))                                          clip/model.py:215
+    if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+    if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, ACX_F32, 3 * W, (int)rows, 3 * W, W,
+                     b.in_proj_b, ACX_ACT_NONE, nullptr, s))) return rc;
+    if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
+    if ((rc = linear(ctx, prec, ws.att, ACX_F32, W, b.out_proj_w, b.out_proj_w_bf16, W, x, ACX_F32, W, (int)rows, W, W,
+                     b.out_proj_b, ACX_ACT_NONE, x, s))) return rc;
+    // x = x + mlp(ln_2(x))                                           clip/model.py:216
+    if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+    if ((rc = linear(ctx, prec, ws.h, hdt, W, b.fc_w, b.fc_w_bf16, W, ws.mlp, hdt, 4 * W, (int)rows, 4 * W, W, b.fc_b,
+                     ACX_ACT_QUICKGELU, nullptr, s))) return rc;
+    if ((rc = linear(ctx, prec, ws.mlp, hdt, 4 * W, b.proj_w, b.proj_w_bf16, 4 * W, x, ACX_F32, W, (int)rows, W, 4 * W,
+                     b.proj_b, ACX_ACT_NONE, x, s))) return rc;
+  }
+  return ACX_OK;
+}
+
+}  // namespace
+
+extern "C" size_t acx_transformer_workspace_bytes(int32_t width, int32_t rows) {
+  return carve_tf(nullptr, rows, width).total;
+}
+
+extern "C" int acx_transformer_forward(acx_ctx* ctx, float* x, int32_t batch, int32_t L, int32_t width, int32_t heads,
+                                       int32_t layers, int32_t causal, int32_t prec, const acx_block_weights* blocks,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !blocks || !workspace) return acx_fail(ctx, ACX_E_BADARG, "acx_transformer_forward: null pointer%s");
+  if (width != heads * 64) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_transformer_forward: head dim must be 64%s");
+  const TfWs ws = carve_tf((char*)workspace, (int64_t)batch * L, width);
+  if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_transformer_forward: workspace too small%s");
+  return transformer_layers(ctx, x, batch, L, width, heads, layers, causal, prec, blocks, ws, (hipStream_t)stream);
+}
+
+namespace {
+struct VitWs {
+  char *patches, *patch_out, *x, *cls;
+  size_t tf_off, total;
+};
+VitWs carve_vit(char* base, const acx_vit_desc* d, int F) {
+  const int g = d->resolution / d->patch, T = g * g, W = d->width;
+  const int K = 3 * d->patch * d->patch;
+  VitWs w;
+  size_t off = 0;
+  w.patches = base + off;   off += al((size_t)F * T * K * 4);
+  w.patch_out = base + off; off += al((size_t)F * T * W * 4);
+  w.x = base + off;         off += al((size_t)F * (T + 1) * W * 4);
+  w.cls = base + off;       off += al((size_t)F * W * 4);
+  w.tf_off = off;
+  off += carve_tf(nullptr, (int64_t)F * (T + 1), W).total;
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t acx_vit_workspace_bytes(const acx_vit_desc* d, int32_t frames) {
+  if (!d || frames <= 0) return 0;
+  return carve_vit(nullptr, d, frames).total;
+}
+
+extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit_weights* w, const float* frames,
+                              int32_t nframes, float* features, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !w || !frames || !features || !workspace) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_encode: null pointer%s");
+  if (nframes <= 0) return ACX_OK;
+  if (d->width != d->heads * 64) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_vit_encode: head dim must be 64%s");
+  if (d->resolution % d->patch || d->patch % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_encode: bad patch geometry%s");
+  const int g = d->resolution / d->patch, T = g * g, W = d->width, F = nframes;
+  const int K = 3 * d->patch * d->patch;
+  if (T + 1 > 224) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_vit_encode: more than 224 tokens%s");
+  const VitWs ws = carve_vit((char*)workspace, d, F);
+  if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_vit_encode: workspace too small%s");
+  hipStream_t s = (hipStream_t)stream;
+  const int prec = d->prec;
+  const int pdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
+  int rc;
+  // conv1 as GEMM over im2col'ed patches                               clip/model.py:267-269
+  if ((rc = acx_vit_patches(ctx, frames, ws.patches, pdt, F, d->resolution, d->patch, s))) return rc;
+  if ((rc = linear(ctx, prec, ws.patches, pdt, K, w->conv1_w, w->conv1_w_bf16, K, ws.patch_out, ACX_F32, W, F * T, W, K,
+                   nullptr, ACX_ACT_NONE, nullptr, s))) return rc;
+  // CLS + positional embedding + ln_pre                                :270-279
+  if ((rc = acx_vit_embed(ctx, (const float*)ws.patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
+                          w->ln_pre_b, (float*)ws.x, F, T, W, s))) return rc;
+  const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W);
+  if ((rc = transformer_layers(ctx, (float*)ws.x, F, T + 1, W, d->heads, d->layers, 0, prec, w->blocks, tf, s))) return rc;
+  // ln_post on the CLS rows, then @ proj                                :285-288
+  if ((rc = acx_layernorm(ctx, (const float*)ws.x, (int64_t)(T + 1) * W, w->ln_post_w, w->ln_post_b, ws.cls, W, ACX_F32,
+                          F, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+  return linear(ctx, prec, ws.cls, ACX_F32, W, w->proj_t, w->proj_t_bf16, W, features, ACX_F32, d->embed_dim, F,
+                d->embed_dim, W, nullptr, ACX_ACT_NONE, nullptr, s);
+}

@@ -1,0 +1,507 @@
+// HBM-bound / small kernels of the AnomalyCLIP head and the frame front-end:
+//   acx_vit_patches, acx_text_directions, acx_selector_project, acx_selector_bn, acx_bn_stats,
+//   acx_axial_attention, acx_class_probs, acx_cast_bf16, acx_colsum
+// Every kernel makes one coalesced pass over its input with 16-byte accesses where the layout
+// allows; none of them is reshaped into a GEMM.
+#include "acx_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------ patch im2col
+// out[(f*g*g + gy*g + gx), c*P*P + ky*P + kx] = frames[f, c, gy*P+ky, gx*P+kx]   (P % 4 == 0)
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ frames, void* __restrict__ out,
+                                                      int64_t total4, int R, int P, int g) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int K = 3 * P * P, K4 = K / 4;
+  const int64_t row = i / K4;
+  const int k = (int)(i - row * K4) * 4;
+  const int c = k / (P * P), rem = k - c * P * P, ky = rem / P, kx = rem - ky * P;
+  const int64_t f = row / (g * g);
+  const int tok = (int)(row - f * g * g), gy = tok / g, gx = tok - gy * g;
+  const float4 v = *reinterpret_cast<const float4*>(
+      frames + ((f * 3 + c) * R + gy * P + ky) * (int64_t)R + gx * P + kx);
+  if constexpr (OUT_BF16) {
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>((u16*)out + row * K + k) = pk;
+  } else {
+    *reinterpret_cast<float4*>((float*)out + row * K + k) = v;
+  }
+}
+
+// ------------------------------------------------------------------ text directions
+__global__ __launch_bounds__(256) void text_dirs_kernel(const float* __restrict__ text, const float* __restrict__ nc,
+                                                        float* __restrict__ dirs, int D, int normal_id) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const int src = c < normal_id ? c : c + 1;      // selector_model.py:44-50
+  float ss = 0.f;
+  for (int e = threadIdx.x; e < D; e += 256) {
+    const float v = text[(size_t)src * D + e] - nc[e];
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  for (int e = threadIdx.x; e < D; e += 256)
+    dirs[(size_t)c * D + e] = (text[(size_t)src * D + e] - nc[e]) / norm;
+}
+
+// ------------------------------------------------------------------ selector projection
+// raw[r, c] = (x[r,:] - nc) . dirs[c,:]      one wavefront per row, directions resident in LDS
+template <int VPL>
+__global__ __launch_bounds__(256) void selector_project_kernel(const float* __restrict__ x, const float* __restrict__ nc,
+                                                               const float* __restrict__ dirs, float* __restrict__ raw,
+                                                               int64_t rows, int C1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sd = reinterpret_cast<float*>(smem);     // [C1][D]
+  constexpr int D = 64 * VPL;
+  for (int i = threadIdx.x; i < C1 * D / 4; i += 256)
+    reinterpret_cast<float4*>(sd)[i] = reinterpret_cast<const float4*>(dirs)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float cen[VPL];
+  load_row<VPL>(nc, lane, cen);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float v[VPL];
+    load_row<VPL>(x + row * D, lane, v);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] -= cen[i];
+    float mine = 0.f;
+    for (int c = 0; c < C1; ++c) {
+      float dd[VPL];
+      load_row<VPL>(sd + c * D, lane, dd);
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) acc += v[i] * dd[i];
+      acc = wave_sum(acc);
+      if (lane == c) mine = acc;
+    }
+    if (lane < C1) raw[row * C1 + lane] = mine;
+  }
+}
+
+// ------------------------------------------------------------------ batch-norm statistics
+// deterministic (fixed-order) per-column mean / biased var / unbiased var of raw[rows, C1]
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ raw, int64_t rows, int C1,
+                                                       float* __restrict__ mean, float* __restrict__ var_b,
+                                                       float* __restrict__ var_u) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) s += (double)raw[r * C1 + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double m = red[0] / (double)rows;
+  __syncthreads();
+  double q = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) {
+    const double dlt = (double)raw[r * C1 + c] - m;
+    q += dlt * dlt;
+  }
+  red[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    mean[c] = (float)m;
+    var_b[c] = (float)(red[0] / (double)rows);
+    var_u[c] = rows > 1 ? (float)(red[0] / (double)(rows - 1)) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void selector_bn_kernel(const float* __restrict__ raw, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, float* __restrict__ logits,
+                                                          int64_t ldl, int64_t total, int C1, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t r = i / C1;
+  const int c = (int)(i - r * C1);
+  logits[r * ldl + c] = (raw[i] - mean[c]) / sqrtf(var[c] + eps);
+}
+
+// ------------------------------------------------------------------ axial attention core
+// thread = (line, head, query i); K/V of the block's lines in LDS, broadcast reads.
+template <int T, int E>
+__global__ __launch_bounds__(256) void axial_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                         int tiles, int gn, int gl, int heads, int axis,
+                                                         int64_t nlines) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int He = heads * E;
+  const int lpb = 256 / (T * heads);            // lines per block
+  float* sK = reinterpret_cast<float*>(smem);   // [lpb][T][He]
+  float* sV = sK + lpb * T * He;
+  const int t = threadIdx.x;
+  const int64_t line0 = (int64_t)blockIdx.x * lpb;
+  const int ld = 3 * He;
+  const int other = axis == 0 ? gl : gn;        // number of lines per tile
+  auto row_of = [&](int64_t line, int j) -> int64_t {
+    const int64_t tile = line / other;
+    const int o = (int)(line - tile * other);
+    return axis == 0 ? (tile * gn + j) * gl + o : (tile * gn + o) * gl + j;
+  };
+  // cooperative K/V staging
+  const int f4_per_tok = He / 4;
+  for (int i = t; i < lpb * T * f4_per_tok; i += 256) {
+    const int c4 = i % f4_per_tok, tokl = i / f4_per_tok;
+    const int lb = tokl / T, j = tokl - lb * T;
+    const int64_t line = line0 + lb;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (line < nlines) {
+      const float* p = qkv + row_of(line, j) * ld + 4 * c4;
+      kv = *reinterpret_cast<const float4*>(p + He);
+      vv = *reinterpret_cast<const float4*>(p + 2 * He);
+    }
+    reinterpret_cast<float4*>(sK)[i] = kv;
+    reinterpret_cast<float4*>(sV)[i] = vv;
+  }
+  __syncthreads();
+  const int i = t % T, h = (t / T) % heads, lb = t / (T * heads);
+  const int64_t line = line0 + lb;
+  if (line >= nlines) return;
+  const int64_t row = row_of(line, i);
+  float q[E];
+  const float scale = E == 32 ? 0.17677669529663687f : 0.25f;    // e^-0.5
+#pragma unroll
+  for (int c = 0; c < E / 4; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(qkv + row * ld + h * E + 4 * c);
+    q[4 * c] = v.x; q[4 * c + 1] = v.y; q[4 * c + 2] = v.z; q[4 * c + 3] = v.w;
+  }
+  float s[T];
+  float mx = -INFINITY;
+  const float* kb = sK + (lb * T) * He + h * E;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < E / 4; ++c) {
+      const float4 kk = *reinterpret_cast<const float4*>(kb + j * He + 4 * c);
+      acc += q[4 * c] * kk.x + q[4 * c + 1] * kk.y + q[4 * c + 2] * kk.z + q[4 * c + 3] * kk.w;
+    }
+    s[j] = acc * scale;
+    mx = fmaxf(mx, s[j]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    s[j] = __expf(s[j] - mx);
+    sum += s[j];
+  }
+  const float inv = 1.f / sum;
+  float o[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) o[e] = 0.f;
+  const float* vb = sV + (lb * T) * He + h * E;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const float p = s[j] * inv;
+#pragma unroll
+    for (int c = 0; c < E / 4; ++c) {
+      const float4 vv = *reinterpret_cast<const float4*>(vb + j * He + 4 * c);
+      o[4 * c] += p * vv.x; o[4 * c + 1] += p * vv.y; o[4 * c + 2] += p * vv.z; o[4 * c + 3] += p * vv.w;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < E / 4; ++c)
+    *reinterpret_cast<float4*>(out + row * He + h * E + 4 * c) =
+        make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+}
+
+// ------------------------------------------------------------------ eval post-processing
+__global__ __launch_bounds__(256) void class_probs_kernel(const float* __restrict__ sim, const float* __restrict__ scores,
+                                                          float* __restrict__ probs, int64_t rows, int C1) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float mx = -INFINITY;
+  for (int c = 0; c < C1; ++c) mx = fmaxf(mx, sim[r * C1 + c]);
+  float sum = 0.f;
+  for (int c = 0; c < C1; ++c) sum += expf(sim[r * C1 + c] - mx);
+  const float k = scores[r] / sum;
+  for (int c = 0; c < C1; ++c) probs[r * C1 + c] = expf(sim[r * C1 + c] - mx) * k;
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(dst + i) = pk;
+  } else {
+    for (int64_t j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+  }
+}
+
+// column sums: block handles a slab of rows, thread = 4 columns; one atomicAdd per column per block
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ acc,
+                                                     int64_t rows, int D, int rows_per_block) {
+  const int c4 = threadIdx.x % (D / 4);
+  const int rsub = threadIdx.x / (D / 4), nsub = 256 / (D / 4);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rsub < nsub) {
+    for (int64_t r = r0 + rsub; r < r1; r += nsub) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * D + 4 * c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    atomicAdd(acc + 4 * c4, s.x);
+    atomicAdd(acc + 4 * c4 + 1, s.y);
+    atomicAdd(acc + 4 * c4 + 2, s.z);
+    atomicAdd(acc + 4 * c4 + 3, s.w);
+  }
+}
+
+
+// ------------------------------------------------------------------ prompt assembly + positional embedding
+// out[c, t, :] = {prefix | ctx | suffix}[c, t, :] + pos[t, :]     (coop.py:74-90, text_encoder.py:15)
+__global__ __launch_bounds__(256) void prompt_embed_kernel(const float* __restrict__ prefix, const float* __restrict__ ctxv,
+                                                           const float* __restrict__ suffix, const float* __restrict__ pos,
+                                                           float* __restrict__ out, int64_t total4, int n_ctx, int Lc, int W,
+                                                           int shared_ctx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int W4 = W / 4;
+  const int w4 = (int)(i % W4);
+  const int64_t tokg = i / W4;
+  const int tkn = (int)(tokg % Lc);
+  const int64_t c = tokg / Lc;
+  const float* src;
+  if (tkn == 0) src = prefix + c * W;
+  else if (tkn <= n_ctx) src = ctxv + ((shared_ctx ? 0 : c * n_ctx) + (tkn - 1)) * (int64_t)W;
+  else src = suffix + (c * (Lc - 1 - n_ctx) + (tkn - 1 - n_ctx)) * (int64_t)W;
+  const float4 a = *reinterpret_cast<const float4*>(src + 4 * w4);
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pos) p = *reinterpret_cast<const float4*>(pos + (int64_t)tkn * W + 4 * w4);
+  *reinterpret_cast<float4*>(out + tokg * W + 4 * w4) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+}
+
+// out[i, :] = x[idx[i], :]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t total4, int W) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int W4 = W / 4;
+  const int64_t r = i / W4;
+  const int w4 = (int)(i - r * W4);
+  *reinterpret_cast<float4*>(out + r * W + 4 * w4) = *reinterpret_cast<const float4*>(x + idx[r] * W + 4 * w4);
+}
+
+
+// out[r, :] = x[r, :] + p[:]  with r over n rows of width LW (positional embedding add, text_encoder.py:15)
+__global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ p,
+                                                        float* __restrict__ out, int64_t total4, int64_t LW4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const float4 a = reinterpret_cast<const float4*>(x)[i];
+  const float4 b = reinterpret_cast<const float4*>(p)[i % LW4];
+  reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// temporal-model input with concat_features: out[r, :] = [ logits[r, 0:C1] | x[r, 0:D] - nc | 0-pad ]
+// (anomaly_clip.py:143,223-233)
+__global__ __launch_bounds__(256) void concat_features_kernel(const float* __restrict__ logits, const float* __restrict__ x,
+                                                              const float* __restrict__ nc, float* __restrict__ out,
+                                                              int64_t rows, int C1, int D, int Kp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * Kp) return;
+  const int64_t r = i / Kp;
+  const int k = (int)(i - r * Kp);
+  float v = 0.f;
+  if (k < C1) v = logits[r * C1 + k];
+  else if (k < C1 + D) v = x[r * D + (k - C1)] - nc[k - C1];
+  out[i] = v;
+}
+
+}  // namespace
+
+extern "C" int acx_vit_patches(acx_ctx* ctx, const float* frames, void* patches, int32_t out_dtype, int32_t F,
+                               int32_t R, int32_t P, void* stream) {
+  if (!frames || !patches) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_patches: null pointer%s");
+  if (F <= 0) return ACX_OK;
+  if (P % 4 || R % P) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_patches: need P%%4==0 and R%%P==0%s");
+  const int g = R / P;
+  const int64_t total4 = (int64_t)F * g * g * 3 * P * P / 4;
+  const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == ACX_BF16) hipLaunchKernelGGL((patches_kernel<1>), grid, block, 0, s, frames, patches, total4, R, P, g);
+  else hipLaunchKernelGGL((patches_kernel<0>), grid, block, 0, s, frames, patches, total4, R, P, g);
+  ACX_CHECK_LAUNCH(ctx, "acx_vit_patches");
+  return ACX_OK;
+}
+
+extern "C" int acx_text_directions(acx_ctx* ctx, const float* text, const float* ncentroid, float* dirs, int32_t C,
+                                   int32_t D, int32_t normal_id, void* stream) {
+  if (!text || !ncentroid || !dirs) return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions: null pointer%s");
+  if (C < 2 || normal_id < 0 || normal_id >= C) return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions: bad C/normal_id%s");
+  hipLaunchKernelGGL(text_dirs_kernel, dim3(C - 1), dim3(256), 0, (hipStream_t)stream, text, ncentroid, dirs, D, normal_id);
+  ACX_CHECK_LAUNCH(ctx, "acx_text_directions");
+  return ACX_OK;
+}
+
+extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
+                                    int64_t rows, int32_t D, int32_t C1, void* stream) {
+  if (!x || !ncentroid || !dirs || !raw) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  if (C1 <= 0 || C1 > 64) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_project: need 1 <= C-1 <= 64%s");
+  if (D % 64 || D > 1024 || (D / 64 != 1 && D / 64 != 2 && (D / 64) % 4))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_project: D must be 64/128/256/512/768/1024%s");
+  const size_t lds = (size_t)C1 * D * 4;
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  const dim3 grid((unsigned)nb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define ACX_SEL(V)                                                                                         \
+  do {                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)selector_project_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((selector_project_kernel<V>), grid, block, lds, s, x, ncentroid, dirs, raw, rows, C1); \
+  } while (0)
+  switch (D / 64) {
+    case 1: ACX_SEL(1); break;
+    case 2: ACX_SEL(2); break;
+    case 4: ACX_SEL(4); break;
+    case 8: ACX_SEL(8); break;
+    case 12: ACX_SEL(12); break;
+    default: ACX_SEL(16); break;
+  }
+#undef ACX_SEL
+  ACX_CHECK_LAUNCH(ctx, "acx_selector_project");
+  return ACX_OK;
+}
+
+extern "C" int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_t C1, float* mean, float* var_biased,
+                            float* var_unbiased, void* stream) {
+  if (!raw || !mean || !var_biased || !var_unbiased) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: null pointer%s");
+  if (rows <= 0 || C1 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: empty%s");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C1), dim3(256), 0, (hipStream_t)stream, raw, rows, C1, mean, var_biased, var_unbiased);
+  ACX_CHECK_LAUNCH(ctx, "acx_bn_stats");
+  return ACX_OK;
+}
+
+extern "C" int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean, const float* var, float* logits,
+                               int64_t ldl, int64_t rows, int32_t C1, float eps, void* stream) {
+  if (!raw || !mean || !var || !logits) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_bn: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  const int64_t total = rows * C1;
+  hipLaunchKernelGGL(selector_bn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw,
+                     mean, var, logits, ldl, total, C1, eps);
+  ACX_CHECK_LAUNCH(ctx, "acx_selector_bn");
+  return ACX_OK;
+}
+
+extern "C" int acx_axial_attention(acx_ctx* ctx, const float* qkv, float* out, int32_t tiles, int32_t gn, int32_t gl,
+                                   int32_t heads, int32_t e, int32_t axis, void* stream) {
+  if (!qkv || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_axial_attention: null pointer%s");
+  if (tiles <= 0) return ACX_OK;
+  const int T = axis == 0 ? gn : gl;
+  if ((T != 16 && T != 32) || (e != 16 && e != 32) || heads <= 0 || 256 % (T * heads))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_axial_attention: need axis length in {16,32}, e in {16,32}, T*heads | 256%s");
+  const int lpb = 256 / (T * heads);
+  const int64_t nlines = (int64_t)tiles * (axis == 0 ? gl : gn);
+  const size_t lds = (size_t)lpb * T * heads * e * 2 * 4;
+  const dim3 grid((unsigned)((nlines + lpb - 1) / lpb)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define ACX_AX(TT, EE)                                                                                     \
+  do {                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)axial_attn_kernel<TT, EE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((axial_attn_kernel<TT, EE>), grid, block, lds, s, qkv, out, tiles, gn, gl, heads, axis, nlines); \
+  } while (0)
+  if (T == 32 && e == 32) ACX_AX(32, 32);
+  else if (T == 32) ACX_AX(32, 16);
+  else if (e == 32) ACX_AX(16, 32);
+  else ACX_AX(16, 16);
+#undef ACX_AX
+  ACX_CHECK_LAUNCH(ctx, "acx_axial_attention");
+  return ACX_OK;
+}
+
+extern "C" int acx_class_probs(acx_ctx* ctx, const float* sim, const float* scores, float* probs, int64_t rows,
+                               int32_t C1, void* stream) {
+  if (!sim || !scores || !probs) return acx_fail(ctx, ACX_E_BADARG, "acx_class_probs: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  hipLaunchKernelGGL(class_probs_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sim,
+                     scores, probs, rows, C1);
+  ACX_CHECK_LAUNCH(ctx, "acx_class_probs");
+  return ACX_OK;
+}
+
+extern "C" int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst) return acx_fail(ctx, ACX_E_BADARG, "acx_cast_bf16: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  const int64_t nt = (n + 3) / 4;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (u16*)dst, n);
+  ACX_CHECK_LAUNCH(ctx, "acx_cast_bf16");
+  return ACX_OK;
+}
+
+extern "C" int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows, int32_t D, void* stream) {
+  if (!x || !acc) return acx_fail(ctx, ACX_E_BADARG, "acx_colsum: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  if (D % 4 || D / 4 > 256 || D <= 0) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_colsum: need D%%4==0 and D<=1024%s");
+  const int rpb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, acc,
+                     rows, D, rpb);
+  ACX_CHECK_LAUNCH(ctx, "acx_colsum");
+  return ACX_OK;
+}
+
+extern "C" int acx_prompt_embed(acx_ctx* ctx, const float* prefix, const float* ctxv, const float* suffix, const float* pos,
+                                float* out, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W, int32_t shared_ctx,
+                                void* stream) {
+  if (!prefix || !ctxv || !suffix || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_prompt_embed: null pointer%s");
+  if (C <= 0) return ACX_OK;
+  if (W % 4 || n_ctx < 0 || n_ctx + 1 >= Lc) return acx_fail(ctx, ACX_E_BADARG, "acx_prompt_embed: bad geometry%s");
+  const int64_t total4 = (int64_t)C * Lc * W / 4;
+  hipLaunchKernelGGL(prompt_embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prefix,
+                     ctxv, suffix, pos, out, total4, n_ctx, Lc, W, shared_ctx);
+  ACX_CHECK_LAUNCH(ctx, "acx_prompt_embed");
+  return ACX_OK;
+}
+
+extern "C" int acx_gather_rows(acx_ctx* ctx, const float* x, const int64_t* idx, float* out, int64_t n, int32_t W,
+                               void* stream) {
+  if (!x || !idx || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_gather_rows: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  if (W % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_gather_rows: W%%4%s");
+  const int64_t total4 = n * W / 4;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, idx,
+                     out, total4, W);
+  ACX_CHECK_LAUNCH(ctx, "acx_gather_rows");
+  return ACX_OK;
+}
+
+extern "C" int acx_add_bcast(acx_ctx* ctx, const float* x, const float* p, float* out, int64_t n, int64_t LW,
+                             void* stream) {
+  if (!x || !p || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_add_bcast: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  if (LW % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_add_bcast: LW%%4%s");
+  const int64_t total4 = n * LW / 4;
+  hipLaunchKernelGGL(add_bcast_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, p, out,
+                     total4, LW / 4);
+  ACX_CHECK_LAUNCH(ctx, "acx_add_bcast");
+  return ACX_OK;
+}
+
+extern "C" int acx_concat_features(acx_ctx* ctx, const float* logits, const float* x, const float* ncentroid, float* out,
+                                   int64_t rows, int32_t C1, int32_t D, int32_t Kp, void* stream) {
+  if (!logits || !x || !ncentroid || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_concat_features: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  if (Kp < C1 + D) return acx_fail(ctx, ACX_E_BADARG, "acx_concat_features: Kp < C1 + D%s");
+  const int64_t total = rows * Kp;
+  hipLaunchKernelGGL(concat_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     logits, x, ncentroid, out, rows, C1, D, Kp);
+  ACX_CHECK_LAUNCH(ctx, "acx_concat_features");
+  return ACX_OK;
+}

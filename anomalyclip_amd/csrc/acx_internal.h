@@ -1,0 +1,83 @@
+// Internal helpers shared by the libacx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/acx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+struct acx_ctx {
+  int device;
+  char err[512];
+};
+
+// thread-local error slot for calls made with ctx == NULL
+extern thread_local char acx_tls_err[512];
+
+static inline int acx_fail(acx_ctx* ctx, int code, const char* fmt, const char* a = "", long b = 0,
+                           long c = 0) {
+  char* dst = ctx ? ctx->err : acx_tls_err;
+  snprintf(dst, 512, fmt, a, b, c);
+  return code;
+}
+
+static inline int acx_check_launch(acx_ctx* ctx, const char* name) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return ACX_OK;
+  snprintf(ctx ? ctx->err : acx_tls_err, 512, "%s: launch failed: %s", name, hipGetErrorString(e));
+  return ACX_E_HIP;
+}
+#define ACX_CHECK_LAUNCH(ctx, name)              \
+  do {                                           \
+    int rc__ = acx_check_launch(ctx, name);      \
+    if (rc__ != ACX_OK) return rc__;             \
+  } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// f32 -> bf16 round-to-nearest-even (same rounding torch uses for .to(torch.bfloat16))
+__device__ __forceinline__ u16 f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// ---- wave-per-row register layout shared by the row kernels
+// lane owns elements: VPL%4==0 -> float4 groups at 4*lane + 256*i ; else scalar at lane + 64*i
+template <int VPL>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int lane, float (&v)[VPL]) {
+  if constexpr (VPL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < VPL / 4; ++i) {
+      const float4 t = *reinterpret_cast<const float4*>(p + 4 * lane + 256 * i);
+      v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = p[lane + 64 * i];
+  }
+}
+template <int VPL>
+__device__ __forceinline__ int elem_index(int lane, int i) {
+  if constexpr (VPL % 4 == 0) return 4 * lane + 256 * (i >> 2) + (i & 3);
+  return lane + 64 * i;
+}
+

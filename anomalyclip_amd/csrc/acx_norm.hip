@@ -1,0 +1,189 @@
+// Row-wise normalisation kernels (HBM-bound): one 64-lane wavefront per row, values kept in
+// registers between the two reduction passes, 16-byte loads/stores when the row allows.
+//   acx_layernorm  : nn.LayerNorm (clip/model.py:174-180, classification_head.py:7) and the
+//                    axial_attention ChanLayerNorm variant (eps added to the std)
+//   acx_vit_embed  : CLS concat + positional embedding + ln_pre (clip/model.py:270-279)
+//   acx_cls_head   : mean of the two reversible streams + LayerNorm + Linear(E,1) + sigmoid
+//                    (classification_head.py:11-15), with the inverse test-mode tiling on store
+#include "acx_internal.h"
+
+namespace {
+
+template <int VPL>
+__device__ __forceinline__ void normalize(float (&v)[VPL], float eps, int mode) {
+  constexpr float invD = 1.f / (64 * VPL);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) s += v[i];
+  const float mean = wave_sum(s) * invD;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] -= mean;
+    q += v[i] * v[i];
+  }
+  const float var = wave_sum(q) * invD;
+  const float scale = mode == ACX_NORM_LAYER ? 1.f / sqrtf(var + eps) : 1.f / (sqrtf(var) + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) v[i] *= scale;
+}
+
+template <int VPL, int OUT_BF16>
+__device__ __forceinline__ void store_row_affine(void* y, int lane, const float (&v)[VPL],
+                                                 const float* __restrict__ w, const float* __restrict__ b) {
+  if constexpr (VPL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < VPL / 4; ++i) {
+      const int e = 4 * lane + 256 * i;
+      const float4 ww = *reinterpret_cast<const float4*>(w + e);
+      const float4 bb = *reinterpret_cast<const float4*>(b + e);
+      float4 o;
+      o.x = v[4 * i] * ww.x + bb.x; o.y = v[4 * i + 1] * ww.y + bb.y;
+      o.z = v[4 * i + 2] * ww.z + bb.z; o.w = v[4 * i + 3] * ww.w + bb.w;
+      if constexpr (OUT_BF16) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+        pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+        *reinterpret_cast<uint2*>((u16*)y + e) = pk;
+      } else {
+        *reinterpret_cast<float4*>((float*)y + e) = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int e = lane + 64 * i;
+      const float o = v[i] * w[e] + b[e];
+      if constexpr (OUT_BF16) ((u16*)y)[e] = f2bf(o); else ((float*)y)[e] = o;
+    }
+  }
+}
+
+template <int VPL, int OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        void* __restrict__ y, int64_t ldy, int64_t rows,
+                                                        float eps, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[VPL];
+  load_row<VPL>(x + row * ldx, lane, v);
+  normalize<VPL>(v, eps, mode);
+  void* yr = OUT_BF16 ? (void*)((u16*)y + row * ldy) : (void*)((float*)y + row * ldy);
+  store_row_affine<VPL, OUT_BF16>(yr, lane, v, w, b);
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void vit_embed_kernel(const float* __restrict__ patch_out,
+                                                        const float* __restrict__ cls, const float* __restrict__ pos,
+                                                        const float* __restrict__ lw, const float* __restrict__ lb,
+                                                        float* __restrict__ x, int64_t rows, int T) {
+  constexpr int W = 64 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t f = row / (T + 1);
+  const int tok = (int)(row - f * (T + 1));
+  float v[VPL], p[VPL];
+  load_row<VPL>(tok == 0 ? cls : patch_out + (f * T + tok - 1) * W, lane, v);
+  load_row<VPL>(pos + (int64_t)tok * W, lane, p);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) v[i] += p[i];
+  normalize<VPL>(v, 1e-5f, ACX_NORM_LAYER);
+  store_row_affine<VPL, 0>(x + row * W, lane, v, lw, lb);
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void cls_head_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                       const float* __restrict__ lw, const float* __restrict__ lb,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ scores, int64_t rows, int gn, int gl, int seg) {
+  constexpr int E = 64 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float a[VPL], c[VPL];
+  load_row<VPL>(x1 + row * E, lane, a);
+  load_row<VPL>(x2 + row * E, lane, c);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) a[i] = (a[i] + c[i]) * 0.5f;   // torch.stack(chunks).mean(0)
+  normalize<VPL>(a, 1e-5f, ACX_NORM_LAYER);
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int e = elem_index<VPL>(lane, i);
+    dot += (a[i] * lw[e] + lb[e]) * w[e];
+  }
+  dot = wave_sum(dot) + bias[0];
+  if (lane == 0) {
+    int64_t dst = row;
+    if (seg > 0) {  // row is ((b s) n l) -> write at ((b n s l))  (temporal_model.py:69-71)
+      const int grid_sz = gn * gl;
+      const int64_t per = (int64_t)grid_sz * seg;
+      const int64_t bb = row / per, rem = row - bb * per;
+      const int s = (int)(rem / grid_sz), rem2 = (int)(rem - (int64_t)s * grid_sz);
+      const int n = rem2 / gl, l = rem2 - n * gl;
+      dst = ((bb * gn + n) * seg + s) * gl + l;
+    }
+    scores[dst] = 1.f / (1.f + expf(-dot));
+  }
+}
+
+}  // namespace
+
+#define COMMA ,
+#define DISPATCH_VPL(D, CALL)                          \
+  switch ((D) / 64) {                                  \
+    case 1: { constexpr int V = 1; CALL; } break;      \
+    case 2: { constexpr int V = 2; CALL; } break;      \
+    case 4: { constexpr int V = 4; CALL; } break;      \
+    case 8: { constexpr int V = 8; CALL; } break;      \
+    case 12: { constexpr int V = 12; CALL; } break;    \
+    case 16: { constexpr int V = 16; CALL; } break;    \
+    default: return acx_fail(ctx, ACX_E_UNSUPPORTED, "row width %s%ld not in {64,128,256,512,768,1024}", "", (long)(D)); \
+  }
+
+extern "C" int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* b,
+                             void* y, int64_t ldy, int32_t y_dtype, int64_t rows, int32_t D, float eps,
+                             int32_t mode, void* stream) {
+  if (!x || !w || !b || !y) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  if (D % 64 || ldx % 4 || ldy % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm: D%%64 / ld%%4%s");
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dtype == ACX_BF16) {
+    DISPATCH_VPL(D, layernorm_kernel<V COMMA 1><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));
+  } else {
+    DISPATCH_VPL(D, layernorm_kernel<V COMMA 0><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_layernorm");
+  return ACX_OK;
+}
+
+extern "C" int acx_vit_embed(acx_ctx* ctx, const float* patch_out, const float* cls, const float* pos,
+                             const float* ln_w, const float* ln_b, float* x, int32_t F, int32_t T, int32_t W,
+                             void* stream) {
+  if (!patch_out || !cls || !pos || !ln_w || !ln_b || !x) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_embed: null pointer%s");
+  const int64_t rows = (int64_t)F * (T + 1);
+  if (rows <= 0) return ACX_OK;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_VPL(W, vit_embed_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(patch_out, cls, pos, ln_w, ln_b, x, rows, T));
+  ACX_CHECK_LAUNCH(ctx, "acx_vit_embed");
+  return ACX_OK;
+}
+
+extern "C" int acx_cls_head(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w, const float* ln_b,
+                            const float* lin_w, const float* lin_b, float* scores, int64_t rows, int32_t E,
+                            int32_t gn, int32_t gl, int32_t seg, void* stream) {
+  if (!x1 || !x2 || !ln_w || !ln_b || !lin_w || !lin_b || !scores) return acx_fail(ctx, ACX_E_BADARG, "acx_cls_head: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  if (seg > 0 && (gn <= 0 || gl <= 0 || rows % ((int64_t)gn * gl * seg)))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_cls_head: rows not a multiple of gn*gl*seg%s");
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_VPL(E, cls_head_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, lin_b, scores, rows, gn, gl, seg));
+  ACX_CHECK_LAUNCH(ctx, "acx_cls_head");
+  return ACX_OK;
+}

@@ -1,0 +1,217 @@
+/* acx.h -- C ABI of libacx, the MI355X (gfx950) hot-path library for AnomalyCLIP.
+ *
+ * The reference (lucazanella/AnomalyCLIP) is pure Python over stock PyTorch ops and has NO FFI of
+ * its own; this header therefore defines the boundary SURVEY.md section 8(b) recommends: plain C
+ * types, raw device pointers, caller-owned memory, one HIP stream per call.  Each entry point
+ * names the reference code it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ACX_E_* code otherwise; the text of the
+ *     last error is available from acx_last_error(ctx) (ctx may be NULL: thread-local slot).
+ *   - never aborts, never throws across the ABI; asynchronous kernel faults surface at the
+ *     caller's next synchronisation.
+ *   - ALL buffers (inputs, outputs, weights, workspace) are owned by the caller (PyTorch);
+ *     the library never allocates or frees device memory and retains no pointer after a call.
+ *   - tensors are row-major; leading dimensions are in ELEMENTS.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ */
+#ifndef ACX_H_
+#define ACX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACX_VERSION 100 /* 0.1.0 */
+
+enum {
+  ACX_OK = 0,
+  ACX_E_BADARG = -1,   /* null pointer, bad shape, misaligned leading dimension */
+  ACX_E_UNSUPPORTED = -2, /* dtype / geometry this build has no kernel for */
+  ACX_E_HIP = -3,      /* a HIP runtime call failed (text in acx_last_error) */
+  ACX_E_WORKSPACE = -4 /* workspace too small */
+};
+
+enum { ACX_F32 = 0, ACX_BF16 = 1 };                 /* storage dtypes */
+enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1 };       /* MFMA arithmetic: exact f32 (v_mfma_f32_32x32x2_f32) or bf16 in / f32 acc */
+enum { ACX_ACT_NONE = 0, ACX_ACT_QUICKGELU = 1, ACX_ACT_LEAKYRELU = 2 };
+enum { ACX_AMAP_IDENTITY = 0, ACX_AMAP_CONV3X3 = 1, ACX_AMAP_TESTTILE = 2 };
+enum { ACX_NORM_LAYER = 0, ACX_NORM_CHAN = 1 };     /* nn.LayerNorm vs axial_attention ChanLayerNorm (eps added to std) */
+
+typedef struct acx_ctx acx_ctx;
+
+int acx_version(void);
+int acx_create(acx_ctx** out, int device);
+void acx_destroy(acx_ctx* ctx);
+const char* acx_last_error(acx_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * acx_gemm: C[M,N] = epilogue( amap(A)[M,K] . W[N,K]^T )            (MFMA-bound workhorse)
+ * replaces every nn.Linear / F.linear / `@` / nn.Conv2d on the path:
+ *   clip/model.py:192,197-199 (QKV, out-proj, MLP), :246-252 (patch conv as GEMM), :287-288
+ *   (proj), text_encoder.py:23, temporal_model.py:31,43 (projection), axial_attention
+ *   SelfAttention.to_q/to_kv/to_out and the two 3x3 convs of each feed-forward (implicit GEMM),
+ *   selector_model.py:62 is a separate HBM-bound kernel (acx_selector_*).
+ * epilogue order: +bias[n] -> activation -> +pos0[(m/gl)%gn][n] -> +pos1[m%gl][n] -> +residual[m][n]
+ */
+typedef struct acx_gemm_desc {
+  const void* A;          /* [rows_of_A, lda]  f32 or bf16 */
+  const void* W;          /* [N, ldw]          f32 (PREC_F32) or bf16 (PREC_BF16) */
+  void* C;                /* [M, ldc]          f32 or bf16 */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldc;
+  int32_t a_dtype, c_dtype;
+  int32_t prec;
+  const float* bias;      /* [N] or NULL */
+  int32_t act;
+  const float* residual;  /* [M, ldr] f32 or NULL (may alias C) */
+  int32_t ldr;
+  const float* a_sub;     /* [K] subtracted from every A row before the product, or NULL
+                             (selector_model.py:54 / anomaly_clip.py:143,201 re-centring) */
+  int32_t amap;           /* ACX_AMAP_* */
+  int32_t gn, gl;         /* grid (num_segments, seg_length) for CONV3X3 / TESTTILE / pos */
+  int32_t cin;            /* CONV3X3: input channels; K == 9*cin, W laid out [N][tap=kh*3+kw][cin] */
+  int32_t seg;            /* TESTTILE: segment_size S; row ((b s) n l) reads source row ((b n s l))
+                             (temporal_model.py:46-53) */
+  const float* pos0;      /* [gn, N] axial positional embedding param_0 (or NULL) */
+  const float* pos1;      /* [gl, N] axial positional embedding param_1 (or NULL) */
+} acx_gemm_desc;
+int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * acx_layernorm: y[r,:] = norm(x[r,:]) * w + b     (HBM-bound; one wavefront per row)
+ * replaces clip/model.py:174-180 (LayerNorm), classification_head.py:7,12, axial PreNorm and
+ * ChanLayerNorm.  D must be a multiple of 64 and <= 1024... rows gathered with stride ldx. */
+int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* b,
+                  void* y, int64_t ldy, int32_t y_dtype, int64_t rows, int32_t D, float eps,
+                  int32_t mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * acx_attention: multi-head softmax(q k^T / sqrt(64)) v for head dim 64, sequence <= 224.
+ * replaces nn.MultiheadAttention's core as used by clip/model.py:206-212 (ViT: L=197, no mask;
+ * text: L=77, causal mask clip/model.py:386-392).  qkv: [batch*L, 3*heads*64] packed as
+ * in_proj output (q | k | v); out: [batch*L, heads*64]. */
+int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                  int32_t batch, int32_t L, int32_t heads, int32_t causal, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * acx_vit_patches: im2col of 16x16/16 patches (clip/model.py:246-252,267-269).
+ * frames [F,3,R,R] f32 -> patches [F*g*g, 3*P*P] (k = c*P*P + ky*P + kx, token = gy*g+gx). */
+int acx_vit_patches(acx_ctx* ctx, const float* frames, void* patches, int32_t out_dtype,
+                    int32_t F, int32_t R, int32_t P, void* stream);
+/* acx_vit_embed: x[f,0,:] = cls + pos[0]; x[f,1+t,:] = patch_out[f,t,:] + pos[1+t]; then ln_pre
+ * (clip/model.py:270-279).  patch_out [F*T, W] f32 -> x [F*(T+1), W] f32. */
+int acx_vit_embed(acx_ctx* ctx, const float* patch_out, const float* cls, const float* pos,
+                  const float* ln_w, const float* ln_b, float* x, int32_t F, int32_t T, int32_t W,
+                  void* stream);
+
+/* Transformer block weights (clip/model.py:188-217).  All f32 masters; the *_bf16 pointers are
+ * the bf16 copies used when prec == ACX_PREC_BF16 (may be NULL otherwise). */
+typedef struct acx_block_weights {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  const float *in_proj_w, *in_proj_b;     /* [3W, W], [3W] */
+  const float *out_proj_w, *out_proj_b;   /* [W, W], [W] */
+  const float *fc_w, *fc_b;               /* [4W, W], [4W] */
+  const float *proj_w, *proj_b;           /* [W, 4W], [W] */
+  const void *in_proj_w_bf16, *out_proj_w_bf16, *fc_w_bf16, *proj_w_bf16;
+} acx_block_weights;
+
+typedef struct acx_vit_weights {
+  const float* conv1_w;       /* [W, 3*P*P]  (conv1.weight viewed 2-D) */
+  const void* conv1_w_bf16;
+  const float* class_embedding;  /* [W] */
+  const float* positional_embedding; /* [T+1, W] */
+  const float *ln_pre_w, *ln_pre_b, *ln_post_w, *ln_post_b;
+  const float* proj_t;        /* [E, W] = proj^T (proj is [W,E] in the reference, clip/model.py:264) */
+  const void* proj_t_bf16;
+  const acx_block_weights* blocks; /* [layers] (host array) */
+} acx_vit_weights;
+
+typedef struct acx_vit_desc {
+  int32_t resolution, patch, width, layers, heads, embed_dim;
+  int32_t prec;               /* ACX_PREC_* */
+} acx_vit_desc;
+
+/* acx_vit_encode: VisionTransformer.forward (clip/model.py:266-290): frames [F,3,R,R] f32 ->
+ * features [F, embed_dim] f32.  Workspace from acx_vit_workspace_bytes(desc, F). */
+size_t acx_vit_workspace_bytes(const acx_vit_desc* d, int32_t frames);
+int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit_weights* w,
+                   const float* frames, int32_t nframes, float* features, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* acx_transformer_forward: Transformer.forward (clip/model.py:220-230) in place on x
+ * [batch*L, W] f32 -- used by the text encoder (text_encoder.py:16-18). */
+size_t acx_transformer_workspace_bytes(int32_t width, int32_t rows);
+int acx_transformer_forward(acx_ctx* ctx, float* x, int32_t batch, int32_t L, int32_t width,
+                            int32_t heads, int32_t layers, int32_t causal, int32_t prec,
+                            const acx_block_weights* blocks, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head, forward (HBM-bound rows of SURVEY.md 8a). */
+
+/* acx_text_directions: selector_model.py:44-59: drop row normal_id, subtract ncentroid,
+ * L2-normalise.  text [C, D] -> dirs [C-1, D]. */
+int acx_text_directions(acx_ctx* ctx, const float* text, const float* ncentroid, float* dirs,
+                        int32_t C, int32_t D, int32_t normal_id, void* stream);
+/* acx_selector_project: raw[r, c] = (x[r,:] - ncentroid) . dirs[c,:]  (selector_model.py:54,62).
+ * x [rows, D] (D in {64,128,256,512,768,1024}), raw [rows, C1], C1 <= 64. */
+int acx_selector_project(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs,
+                         float* raw, int64_t rows, int32_t D, int32_t C1, void* stream);
+/* acx_bn_stats: deterministic per-column batch statistics of raw[rows, C1] (training BatchNorm1d:
+ * biased variance normalises, unbiased variance feeds running_var). */
+int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_t C1, float* mean,
+                 float* var_biased, float* var_unbiased, void* stream);
+/* acx_selector_bn: logits = (raw - mean) / sqrt(var + eps)  (BatchNorm1d(C-1, affine=False),
+ * selector_model.py:30,65).  mean/var [C1] (running stats in eval, batch stats in train). */
+int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean, const float* var,
+                    float* logits, int64_t ldl, int64_t rows, int32_t C1, float eps, void* stream);
+
+/* acx_axial_attention: the softmax(q k^T e^-1/2) v core of axial_attention.SelfAttention along one
+ * axis of the (tiles, gn, gl) token grid.  qkv [rows, 3*heads*e] = (q | k | v) per token, out
+ * [rows, heads*e].  axis 0: attend along gn (tokens with equal (tile, l)); axis 1: along gl. */
+int acx_axial_attention(acx_ctx* ctx, const float* qkv, float* out, int32_t tiles, int32_t gn,
+                        int32_t gl, int32_t heads, int32_t e, int32_t axis, void* stream);
+
+/* acx_cls_head: score = sigmoid(LayerNorm((x1+x2)/2) . w + b) (ReversibleSequence mean +
+ * classification_head.py:11-15); out_index maps row ((b s) n l) back to ((b n s l)) when seg > 0
+ * (temporal_model.py:69-71). */
+int acx_cls_head(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w,
+                 const float* ln_b, const float* lin_w, const float* lin_b, float* scores,
+                 int64_t rows, int32_t E, int32_t gn, int32_t gl, int32_t seg, void* stream);
+
+/* acx_class_probs: softmax(similarity, dim=1) * score  (anomaly_clip_module.py:474-477). */
+int acx_class_probs(acx_ctx* ctx, const float* sim, const float* scores, float* probs,
+                    int64_t rows, int32_t C1, void* stream);
+
+/* acx_prompt_embed: out[c,t,:] = cat(token_prefix, ctx, token_suffix)[c,t,:] + positional_embedding[t,:]
+ * (coop.py:74-90 class_token_position "end" + text_encoder.py:15).  ctx is [C,n_ctx,W] or, when
+ * shared_ctx != 0, [n_ctx,W] broadcast over classes (coop.py:76-77).  pos may be NULL (no add). */
+int acx_prompt_embed(acx_ctx* ctx, const float* prefix, const float* ctxv, const float* suffix,
+                     const float* pos, float* out, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
+                     int32_t shared_ctx, void* stream);
+/* acx_gather_rows: out[i,:] = x[idx[i],:]  (EOT-token gather, text_encoder.py:23). idx int64 on device. */
+int acx_gather_rows(acx_ctx* ctx, const float* x, const int64_t* idx, float* out, int64_t n,
+                    int32_t W, void* stream);
+
+/* acx_add_bcast: out[r,:] = x[r,:] + p[:] over n rows of LW floats (text_encoder.py:15 when the
+ * prompts were assembled without the positional embedding). */
+int acx_add_bcast(acx_ctx* ctx, const float* x, const float* p, float* out, int64_t n, int64_t LW,
+                  void* stream);
+/* acx_concat_features: temporal-model input when concat_features is on: [logits | x - ncentroid | 0]
+ * padded to Kp columns (anomaly_clip.py:143,201,223-233). */
+int acx_concat_features(acx_ctx* ctx, const float* logits, const float* x, const float* ncentroid,
+                        float* out, int64_t rows, int32_t C1, int32_t D, int32_t Kp, void* stream);
+
+/* utility: f32 -> bf16 (round-to-nearest-even) copy, used to prepare bf16 weight copies. */
+int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* stream);
+/* utility: column sums of x[rows, D] accumulated into acc[D] (ncentroid, anomaly_clip_module.py:145-171). */
+int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows, int32_t D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACX_H_ */

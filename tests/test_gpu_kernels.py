@@ -1,0 +1,200 @@
+"""-m gpu: every libacx kernel against the oracle / a plain fp32 torch CPU reference of the same op.
+All calls go through the C ABI (ctypes).  Tolerances are written per test: the PREC_F32 path is an
+exact-f32 fma chain (only summation order differs from the CPU), so 1e-5-class tolerances hold;
+the bf16 path is checked at bf16 round-off."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from anomalyclip_amd import _lib as L
+from anomalyclip_amd import ops
+from oracle import anomalyclip_oracle as O
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (197 * 3, 2304, 768), (130, 70, 36), (1, 5, 4), (512, 256, 512)])
+def test_gemm_f32_plain(M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    # asymmetric weights: a transposed C-write cannot pass (guide rule 16)
+    w = torch.randn(N, K, generator=g) + torch.arange(N).view(-1, 1) * 0.01
+    bias = torch.randn(N, generator=g)
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV))
+    ref = a.double() @ w.double().t() + bias.double()
+    assert relerr(out, ref) < 2e-6
+
+
+def test_gemm_epilogues_and_asub():
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 200, 96
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, res, sub = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(K, generator=g)
+    base = (a - sub) @ w.t() + bias
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=L.ACT_QUICKGELU, residual=res.to(DEV), a_sub=sub.to(DEV))
+    assert relerr(out, O.quick_gelu(base) + res) < 1e-5
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=L.ACT_LEAKYRELU, a_sub=sub.to(DEV))
+    assert relerr(out, torch.nn.functional.leaky_relu(base, 0.01)) < 1e-5
+    # in-place residual (C aliases residual), as the transformer driver uses it
+    x = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), residual=x, out=x)
+    assert relerr(x, a @ w.t() + bias + res) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,tiles", [(64, 256, 2), (256, 64, 1)])
+def test_gemm_conv3x3(cin, cout, tiles):
+    g = torch.Generator().manual_seed(cin)
+    N, Lg = 32, 16
+    x = torch.randn(tiles, N, Lg, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    wk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = ops.gemm(x.reshape(-1, cin).to(DEV), wk.to(DEV), bias=b.to(DEV), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=cin)
+    assert relerr(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("S", [1, 2, 3])
+def test_gemm_testtile_and_pos(S):
+    g = torch.Generator().manual_seed(S)
+    N, Lg, K, E, b = 32, 16, 64, 64, 2
+    rows = b * N * S * Lg
+    a, w = torch.randn(rows, K, generator=g), torch.randn(E, K, generator=g) * 0.2
+    p0, p1 = torch.randn(N, E, generator=g), torch.randn(Lg, E, generator=g)
+    src = O.test_tile_index(rows, N, Lg, S)
+    ref = (a[src] @ w.t()).view(-1, N, Lg, E) + p0.view(1, N, 1, E) + p1.view(1, 1, Lg, E)
+    out = ops.gemm(a.to(DEV), w.to(DEV), amap=L.AMAP_TESTTILE, gn=N, gl=Lg, seg=S, pos0=p0.to(DEV), pos1=p1.to(DEV))
+    assert relerr(out, ref.reshape(-1, E)) < 1e-5
+
+
+def test_gemm_bf16():
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 394, 768, 768
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    ab, wb = a.bfloat16().float(), w.bfloat16().float()
+    ref = ab.double() @ wb.double().t() + bias.double()
+    wd = ops.cast_bf16(w.to(DEV))
+    assert torch.equal(wd.cpu(), w.bfloat16())           # RNE cast is bit-exact with torch
+    out = ops.gemm(a.to(DEV), wd, bias=bias.to(DEV), prec=L.PREC_BF16)            # f32 A converted in the loader
+    assert relerr(out, ref) < 1e-5
+    out = ops.gemm(ops.cast_bf16(a.to(DEV)), wd, bias=bias.to(DEV), prec=L.PREC_BF16, out_dtype=torch.bfloat16)
+    assert relerr(out.float(), ref) < 1e-2
+
+
+def test_gemm_errors():
+    a, w = torch.randn(8, 6, device=DEV), torch.randn(4, 6, device=DEV)
+    with pytest.raises(L.AcxError):
+        ops.gemm(a, w)                                   # K % 4 != 0
+    with pytest.raises(L.AcxError):
+        ops.gemm(torch.randn(8, 8), torch.randn(4, 8))   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("D", [64, 128, 256, 512, 768, 1024])
+@pytest.mark.parametrize("mode", [L.NORM_LAYER, L.NORM_CHAN])
+def test_layernorm(D, mode):
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(37, D, generator=g) * 2 + 0.5
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = O.layer_norm(x, w, b) if mode == L.NORM_LAYER else O.chan_layer_norm_last(x, w, b)
+    out = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), mode=mode)
+    assert relerr(out, ref) < 2e-6
+    outb = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), mode=mode, out_dtype=torch.bfloat16)
+    assert relerr(outb.float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("L_,heads,batch,causal", [(197, 12, 2, False), (77, 8, 3, True), (5, 2, 3, False), (224, 1, 1, False), (33, 2, 1, True)])
+def test_attention(L_, heads, batch, causal):
+    g = torch.Generator().manual_seed(L_)
+    W = heads * 64
+    qkv = torch.randn(batch * L_, 3 * W, generator=g)
+    q, k, v = qkv.view(batch, L_, 3, heads, 64).permute(2, 0, 3, 1, 4).double()
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L_, L_), float("-inf"), dtype=torch.float64).triu_(1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(batch * L_, W)
+    out = ops.attention(qkv.to(DEV), batch, L_, heads, causal)
+    assert relerr(out, ref) < 3e-6
+
+
+def test_attention_spiked_scores():
+    """one key dominating one query row (guide rule 26: force the extreme softmax case)."""
+    L_, heads = 197, 1
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(L_, 192, generator=g)
+    qkv[7, :64] *= 30.0
+    qkv[100, 64:128] = qkv[7, :64] / 30.0 * 3
+    q, k, v = qkv.view(1, L_, 3, 1, 64).permute(2, 0, 3, 1, 4).double()
+    ref = (torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(L_, 64)
+    out = ops.attention(qkv.to(DEV), 1, L_, heads, False)
+    assert relerr(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("T_axis,e,heads", [(0, 32, 8), (1, 32, 8), (0, 16, 8), (1, 16, 8), (0, 32, 2), (1, 32, 2)])
+def test_axial_attention(T_axis, e, heads):
+    g = torch.Generator().manual_seed(e + heads)
+    tiles, N, Lg = 3, 32, 16
+    He = heads * e
+    qkv = torch.randn(tiles * N * Lg, 3 * He, generator=g)
+    q, k, v = qkv.view(tiles, N, Lg, 3, heads, e).permute(3, 0, 1, 2, 4, 5).double()
+    if T_axis == 0:
+        q, k, v = (z.transpose(1, 2) for z in (q, k, v))        # (tiles, Lg, N, H, e)
+    q, k, v = (z.transpose(2, 3) for z in (q, k, v))            # (tiles, A, H, S, e)
+    o = torch.softmax(q @ k.transpose(-1, -2) * e ** -0.5, -1) @ v
+    o = o.transpose(2, 3)
+    if T_axis == 0:
+        o = o.transpose(1, 2)
+    ref = o.reshape(tiles * N * Lg, He)
+    out = ops.axial_attention(qkv.to(DEV), tiles, N, Lg, heads, e, T_axis)
+    assert relerr(out, ref) < 3e-6
+
+
+def test_selector_kernels():
+    g = torch.Generator().manual_seed(3)
+    for D, C in ((512, 14), (128, 18), (64, 7)):
+        rows, normal_id = 777, 4
+        x = torch.randn(rows, D, generator=g) * 0.3 + 0.1
+        tf = torch.randn(C, D, generator=g)
+        nc = torch.randn(D, generator=g) * 0.1
+        rm, rv = torch.randn(C - 1, generator=g) * 0.1, torch.rand(C - 1, generator=g) + 0.1
+        dirs = ops.text_directions(tf.to(DEV), nc.to(DEV), normal_id)
+        assert relerr(dirs, O.selector_directions(tf, nc, normal_id)) < 2e-6
+        raw = ops.selector_project(x.to(DEV), nc.to(DEV), dirs)
+        ref_raw = (x - nc).double() @ O.selector_directions(tf, nc, normal_id).double().t()
+        assert relerr(raw, ref_raw) < 3e-6
+        ev, _, _ = O.selector_logits(x, tf, nc, normal_id, rm, rv, training=False)
+        out = ops.selector_bn(raw, rm.to(DEV), rv.to(DEV))
+        assert relerr(out, ev) < 1e-5
+        m, vb, vu = ops.bn_stats(raw)
+        assert relerr(m, ref_raw.mean(0)) < 1e-5 and relerr(vb, ref_raw.var(0, unbiased=False)) < 1e-5
+        assert relerr(vu, ref_raw.var(0, unbiased=True)) < 1e-5
+
+
+def test_cls_head_class_probs_misc():
+    g = torch.Generator().manual_seed(4)
+    E, N, Lg, S = 256, 32, 16, 2
+    rows = N * Lg * S
+    x1, x2 = torch.randn(rows, E, generator=g), torch.randn(rows, E, generator=g)
+    lw, lb = torch.randn(E, generator=g), torch.randn(E, generator=g)
+    w, b = torch.randn(1, E, generator=g) * 0.1, torch.randn(1, generator=g)
+    ref = torch.sigmoid(O.layer_norm((x1 + x2) / 2, lw, lb) @ w.t() + b).view(-1)
+    out = ops.cls_head(x1.to(DEV), x2.to(DEV), lw.to(DEV), lb.to(DEV), w.to(DEV), b.to(DEV), N, Lg, 0)
+    assert relerr(out, ref) < 1e-5
+    src = O.test_tile_index(rows, N, Lg, S)
+    out = ops.cls_head(x1.to(DEV), x2.to(DEV), lw.to(DEV), lb.to(DEV), w.to(DEV), b.to(DEV), N, Lg, S)
+    exp = torch.empty(rows)
+    exp[src] = ref
+    assert relerr(out, exp) < 1e-5
+    sim, sc = torch.randn(rows, 13, generator=g), torch.rand(rows, generator=g)
+    cp, _ = O.eval_postprocess(sim, sc, rows)
+    assert relerr(ops.class_probs(sim.to(DEV), sc.to(DEV)), cp) < 1e-5
+    acc = torch.zeros(E, device=DEV)
+    ops.colsum_(acc, x1.to(DEV))
+    assert relerr(acc, x1.double().sum(0)) < 1e-5
