@@ -84,6 +84,8 @@ _SIGS = {
     "acx_gather_rows": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_add_bcast": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "acx_concat_features": (C.c_int, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_prof_enable": (C.c_int, [c_void_p, C.c_int]),
+    "acx_prof_collect": (C.c_int, [c_void_p, C.POINTER(c_int32), C.POINTER(C.c_double)]),
     "acx_cast_bf16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_colsum": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
 }
@@ -109,8 +111,10 @@ def lib() -> C.CDLL:
     global _lib
     with _lock:
         if _lib is None:
-            path = _build.LIB
-            if not os.path.exists(path) or (_build._stale() and os.path.exists(_build.HIPCC)):
+            path = os.environ.get("ACX_LIB_PATH") or _build.LIB
+            if os.environ.get("ACX_LIB_PATH"):
+                pass
+            elif not os.path.exists(path) or (_build._stale() and os.path.exists(_build.HIPCC)):
                 path = _build.build(verbose=False)
             try:
                 L = C.CDLL(path)

@@ -32,11 +32,46 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   if (!c) return acx_fail(nullptr, ACX_E_HIP, "acx_create: out of host memory%s");
   c->device = device;
   c->err[0] = 0;
+  c->prof_on = false;
+  c->prof_n = c->prof_created = 0;
+  c->prof_ev = new (std::nothrow) hipEvent_t[2 * ACX_PROF_MAX];
+  c->prof_kind = new (std::nothrow) unsigned char[ACX_PROF_MAX];
   *out = c;
   return ACX_OK;
 }
 
-extern "C" void acx_destroy(acx_ctx* ctx) { delete ctx; }
+extern "C" void acx_destroy(acx_ctx* ctx) {
+  if (!ctx) return;
+  for (int i = 0; i < 2 * ctx->prof_created; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+  delete[] ctx->prof_ev;
+  delete[] ctx->prof_kind;
+  delete ctx;
+}
+
+extern "C" int acx_prof_enable(acx_ctx* ctx, int on) {
+  if (!ctx || !ctx->prof_ev || !ctx->prof_kind) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_enable: no context%s");
+  ctx->prof_on = on != 0;
+  if (on) ctx->prof_n = 0;
+  return ACX_OK;
+}
+
+extern "C" int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms) {
+  if (!ctx || !counts || !total_ms) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_collect: null pointer%s");
+  for (int k = 0; k < ACX_K_COUNT; ++k) { counts[k] = 0; total_ms[k] = 0.0; }
+  for (int i = 0; i < ctx->prof_n; ++i) {
+    hipError_t e = hipEventSynchronize(ctx->prof_ev[2 * i + 1]);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]);
+    if (e != hipSuccess) {
+      snprintf(ctx->err, 512, "acx_prof_collect: %s", hipGetErrorString(e));
+      return ACX_E_HIP;
+    }
+    counts[ctx->prof_kind[i]]++;
+    total_ms[ctx->prof_kind[i]] += ms;
+  }
+  ctx->prof_n = 0;
+  return ACX_OK;
+}
 
 extern "C" const char* acx_last_error(acx_ctx* ctx) { return ctx ? ctx->err : acx_tls_err; }
 

@@ -156,6 +156,7 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   const int nt = (L + 31) / 32;
   const dim3 grid((unsigned)(batch * heads)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_ATTN, (hipStream_t)stream);
 #define ACX_ATTN(NT)                                                                               \
   do {                                                                                             \
     const size_t lds = (size_t)NT * 32 * (KROW + VROW) * 4 + 4 * 32 * 4;                           \

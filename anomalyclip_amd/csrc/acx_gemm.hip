@@ -26,6 +26,10 @@
 //     contiguous run of tiles (n fastest) so the A tile of a row of tiles stays in that XCD's L2.
 #include "acx_internal.h"
 
+#ifndef ACX_STORE_SCHED
+#define ACX_STORE_SCHED 2
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -50,12 +54,17 @@ __device__ __forceinline__ uint4 pack_bf16x8(float4 a, float4 b) {
 }
 
 // PREC: 0 f32 MFMA, 1 bf16 MFMA.  A_BF16: A stored as bf16 in global (PREC 1 only).
-template <int PREC, int A_BF16, int C_BF16>
+// FAST: identity row map, no a_sub / positional epilogue, K % KE == 0 -> branch-free staging
+//       (out-of-range rows are CLAMPED to a valid row and masked at the store) and a compile-time
+//       epilogue (ACT activation, RES residual).  FAST == 0 is the generic runtime-flag path.
+template <int PREC, int A_BF16, int C_BF16, int FAST, int ACT, int RES>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const acx_gemm_desc& d = g.d;
   constexpr int KE = PREC == 0 ? 32 : 64;     // K elements per step
   constexpr int CE = PREC == 0 ? 4 : 8;       // elements per 16-B LDS chunk
+  constexpr int NLA = (PREC == 1 && !A_BF16) ? 2 : 1;   // 16-B global loads per staged A chunk
+  constexpr int WB = PREC == 0 ? 4 : 2;       // bytes per W element
 
   // ---- XCD-aware tile assignment (bijective remap, guide T1)
   const int nwg = gridDim.x;
@@ -69,100 +78,136 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int chunk = t & 7, rbase = t >> 3;
 
   // ---- per-thread source rows for the 4 staged A rows and 4 staged W rows
-  const int grid_sz = d.gn * d.gl;
-  long a_row[4];        // identity/testtile: source row (or -1); conv: base row of the tile
+  const int grid_sz = FAST ? 1 : d.gn * d.gl;
+  long a_row[4];        // identity/testtile: source row (clamped); conv: base row of the tile
   int a_n[4], a_l[4];   // conv: grid coordinates
-  bool a_ok[4];
+  bool a_ok[4], w_ok[4];
   const char* w_ptr[4];
-  bool w_ok[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int m = m0 + rbase + 32 * r;
+    int m = m0 + rbase + 32 * r;
     a_ok[r] = m < d.M;
+    m = a_ok[r] ? m : d.M - 1;
     a_row[r] = m;
     a_n[r] = a_l[r] = 0;
-    if (d.amap == ACX_AMAP_TESTTILE) {
-      const int per = grid_sz * d.seg;
-      const int b = m / per, rem = m - b * per;
-      const int s = rem / grid_sz, rem2 = rem - s * grid_sz;
-      const int n = rem2 / d.gl, l = rem2 - n * d.gl;
-      a_row[r] = (((long)b * d.gn + n) * d.seg + s) * d.gl + l;
-    } else if (d.amap == ACX_AMAP_CONV3X3) {
-      const int tile = m / grid_sz, rem = m - tile * grid_sz;
-      a_n[r] = rem / d.gl;
-      a_l[r] = rem - a_n[r] * d.gl;
-      a_row[r] = (long)tile * grid_sz;
+    if constexpr (!FAST) {
+      if (d.amap == ACX_AMAP_TESTTILE) {
+        const int per = grid_sz * d.seg;
+        const int b = m / per, rem = m - b * per;
+        const int sg = rem / grid_sz, rem2 = rem - sg * grid_sz;
+        const int n = rem2 / d.gl, l = rem2 - n * d.gl;
+        a_row[r] = (((long)b * d.gn + n) * d.seg + sg) * d.gl + l;
+      } else if (d.amap == ACX_AMAP_CONV3X3) {
+        const int tile = m / grid_sz, rem = m - tile * grid_sz;
+        a_n[r] = rem / d.gl;
+        a_l[r] = rem - a_n[r] * d.gl;
+        a_row[r] = (long)tile * grid_sz;
+      }
     }
-    const int n = n0 + rbase + 32 * r;
+    int n = n0 + rbase + 32 * r;
     w_ok[r] = n < d.N;
-    w_ptr[r] = (const char*)d.W + (size_t)(w_ok[r] ? n : 0) * d.ldw * (PREC == 0 ? 4 : 2);
+    n = w_ok[r] ? n : d.N - 1;
+    w_ptr[r] = (const char*)d.W + ((size_t)n * d.ldw + chunk * CE) * WB;
   }
 
-  // ---- staging registers
-  float4 ra[4][PREC == 1 && !A_BF16 ? 2 : 1];
-  uint4 rw[4];
+  // ---- staging registers: NAMED variables, not arrays (an array here is demoted to scratch memory by
+  // hipcc's alloca handling as soon as anything indexes it from a lambda -- guide rule 20)
+  float4 ra0, ra1, ra2, ra3;      // A chunk (f32: 4 floats; bf16-in-global: 8 bf16 bit-cast)
+  float4 rb0, rb1, rb2, rb3;      // second half of the A chunk when f32 A is converted to bf16 (NLA == 2)
+  uint4 rw0, rw1, rw2, rw3;       // W chunk
+  rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load_tiles = [&](int k0) {
-    // A operand
-    int kcol = k0 + chunk * CE;     // first K element of this thread's chunk
-    int dn = 0, dl = 0, kc = kcol;
-    if (d.amap == ACX_AMAP_CONV3X3) {
-      const int tap = k0 / d.cin;   // uniform over the block (cin % KE == 0)
-      dn = tap / 3 - 1;
-      dl = tap - (tap / 3) * 3 - 1;
-      kc = kcol - tap * d.cin;
-    }
-    const bool kin = kcol < d.K;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bool ok = a_ok[r] && kin;
-      long srow = a_row[r];
-      if (d.amap == ACX_AMAP_CONV3X3) {
-        const int nn = a_n[r] + dn, ll = a_l[r] + dl;
-        ok = ok && nn >= 0 && nn < d.gn && ll >= 0 && ll < d.gl;
-        srow += (long)nn * d.gl + ll;
-      }
-      if constexpr (A_BF16) {
-        const u16* p = (const u16*)d.A + (size_t)srow * d.lda + kc;
-        uint4 v = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
-        ra[r][0] = *reinterpret_cast<float4*>(&v);
-      } else {
-        const float* p = (const float*)d.A + (size_t)srow * d.lda + kc;
-        constexpr int NL = PREC == 1 ? 2 : 1;
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
-          float4 v = ok ? ld4(p + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-          if (d.a_sub && ok) {
-            const float4 s = ld4(d.a_sub + kc + 4 * u);
-            v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w;
-          }
-          ra[r][u] = v;
-        }
-      }
-    }
-    // W operand
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = w_ok[r] && kin;
-      const char* p = w_ptr[r] + (size_t)kcol * (PREC == 0 ? 4 : 2);
-      rw[r] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
-    }
-  };
+  // FAST-path staging loads as a macro (straight-line code keeps `ra`/`rw` in VGPRs; the lambda form
+  // made the register allocator demote them to scratch)
+#define ACX_FAST_LOAD_ROW(r, k0)                                                                   \
+  do {                                                                                             \
+    const int kcol_ = (k0) + chunk * CE;                                                           \
+    if constexpr (A_BF16) {                                                                        \
+      const uint4 v_ = *reinterpret_cast<const uint4*>((const u16*)d.A + (size_t)a_row[r] * d.lda + kcol_); \
+      ra##r = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
+    } else {                                                                                       \
+      const float* p_ = (const float*)d.A + (size_t)a_row[r] * d.lda + kcol_;                      \
+      ra##r = ld4(p_);                                                                             \
+      if constexpr (NLA == 2) rb##r = ld4(p_ + 4);                                                 \
+    }                                                                                              \
+    rw##r = *reinterpret_cast<const uint4*>(w_ptr[r] + (size_t)(k0) * WB);                         \
+  } while (0)
+#define ACX_FAST_LOAD(k0) \
+  do { ACX_FAST_LOAD_ROW(0, k0); ACX_FAST_LOAD_ROW(1, k0); ACX_FAST_LOAD_ROW(2, k0); ACX_FAST_LOAD_ROW(3, k0); } while (0)
 
-  auto store_tiles = [&](int stage) {
-    char* sA = smem + stage * 2 * TILE_B;
-    char* sW = sA + TILE_B;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int off = (rbase + 32 * r) * ROWB + chunk * 16;
-      if constexpr (PREC == 1 && !A_BF16) {
-        *reinterpret_cast<uint4*>(sA + off) = pack_bf16x8(ra[r][0], ra[r][1]);
-      } else {
-        *reinterpret_cast<float4*>(sA + off) = ra[r][0];
-      }
-      *reinterpret_cast<uint4*>(sW + off) = rw[r];
-    }
-  };
+  // generic-path staging (runtime row map / a_sub / bounds): per-step uniforms then one macro per row
+  int g_dn = 0, g_dl = 0, g_kc = 0, g_kw = 0;
+  bool g_kin = true;
+  float4 g_sub0 = make_float4(0.f, 0.f, 0.f, 0.f), g_sub1 = g_sub0;
+#define ACX_GEN_SETUP(k0)                                                                          \
+  do {                                                                                             \
+    int kcol_ = (k0) + chunk * CE;                                                                 \
+    g_dn = g_dl = 0;                                                                               \
+    g_kc = kcol_;                                                                                  \
+    if (d.amap == ACX_AMAP_CONV3X3) {                                                              \
+      const int tap_ = (k0) / d.cin; /* uniform over the block (cin % KE == 0) */                  \
+      g_dn = tap_ / 3 - 1;                                                                         \
+      g_dl = tap_ - (tap_ / 3) * 3 - 1;                                                            \
+      g_kc = kcol_ - tap_ * d.cin;                                                                 \
+    }                                                                                              \
+    g_kin = kcol_ < d.K;                                                                           \
+    if (!g_kin) { g_kc = 0; kcol_ = chunk * CE; } /* clamp: loaded, then zeroed by the select */   \
+    g_kw = kcol_ - chunk * CE;                                                                     \
+    g_sub0 = g_sub1 = make_float4(0.f, 0.f, 0.f, 0.f);                                             \
+    if (d.a_sub) { /* depends on k only: one load per step, not per row */                         \
+      g_sub0 = ld4(d.a_sub + g_kc);                                                                \
+      if constexpr (NLA == 2) g_sub1 = ld4(d.a_sub + g_kc + 4);                                    \
+    }                                                                                              \
+  } while (0)
+#define ACX_GEN_LOAD_ROW(r)                                                                        \
+  do {                                                                                             \
+    bool ok_ = a_ok[r] && g_kin;                                                                   \
+    long srow_ = a_row[r];                                                                         \
+    if (d.amap == ACX_AMAP_CONV3X3) {                                                              \
+      int nn_ = a_n[r] + g_dn, ll_ = a_l[r] + g_dl;                                                \
+      ok_ = ok_ && nn_ >= 0 && nn_ < d.gn && ll_ >= 0 && ll_ < d.gl;                               \
+      nn_ = min(max(nn_, 0), d.gn - 1);                                                            \
+      ll_ = min(max(ll_, 0), d.gl - 1);                                                            \
+      srow_ += (long)nn_ * d.gl + ll_;                                                             \
+    }                                                                                              \
+    if constexpr (A_BF16) {                                                                        \
+      uint4 v_ = *reinterpret_cast<const uint4*>((const u16*)d.A + (size_t)srow_ * d.lda + g_kc);  \
+      if (!ok_) v_ = make_uint4(0, 0, 0, 0);                                                       \
+      ra##r = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
+    } else {                                                                                       \
+      const float* p_ = (const float*)d.A + (size_t)srow_ * d.lda + g_kc;                          \
+      float4 v_ = ld4(p_);                                                                         \
+      v_.x -= g_sub0.x; v_.y -= g_sub0.y; v_.z -= g_sub0.z; v_.w -= g_sub0.w;                      \
+      if (!ok_) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
+      ra##r = v_;                                                                                  \
+      if constexpr (NLA == 2) {                                                                    \
+        float4 u_ = ld4(p_ + 4);                                                                   \
+        u_.x -= g_sub1.x; u_.y -= g_sub1.y; u_.z -= g_sub1.z; u_.w -= g_sub1.w;                    \
+        if (!ok_) u_ = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
+        rb##r = u_;                                                                                \
+      }                                                                                            \
+    }                                                                                              \
+    uint4 w_ = *reinterpret_cast<const uint4*>(w_ptr[r] + (size_t)g_kw * WB);                     \
+    if (!(w_ok[r] && g_kin)) w_ = make_uint4(0, 0, 0, 0);                                          \
+    rw##r = w_;                                                                                    \
+  } while (0)
+#define ACX_GEN_LOAD(k0) \
+  do { ACX_GEN_SETUP(k0); ACX_GEN_LOAD_ROW(0); ACX_GEN_LOAD_ROW(1); ACX_GEN_LOAD_ROW(2); ACX_GEN_LOAD_ROW(3); } while (0)
+
+  // (macro, not a lambda: the row index must stay a compile-time constant or `ra`/`rw` are demoted
+  //  to scratch memory -- guide rule 20)
+#define ACX_STORE_ROW(stage, r)                                                        \
+  do {                                                                                 \
+    char* sA_ = smem + (stage) * 2 * TILE_B;                                           \
+    char* sW_ = sA_ + TILE_B;                                                          \
+    const int off_ = (rbase + 32 * (r)) * ROWB + chunk * 16;                           \
+    if constexpr (NLA == 2) {                                                          \
+      *reinterpret_cast<uint4*>(sA_ + off_) = pack_bf16x8(ra##r, rb##r);               \
+    } else {                                                                           \
+      *reinterpret_cast<float4*>(sA_ + off_) = ra##r;                                  \
+    }                                                                                  \
+    *reinterpret_cast<uint4*>(sW_ + off_) = rw##r;                                     \
+  } while (0)
 
   // ---- accumulators
   f32x16 acc[2][2];
@@ -180,12 +225,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int w_off = (wn * 64 + li) * ROWB + hh * 16;
 
   const int nk = (d.K + KE - 1) / KE;
-  load_tiles(0);
-  store_tiles(0);
+  if constexpr (FAST) ACX_FAST_LOAD(0); else ACX_GEN_LOAD(0);
+  ACX_STORE_ROW(0, 0); ACX_STORE_ROW(0, 1); ACX_STORE_ROW(0, 2); ACX_STORE_ROW(0, 3);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * KE);
+    const bool more = kt + 1 < nk;
+    if (more) { if constexpr (FAST) ACX_FAST_LOAD((kt + 1) * KE); else ACX_GEN_LOAD((kt + 1) * KE); }
     const char* sA = smem + cur * 2 * TILE_B;
     const char* sW = sA + TILE_B;
 #pragma unroll
@@ -219,39 +265,102 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
       }
+      // stage the next K-step into the other LDS buffer in the shadow of this phase's MFMAs:
+      // one quarter of the rows after each of the 4 phases (the loads were issued a phase or
+      // more ago; the write costs issue slots while the matrix pipe is busy, not pipe time)
+#if ACX_STORE_SCHED == 1
+      if (more) {
+        if (q == 0) ACX_STORE_ROW(cur ^ 1, 0);
+        if (q == 1) ACX_STORE_ROW(cur ^ 1, 1);
+        if (q == 2) ACX_STORE_ROW(cur ^ 1, 2);
+        if (q == 3) ACX_STORE_ROW(cur ^ 1, 3);
+      }
+#elif ACX_STORE_SCHED == 2
+      if (more) {
+        if (q == 2) { ACX_STORE_ROW(cur ^ 1, 0); ACX_STORE_ROW(cur ^ 1, 1); }
+        if (q == 3) { ACX_STORE_ROW(cur ^ 1, 2); ACX_STORE_ROW(cur ^ 1, 3); }
+      }
+#endif
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
+#if ACX_STORE_SCHED == 0
+    if (more) { ACX_STORE_ROW(cur ^ 1, 0); ACX_STORE_ROW(cur ^ 1, 1); ACX_STORE_ROW(cur ^ 1, 2); ACX_STORE_ROW(cur ^ 1, 3); }
+#endif
     __syncthreads();
   }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if constexpr (FAST) {
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + wn * 64 + ni * 32 + li;
-    if (col >= d.N) continue;
-    const float bias = d.bias ? d.bias[col] : 0.f;
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + li;
+      const bool cok = col < d.N;
+      const int colc = cok ? col : d.N - 1;
+      const float bias = d.bias ? d.bias[colc] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < 2; ++mi) {
+        const int rowb = m0 + wm * 64 + mi * 32 + 4 * hh;
+        float resv[16];
+        if constexpr (RES) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row >= d.M) continue;
-        float v = acc[mi][ni][r] + bias;
-        if (d.act == ACX_ACT_QUICKGELU) {
-          v = v * (1.f / (1.f + __expf(-1.702f * v)));
-        } else if (d.act == ACX_ACT_LEAKYRELU) {
-          v = v > 0.f ? v : 0.01f * v;
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
+            resv[r] = d.residual[(size_t)row * d.ldr + colc];
+          }
         }
-        if (d.pos0) {
-          const int l = row % d.gl, n = (row / d.gl) % d.gn;
-          v += d.pos0[(size_t)n * d.N + col];
-          v += d.pos1[(size_t)l * d.N + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rowb + (r & 3) + 8 * (r >> 2);
+          float v = acc[mi][ni][r] + bias;
+          if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+          if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
+          if constexpr (RES) v += resv[r];
+          if (cok && row < d.M) {
+            if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);
+            else ((float*)d.C)[(size_t)row * d.ldc + col] = v;
+          }
         }
-        if (d.residual) v += d.residual[(size_t)row * d.ldr + col];
-        if constexpr (C_BF16) {
-          ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);
-        } else {
-          ((float*)d.C)[(size_t)row * d.ldc + col] = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + li;
+      const bool cok = col < d.N;
+      const int colc = cok ? col : d.N - 1;
+      const float bias = d.bias ? d.bias[colc] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int rowb = m0 + wm * 64 + mi * 32 + 4 * hh;
+        float extra[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) extra[r] = 0.f;
+        if (d.residual) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
+            extra[r] = d.residual[(size_t)row * d.ldr + colc];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rowb + (r & 3) + 8 * (r >> 2);
+          float v = acc[mi][ni][r] + bias;
+          if (d.act == ACX_ACT_QUICKGELU) {
+            v = v * (1.f / (1.f + __expf(-1.702f * v)));
+          } else if (d.act == ACX_ACT_LEAKYRELU) {
+            v = v > 0.f ? v : 0.01f * v;
+          }
+          if (d.pos0) {
+            const int rc = min(row, d.M - 1);
+            const int l = rc % d.gl, n = (rc / d.gl) % d.gn;
+            v += d.pos0[(size_t)n * d.N + colc];
+            v += d.pos1[(size_t)l * d.N + colc];
+          }
+          v += extra[r];
+          if (cok && row < d.M) {
+            if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);
+            else ((float*)d.C)[(size_t)row * d.ldc + col] = v;
+          }
         }
       }
     }
@@ -297,22 +406,49 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
   const size_t lds = 4 * TILE_B;
   hipStream_t s = (hipStream_t)stream;
-#define ACX_LAUNCH(P, AB, CB)                                                                       \
+  AcxProfScope prof__(ctx, ACX_K_GEMM, (hipStream_t)stream);
+#define ACX_LAUNCH(P, AB, CB, F, ACT, RES)                                                          \
   do {                                                                                              \
     static bool attr_done = false;                                                                  \
     if (!attr_done) {                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<P, AB, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<P, AB, CB, F, ACT, RES>,                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
       attr_done = true;                                                                             \
     }                                                                                               \
-    hipLaunchKernelGGL((gemm_kernel<P, AB, CB>), grid, block, lds, s, g);                           \
+    hipLaunchKernelGGL((gemm_kernel<P, AB, CB, F, ACT, RES>), grid, block, lds, s, g);              \
   } while (0)
-  if (prec == ACX_PREC_F32) {
-    if (c_bf16) ACX_LAUNCH(0, 0, 1); else ACX_LAUNCH(0, 0, 0);
-  } else if (a_bf16) {
-    if (c_bf16) ACX_LAUNCH(1, 1, 1); else ACX_LAUNCH(1, 1, 0);
+  const int ke = prec == ACX_PREC_F32 ? 32 : 64;
+  const bool fast = d->amap == ACX_AMAP_IDENTITY && !d->a_sub && !d->pos0 && d->K % ke == 0 &&
+                    d->act != ACX_ACT_LEAKYRELU;
+  const int variant = (prec == ACX_PREC_F32 ? 0 : (a_bf16 ? 1 : 2)) * 2 + c_bf16;   // 0..5
+#define ACX_FAST(P, AB, CB)                                                           \
+  do {                                                                                \
+    if (d->act == ACX_ACT_QUICKGELU) {                                                \
+      if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 1, 1); else ACX_LAUNCH(P, AB, CB, 1, 1, 0); \
+    } else {                                                                          \
+      if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 0, 1); else ACX_LAUNCH(P, AB, CB, 1, 0, 0); \
+    }                                                                                 \
+  } while (0)
+  if (fast) {
+    switch (variant) {
+      case 0: ACX_FAST(0, 0, 0); break;
+      case 1: ACX_FAST(0, 0, 1); break;
+      case 2: ACX_FAST(1, 1, 0); break;
+      case 3: ACX_FAST(1, 1, 1); break;
+      case 4: ACX_FAST(1, 0, 0); break;
+      default: ACX_FAST(1, 0, 1); break;
+    }
   } else {
-    if (c_bf16) ACX_LAUNCH(1, 0, 1); else ACX_LAUNCH(1, 0, 0);
+    switch (variant) {
+      case 0: ACX_LAUNCH(0, 0, 0, 0, 0, 0); break;
+      case 1: ACX_LAUNCH(0, 0, 1, 0, 0, 0); break;
+      case 2: ACX_LAUNCH(1, 1, 0, 0, 0, 0); break;
+      case 3: ACX_LAUNCH(1, 1, 1, 0, 0, 0); break;
+      case 4: ACX_LAUNCH(1, 0, 0, 0, 0, 0); break;
+      default: ACX_LAUNCH(1, 0, 1, 0, 0, 0); break;
+    }
   }
+#undef ACX_FAST
 #undef ACX_LAUNCH
   ACX_CHECK_LAUNCH(ctx, "acx_gemm");
   return ACX_OK;

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void concat_features_kernel(const float* __res
 
 extern "C" int acx_vit_patches(acx_ctx* ctx, const float* frames, void* patches, int32_t out_dtype, int32_t F,
                                int32_t R, int32_t P, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!frames || !patches) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_patches: null pointer%s");
   if (F <= 0) return ACX_OK;
   if (P % 4 || R % P) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_patches: need P%%4==0 and R%%P==0%s");
@@ -343,6 +344,7 @@ extern "C" int acx_vit_patches(acx_ctx* ctx, const float* frames, void* patches,
 
 extern "C" int acx_text_directions(acx_ctx* ctx, const float* text, const float* ncentroid, float* dirs, int32_t C,
                                    int32_t D, int32_t normal_id, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!text || !ncentroid || !dirs) return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions: null pointer%s");
   if (C < 2 || normal_id < 0 || normal_id >= C) return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions: bad C/normal_id%s");
   hipLaunchKernelGGL(text_dirs_kernel, dim3(C - 1), dim3(256), 0, (hipStream_t)stream, text, ncentroid, dirs, D, normal_id);
@@ -352,6 +354,7 @@ extern "C" int acx_text_directions(acx_ctx* ctx, const float* text, const float*
 
 extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
                                     int64_t rows, int32_t D, int32_t C1, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!x || !ncentroid || !dirs || !raw) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project: null pointer%s");
   if (rows <= 0) return ACX_OK;
   if (C1 <= 0 || C1 > 64) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_project: need 1 <= C-1 <= 64%s");
@@ -382,6 +385,7 @@ extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* n
 
 extern "C" int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_t C1, float* mean, float* var_biased,
                             float* var_unbiased, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!raw || !mean || !var_biased || !var_unbiased) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: null pointer%s");
   if (rows <= 0 || C1 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: empty%s");
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C1), dim3(256), 0, (hipStream_t)stream, raw, rows, C1, mean, var_biased, var_unbiased);
@@ -391,6 +395,7 @@ extern "C" int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_
 
 extern "C" int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean, const float* var, float* logits,
                                int64_t ldl, int64_t rows, int32_t C1, float eps, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!raw || !mean || !var || !logits) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_bn: null pointer%s");
   if (rows <= 0) return ACX_OK;
   const int64_t total = rows * C1;
@@ -402,6 +407,7 @@ extern "C" int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean
 
 extern "C" int acx_axial_attention(acx_ctx* ctx, const float* qkv, float* out, int32_t tiles, int32_t gn, int32_t gl,
                                    int32_t heads, int32_t e, int32_t axis, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!qkv || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_axial_attention: null pointer%s");
   if (tiles <= 0) return ACX_OK;
   const int T = axis == 0 ? gn : gl;
@@ -428,6 +434,7 @@ extern "C" int acx_axial_attention(acx_ctx* ctx, const float* qkv, float* out, i
 
 extern "C" int acx_class_probs(acx_ctx* ctx, const float* sim, const float* scores, float* probs, int64_t rows,
                                int32_t C1, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!sim || !scores || !probs) return acx_fail(ctx, ACX_E_BADARG, "acx_class_probs: null pointer%s");
   if (rows <= 0) return ACX_OK;
   hipLaunchKernelGGL(class_probs_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sim,
@@ -437,6 +444,7 @@ extern "C" int acx_class_probs(acx_ctx* ctx, const float* sim, const float* scor
 }
 
 extern "C" int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!src || !dst) return acx_fail(ctx, ACX_E_BADARG, "acx_cast_bf16: null pointer%s");
   if (n <= 0) return ACX_OK;
   const int64_t nt = (n + 3) / 4;
@@ -447,6 +455,7 @@ extern "C" int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t 
 }
 
 extern "C" int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows, int32_t D, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!x || !acc) return acx_fail(ctx, ACX_E_BADARG, "acx_colsum: null pointer%s");
   if (rows <= 0) return ACX_OK;
   if (D % 4 || D / 4 > 256 || D <= 0) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_colsum: need D%%4==0 and D<=1024%s");
@@ -460,6 +469,7 @@ extern "C" int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows
 extern "C" int acx_prompt_embed(acx_ctx* ctx, const float* prefix, const float* ctxv, const float* suffix, const float* pos,
                                 float* out, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W, int32_t shared_ctx,
                                 void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!prefix || !ctxv || !suffix || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_prompt_embed: null pointer%s");
   if (C <= 0) return ACX_OK;
   if (W % 4 || n_ctx < 0 || n_ctx + 1 >= Lc) return acx_fail(ctx, ACX_E_BADARG, "acx_prompt_embed: bad geometry%s");
@@ -472,6 +482,7 @@ extern "C" int acx_prompt_embed(acx_ctx* ctx, const float* prefix, const float* 
 
 extern "C" int acx_gather_rows(acx_ctx* ctx, const float* x, const int64_t* idx, float* out, int64_t n, int32_t W,
                                void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!x || !idx || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_gather_rows: null pointer%s");
   if (n <= 0) return ACX_OK;
   if (W % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_gather_rows: W%%4%s");
@@ -484,6 +495,7 @@ extern "C" int acx_gather_rows(acx_ctx* ctx, const float* x, const int64_t* idx,
 
 extern "C" int acx_add_bcast(acx_ctx* ctx, const float* x, const float* p, float* out, int64_t n, int64_t LW,
                              void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!x || !p || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_add_bcast: null pointer%s");
   if (n <= 0) return ACX_OK;
   if (LW % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_add_bcast: LW%%4%s");
@@ -496,6 +508,7 @@ extern "C" int acx_add_bcast(acx_ctx* ctx, const float* x, const float* p, float
 
 extern "C" int acx_concat_features(acx_ctx* ctx, const float* logits, const float* x, const float* ncentroid, float* out,
                                    int64_t rows, int32_t C1, int32_t D, int32_t Kp, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!logits || !x || !ncentroid || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_concat_features: null pointer%s");
   if (rows <= 0) return ACX_OK;
   if (Kp < C1 + D) return acx_fail(ctx, ACX_E_BADARG, "acx_concat_features: Kp < C1 + D%s");

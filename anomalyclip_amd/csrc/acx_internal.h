@@ -13,9 +13,39 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
+// in-library launch timer (bench.py's roofline leg): HIP events recorded on the caller's stream
+// around every kernel launch of a kind, summed by acx_prof_collect.
+enum { ACX_K_GEMM = 0, ACX_K_ATTN = 1, ACX_K_NORM = 2, ACX_K_OTHER = 3, ACX_K_COUNT = 4 };
+constexpr int ACX_PROF_MAX = 32768;
+
 struct acx_ctx {
   int device;
   char err[512];
+  bool prof_on;
+  int prof_n;          // recorded pairs
+  int prof_created;    // event pairs created so far
+  hipEvent_t* prof_ev; // [2 * ACX_PROF_MAX]
+  unsigned char* prof_kind;
+};
+
+struct AcxProfScope {
+  acx_ctx* c;
+  hipStream_t s;
+  int slot;
+  AcxProfScope(acx_ctx* ctx, int kind, hipStream_t stream) : c(ctx), s(stream), slot(-1) {
+    if (!c || !c->prof_on || c->prof_n >= ACX_PROF_MAX) return;
+    if (c->prof_n >= c->prof_created) {
+      if (hipEventCreate(&c->prof_ev[2 * c->prof_created]) != hipSuccess) return;
+      if (hipEventCreate(&c->prof_ev[2 * c->prof_created + 1]) != hipSuccess) return;
+      c->prof_created++;
+    }
+    slot = c->prof_n++;
+    c->prof_kind[slot] = (unsigned char)kind;
+    (void)hipEventRecord(c->prof_ev[2 * slot], s);
+  }
+  ~AcxProfScope() {
+    if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], s);
+  }
 };
 
 // thread-local error slot for calls made with ctx == NULL

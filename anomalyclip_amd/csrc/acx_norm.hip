@@ -152,6 +152,7 @@ extern "C" int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const fl
   if (D % 64 || ldx % 4 || ldy % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm: D%%64 / ld%%4%s");
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_NORM, s);
   if (y_dtype == ACX_BF16) {
     DISPATCH_VPL(D, layernorm_kernel<V COMMA 1><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));
   } else {
@@ -169,6 +170,7 @@ extern "C" int acx_vit_embed(acx_ctx* ctx, const float* patch_out, const float* 
   if (rows <= 0) return ACX_OK;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_NORM, s);
   DISPATCH_VPL(W, vit_embed_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(patch_out, cls, pos, ln_w, ln_b, x, rows, T));
   ACX_CHECK_LAUNCH(ctx, "acx_vit_embed");
   return ACX_OK;
@@ -183,6 +185,7 @@ extern "C" int acx_cls_head(acx_ctx* ctx, const float* x1, const float* x2, cons
     return acx_fail(ctx, ACX_E_BADARG, "acx_cls_head: rows not a multiple of gn*gl*seg%s");
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_NORM, s);
   DISPATCH_VPL(E, cls_head_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, lin_b, scores, rows, gn, gl, seg));
   ACX_CHECK_LAUNCH(ctx, "acx_cls_head");
   return ACX_OK;

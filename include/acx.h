@@ -211,6 +211,14 @@ int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* st
 /* utility: column sums of x[rows, D] accumulated into acc[D] (ncentroid, anomaly_clip_module.py:145-171). */
 int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows, int32_t D, void* stream);
 
+/* In-library launch timer used by bench.py's roofline leg: when enabled, every kernel launch is
+ * bracketed by HIP events on the caller's stream.  kinds: 0 GEMM, 1 attention, 2 norm rows, 3 other.
+ * acx_prof_collect synchronises the recorded events and returns per-kind launch counts and summed
+ * durations (ms), then resets the recording. */
+#define ACX_PROF_KINDS 4
+int acx_prof_enable(acx_ctx* ctx, int on);
+int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif
