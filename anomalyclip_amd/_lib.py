@@ -86,6 +86,30 @@ _SIGS = {
     "acx_concat_features": (C.c_int, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_prof_enable": (C.c_int, [c_void_p, C.c_int]),
     "acx_prof_collect": (C.c_int, [c_void_p, C.POINTER(c_int32), C.POINTER(C.c_double)]),
+    "acx_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "acx_gemm_tn": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                              c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
+    "acx_reduce_rows": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "acx_layernorm_bwd": (C.c_int, [c_void_p] * 6 + [c_int64, c_int32, c_float, c_int32, c_float, c_void_p]),
+    "acx_cls_head_bwd": (C.c_int, [c_void_p] * 10 + [c_int64, c_int32, c_void_p]),
+    "acx_act": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "acx_add": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "acx_transpose": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "acx_conv_weight_dx": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "acx_seq_attention_bwd": (C.c_int, [c_void_p] * 4 + [c_int32] * 7 + [c_void_p]),
+    "acx_pos_grad": (C.c_int, [c_void_p] * 4 + [c_int32] * 4 + [c_void_p]),
+    "acx_bn_bwd_stats": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
+    "acx_bn_bwd_apply": (C.c_int, [c_void_p] * 6 + [c_int32, c_int64, c_int64, c_int32, c_float, c_void_p]),
+    "acx_axpby": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
+    "acx_colsum_partials": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "acx_text_directions_bwd": (C.c_int, [c_void_p] * 5 + [c_int32] * 3 + [c_void_p]),
+    "acx_select_idx": (C.c_int, [c_void_p] * 7 + [c_int32] * 7 + [c_void_p]),
+    "acx_gather_segments": (C.c_int, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
+    "acx_scatter_segments": (C.c_int, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
+    "acx_mil_loss": (C.c_int, [c_void_p] * 13 + [c_size_t] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p]),
+    "acx_adamw": (C.c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int32, c_void_p]),
+    "acx_ctx_grad": (C.c_int, [c_void_p] * 3 + [c_int32] * 5 + [c_void_p]),
+    "acx_scatter_rows": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
     "acx_cast_bf16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_colsum": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
 }

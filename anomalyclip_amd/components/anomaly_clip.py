@@ -131,6 +131,9 @@ class AnomalyCLIP(nn.Module):
         x = image_features.reshape(-1, image_features.shape[-1]).contiguous()
         if self.concat_features:
             Kp = self.temporal_model.prepared()["Kp"]
+            if torch.is_grad_enabled() and similarity.requires_grad:
+                from .functional import ConcatFeaturesFn
+                return ConcatFeaturesFn.apply(similarity, x, ncentroid, Kp), None
             return ops.concat_features(similarity.contiguous(), x, ncentroid, Kp), None
         return x, ncentroid
 

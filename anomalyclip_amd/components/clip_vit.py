@@ -85,7 +85,7 @@ class Transformer(nn.Module):
 
     # -- weight table handed to the C ABI (host array of device pointers), rebuilt when parameters change
     def _key(self, prec):
-        return (prec,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (prec, ops.WEIGHT_EPOCH[0]) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def block_table(self, prec: int):
         key = self._key(prec)
@@ -153,7 +153,7 @@ class VisionTransformer(nn.Module):
         self._ws: Optional[torch.Tensor] = None
 
     def _weights(self, prec: int):
-        key = (prec,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (prec, ops.WEIGHT_EPOCH[0]) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._wcache is not None and self._wcache[0] == key:
             return self._wcache[1]
         keep = []

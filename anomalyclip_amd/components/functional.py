@@ -1,22 +1,354 @@
-"""Training-side (autograd) glue.  Filled in by the training milestone; the inference path does
-not depend on it."""
+"""Training-side glue: torch.autograd.Function wrappers whose forward AND backward run libacx
+kernels (PyTorch supplies the autograd graph, device memory and streams only).
+
+Three coarse functions mirror the reference's trainable sub-graphs:
+  TextFeaturesFn   prompt_learner.ctx, text_encoder.text_projection -> text features
+                   (coop.py:74-90, text_encoder.py:14-25; frozen CLIP text layers, dX only)
+  SelectorTrainFn  text features -> (logits, logits_topk, logits_bottomk) + MIL indices
+                   (selector_model.py:32-99, 119-333)
+  TemporalFn       temporal_model.* -> scores (temporal_model.py:42-77 + restated axial transformer)
+  MilLossFn        loss.py:51-195 (forward+backward in one kernel pass)
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .. import _lib as L
+from .. import ops
 
 
-def _todo(name):
-    raise NotImplementedError(f"{name}: training path not built yet in this revision")
+# ------------------------------------------------------------------------------------------------------
+def _parallel():
+    from .. import parallel
+    return parallel
 
 
-def selector_train(*a, **k):
-    _todo("selector_train")
+# ====================================================================================================== text path
+class TextFeaturesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ctx_param, text_projection, net):
+        te, pl = net.text_encoder, net.prompt_learner
+        tr = te.transformer
+        W, heads, Lc = tr.width, tr.heads, te.positional_embedding.shape[0]
+        x0 = ops.prompt_embed(pl.token_prefix, ctx_param.detach(), pl.token_suffix, te.positional_embedding.detach(), pl.n_ctx)
+        C = x0.shape[0]
+        x = x0.view(C * Lc, W)
+        saved = []
+        for blk in tr.resblocks:
+            h1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+            qkv = ops.gemm(h1, blk.attn.in_proj_weight.detach(), bias=blk.attn.in_proj_bias.detach())
+            att = ops.attention(qkv, C, Lc, heads, True)
+            x_mid = ops.gemm(att, blk.attn.out_proj.weight.detach(), bias=blk.attn.out_proj.bias.detach(), residual=x)
+            h2 = ops.layernorm(x_mid, blk.ln_2.weight, blk.ln_2.bias)
+            pre = ops.gemm(h2, blk.mlp.c_fc.weight.detach(), bias=blk.mlp.c_fc.bias.detach())
+            act = ops.act(pre, None, 2)
+            x_next = ops.gemm(act, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid)
+            saved.append((x, qkv, x_mid, pre))
+            x = x_next
+        rows_idx = torch.arange(C, device=x.device, dtype=torch.int64) * Lc + net.eot_index
+        eot = ops.gather_rows(x, rows_idx)
+        eln = ops.layernorm(eot, te.ln_final.weight, te.ln_final.bias)
+        tf = ops.gemm(eln, text_projection.detach().t().contiguous())
+        ctx.net, ctx.saved_acts, ctx.misc = net, saved, (rows_idx, eot, eln, C, Lc, W, heads)
+        ctx.save_for_backward(text_projection)
+        return tf
+
+    @staticmethod
+    def backward(ctx, d_tf):
+        net = ctx.net
+        te, pl = net.text_encoder, net.prompt_learner
+        rows_idx, eot, eln, C, Lc, W, heads = ctx.misc
+        (P,) = ctx.saved_tensors
+        d_tf = d_tf.contiguous()
+        d_P = ops.gemm_tn(eln, d_tf)                                             # [W, E]
+        d_eln = ops.gemm(d_tf, P.detach().contiguous())                          # d_tf @ P^T  (W_op = P [W,E])
+        d_eot, _, _ = ops.layernorm_bwd(eot, te.ln_final.weight, d_eln, need_params=False)
+        d_x = ops.scatter_rows(d_eot, rows_idx, C * Lc)
+        wt = _frozen_transposes(te)
+        for li in range(len(ctx.saved_acts) - 1, -1, -1):
+            blk = te.transformer.resblocks[li]
+            x, qkv, x_mid, pre = ctx.saved_acts[li]
+            t_in, t_out, t_fc, t_proj = wt[li]
+            d_act = ops.gemm(d_x, t_proj)                                        # [rows,4W] = d_x @ proj_w
+            d_pre = ops.act(pre, d_act, 1)
+            d_h2 = ops.gemm(d_pre, t_fc)                                         # [rows,W]
+            d_ln, _, _ = ops.layernorm_bwd(x_mid, blk.ln_2.weight, d_h2, need_params=False)
+            d_x_mid = ops.add(d_x, d_ln)
+            d_att = ops.gemm(d_x_mid, t_out)
+            d_qkv = ops.seq_attention_bwd(qkv, d_att, C, 1, Lc, heads, 64, 1, causal=True)
+            d_h1 = ops.gemm(d_qkv, t_in)
+            d_ln, _, _ = ops.layernorm_bwd(x, blk.ln_1.weight, d_h1, need_params=False)
+            d_x = ops.add(d_x_mid, d_ln)
+        d_ctx = ops.ctx_grad(d_x, C, pl.n_ctx, Lc, W, pl.ctx.dim() == 2)
+        ctx.saved_acts = None
+        return d_ctx, d_P, None
 
 
-def temporal_train(*a, **k):
-    _todo("temporal_train")
+def _frozen_transposes(te):
+    """Transposed copies of the FROZEN text-transformer weights (dX = dY @ W needs W^T as the [N,K] operand)."""
+    key = (ops.WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in te.transformer.parameters())
+    cache = getattr(te, "_wt_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    out = []
+    for blk in te.transformer.resblocks:
+        out.append((ops.transpose(blk.attn.in_proj_weight.detach()), ops.transpose(blk.attn.out_proj.weight.detach()),
+                    ops.transpose(blk.mlp.c_fc.weight.detach()), ops.transpose(blk.mlp.c_proj.weight.detach())))
+    te._wt_cache = (key, out)
+    return out
 
 
-def text_features_train(*a, **k):
-    _todo("text_features_train")
+def text_features_train(net):
+    return TextFeaturesFn.apply(net.prompt_learner.ctx, net.text_encoder.text_projection, net)
 
 
-def anomaly_clip_train_forward(*a, **k):
-    _todo("anomaly_clip_train_forward")
+# ====================================================================================================== selector
+class SelectorTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, text_features, x, labels, ncentroid, mask_top, mask_bot, sel):
+        N, Lg, C1 = sel.num_segments, sel.seg_length, len(sel.classnames) - 1
+        x = x.contiguous()
+        tf = text_features.detach().contiguous()
+        dirs = ops.text_directions(tf, ncentroid, sel.normal_id)
+        raw = ops.selector_project(x, ncentroid, dirs)
+        mean, var_b, var_u = ops.bn_stats(raw)
+        par = _parallel()
+        rows = raw.shape[0]
+        total_rows = rows
+        if par.is_distributed():                                                # SyncBatchNorm (configs/trainer/ddp.yaml:9)
+            mean, var_b, var_u, total_rows = par.sync_bn_stats(mean, var_b, rows)
+        logits = ops.selector_bn(raw, mean, var_b, sel.bn_layer.eps)
+        bn = sel.bn_layer
+        ops.axpby_(bn.running_mean, mean, bn.momentum, 1.0 - bn.momentum)        # BatchNorm1d running stats
+        ops.axpby_(bn.running_var, var_u, bn.momentum, 1.0 - bn.momentum)
+        bn.num_batches_tracked += 1
+        B = labels.shape[0]
+        labels_d = labels.to(device=x.device, dtype=torch.int64).contiguous()
+        mt = mask_top.to(device=x.device, dtype=torch.float32).contiguous()
+        mb = mask_bot.to(device=x.device, dtype=torch.float32).contiguous()
+        idx_top, idx_bot = ops.select_idx(logits, labels_d, mt, mb, N, Lg, sel.normal_id, sel.num_topk, sel.num_bottomk)
+        logits_topk = ops.gather_segments(logits, idx_top, N, Lg)
+        logits_bottomk = ops.gather_segments(logits, idx_bot, N, Lg)
+        ctx.sel, ctx.dims = sel, (N, Lg, C1, total_rows)
+        ctx.save_for_backward(tf, x, ncentroid, logits, var_b, idx_top, idx_bot)
+        ctx.mark_non_differentiable(idx_top, idx_bot)
+        return logits, logits_topk, logits_bottomk, idx_top, idx_bot
+
+    @staticmethod
+    def backward(ctx, d_logits, d_topk, d_bottomk, _a, _b):
+        sel = ctx.sel
+        N, Lg, C1, total_rows = ctx.dims
+        tf, x, nc, logits, var_b, idx_top, idx_bot = ctx.saved_tensors
+        dl = d_logits.contiguous().clone() if d_logits is not None else torch.zeros_like(logits)
+        if d_topk is not None:
+            ops.scatter_segments_(dl, d_topk.contiguous(), idx_top, N, Lg)
+        if d_bottomk is not None:
+            ops.scatter_segments_(dl, d_bottomk.contiguous(), idx_bot, N, Lg)
+        sums = ops.bn_bwd_stats(logits, dl)
+        par = _parallel()
+        if par.is_distributed():
+            par.all_reduce_sum_(sums)
+        draw = ops.bn_bwd_apply(logits, dl, var_b, sums, total_rows, sel.bn_layer.eps)     # [rows, C1 padded to 4]
+        d_dirs = ops.gemm_tn(draw, x, b_sub=nc)[:C1].contiguous()                          # [C1, D]
+        d_text = ops.text_directions_bwd(tf, nc, d_dirs, sel.normal_id)
+        return d_text, None, None, None, None, None, None
+
+
+def selector_train(sel, x, text_features, labels, ncentroid, masks):
+    logits, lt, lb, idx_top, idx_bot = SelectorTrainFn.apply(text_features, x, labels, ncentroid, masks[0], masks[1], sel)
+    half = idx_top.shape[0] // 2
+    return logits, lt, lb, idx_top[:half], idx_top[half:], idx_bot[:half]
+
+
+# ====================================================================================================== temporal
+def _temporal_param_list(tm) -> List[torch.nn.Parameter]:
+    return list(tm.parameters())
+
+
+class TemporalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, a_sub, tm, *params):
+        P = tm.prepared()
+        N, Lg, E, depth = tm.num_segments, tm.seg_length, tm.emb_size, tm.depth
+        heads, e = tm.heads, tm.axial_attn.e
+        x = feats.reshape(-1, feats.shape[-1]).contiguous()
+        tiles = x.shape[0] // (N * Lg)
+        x0 = ops.gemm(x, P["proj_w"], bias=tm.projection.bias.detach(), a_sub=a_sub, gn=N, gl=Lg, seg=1,
+                      pos0=P["pos0"], pos1=P["pos1"])
+        blks = tm.axial_attn.layers.blocks
+        saved = []
+
+        def attn(x_in, resid, d, fg, axis):
+            pn = getattr(blks[2 * d], fg).net.fn
+            h = ops.layernorm(x_in, pn.norm.weight, pn.norm.bias)
+            qkv = ops.gemm(h, P[f"qkv_w{d}{fg}"])
+            o = ops.axial_attention(qkv, tiles, N, Lg, heads, e, axis)
+            out = ops.gemm(o, pn.fn.to_out.weight.detach(), bias=pn.fn.to_out.bias.detach(), residual=resid)
+            saved.append(("attn", d, fg, axis, x_in, h, qkv, o))
+            return out
+
+        def ff(x_in, resid, d, fg):
+            f = getattr(blks[2 * d + 1], fg).net
+            h = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN)
+            u = ops.gemm(h, P[f"c1_w{d}{fg}"], bias=f[1].bias.detach(), act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
+            out = ops.gemm(u, P[f"c2_w{d}{fg}"], bias=f[3].bias.detach(), residual=resid, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
+            saved.append(("ff", d, fg, 0, x_in, h, u, None))
+            return out
+
+        x1 = x2 = x0
+        for d in range(depth):
+            y1 = attn(x2, x1, d, "f", 0)
+            y2 = attn(y1, x2, d, "g", 1)
+            x1 = ff(y2, y1, d, "f")
+            x2 = ff(x1, y2, d, "g")
+        c = tm.classifier
+        scores = ops.cls_head(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight, c.linear.bias, N, Lg, 0)
+        ctx.tm, ctx.saved_acts = tm, saved
+        ctx.misc = (x, a_sub, x1, x2, scores, tiles, ctx.needs_input_grad[0])
+        return scores.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        tm = ctx.tm
+        x, a_sub, x1, x2, scores, tiles, need_dfeats = ctx.misc
+        N, Lg, E = tm.num_segments, tm.seg_length, tm.emb_size
+        heads, e = tm.heads, tm.axial_attn.e
+        blks = tm.axial_attn.layers.blocks
+        grads = {}
+        c = tm.classifier
+        dz, g_lnw, g_lnb, g_w, g_b = ops.cls_head_bwd(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight,
+                                                      scores, d_scores.contiguous().view(-1))
+        grads[c.layer_norm.weight], grads[c.layer_norm.bias] = g_lnw, g_lnb
+        grads[c.linear.weight], grads[c.linear.bias] = g_w.view(1, -1), g_b
+        d1, d2 = dz, dz                                   # d(x1), d(x2) of the last block pair
+
+        def attn_bwd(rec, d_out):
+            _, d, fg, axis, x_in, h, qkv, o = rec
+            pn = getattr(blks[2 * d], fg).net.fn
+            sa = pn.fn
+            He = heads * e
+            grads[sa.to_out.weight] = ops.gemm_tn(d_out, o)                           # [E, He]
+            grads[sa.to_out.bias] = ops.colsum(d_out)
+            d_o = ops.gemm(d_out, ops.transpose(sa.to_out.weight.detach()))            # [rows, He]
+            d_qkv = ops.seq_attention_bwd(qkv, d_o, tiles, N, Lg, heads, e, axis)
+            g_qkv = ops.gemm_tn(d_qkv, h)                                              # [3He, E]
+            grads[sa.to_q.weight] = g_qkv[:He]
+            grads[sa.to_kv.weight] = g_qkv[He:]
+            qkv_w = tm.prepared()[f"qkv_w{d}{fg}"]
+            d_h = ops.gemm(d_qkv, ops.transpose(qkv_w))                                # [rows, E]
+            d_in, gw, gb = ops.layernorm_bwd(x_in, pn.norm.weight, d_h)
+            grads[pn.norm.weight], grads[pn.norm.bias] = gw, gb
+            return d_in
+
+        def ff_bwd(rec, d_out):
+            _, d, fg, _, x_in, h, u, _ = rec
+            f = getattr(blks[2 * d + 1], fg).net
+            P = tm.prepared()
+            grads[f[3].bias] = ops.colsum(d_out)
+            gw2 = ops.gemm_tn(d_out, u, conv=True, gn=N, gl=Lg, cin=4 * E)             # [E, 9*4E]  ([Cout][tap][Cin])
+            grads[f[3].weight] = gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2)
+            d_u = ops.gemm(d_out, ops.conv_weight_dx(f[3].weight.detach()), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
+            d_pre = ops.act(u, d_u, 0)                                                 # LeakyReLU'
+            grads[f[1].bias] = ops.colsum(d_pre)
+            gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E)                 # [4E, 9E]
+            grads[f[1].weight] = gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2)
+            d_h = ops.gemm(d_pre, ops.conv_weight_dx(f[1].weight.detach()), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
+            d_in, gg, gb = ops.layernorm_bwd(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN)
+            grads[f[0].g], grads[f[0].b] = gg.view(1, -1, 1, 1), gb.view(1, -1, 1, 1)
+            return d_in
+
+        recs = ctx.saved_acts
+        for d in range(tm.depth - 1, -1, -1):
+            r_af, r_ag, r_ff, r_fg = recs[4 * d: 4 * d + 4]
+            # x2' = y2 + ffG(x1')  ;  x1' = y1 + ffF(y2)
+            d_y2 = d2
+            d1 = ops.add(d1, ff_bwd(r_fg, d2))
+            d_y1 = d1
+            d_y2 = ops.add(d_y2, ff_bwd(r_ff, d1))
+            # y2 = x2 + attnG(y1) ; y1 = x1 + attnF(x2)
+            d_x2 = d_y2
+            d_y1 = ops.add(d_y1, attn_bwd(r_ag, d_y2))
+            d_x1 = d_y1
+            d_x2 = ops.add(d_x2, attn_bwd(r_af, d_y1))
+            d1, d2 = d_x1, d_x2
+        d_x0 = ops.add(d1, d2)
+        pe = tm.axial_attn.pos_emb
+        g0, g1 = ops.pos_grad(d_x0, tiles, N, Lg)
+        grads[pe.param_0] = g0.t().reshape(1, E, N, 1)
+        grads[pe.param_1] = g1.t().reshape(1, E, 1, Lg)
+        K = tm.input_size
+        gw = ops.gemm_tn(d_x0, x, b_sub=a_sub)                                         # [E, Kp]
+        grads[tm.projection.weight] = gw[:, :K]
+        grads[tm.projection.bias] = ops.colsum(d_x0)
+        d_feats = None
+        if need_dfeats:
+            d_feats = ops.gemm(d_x0, ops.transpose(tm.prepared()["proj_w"]))           # [rows, Kp]
+        ctx.saved_acts = None
+        out = [grads.get(p) for p in tm.parameters()]
+        out = [g.contiguous() if g is not None else None for g in out]
+        return (d_feats, None, None, *out)
+
+
+def temporal_train(tm, features, a_sub):
+    return TemporalFn.apply(features, a_sub, tm, *tm.parameters())
+
+
+class ConcatFeaturesFn(torch.autograd.Function):
+    """[logits | x - ncentroid | 0-pad] (anomaly_clip.py:223-233); gradient flows to the logits part only."""
+
+    @staticmethod
+    def forward(ctx, logits, x, ncentroid, Kp):
+        ctx.C1 = logits.shape[1]
+        return ops.concat_features(logits.contiguous(), x, ncentroid, Kp)
+
+    @staticmethod
+    def backward(ctx, d_feats):
+        return d_feats[:, :ctx.C1].contiguous(), None, None, None
+
+
+# ====================================================================================================== loss
+class MilLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sim, sim_topk, scores, labels, ia, in_, ba, cfg):
+        N, Lg, K, normal_id, lambdas = cfg
+        sim, sim_topk, scores = sim.contiguous(), sim_topk.contiguous(), scores.contiguous()
+        labels = labels.to(device=sim.device, dtype=torch.int64).contiguous()
+        losses, dsim, dtopk, dsc = ops.mil_loss(sim, sim_topk, labels, scores, ia.contiguous(), in_.contiguous(),
+                                                ba.contiguous(), N, Lg, K, normal_id, lambdas)
+        ctx.cfg = cfg
+        ctx.save_for_backward(sim, sim_topk, scores, labels, ia, in_, ba)
+        return losses
+
+    @staticmethod
+    def backward(ctx, d_losses):
+        # Only the total cost (element 0) is meant to be differentiated (module.training_step returns it);
+        # the upstream gradient is read on the device, no host sync.
+        N, Lg, K, normal_id, lambdas = ctx.cfg
+        sim, sim_topk, scores, labels, ia, in_, ba = ctx.saved_tensors
+        gout = d_losses.contiguous()[0:1]
+        _, dsim, dtopk, dsc = ops.mil_loss(sim, sim_topk, labels, scores, ia.contiguous(), in_.contiguous(), ba.contiguous(),
+                                           N, Lg, K, normal_id, lambdas, gout=gout)
+        return dsim, dtopk, dsc, None, None, None, None, None
+
+
+# ====================================================================================================== assembly
+def anomaly_clip_train_forward(net, image_features, labels, ncentroid, masks=None):
+    """anomaly_clip.py:156-215."""
+    if not net.load_from_features:
+        b, t, c, h, w = image_features.size()
+        f = net.image_encoder(image_features.view(-1, c, h, w))                    # frozen, forward only
+        image_features = f.view(b, net.ncrops, -1, f.shape[-1])
+    b, ncrops, t, d = image_features.shape
+    if ncrops != 1:
+        raise ValueError("training expects ncrops == 1 (the reference squeezes the crop axis, anomaly_clip.py:178-181)")
+    x = image_features.reshape(-1, d).contiguous().float()
+    text_features = net.get_text_features()
+    sel = net.selector_model
+    if masks is None:
+        masks = sel.generate_mask(b)
+    logits, logits_topk, logits_bottomk, ia, in_, ba = selector_train(sel, x, text_features, labels, ncentroid, masks)
+    feats, a_sub = net.get_temporal_model_input(x, logits, ncentroid)
+    scores = net.temporal_model(feats, 1, False, a_sub=a_sub).view(-1)
+    return logits, logits_topk, scores, ia, in_, ba

@@ -111,7 +111,7 @@ class TemporalModel(nn.Module):
 
     # ---- derived weight layouts for the kernels (cached; rebuilt when a parameter changes)
     def prepared(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (ops.WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._prep is not None and self._prep[0] == key:
             return self._prep[1]
         with torch.no_grad():

@@ -367,6 +367,154 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   }
 }
 
+
+// =====================================================================================================
+// acx_gemm_tn -- weight-gradient GEMM:  C[N1,N2] = sum_m A[m,n1] * bmap(B)[m,n2]      (exact f32 MFMA)
+//
+// Both operands are stored with the REDUCTION index m as the slow (row) index -- dY [M,N1] and
+// X [M,N2] exactly as the forward pass left them -- so no transposes are materialised.  A K-step is
+// 32 rows of m; the LDS image is [32 m][128 n] (+pad), a lane of the 32x32x2 MFMA reads its operand
+// with ds_read_b32 (32 consecutive floats per half-wave: conflict free for any row stride).
+// bmap: identity, or the 3x3-conv gather (column k = tap*cin + ci reads row shift_tap(m), zero outside
+// the (gn,gl) grid) for the conv weight gradient, optionally minus a per-column vector (b_sub) for the
+// selector's direction gradient.  The M reduction is split over gridDim.y; partial tiles go to a
+// workspace and are summed in fixed order by tn_reduce_kernel (deterministic, no atomics).
+constexpr int TN_ROWF = 132;   // floats per LDS row (128 + 4 pad keeps 16-B alignment of the b128 writes)
+
+struct TnArgs {
+  const float* A; const float* B; float* C;   // C: [splits][N1][ldc] partials (or the result when splits == 1)
+  int M, N1, N2, lda, ldb, ldc;
+  const float* b_sub;
+  int conv, gn, gl, cin;
+  int m_per_split;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const TnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem);           // [stage][A|B][32][TN_ROWF]
+  constexpr int TILE_F = 32 * TN_ROWF;
+  const int tiles_n2 = (g.N2 + 127) / 128;
+  const int tm = blockIdx.x / tiles_n2, tn = blockIdx.x % tiles_n2;
+  const int n1_0 = tm * 128, n2_0 = tn * 128;
+  const int split = blockIdx.y;
+  const int m_begin = split * g.m_per_split;
+  const int m_end = min(g.M, m_begin + g.m_per_split);
+
+  const int t = threadIdx.x;
+  const int c16 = t & 31, r0 = t >> 5;                  // chunk column (4 floats), base row (0..7) + 8*r
+  // column validity / conv tap of this thread's chunk (fixed over the K loop)
+  const int ca = n1_0 + 4 * c16, cb = n2_0 + 4 * c16;
+  const bool a_cok = ca < g.N1, b_cok = cb < g.N2;      // N1, N2 multiples of 4 (checked on the host)
+  int tap_dn = 0, tap_dl = 0, b_col = cb;
+  if (g.conv && b_cok) {
+    const int tap = cb / g.cin;
+    tap_dn = tap / 3 - 1;
+    tap_dl = tap - (tap / 3) * 3 - 1;
+    b_col = cb - tap * g.cin;
+  }
+  float4 bsub = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.b_sub && b_cok) bsub = *reinterpret_cast<const float4*>(g.b_sub + cb);
+  const int grid_sz = g.conv ? g.gn * g.gl : 1;
+
+  float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+#define TN_LOAD_ROW(r, mbase)                                                                      \
+  do {                                                                                             \
+    const int m_ = (mbase) + r0 + 8 * (r);                                                         \
+    const bool mok_ = m_ < m_end;                                                                  \
+    const int mc_ = mok_ ? m_ : m_end - 1;                                                         \
+    float4 va_ = *reinterpret_cast<const float4*>(g.A + (size_t)mc_ * g.lda + (a_cok ? ca : 0));   \
+    if (!(mok_ && a_cok)) va_ = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+    sa##r = va_;                                                                                   \
+    long srow_ = mc_;                                                                              \
+    bool bok_ = mok_ && b_cok;                                                                     \
+    if (g.conv) {                                                                                  \
+      const int tile_ = mc_ / grid_sz, rem_ = mc_ - tile_ * grid_sz;                               \
+      int nn_ = rem_ / g.gl + tap_dn, ll_ = rem_ % g.gl + tap_dl;                                  \
+      bok_ = bok_ && nn_ >= 0 && nn_ < g.gn && ll_ >= 0 && ll_ < g.gl;                             \
+      nn_ = min(max(nn_, 0), g.gn - 1);                                                            \
+      ll_ = min(max(ll_, 0), g.gl - 1);                                                            \
+      srow_ = (long)tile_ * grid_sz + (long)nn_ * g.gl + ll_;                                      \
+    }                                                                                              \
+    float4 vb_ = *reinterpret_cast<const float4*>(g.B + (size_t)srow_ * g.ldb + (b_cok ? b_col : 0)); \
+    vb_.x -= bsub.x; vb_.y -= bsub.y; vb_.z -= bsub.z; vb_.w -= bsub.w;                             \
+    if (!bok_) vb_ = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
+    sb##r = vb_;                                                                                   \
+  } while (0)
+#define TN_STORE_ROW(stage, r)                                                                     \
+  do {                                                                                             \
+    float* pa_ = sm + (stage) * 2 * TILE_F + (r0 + 8 * (r)) * TN_ROWF + 4 * c16;                   \
+    *reinterpret_cast<float4*>(pa_) = sa##r;                                                       \
+    *reinterpret_cast<float4*>(pa_ + TILE_F) = sb##r;                                              \
+  } while (0)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+
+  const int nk = (m_end - m_begin + 31) / 32;
+  if (nk > 0) {
+    TN_LOAD_ROW(0, m_begin); TN_LOAD_ROW(1, m_begin); TN_LOAD_ROW(2, m_begin); TN_LOAD_ROW(3, m_begin);
+    TN_STORE_ROW(0, 0); TN_STORE_ROW(0, 1); TN_STORE_ROW(0, 2); TN_STORE_ROW(0, 3);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int mb = m_begin + (kt + 1) * 32;
+      TN_LOAD_ROW(0, mb); TN_LOAD_ROW(1, mb); TN_LOAD_ROW(2, mb); TN_LOAD_ROW(3, mb);
+    }
+    const float* pa = sm + cur * 2 * TILE_F + hh * TN_ROWF + wm * 64 + li;
+    const float* pb = sm + cur * 2 * TILE_F + TILE_F + hh * TN_ROWF + wn * 64 + li;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float a0 = pa[2 * s2 * TN_ROWF], a1 = pa[2 * s2 * TN_ROWF + 32];
+      const float b0 = pb[2 * s2 * TN_ROWF], b1 = pb[2 * s2 * TN_ROWF + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) { TN_STORE_ROW(cur ^ 1, 0); TN_STORE_ROW(cur ^ 1, 1); TN_STORE_ROW(cur ^ 1, 2); TN_STORE_ROW(cur ^ 1, 3); }
+    __syncthreads();
+  }
+  float* Cs = g.C + (size_t)split * g.N1 * g.ldc;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n2_0 + wn * 64 + ni * 32 + li;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n1_0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < g.N1 && col < g.N2) Cs[(size_t)row * g.ldc + col] = acc[mi][ni][r];
+      }
+  }
+#undef TN_LOAD_ROW
+#undef TN_STORE_ROW
+}
+
+// out[i] = sum_s part[s][i]   (fixed order)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                        int64_t n4, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = reinterpret_cast<const float4*>(part)[i];
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)k * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = s;
+}
+
 }  // namespace
 
 extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
@@ -451,5 +599,50 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
 #undef ACX_FAST
 #undef ACX_LAUNCH
   ACX_CHECK_LAUNCH(ctx, "acx_gemm");
+  return ACX_OK;
+}
+
+extern "C" size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2) {
+  const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+  int splits = 1;
+  while (tiles * splits < 512 && splits < 64 && (int64_t)M / (splits * 2) >= 256) splits *= 2;
+  return splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;
+}
+
+extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                           int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                           int32_t cin, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!A || !B || !C) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: null pointer%s");
+  if (M <= 0 || N1 <= 0 || N2 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: empty shape%s");
+  if (N1 % 4 || N2 % 4 || lda % 4 || ldb % 4 || ldc != N2 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: N1/N2/lda/ldb must be multiples of 4, C dense, 16-byte aligned%s");
+  if (conv && (cin <= 0 || N2 != 9 * cin || cin % 4 || gn <= 0 || gl <= 0 || M % (gn * gl)))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: bad conv geometry%s");
+  if (b_sub && ((uintptr_t)b_sub & 15)) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: b_sub alignment%s");
+  const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+  int splits = 1;
+  while (tiles * splits < 512 && splits < 64 && (int64_t)M / (splits * 2) >= 256) splits *= 2;
+  const size_t need = splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace)) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_gemm_tn: workspace too small%s");
+  TnArgs g;
+  g.A = A; g.B = B; g.C = splits > 1 ? (float*)workspace : C;
+  g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.b_sub = b_sub; g.conv = conv; g.gn = gn; g.gl = gl; g.cin = cin;
+  g.m_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
+  const size_t lds = 4 * 32 * TN_ROWF * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_GEMM, s);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(NTHREADS), lds, s, g);
+  if (splits > 1) {
+    const int64_t n4 = (int64_t)N1 * N2 / 4;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, n4,
+                       splits);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_gemm_tn");
   return ACX_OK;
 }

@@ -1,0 +1,1003 @@
+// Training-side kernels of the AnomalyCLIP head (backward passes, MIL selection, loss, AdamW).
+// All reductions over rows are two-stage and fixed-order (per-block partials -> acx_reduce_rows), so a
+// training step is bit-reproducible run to run; no float atomics on the gradient path.
+#include "acx_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------ generic helpers
+// out[c] = sum_p part[p][c]   (fixed order; part is [nparts][width])
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int nparts, int width) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * width + c];
+  out[c] = s;
+}
+
+// block-level sum of a per-thread value (256 threads), result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------ LayerNorm / ChanLayerNorm backward
+// one wave per row, 16 rows per wave, 64 rows per block; per-block partial dw/db -> part[blk][2*D]
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            float* __restrict__ part, int64_t rows, float eps, int mode,
+                                                            float dx_scale) {
+  constexpr int D = 64 * VPL;
+  constexpr float invD = 1.f / D;
+  __shared__ float sred[4][2 * D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ww[VPL], dwa[VPL], dba[VPL];
+  load_row<VPL>(w, lane, ww);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) dwa[i] = dba[i] = 0.f;
+  const int64_t rbase = (int64_t)blockIdx.x * 64 + wave * 16;
+  for (int rr = 0; rr < 16; ++rr) {
+    const int64_t row = rbase + rr;
+    if (row >= rows) break;
+    float v[VPL], g[VPL];
+    load_row<VPL>(x + row * D, lane, v);
+    load_row<VPL>(dy + row * D, lane, g);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float var = wave_sum(q) * invD;
+    float sc, c2;   // y = xc * sc * w + b
+    if (mode == ACX_NORM_LAYER) { sc = 1.f / sqrtf(var + eps); } else { sc = 1.f / (sqrtf(var) + eps); }
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      dba[i] += g[i];
+      dwa[i] += g[i] * v[i] * sc;
+      g[i] *= ww[i];
+      sg += g[i];
+      sgx += g[i] * v[i];
+    }
+    sg = wave_sum(sg) * invD;
+    sgx = wave_sum(sgx);
+    if (mode == ACX_NORM_LAYER) c2 = sc * sc * sc * sgx * invD;          // d(rstd)/dx term
+    else { const float sd = sqrtf(var); c2 = sd > 0.f ? sc * sc * sgx * invD / sd : 0.f; }
+    if (dx) {
+      float o[VPL];
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) o[i] = (sc * (g[i] - sg) - c2 * v[i]) * dx_scale;
+      if constexpr (VPL % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < VPL / 4; ++i)
+          *reinterpret_cast<float4*>(dx + row * D + 4 * lane + 256 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) dx[row * D + lane + 64 * i] = o[i];
+      }
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int e = elem_index<VPL>(lane, i);
+    sred[wave][e] = dwa[i];
+    sred[wave][D + e] = dba[i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * D; e += 256)
+    part[(size_t)blockIdx.x * 2 * D + e] = sred[0][e] + sred[1][e] + sred[2][e] + sred[3][e];
+}
+
+// ------------------------------------------------------------------ classifier head backward
+// forward: a=(x1+x2)/2; z=LN(a)*lw+lb; s=sigmoid(z.w+b).  part[blk] = [dlw(E) | dlb(E) | dw(E) | db(1) pad]
+template <int VPL>
+__global__ __launch_bounds__(256) void cls_head_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                           const float* __restrict__ lw, const float* __restrict__ lb,
+                                                           const float* __restrict__ w, const float* __restrict__ scores,
+                                                           const float* __restrict__ dscores, float* __restrict__ dx,
+                                                           float* __restrict__ part, int64_t rows) {
+  constexpr int E = 64 * VPL;
+  constexpr float invD = 1.f / E;
+  constexpr int PW = 3 * E + 4;
+  __shared__ float sred[4][PW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float lww[VPL], lbb[VPL], wv[VPL], a_lw[VPL], a_lb[VPL], a_w[VPL];
+  load_row<VPL>(lw, lane, lww);
+  load_row<VPL>(lb, lane, lbb);
+  load_row<VPL>(w, lane, wv);
+  float a_b = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) a_lw[i] = a_lb[i] = a_w[i] = 0.f;
+  const int64_t rbase = (int64_t)blockIdx.x * 64 + wave * 16;
+  for (int rr = 0; rr < 16; ++rr) {
+    const int64_t row = rbase + rr;
+    if (row >= rows) break;
+    float v[VPL], c[VPL];
+    load_row<VPL>(x1 + row * E, lane, v);
+    load_row<VPL>(x2 + row * E, lane, c);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i] = (v[i] + c[i]) * 0.5f; s += v[i]; }
+    const float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rstd = 1.f / sqrtf(wave_sum(q) * invD + 1e-5f);
+    const float sg = scores[row];
+    const float ddot = dscores[row] * sg * (1.f - sg);
+    a_b += ddot;
+    float g[VPL], sgm = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float xh = v[i] * rstd;
+      const float z = xh * lww[i] + lbb[i];
+      a_w[i] += ddot * z;
+      const float dz = ddot * wv[i];
+      a_lb[i] += dz;
+      a_lw[i] += dz * xh;
+      g[i] = dz * lww[i];
+      sgm += g[i];
+      sgx += g[i] * v[i];
+    }
+    sgm = wave_sum(sgm) * invD;
+    sgx = wave_sum(sgx) * invD * rstd * rstd * rstd;
+    float o[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) o[i] = 0.5f * (rstd * (g[i] - sgm) - sgx * v[i]);   // d(x1) == d(x2)
+    if constexpr (VPL % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < VPL / 4; ++i)
+        *reinterpret_cast<float4*>(dx + row * E + 4 * lane + 256 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) dx[row * E + lane + 64 * i] = o[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int e = elem_index<VPL>(lane, i);
+    sred[wave][e] = a_lw[i];
+    sred[wave][E + e] = a_lb[i];
+    sred[wave][2 * E + e] = a_w[i];
+  }
+  if (lane == 0) sred[wave][3 * E] = a_b;    // a_b is identical in all lanes of the wave
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * E + 1; e += 256)
+    part[(size_t)blockIdx.x * PW + e] = sred[0][e] + sred[1][e] + sred[2][e] + sred[3][e];
+}
+
+// ------------------------------------------------------------------ elementwise
+// mode 0: LeakyReLU backward from the saved OUTPUT u (sign(u) == sign(pre-activation)): d *= u>0 ? 1 : 0.01
+// mode 1: QuickGELU backward from the saved pre-activation: d *= sig*(1 + 1.702*x*(1-sig))
+// mode 2: QuickGELU forward: out = x*sigmoid(1.702x)
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ saved, const float* __restrict__ d,
+                                                  float* __restrict__ out, int64_t n4, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 s = reinterpret_cast<const float4*>(saved)[i];
+  float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (d) g = reinterpret_cast<const float4*>(d)[i];
+  float sv[4] = {s.x, s.y, s.z, s.w}, gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (mode == 0) gv[k] *= sv[k] > 0.f ? 1.f : 0.01f;
+    else {
+      const float sg = 1.f / (1.f + __expf(-1.702f * sv[k]));
+      if (mode == 1) gv[k] *= sg * (1.f + 1.702f * sv[k] * (1.f - sg));
+      else gv[k] = sv[k] * sg;
+    }
+  }
+  reinterpret_cast<float4*>(out)[i] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+}
+
+// out = a + b
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+  reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+// out[c, r] = in[r, c]   (weight transposes for the dX GEMMs), 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cn) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < R && bx + tx < Cn) tile[j][tx] = in[(size_t)(by + j) * Cn + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < Cn && by + tx < R) out[(size_t)(bx + j) * R + by + tx] = tile[tx][j];
+}
+
+// conv weight for the dX implicit GEMM: out[ci][tap'][co] = w[co][ci][8 - tap']   (w is [Cout][Cin][3][3])
+__global__ __launch_bounds__(256) void conv_w_dx_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  const int tp = (int)((i / Cout) % 9);
+  const int ci = (int)(i / ((int64_t)Cout * 9));
+  out[i] = w[((size_t)co * Cin + ci) * 9 + (8 - tp)];
+}
+
+// ------------------------------------------------------------------ sequence attention backward
+// qkv rows = [q | k | v] (each heads*E wide); a "line" is a sequence of T tokens whose rows are
+// row_of(line, j).  One thread per (line, head, query/key index); two passes over LDS-staged operands.
+template <int E>
+__global__ __launch_bounds__(256) void seq_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           float* __restrict__ dqkv, int tiles, int gn, int gl, int heads,
+                                                           int axis, int causal, float scale, int T, int gpb,
+                                                           int64_t ngroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sA = reinterpret_cast<float*>(smem);            // [gpb][T][E]   K then Q
+  float* sB = sA + gpb * T * E;                           // [gpb][T][E]   V then dO
+  float* sM = sB + gpb * T * E;                           // [gpb][T] max
+  float* sL = sM + gpb * T;                               // [gpb][T] 1/sum
+  float* sD = sL + gpb * T;                               // [gpb][T] D_i
+  const int He = heads * E, ld = 3 * He;
+  const int t = threadIdx.x;
+  const int gi = t / T, i = t - gi * T;
+  const int64_t grp = (int64_t)blockIdx.x * gpb + gi;     // (line, head) group
+  const bool active = gi < gpb && grp < ngroups;
+  const int other = axis == 0 ? gl : gn;
+  auto row_of = [&](int64_t line, int j) -> int64_t {
+    const int64_t tile = line / other;
+    const int o = (int)(line - tile * other);
+    return axis == 0 ? (tile * gn + j) * gl + o : (tile * gn + o) * gl + j;
+  };
+  // cooperative staging helper: which = 0 (K,V) or 1 (Q,dO)
+  auto stage = [&](int which) {
+    const int f4 = E / 4;
+    for (int idx = t; idx < gpb * T * f4; idx += 256) {
+      const int c4 = idx % f4, tk = idx / f4;
+      const int g2 = tk / T, j = tk - g2 * T;
+      const int64_t gg = (int64_t)blockIdx.x * gpb + g2;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (gg < ngroups) {
+        const int64_t line = gg / heads;
+        const int h = (int)(gg - line * heads);
+        const int64_t r = row_of(line, j);
+        if (which == 0) {
+          a = *reinterpret_cast<const float4*>(qkv + r * ld + He + h * E + 4 * c4);
+          b = *reinterpret_cast<const float4*>(qkv + r * ld + 2 * He + h * E + 4 * c4);
+        } else {
+          a = *reinterpret_cast<const float4*>(qkv + r * ld + h * E + 4 * c4);
+          b = *reinterpret_cast<const float4*>(dout + r * He + h * E + 4 * c4);
+        }
+      }
+      reinterpret_cast<float4*>(sA)[idx] = a;
+      reinterpret_cast<float4*>(sB)[idx] = b;
+    }
+  };
+  stage(0);
+  __syncthreads();
+  int64_t line = 0, myrow = 0;
+  int h = 0;
+  float q[E], dO[E];
+  if (active) {
+    line = grp / heads;
+    h = (int)(grp - line * heads);
+    myrow = row_of(line, i);
+#pragma unroll
+    for (int c = 0; c < E / 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(qkv + myrow * ld + h * E + 4 * c);
+      const float4 b = *reinterpret_cast<const float4*>(dout + myrow * He + h * E + 4 * c);
+      q[4 * c] = a.x; q[4 * c + 1] = a.y; q[4 * c + 2] = a.z; q[4 * c + 3] = a.w;
+      dO[4 * c] = b.x; dO[4 * c + 1] = b.y; dO[4 * c + 2] = b.z; dO[4 * c + 3] = b.w;
+    }
+    const float* kb = sA + gi * T * E;
+    const float* vb = sB + gi * T * E;
+    const int jmax = causal ? i + 1 : T;
+    // sweep 1: max and sum
+    float mx = -INFINITY;
+    for (int j = 0; j < jmax; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc += q[e] * kb[j * E + e];
+      mx = fmaxf(mx, acc * scale);
+    }
+    float sum = 0.f, Di = 0.f;
+    for (int j = 0; j < jmax; ++j) {
+      float acc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { acc += q[e] * kb[j * E + e]; dp += dO[e] * vb[j * E + e]; }
+      const float p = __expf(acc * scale - mx);
+      sum += p;
+      Di += p * dp;
+    }
+    const float inv = 1.f / sum;
+    Di *= inv;
+    // sweep 3: dq
+    float dq[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) dq[e] = 0.f;
+    for (int j = 0; j < jmax; ++j) {
+      float acc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { acc += q[e] * kb[j * E + e]; dp += dO[e] * vb[j * E + e]; }
+      const float ds = __expf(acc * scale - mx) * inv * (dp - Di) * scale;
+#pragma unroll
+      for (int e = 0; e < E; ++e) dq[e] += ds * kb[j * E + e];
+    }
+#pragma unroll
+    for (int c = 0; c < E / 4; ++c)
+      *reinterpret_cast<float4*>(dqkv + myrow * ld + h * E + 4 * c) = make_float4(dq[4 * c], dq[4 * c + 1], dq[4 * c + 2], dq[4 * c + 3]);
+    sM[gi * T + i] = mx;
+    sL[gi * T + i] = inv;
+    sD[gi * T + i] = Di;
+  }
+  __syncthreads();
+  stage(1);       // Q and dO of every token
+  __syncthreads();
+  if (active) {
+    // this thread is now KEY/VALUE index j = i
+    float k[E], v[E], dk[E], dv[E];
+#pragma unroll
+    for (int c = 0; c < E / 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(qkv + myrow * ld + He + h * E + 4 * c);
+      const float4 b = *reinterpret_cast<const float4*>(qkv + myrow * ld + 2 * He + h * E + 4 * c);
+      k[4 * c] = a.x; k[4 * c + 1] = a.y; k[4 * c + 2] = a.z; k[4 * c + 3] = a.w;
+      v[4 * c] = b.x; v[4 * c + 1] = b.y; v[4 * c + 2] = b.z; v[4 * c + 3] = b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) dk[e] = dv[e] = 0.f;
+    const float* qb = sA + gi * T * E;
+    const float* ob = sB + gi * T * E;
+    for (int qi = causal ? i : 0; qi < T; ++qi) {
+      float acc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { acc += qb[qi * E + e] * k[e]; dp += ob[qi * E + e] * v[e]; }
+      const float p = __expf(acc * scale - sM[gi * T + qi]) * sL[gi * T + qi];
+      const float ds = p * (dp - sD[gi * T + qi]) * scale;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { dk[e] += ds * qb[qi * E + e]; dv[e] += p * ob[qi * E + e]; }
+    }
+#pragma unroll
+    for (int c = 0; c < E / 4; ++c) {
+      *reinterpret_cast<float4*>(dqkv + myrow * ld + He + h * E + 4 * c) = make_float4(dk[4 * c], dk[4 * c + 1], dk[4 * c + 2], dk[4 * c + 3]);
+      *reinterpret_cast<float4*>(dqkv + myrow * ld + 2 * He + h * E + 4 * c) = make_float4(dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ positional-embedding gradients
+// d_pos0[n][e] = sum_{tile,l} dx[(tile,n,l)][e];  d_pos1[l][e] = sum_{tile,n} dx[(tile,n,l)][e]
+__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dx, float* __restrict__ d0,
+                                                       float* __restrict__ d1, int tiles, int gn, int gl, int E) {
+  // blockIdx.x < gn : row n of d0 ; else row l of d1.  thread = column(s)
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float s = 0.f;
+    if (b < gn) {
+      for (int tl = 0; tl < tiles; ++tl)
+        for (int l = 0; l < gl; ++l) s += dx[(((size_t)tl * gn + b) * gl + l) * E + e];
+      d0[(size_t)b * E + e] = s;
+    } else {
+      const int l = b - gn;
+      for (int tl = 0; tl < tiles; ++tl)
+        for (int n = 0; n < gn; ++n) s += dx[(((size_t)tl * gn + n) * gl + l) * E + e];
+      d1[(size_t)l * E + e] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm (training) backward
+// logits = (raw - mean) * rstd ;  part A: per column sums  sdl[c] = sum dl, sdx[c] = sum dl*xhat (fixed order)
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ logits, const float* __restrict__ dl,
+                                                           int64_t rows, int C1, float* __restrict__ sdl, float* __restrict__ sdx) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) {
+    const double g = dl[r * C1 + c];
+    a += g;
+    b += g * (double)logits[r * C1 + c];
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const double ta = red[0];
+  __syncthreads();
+  red[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) { sdl[c] = (float)ta; sdx[c] = (float)red[0]; }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ logits, const float* __restrict__ dl,
+                                                           const float* __restrict__ var_b, const float* __restrict__ sdl,
+                                                           const float* __restrict__ sdx, float* __restrict__ draw, int ldo,
+                                                           int64_t total, int C1, float eps, float inv_rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C1);
+  const int64_t r = i / C1;
+  const float rstd = 1.f / sqrtf(var_b[c] + eps);
+  draw[r * ldo + c] = rstd * (dl[i] - sdl[c] * inv_rows - logits[i] * sdx[c] * inv_rows);
+}
+// y = a*x + b*y  (running-statistics update of BatchNorm1d, momentum 0.1)
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, int n, float a, float b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] + b * y[i];
+}
+// per-block column partial sums (deterministic colsum): part[blk][D]
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, float* __restrict__ part, int64_t rows,
+                                                          int D, int ld, int rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
+    part[(size_t)blockIdx.x * D + c] = s;
+  }
+}
+
+// d_text from d_dirs: dirs = v/|v|, v = text[src] - nc  (selector_model.py:44-59)
+__global__ __launch_bounds__(256) void text_dirs_bwd_kernel(const float* __restrict__ text, const float* __restrict__ nc,
+                                                            const float* __restrict__ ddirs, float* __restrict__ dtext,
+                                                            int C, int D, int normal_id) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;              // row of text (0..C-1)
+  if (row == normal_id) {
+    for (int e = threadIdx.x; e < D; e += 256) dtext[(size_t)row * D + e] = 0.f;
+    return;
+  }
+  const int c = row < normal_id ? row : row - 1;
+  float ss = 0.f, dot = 0.f;
+  for (int e = threadIdx.x; e < D; e += 256) {
+    const float v = text[(size_t)row * D + e] - nc[e];
+    ss += v * v;
+    dot += v * ddirs[(size_t)c * D + e];
+  }
+  const float tss = block_sum(ss, red);
+  const float tdot = block_sum(dot, red);
+  const float norm = sqrtf(tss);
+  for (int e = threadIdx.x; e < D; e += 256) {
+    const float v = text[(size_t)row * D + e] - nc[e];
+    dtext[(size_t)row * D + e] = (ddirs[(size_t)c * D + e] - v * tdot / tss) / norm;
+  }
+}
+
+// ------------------------------------------------------------------ MIL top-k / bottom-k selection
+// one block per video.  seg[n][c] = sum_l logits[(v,n,l)][c]; masked to -/+1e6; abnormal half: own-class
+// column; normal half: sum over classes; k largest / smallest, ties -> lower index first.
+__global__ __launch_bounds__(256) void select_idx_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ mask_top, const float* __restrict__ mask_bot,
+                                                         int64_t* __restrict__ idx_top, int64_t* __restrict__ idx_bot,
+                                                         int B, int N, int Lg, int C1, int normal_id, int ktop, int kbot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* seg = reinterpret_cast<float*>(smem);       // [N][C1]
+  float* keyt = seg + N * C1;                        // [N]
+  float* keyb = keyt + N;                            // [N]
+  const int v = blockIdx.x;
+  for (int i = threadIdx.x; i < N * C1; i += 256) {
+    const int n = i / C1, c = i - n * C1;
+    float s = 0.f;
+    for (int l = 0; l < Lg; ++l) s += logits[(((size_t)v * N + n) * Lg + l) * C1 + c];   // torch.sum over dim 2, in order
+    seg[i] = s;
+  }
+  __syncthreads();
+  const bool abn = v < B / 2;
+  int col = 0;
+  if (abn) {
+    const int64_t lab = labels[v];
+    col = (int)(lab > normal_id ? lab - 1 : lab);
+  }
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float vt, vb;
+    if (abn) {
+      vt = mask_top[v * N + n] == 0.f ? -1e6f : seg[n * C1 + col];
+      vb = mask_bot[v * N + n] == 0.f ? 1e6f : seg[n * C1 + col];
+    } else {   // masked values are summed over the classes too (selector_model.py:127-130,152-153)
+      float st = 0.f, sb = 0.f;
+      const bool mt = mask_top[v * N + n] == 0.f, mb = mask_bot[v * N + n] == 0.f;
+      for (int c = 0; c < C1; ++c) {
+        st += mt ? -1e6f : seg[n * C1 + c];
+        sb += mb ? 1e6f : seg[n * C1 + c];
+      }
+      vt = st; vb = sb;
+    }
+    keyt[n] = vt;
+    keyb[n] = vb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < ktop; ++k) {
+      int best = -1;
+      for (int n = 0; n < N; ++n) {
+        bool used = false;
+        for (int j = 0; j < k; ++j) used |= idx_top[v * ktop + j] == n;
+        if (!used && (best < 0 || keyt[n] > keyt[best])) best = n;
+      }
+      idx_top[v * ktop + k] = best;
+    }
+    for (int k = 0; k < kbot; ++k) {
+      int best = -1;
+      for (int n = 0; n < N; ++n) {
+        bool used = false;
+        for (int j = 0; j < k; ++j) used |= idx_bot[v * kbot + j] == n;
+        if (!used && (best < 0 || keyb[n] < keyb[best])) best = n;
+      }
+      idx_bot[v * kbot + k] = best;
+    }
+  }
+}
+
+// out[(v*K + k)*Lg + l][:] = logits[(v, idx[v][k], l)][:]      (selector_model.py:160-225)
+__global__ __launch_bounds__(256) void gather_segments_kernel(const float* __restrict__ logits, const int64_t* __restrict__ idx,
+                                                              float* __restrict__ out, int64_t total, int N, int Lg, int C1, int K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C1);
+  const int64_t r = i / C1;
+  const int l = (int)(r % Lg);
+  const int64_t vk = r / Lg;
+  const int64_t v = vk / K;
+  const int64_t n = idx[vk];
+  out[i] = logits[(((size_t)v * N + n) * Lg + l) * C1 + c];
+}
+// dlogits[(v, idx[v][k], l)][:] += dout[(v*K+k)*Lg + l][:]    (segments of one video are distinct)
+__global__ __launch_bounds__(256) void scatter_segments_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ dlogits, int64_t total, int N, int Lg, int C1, int K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C1);
+  const int64_t r = i / C1;
+  const int l = (int)(r % Lg);
+  const int64_t vk = r / Lg;
+  const int64_t v = vk / K;
+  const int64_t n = idx[vk];
+  dlogits[(((size_t)v * N + n) * Lg + l) * C1 + c] += dout[i];
+}
+
+// ------------------------------------------------------------------ MIL loss forward + backward (loss.py:51-195)
+struct LossArgs {
+  const float* sim; const float* sim_topk; const int64_t* labels; const float* scores;
+  const int64_t* idx_topk_abn; const int64_t* idx_topk_nor; const int64_t* idx_bottomk_abn;
+  float* dsim; float* dsim_topk; float* dscores; float* part;
+  int B, N, Lg, C1, K, normal_id;
+  float l_dir_abn, l_dir_nor, l_topk_abn, l_bottomk_abn, l_topk_nor, l_smooth, l_sparse;
+  const float* gout_ptr;   // device scalar: upstream gradient of the total cost (NULL -> 1)
+};
+// thread per frame row; block partial sums of the 7 terms -> part[blk][8]
+__global__ __launch_bounds__(256) void loss_rows_kernel(const LossArgs a) {
+  __shared__ float red[4];
+  const int64_t R = (int64_t)a.B * a.N * a.Lg;
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float gout = a.gout_ptr ? a.gout_ptr[0] : 1.f;
+  float t_dir_nor = 0.f, t_topk_abn = 0.f, t_bot_abn = 0.f, t_topk_nor = 0.f, t_smooth = 0.f, t_sparse = 0.f;
+  if (r < R) {
+    const int C1 = a.C1;
+    const int64_t per = (int64_t)a.N * a.Lg;
+    const int v = (int)(r / per);
+    const int n = (int)((r / a.Lg) % a.N);
+    const bool abn = v < a.B / 2;
+    const float* s = a.sim + r * C1;
+    const float sc = a.scores[r];
+    float ds = 0.f;
+    float* dsim = a.dsim + r * C1;       // this thread owns row r of the gradient
+    for (int c = 0; c < C1; ++c) dsim[c] = 0.f;
+    const float cntK = (float)((int64_t)(a.B / 2) * a.K * a.Lg);
+    if (abn) {
+      const int64_t lab = a.labels[v];
+      const int y = (int)(lab > a.normal_id ? lab - 1 : lab);
+      bool in_top = false, in_bot = false;
+      for (int k = 0; k < a.K; ++k) {
+        in_top |= a.idx_topk_abn[v * a.K + k] == n;
+        in_bot |= a.idx_bottomk_abn[v * a.K + k] == n;
+      }
+      if (in_top) {   // NLL(log(softmax(sim)[y] * score))
+        float mx = -INFINITY;
+        for (int c = 0; c < C1; ++c) mx = fmaxf(mx, s[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C1; ++c) sum += expf(s[c] - mx);
+        const float py = expf(s[y] - mx) / sum;
+        t_topk_abn = -logf(py * sc);
+        const float w = a.l_topk_abn / cntK * gout;
+        for (int c = 0; c < C1; ++c) dsim[c] += w * (expf(s[c] - mx) / sum - (c == y ? 1.f : 0.f));
+        ds += -w / sc;
+      }
+      if (in_bot) {   // NLL(log(1 - score))
+        t_bot_abn = -logf(1.f - sc);
+        ds += a.l_bottomk_abn / cntK * gout / (1.f - sc);
+      }
+      // smoothness over the FLATTENED abnormal scores (crosses video boundaries) + sparsity
+      const int64_t Ta = (int64_t)(a.B / 2) * per;
+      float g = 0.f;
+      if (r + 1 < Ta) { const float d1 = a.scores[r + 1] - sc; t_smooth = d1 * d1; g -= 2.f * d1; }
+      if (r > 0) { g += 2.f * (sc - a.scores[r - 1]); }
+      ds += a.l_smooth * gout * g;
+      t_sparse = sc;
+      ds += a.l_sparse * gout / (float)Ta;
+    } else {
+      const int vn = v - a.B / 2;
+      // max over directions, mean over normal frames
+      int am = 0;
+      for (int c = 1; c < C1; ++c) if (s[c] > s[am]) am = c;
+      t_dir_nor = s[am];
+      dsim[am] += a.l_dir_nor * gout / (float)((int64_t)(a.B - a.B / 2) * per);
+      bool in_top = false;
+      for (int k = 0; k < a.K; ++k) in_top |= a.idx_topk_nor[vn * a.K + k] == n;
+      if (in_top) {
+        t_topk_nor = -logf(1.f - sc);
+        ds += a.l_topk_nor / (float)((int64_t)(a.B - a.B / 2) * a.K * a.Lg) * gout / (1.f - sc);
+      }
+    }
+    a.dscores[r] = ds;
+  }
+  float vals[6] = {t_dir_nor, t_topk_abn, t_bot_abn, t_topk_nor, t_smooth, t_sparse};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float tot = block_sum(vals[k], red);
+    if (threadIdx.x == 0) a.part[(size_t)blockIdx.x * 8 + k] = tot;
+  }
+}
+// thread per row of sim_topk (abnormal part only contributes): ldir_abn = -mean(own-class logit)
+__global__ __launch_bounds__(256) void loss_topk_kernel(const LossArgs a, float* __restrict__ part2) {
+  __shared__ float red[4];
+  const int64_t RT = (int64_t)a.B * a.K * a.Lg;
+  const int64_t RA = (int64_t)(a.B / 2) * a.K * a.Lg;
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float gout = a.gout_ptr ? a.gout_ptr[0] : 1.f;
+  float t = 0.f;
+  if (r < RT) {
+    for (int c = 0; c < a.C1; ++c) a.dsim_topk[r * a.C1 + c] = 0.f;
+    if (r < RA) {
+      const int v = (int)(r / ((int64_t)a.K * a.Lg));
+      const int64_t lab = a.labels[v];
+      const int y = (int)(lab > a.normal_id ? lab - 1 : lab);
+      t = a.sim_topk[r * a.C1 + y];
+      a.dsim_topk[r * a.C1 + y] = -a.l_dir_abn * gout / (float)RA;
+    }
+  }
+  const float tot = block_sum(t, red);
+  if (threadIdx.x == 0) part2[blockIdx.x] = tot;
+}
+// final: losses[8] = (cost, ldir_abn, ldir_nor, ltopk_abn, lbottomk_abn, ltopk_nor, lsmooth, lsparse)
+__global__ void loss_final_kernel(const LossArgs a, const float* __restrict__ part, int nparts, const float* __restrict__ part2,
+                                  int nparts2, float* __restrict__ losses) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double t[6] = {0, 0, 0, 0, 0, 0}, d = 0;
+  for (int p = 0; p < nparts; ++p)
+    for (int k = 0; k < 6; ++k) t[k] += part[(size_t)p * 8 + k];
+  for (int p = 0; p < nparts2; ++p) d += part2[p];
+  const double per = (double)a.N * a.Lg, Bh = a.B / 2, Bn = a.B - a.B / 2;
+  const float ldir_abn = (float)(-a.l_dir_abn * d / (Bh * a.K * a.Lg));
+  const float ldir_nor = (float)(a.l_dir_nor * t[0] / (Bn * per));
+  const float ltopk_abn = (float)(a.l_topk_abn * t[1] / (Bh * a.K * a.Lg));
+  const float lbot_abn = (float)(a.l_bottomk_abn * t[2] / (Bh * a.K * a.Lg));
+  const float ltopk_nor = (float)(a.l_topk_nor * t[3] / (Bn * a.K * a.Lg));
+  const float lsmooth = (float)(a.l_smooth * t[4]);
+  const float lsparse = (float)(a.l_sparse * t[5] / (Bh * per));
+  losses[1] = ldir_abn; losses[2] = ldir_nor; losses[3] = ltopk_abn; losses[4] = lbot_abn;
+  losses[5] = ltopk_nor; losses[6] = lsmooth; losses[7] = lsparse;
+  losses[0] = ldir_abn + ldir_nor + ltopk_abn + lbot_abn + ltopk_nor + lsmooth + lsparse;
+}
+
+// ------------------------------------------------------------------ AdamW (torch.optim.AdamW, no amsgrad)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float pi = p[i];
+  const float gi = g[i];
+  pi *= 1.f - lr * wd;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+// d_ctx[c][t][:] = dx[c][1+t][:]  (or summed over classes when the context is shared)  (coop.py:74-90)
+__global__ __launch_bounds__(256) void ctx_grad_kernel(const float* __restrict__ dx, float* __restrict__ dctx, int C, int n_ctx,
+                                                       int Lc, int W, int shared_ctx) {
+  const int64_t total = (int64_t)(shared_ctx ? 1 : C) * n_ctx * W;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int w = (int)(i % W);
+  const int tk = (int)((i / W) % n_ctx);
+  const int c = (int)(i / ((int64_t)W * n_ctx));
+  if (!shared_ctx) { dctx[i] = dx[((size_t)c * Lc + 1 + tk) * W + w]; return; }
+  float s = 0.f;
+  for (int cc = 0; cc < C; ++cc) s += dx[((size_t)cc * Lc + 1 + tk) * W + w];
+  dctx[i] = s;
+}
+
+// out[idx[i], :] = src[i, :]  into a zero-filled [rows, W] buffer (backward of acx_gather_rows; idx distinct)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ out, int64_t total4, int W) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int W4 = W / 4;
+  const int64_t r = i / W4;
+  const int w4 = (int)(i - r * W4);
+  *reinterpret_cast<float4*>(out + idx[r] * W + 4 * w4) = *reinterpret_cast<const float4*>(src + r * W + 4 * w4);
+}
+
+}  // namespace
+
+#define COMMA ,
+#define DISPATCH_VPL(D, CALL)                          \
+  switch ((D) / 64) {                                  \
+    case 1: { constexpr int V = 1; CALL; } break;      \
+    case 2: { constexpr int V = 2; CALL; } break;      \
+    case 4: { constexpr int V = 4; CALL; } break;      \
+    case 8: { constexpr int V = 8; CALL; } break;      \
+    case 12: { constexpr int V = 12; CALL; } break;    \
+    case 16: { constexpr int V = 16; CALL; } break;    \
+    default: return acx_fail(ctx, ACX_E_UNSUPPORTED, "row width %s%ld not in {64,128,256,512,768,1024}", "", (long)(D)); \
+  }
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256))
+
+extern "C" int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int32_t nparts, int32_t width, void* stream) {
+  if (!part || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_reduce_rows: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(reduce_rows_kernel, GRID1(width), dim3(256), 0, (hipStream_t)stream, part, out, nparts, width);
+  ACX_CHECK_LAUNCH(ctx, "acx_reduce_rows");
+  return ACX_OK;
+}
+
+extern "C" int acx_layernorm_bwd(acx_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* part,
+                                 int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, void* stream) {
+  if (!x || !w || !dy) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm_bwd: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_NORM, s);
+  const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+  DISPATCH_VPL(D, layernorm_bwd_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x, w, dy, dx, part, rows, eps, mode, dx_scale));
+  ACX_CHECK_LAUNCH(ctx, "acx_layernorm_bwd");
+  return ACX_OK;
+}
+
+extern "C" int acx_cls_head_bwd(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w, const float* ln_b,
+                                const float* lin_w, const float* scores, const float* dscores, float* dx, float* part,
+                                int64_t rows, int32_t E, void* stream) {
+  if (!x1 || !x2 || !ln_w || !ln_b || !lin_w || !scores || !dscores || !dx || !part)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_cls_head_bwd: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_NORM, s);
+  const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+  DISPATCH_VPL(E, cls_head_bwd_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, scores, dscores, dx, part, rows));
+  ACX_CHECK_LAUNCH(ctx, "acx_cls_head_bwd");
+  return ACX_OK;
+}
+
+extern "C" int acx_act(acx_ctx* ctx, const float* saved, const float* d, float* out, int64_t n, int32_t mode, void* stream) {
+  if (!saved || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_act: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  if (n % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_act: n%%4%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(act_kernel, GRID1(n / 4), dim3(256), 0, (hipStream_t)stream, saved, d, out, n / 4, mode);
+  ACX_CHECK_LAUNCH(ctx, "acx_act");
+  return ACX_OK;
+}
+
+extern "C" int acx_add(acx_ctx* ctx, const float* a, const float* b, float* out, int64_t n, void* stream) {
+  if (!a || !b || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_add: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  if (n % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_add: n%%4%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(add_kernel, GRID1(n / 4), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
+  ACX_CHECK_LAUNCH(ctx, "acx_add");
+  return ACX_OK;
+}
+
+extern "C" int acx_transpose(acx_ctx* ctx, const float* in, float* out, int32_t R, int32_t Cn, void* stream) {
+  if (!in || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_transpose: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(transpose_kernel, dim3((Cn + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, Cn);
+  ACX_CHECK_LAUNCH(ctx, "acx_transpose");
+  return ACX_OK;
+}
+
+extern "C" int acx_conv_weight_dx(acx_ctx* ctx, const float* w, float* out, int32_t Cout, int32_t Cin, void* stream) {
+  if (!w || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_conv_weight_dx: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  hipLaunchKernelGGL(conv_w_dx_kernel, GRID1(total), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin);
+  ACX_CHECK_LAUNCH(ctx, "acx_conv_weight_dx");
+  return ACX_OK;
+}
+
+extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int32_t tiles, int32_t gn,
+                                     int32_t gl, int32_t heads, int32_t e, int32_t axis, int32_t causal, void* stream) {
+  if (!qkv || !dout || !dqkv) return acx_fail(ctx, ACX_E_BADARG, "acx_seq_attention_bwd: null pointer%s");
+  if (tiles <= 0) return ACX_OK;
+  const int T = axis == 0 ? gn : gl;
+  if (T <= 0 || T > 256 || (e != 16 && e != 32 && e != 64))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_seq_attention_bwd: need sequence <= 256, head dim in {16,32,64}%s");
+  const int64_t nlines = (int64_t)tiles * (axis == 0 ? gl : gn);
+  const int64_t ngroups = nlines * heads;
+  int gpb = 256 / T;
+  while (gpb > 1 && (size_t)gpb * T * (2 * e + 3) * 4 > 96 * 1024) --gpb;
+  const size_t lds = (size_t)gpb * T * (2 * e + 3) * 4;
+  if (lds > 160 * 1024) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_seq_attention_bwd: sequence too long for LDS%s");
+  const float scale = 1.f / sqrtf((float)e);
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_ATTN, s);
+  const dim3 grid((unsigned)((ngroups + gpb - 1) / gpb)), block(256);
+#define ACX_SAB(EE)                                                                                          \
+  do {                                                                                                       \
+    (void)hipFuncSetAttribute((const void*)seq_attn_bwd_kernel<EE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((seq_attn_bwd_kernel<EE>), grid, block, lds, s, qkv, dout, dqkv, tiles, gn, gl, heads, axis, causal, \
+                       scale, T, gpb, ngroups);                                                              \
+  } while (0)
+  if (e == 16) ACX_SAB(16); else if (e == 32) ACX_SAB(32); else ACX_SAB(64);
+#undef ACX_SAB
+  ACX_CHECK_LAUNCH(ctx, "acx_seq_attention_bwd");
+  return ACX_OK;
+}
+
+extern "C" int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, int32_t tiles, int32_t gn, int32_t gl,
+                            int32_t E, void* stream) {
+  if (!dx || !d0 || !d1) return acx_fail(ctx, ACX_E_BADARG, "acx_pos_grad: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(pos_grad_kernel, dim3(gn + gl), dim3(256), 0, (hipStream_t)stream, dx, d0, d1, tiles, gn, gl, E);
+  ACX_CHECK_LAUNCH(ctx, "acx_pos_grad");
+  return ACX_OK;
+}
+
+extern "C" int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* dlogits, float* sums /* [2*C1] */,
+                                int64_t rows, int32_t C1, void* stream) {
+  if (!logits || !dlogits || !sums) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_stats: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C1), dim3(256), 0, s, logits, dlogits, rows, C1, sums, sums + C1);
+  ACX_CHECK_LAUNCH(ctx, "acx_bn_bwd_stats");
+  return ACX_OK;
+}
+
+extern "C" int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* dlogits, const float* var_biased,
+                                const float* sums, float* draw, int32_t ldo, int64_t rows, int64_t total_rows, int32_t C1,
+                                float eps, void* stream) {
+  if (!logits || !dlogits || !var_biased || !sums || !draw) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_apply: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+  const int64_t total = rows * C1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, GRID1(total), dim3(256), 0, s, logits, dlogits, var_biased, sums, sums + C1, draw, ldo,
+                     total, C1, eps, 1.f / (float)total_rows);
+  ACX_CHECK_LAUNCH(ctx, "acx_bn_bwd_apply");
+  return ACX_OK;
+}
+
+extern "C" int acx_axpby(acx_ctx* ctx, const float* x, float* y, int32_t n, float a, float b, void* stream) {
+  if (!x || !y) return acx_fail(ctx, ACX_E_BADARG, "acx_axpby: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b);
+  ACX_CHECK_LAUNCH(ctx, "acx_axpby");
+  return ACX_OK;
+}
+
+extern "C" int acx_colsum_partials(acx_ctx* ctx, const float* x, int32_t ld, float* part, int64_t rows, int32_t D,
+                                   int32_t rows_per_block, void* stream) {
+  if (!x || !part) return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_partials: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const unsigned nb = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, rows, D, ld, rows_per_block);
+  ACX_CHECK_LAUNCH(ctx, "acx_colsum_partials");
+  return ACX_OK;
+}
+
+extern "C" int acx_text_directions_bwd(acx_ctx* ctx, const float* text, const float* ncentroid, const float* ddirs, float* dtext,
+                                       int32_t C, int32_t D, int32_t normal_id, void* stream) {
+  if (!text || !ncentroid || !ddirs || !dtext) return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions_bwd: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(text_dirs_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, text, ncentroid, ddirs, dtext, C, D, normal_id);
+  ACX_CHECK_LAUNCH(ctx, "acx_text_directions_bwd");
+  return ACX_OK;
+}
+
+extern "C" int acx_select_idx(acx_ctx* ctx, const float* logits, const int64_t* labels, const float* mask_top,
+                              const float* mask_bot, int64_t* idx_top, int64_t* idx_bot, int32_t B, int32_t N, int32_t Lg,
+                              int32_t C1, int32_t normal_id, int32_t ktop, int32_t kbot, void* stream) {
+  if (!logits || !labels || !mask_top || !mask_bot || !idx_top || !idx_bot) return acx_fail(ctx, ACX_E_BADARG, "acx_select_idx: null pointer%s");
+  if (B <= 0 || B % 2 || ktop > N || kbot > N) return acx_fail(ctx, ACX_E_BADARG, "acx_select_idx: need even B and k <= N%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const size_t lds = (size_t)(N * C1 + 2 * N) * 4;
+  hipLaunchKernelGGL(select_idx_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logits, labels, mask_top, mask_bot, idx_top,
+                     idx_bot, B, N, Lg, C1, normal_id, ktop, kbot);
+  ACX_CHECK_LAUNCH(ctx, "acx_select_idx");
+  return ACX_OK;
+}
+
+extern "C" int acx_gather_segments(acx_ctx* ctx, const float* logits, const int64_t* idx, float* out, int32_t B, int32_t N,
+                                   int32_t Lg, int32_t C1, int32_t K, void* stream) {
+  if (!logits || !idx || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_gather_segments: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const int64_t total = (int64_t)B * K * Lg * C1;
+  hipLaunchKernelGGL(gather_segments_kernel, GRID1(total), dim3(256), 0, (hipStream_t)stream, logits, idx, out, total, N, Lg, C1, K);
+  ACX_CHECK_LAUNCH(ctx, "acx_gather_segments");
+  return ACX_OK;
+}
+
+extern "C" int acx_scatter_segments(acx_ctx* ctx, const float* dout, const int64_t* idx, float* dlogits, int32_t B, int32_t N,
+                                    int32_t Lg, int32_t C1, int32_t K, void* stream) {
+  if (!dout || !idx || !dlogits) return acx_fail(ctx, ACX_E_BADARG, "acx_scatter_segments: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const int64_t total = (int64_t)B * K * Lg * C1;
+  hipLaunchKernelGGL(scatter_segments_kernel, GRID1(total), dim3(256), 0, (hipStream_t)stream, dout, idx, dlogits, total, N, Lg, C1, K);
+  ACX_CHECK_LAUNCH(ctx, "acx_scatter_segments");
+  return ACX_OK;
+}
+
+extern "C" int acx_mil_loss(acx_ctx* ctx, const float* sim, const float* sim_topk, const int64_t* labels, const float* scores,
+                            const int64_t* idx_topk_abn, const int64_t* idx_topk_nor, const int64_t* idx_bottomk_abn,
+                            float* dsim, float* dsim_topk, float* dscores, float* losses, float* workspace,
+                            size_t workspace_floats, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K, int32_t normal_id,
+                            const float* lambdas /* [7] */, const float* gout, void* stream) {
+  if (!sim || !sim_topk || !labels || !scores || !idx_topk_abn || !idx_topk_nor || !idx_bottomk_abn || !dsim || !dsim_topk ||
+      !dscores || !losses || !workspace || !lambdas)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_mil_loss: null pointer%s");
+  if (B <= 0 || B % 2 || C1 > 64) return acx_fail(ctx, ACX_E_BADARG, "acx_mil_loss: need even B, C-1 <= 64%s");
+  const int64_t R = (int64_t)B * N * Lg, RT = (int64_t)B * K * Lg;
+  const int np1 = (int)((R + 255) / 256), np2 = (int)((RT + 255) / 256);
+  if ((size_t)np1 * 8 + np2 > workspace_floats) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_mil_loss: workspace too small%s");
+  LossArgs a;
+  a.sim = sim; a.sim_topk = sim_topk; a.labels = labels; a.scores = scores;
+  a.idx_topk_abn = idx_topk_abn; a.idx_topk_nor = idx_topk_nor; a.idx_bottomk_abn = idx_bottomk_abn;
+  a.dsim = dsim; a.dsim_topk = dsim_topk; a.dscores = dscores; a.part = workspace;
+  a.B = B; a.N = N; a.Lg = Lg; a.C1 = C1; a.K = K; a.normal_id = normal_id;
+  a.l_dir_abn = lambdas[0]; a.l_dir_nor = lambdas[1]; a.l_topk_abn = lambdas[2]; a.l_bottomk_abn = lambdas[3];
+  a.l_topk_nor = lambdas[4]; a.l_smooth = lambdas[5]; a.l_sparse = lambdas[6];
+  a.gout_ptr = gout;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+  float* part2 = workspace + (size_t)np1 * 8;
+  hipLaunchKernelGGL(loss_rows_kernel, dim3(np1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(loss_topk_kernel, dim3(np2), dim3(256), 0, s, a, part2);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, a, (const float*)workspace, np1, (const float*)part2, np2, losses);
+  ACX_CHECK_LAUNCH(ctx, "acx_mil_loss");
+  return ACX_OK;
+}
+
+extern "C" int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  if (!p || !g || !m || !v) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  if (step <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw: step starts at 1%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, GRID1(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     bc1, bc2s);
+  ACX_CHECK_LAUNCH(ctx, "acx_adamw");
+  return ACX_OK;
+}
+
+extern "C" int acx_ctx_grad(acx_ctx* ctx, const float* dx, float* dctx, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
+                            int32_t shared_ctx, void* stream) {
+  if (!dx || !dctx) return acx_fail(ctx, ACX_E_BADARG, "acx_ctx_grad: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const int64_t total = (int64_t)(shared_ctx ? 1 : C) * n_ctx * W;
+  hipLaunchKernelGGL(ctx_grad_kernel, GRID1(total), dim3(256), 0, (hipStream_t)stream, dx, dctx, C, n_ctx, Lc, W, shared_ctx);
+  ACX_CHECK_LAUNCH(ctx, "acx_ctx_grad");
+  return ACX_OK;
+}
+
+extern "C" int acx_scatter_rows(acx_ctx* ctx, const float* src, const int64_t* idx, float* out, int64_t n, int32_t W, void* stream) {
+  if (!src || !idx || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_scatter_rows: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  if (W % 4) return acx_fail(ctx, ACX_E_BADARG, "acx_scatter_rows: W%%4%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  const int64_t total4 = n * W / 4;
+  hipLaunchKernelGGL(scatter_rows_kernel, GRID1(total4), dim3(256), 0, (hipStream_t)stream, src, idx, out, total4, W);
+  ACX_CHECK_LAUNCH(ctx, "acx_scatter_rows");
+  return ACX_OK;
+}

@@ -12,6 +12,11 @@ from . import _lib as L
 
 _BF16 = torch.bfloat16
 
+# bumped by every in-place parameter update done through raw pointers (AcxAdamW): derived-weight caches
+# (bf16 copies, transposes, conv layouts) include it in their keys because such writes do not touch
+# torch's tensor version counters.
+WEIGHT_EPOCH = [0]
+
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
@@ -201,4 +206,224 @@ def concat_features(logits: torch.Tensor, x: torch.Tensor, ncentroid: torch.Tens
     h = _h(x)
     L.check(L.lib().acx_concat_features(h, logits.data_ptr(), x.data_ptr(), ncentroid.data_ptr(), out.data_ptr(), rows, C1,
                                         D, Kp, _stream()), h)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# training-side wrappers
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, b_sub=None, conv=False, gn=0, gl=0, cin=0, N2: Optional[int] = None) -> torch.Tensor:
+    """C[N1,N2] = sum_m a[m,n1] * bmap(b)[m,n2]  (weight gradient dW = dY^T X)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.is_contiguous() and b.is_contiguous() and a.shape[0] == b.shape[0]
+    M, N1 = a.shape
+    if N2 is None:
+        N2 = 9 * cin if conv else b.shape[1]
+    out = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
+    lib = L.lib()
+    nbytes = lib.acx_gemm_tn_workspace_bytes(M, N1, N2)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=a.device)
+    h = _h(a)
+    L.check(lib.acx_gemm_tn(h, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N2, M, N1, N2, _ptr(b_sub),
+                            int(conv), gn, gl, cin, ws.data_ptr(), ws.numel(), _stream()), h)
+    return out
+
+
+def reduce_rows(part: torch.Tensor) -> torch.Tensor:
+    nparts, width = part.shape
+    out = torch.empty(width, dtype=torch.float32, device=part.device)
+    h = _h(part)
+    L.check(L.lib().acx_reduce_rows(h, part.data_ptr(), out.data_ptr(), nparts, width, _stream()), h)
+    return out
+
+
+def layernorm_bwd(x, w, dy, *, eps=1e-5, mode=L.NORM_LAYER, need_dx=True, need_params=True, dx_scale=1.0):
+    """returns (dx or None, dw or None, db or None)."""
+    D = w.numel()
+    x = x.reshape(-1, D)
+    dy = dy.reshape(-1, D)
+    assert x.is_contiguous() and dy.is_contiguous()
+    rows = x.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    part = torch.empty((rows + 63) // 64, 2 * D, dtype=torch.float32, device=x.device) if need_params else None
+    h = _h(x)
+    L.check(L.lib().acx_layernorm_bwd(h, x.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(part), rows, D, eps, mode,
+                                      dx_scale, _stream()), h)
+    if need_params:
+        s = reduce_rows(part)
+        return dx, s[:D], s[D:]
+    return dx, None, None
+
+
+def cls_head_bwd(x1, x2, ln_w, ln_b, lin_w, scores, dscores):
+    rows, E = x1.shape
+    dx = torch.empty_like(x1)
+    PW = 3 * E + 4
+    part = torch.empty((rows + 63) // 64, PW, dtype=torch.float32, device=x1.device)
+    h = _h(x1)
+    L.check(L.lib().acx_cls_head_bwd(h, x1.data_ptr(), x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), lin_w.data_ptr(),
+                                     scores.data_ptr(), dscores.data_ptr(), dx.data_ptr(), part.data_ptr(), rows, E, _stream()), h)
+    s = reduce_rows(part)
+    return dx, s[:E], s[E:2 * E], s[2 * E:3 * E], s[3 * E:3 * E + 1]
+
+
+def act(saved: torch.Tensor, d: Optional[torch.Tensor], mode: int) -> torch.Tensor:
+    out = torch.empty_like(saved)
+    h = _h(saved)
+    L.check(L.lib().acx_act(h, saved.data_ptr(), _ptr(d), out.data_ptr(), saved.numel(), mode, _stream()), h)
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    out = torch.empty_like(a)
+    h = _h(a)
+    L.check(L.lib().acx_add(h, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), h)
+    return out
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    assert x.dim() == 2 and x.is_contiguous()
+    out = torch.empty(x.shape[1], x.shape[0], dtype=torch.float32, device=x.device)
+    h = _h(x)
+    L.check(L.lib().acx_transpose(h, x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _stream()), h)
+    return out
+
+
+def conv_weight_dx(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [Cin, 9*Cout] (flipped taps) for the dX implicit GEMM."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    out = torch.empty(Cin, 9 * Cout, dtype=torch.float32, device=w.device)
+    h = _h(w)
+    L.check(L.lib().acx_conv_weight_dx(h, w.data_ptr(), out.data_ptr(), Cout, Cin, _stream()), h)
+    return out
+
+
+def seq_attention_bwd(qkv, dout, tiles, gn, gl, heads, e, axis, causal=False) -> torch.Tensor:
+    dqkv = torch.empty_like(qkv)
+    h = _h(qkv)
+    L.check(L.lib().acx_seq_attention_bwd(h, qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), tiles, gn, gl, heads, e, axis,
+                                          int(causal), _stream()), h)
+    return dqkv
+
+
+def pos_grad(dx, tiles, gn, gl):
+    E = dx.shape[1]
+    d0 = torch.empty(gn, E, dtype=torch.float32, device=dx.device)
+    d1 = torch.empty(gl, E, dtype=torch.float32, device=dx.device)
+    h = _h(dx)
+    L.check(L.lib().acx_pos_grad(h, dx.data_ptr(), d0.data_ptr(), d1.data_ptr(), tiles, gn, gl, E, _stream()), h)
+    return d0, d1
+
+
+def bn_bwd_stats(logits, dlogits) -> torch.Tensor:
+    rows, C1 = logits.shape
+    sums = torch.empty(2 * C1, dtype=torch.float32, device=logits.device)
+    h = _h(logits)
+    L.check(L.lib().acx_bn_bwd_stats(h, logits.data_ptr(), dlogits.data_ptr(), sums.data_ptr(), rows, C1, _stream()), h)
+    return sums
+
+
+def bn_bwd_apply(logits, dlogits, var_biased, sums, total_rows, eps=1e-5, pad_to: int = 4) -> torch.Tensor:
+    """returns draw padded to a multiple of `pad_to` columns (zero pad) so it can feed acx_gemm_tn."""
+    rows, C1 = logits.shape
+    C1p = (C1 + pad_to - 1) // pad_to * pad_to
+    draw = torch.zeros(rows, C1p, dtype=torch.float32, device=logits.device)
+    h = _h(logits)
+    L.check(L.lib().acx_bn_bwd_apply(h, logits.data_ptr(), dlogits.data_ptr(), var_biased.data_ptr(), sums.data_ptr(),
+                                     draw.data_ptr(), C1p, rows, total_rows, C1, eps, _stream()), h)
+    return draw
+
+
+def axpby_(y: torch.Tensor, x: torch.Tensor, a: float, b: float) -> None:
+    h = _h(y)
+    L.check(L.lib().acx_axpby(h, x.data_ptr(), y.data_ptr(), y.numel(), a, b, _stream()), h)
+
+
+def colsum(x: torch.Tensor, D: Optional[int] = None) -> torch.Tensor:
+    """deterministic column sums of x[rows, ld] (first D columns)."""
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, ld = x.shape
+    D = D or ld
+    rpb = 128
+    nb = (rows + rpb - 1) // rpb
+    part = torch.empty(nb, D, dtype=torch.float32, device=x.device)
+    h = _h(x)
+    L.check(L.lib().acx_colsum_partials(h, x.data_ptr(), ld, part.data_ptr(), rows, D, rpb, _stream()), h)
+    return reduce_rows(part)
+
+
+def text_directions_bwd(text, ncentroid, ddirs, normal_id) -> torch.Tensor:
+    Cc, D = text.shape
+    dtext = torch.empty_like(text)
+    h = _h(text)
+    L.check(L.lib().acx_text_directions_bwd(h, text.data_ptr(), ncentroid.data_ptr(), ddirs.data_ptr(), dtext.data_ptr(), Cc, D,
+                                            normal_id, _stream()), h)
+    return dtext
+
+
+def select_idx(logits, labels, mask_top, mask_bot, N, Lg, normal_id, ktop, kbot):
+    B = labels.shape[0]
+    C1 = logits.shape[-1]
+    it = torch.empty(B, ktop, dtype=torch.int64, device=logits.device)
+    ib = torch.empty(B, kbot, dtype=torch.int64, device=logits.device)
+    h = _h(logits)
+    L.check(L.lib().acx_select_idx(h, logits.data_ptr(), labels.data_ptr(), mask_top.data_ptr(), mask_bot.data_ptr(),
+                                   it.data_ptr(), ib.data_ptr(), B, N, Lg, C1, normal_id, ktop, kbot, _stream()), h)
+    return it, ib
+
+
+def gather_segments(logits, idx, N, Lg) -> torch.Tensor:
+    B, K = idx.shape
+    C1 = logits.shape[-1]
+    out = torch.empty(B * K * Lg, C1, dtype=torch.float32, device=logits.device)
+    h = _h(logits)
+    L.check(L.lib().acx_gather_segments(h, logits.data_ptr(), idx.data_ptr(), out.data_ptr(), B, N, Lg, C1, K, _stream()), h)
+    return out
+
+
+def scatter_segments_(dlogits, dout, idx, N, Lg) -> None:
+    B, K = idx.shape
+    C1 = dlogits.shape[-1]
+    h = _h(dlogits)
+    L.check(L.lib().acx_scatter_segments(h, dout.data_ptr(), idx.data_ptr(), dlogits.data_ptr(), B, N, Lg, C1, K, _stream()), h)
+
+
+def mil_loss(sim, sim_topk, labels, scores, idx_topk_abn, idx_topk_nor, idx_bottomk_abn, N, Lg, K, normal_id, lambdas,
+             gout: Optional[torch.Tensor] = None):
+    """returns (losses[8], dsim, dsim_topk, dscores)."""
+    import ctypes
+    B = labels.shape[0]
+    C1 = sim.shape[1]
+    dev = sim.device
+    dsim = torch.empty_like(sim)
+    dtopk = torch.empty_like(sim_topk)
+    dsc = torch.empty_like(scores)
+    losses = torch.empty(8, dtype=torch.float32, device=dev)
+    nws = (B * N * Lg + 255) // 256 * 8 + (B * K * Lg + 255) // 256
+    ws = torch.empty(nws, dtype=torch.float32, device=dev)
+    lam = (ctypes.c_float * 7)(*[float(x) for x in lambdas])
+    h = _h(sim)
+    L.check(L.lib().acx_mil_loss(h, sim.data_ptr(), sim_topk.data_ptr(), labels.data_ptr(), scores.data_ptr(),
+                                 idx_topk_abn.data_ptr(), idx_topk_nor.data_ptr(), idx_bottomk_abn.data_ptr(), dsim.data_ptr(),
+                                 dtopk.data_ptr(), dsc.data_ptr(), losses.data_ptr(), ws.data_ptr(), nws, B, N, Lg, C1, K,
+                                 normal_id, ctypes.cast(lam, ctypes.c_void_p), _ptr(gout), _stream()), h)
+    return losses, dsim, dtopk, dsc
+
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step) -> None:
+    h = _h(p)
+    L.check(L.lib().acx_adamw(h, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                              weight_decay, step, _stream()), h)
+
+
+def ctx_grad(dx, C, n_ctx, Lc, W, shared) -> torch.Tensor:
+    out = torch.empty((n_ctx, W) if shared else (C, n_ctx, W), dtype=torch.float32, device=dx.device)
+    h = _h(dx)
+    L.check(L.lib().acx_ctx_grad(h, dx.data_ptr(), out.data_ptr(), C, n_ctx, Lc, W, int(shared), _stream()), h)
+    return out
+
+
+def scatter_rows(src, idx, rows) -> torch.Tensor:
+    out = torch.zeros(rows, src.shape[1], dtype=torch.float32, device=src.device)
+    h = _h(src)
+    L.check(L.lib().acx_scatter_rows(h, src.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), src.shape[1], _stream()), h)
     return out

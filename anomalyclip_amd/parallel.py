@@ -1,0 +1,141 @@
+"""Data-parallel glue: one process per GPU, torch.distributed ("nccl" == RCCL on
+ROCm, "gloo" in the CPU tests).  The reference gets all of this implicitly from Lightning's
+`strategy: ddp` + `sync_batchnorm: True` (configs/trainer/ddp.yaml:4,9); here the exchange steps are
+explicit and sized for xGMI (point-to-point links, ~153 GB/s each):
+
+  * GradBuckets      -- the 10.4 M trainable fp32 values (41.7 MB at the UCF config) live in ONE flat
+                        buffer cut into a few large buckets in reverse-forward order; each bucket is
+                        all-reduced asynchronously as soon as its last gradient has been produced
+                        (overlaps with the remaining backward), averaged at finish().
+  * sync_bn_stats    -- SyncBatchNorm statistics of the selector's BatchNorm1d(C-1): one all_gather of
+                        (mean, M2, n) per rank, combined with Chan's parallel formula.
+  * all_reduce_sum_  -- backward sums of the same BatchNorm.
+  * shard_videos     -- contiguous, abnormal/normal-balanced split of a batch across ranks (the selector
+                        assumes the first half of the local batch is abnormal, selector_model.py:132-156).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size() -> int:
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if is_distributed() else 0
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def combine_bn_stats(means: torch.Tensor, m2s: torch.Tensor, counts: torch.Tensor):
+    """Chan et al. parallel variance: means/m2s [R, C], counts [R] -> (mean, var_biased, var_unbiased, n)."""
+    n = counts.sum()
+    w = (counts / n).unsqueeze(1)
+    mean = (means * w).sum(0)
+    m2 = (m2s + counts.unsqueeze(1) * (means - mean) ** 2).sum(0)
+    return mean, m2 / n, m2 / (n - 1).clamp(min=1), n
+
+
+def sync_bn_stats(mean: torch.Tensor, var_b: torch.Tensor, rows: int):
+    """Local (mean, biased var, rows) -> global (mean, var_biased, var_unbiased, total_rows)."""
+    C1 = mean.numel()
+    local = torch.cat([mean, var_b * rows, mean.new_tensor([float(rows)])])
+    gathered = [torch.empty_like(local) for _ in range(world_size())]
+    dist.all_gather(gathered, local)
+    g = torch.stack(gathered)
+    m, vb, vu, n = combine_bn_stats(g[:, :C1], g[:, C1:2 * C1], g[:, 2 * C1])
+    return m.contiguous(), vb.contiguous(), vu.contiguous(), int(round(float(n)))
+
+
+def shard_videos(batch: int, world: int, r: int) -> List[int]:
+    """Indices of the videos of a [abnormal..., normal...] batch that rank r processes, again ordered
+    [abnormal..., normal...]; every rank gets batch/(2*world) of each."""
+    half = batch // 2
+    if half % world:
+        raise ValueError(f"batch/2 = {half} videos per class is not divisible by world size {world}")
+    per = half // world
+    a = list(range(r * per, (r + 1) * per))
+    n = list(range(half + r * per, half + (r + 1) * per))
+    return a + n
+
+
+class GradBuckets:
+    """Flat gradient buffer + bucketed asynchronous all-reduce.
+
+    params: trainable parameters in FORWARD order; buckets are filled in reverse order (the order autograd
+    produces gradients) and launched as soon as complete.  Every param.grad is a view into the flat buffer."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 16 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets: List[List[int]] = []          # param indices per bucket
+        self.ranges: List[tuple] = []
+        # assign offsets in reverse-forward order so each bucket is a contiguous slice
+        off = 0
+        cur: List[int] = []
+        cur_start = 0
+        self._views = {}
+        for i in reversed(range(len(self.params))):
+            p = self.params[i]
+            self._views[i] = (off, off + p.numel())
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            cur.append(i)
+            if (off - cur_start) * 4 >= bucket_bytes:
+                self.buckets.append(cur)
+                self.ranges.append((cur_start, off))
+                cur, cur_start = [], off
+        if cur:
+            self.buckets.append(cur)
+            self.ranges.append((cur_start, off))
+        self._bucket_of = {i: b for b, idxs in enumerate(self.buckets) for i in idxs}
+        self._pending = [len(b) for b in self.buckets]
+        self._handles = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def _make_hook(self, i):
+        def hook(p):
+            lo, hi = self._views[i]
+            if p.grad is not None and p.grad.data_ptr() != self.flat[lo:hi].data_ptr():
+                # autograd replaced the view (first accumulation into a None grad): copy back and re-point
+                self.flat[lo:hi].copy_(p.grad.reshape(-1))
+                p.grad = self.flat[lo:hi].view_as(p)
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and is_distributed():
+                lo_b, hi_b = self.ranges[b]
+                self._handles.append(dist.all_reduce(self.flat[lo_b:hi_b], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    def zero(self):
+        self.flat.zero_()
+        self._pending = [len(b) for b in self.buckets]
+        self._handles = []
+
+    def finish(self):
+        """Wait for the in-flight all-reduces, reduce buckets whose gradients never arrived (unused
+        parameters, e.g. selector_model.logit_scale), and average."""
+        if not is_distributed():
+            return
+        for b, pend in enumerate(self._pending):
+            if pend > 0:
+                lo, hi = self.ranges[b]
+                self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for h in self._handles:
+            h.wait()
+        self.flat.div_(world_size())
+        self._handles = []

@@ -211,6 +211,84 @@ int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* st
 /* utility: column sums of x[rows, D] accumulated into acc[D] (ncentroid, anomaly_clip_module.py:145-171). */
 int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows, int32_t D, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training side (SURVEY.md 8a rows a4, a9, a12 and the backward of a2/a3/a6/a7/a8).  Row reductions
+ * are two-stage and fixed-order: kernels emit per-block partials, acx_reduce_rows sums them. */
+
+/* acx_gemm_tn: C[N1,N2] = sum_m A[m,n1] * bmap(B)[m,n2] (exact-f32 MFMA) -- weight gradients
+ * dW = dY^T X of every nn.Linear / Conv2d of the temporal model and text_projection.  conv != 0: B column
+ * k = tap*cin + ci reads token row shift_tap(m) on the (gn,gl) grid (zero outside) = dW of the 3x3 convs in
+ * the [Cout][tap][Cin] layout.  b_sub [N2]: subtracted from every valid B row (selector direction gradient). */
+size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2);
+int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                int32_t cin, void* workspace, size_t workspace_bytes, void* stream);
+int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int32_t nparts, int32_t width, void* stream);
+/* LayerNorm / ChanLayerNorm backward.  dx (may be NULL) = dx_scale * dL/dx; part (may be NULL) receives
+ * ceil(rows/64) rows of [dw(D) | db(D)] partials. */
+int acx_layernorm_bwd(acx_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* part,
+                      int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, void* stream);
+/* backward of acx_cls_head (seg == 0): dx = dL/dx1 = dL/dx2; part: ceil(rows/64) rows of
+ * [d ln_w (E) | d ln_b (E) | d lin_w (E) | d lin_b (1) | pad 3]. */
+int acx_cls_head_bwd(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w, const float* ln_b,
+                     const float* lin_w, const float* scores, const float* dscores, float* dx, float* part,
+                     int64_t rows, int32_t E, void* stream);
+/* elementwise: mode 0 LeakyReLU' from saved output, 1 QuickGELU' from saved pre-activation (out = d * f'),
+ * 2 QuickGELU forward (d ignored). */
+int acx_act(acx_ctx* ctx, const float* saved, const float* d, float* out, int64_t n, int32_t mode, void* stream);
+int acx_add(acx_ctx* ctx, const float* a, const float* b, float* out, int64_t n, void* stream);
+int acx_transpose(acx_ctx* ctx, const float* in, float* out, int32_t R, int32_t Cn, void* stream);
+/* conv weight [Cout,Cin,3,3] -> [Cin][tap'][Cout] with flipped taps: the W operand of the dX implicit GEMM */
+int acx_conv_weight_dx(acx_ctx* ctx, const float* w, float* out, int32_t Cout, int32_t Cin, void* stream);
+/* backward of acx_axial_attention (axis 0/1 on the (tiles,gn,gl) grid) and of acx_attention (tiles=batch,
+ * gn=1, gl=L, axis=1, e=64, causal as in the forward): dqkv [rows, 3*heads*e]. */
+int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int32_t tiles,
+                          int32_t gn, int32_t gl, int32_t heads, int32_t e, int32_t axis, int32_t causal,
+                          void* stream);
+int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, int32_t tiles, int32_t gn, int32_t gl,
+                 int32_t E, void* stream);
+/* BatchNorm1d(affine=False) training backward in two steps (so data-parallel SyncBN can all-reduce the
+ * sums in between): stats -> sums[2*C1] = (sum dl, sum dl*xhat) per column over this rank's rows; apply ->
+ * draw[r*ldo + c] with total_rows = rows of ALL ranks. */
+int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* dlogits, float* sums, int64_t rows,
+                     int32_t C1, void* stream);
+int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* dlogits, const float* var_biased,
+                     const float* sums, float* draw, int32_t ldo, int64_t rows, int64_t total_rows, int32_t C1,
+                     float eps, void* stream);
+/* y = a*x + b*y (BatchNorm running-statistics update, selector_model.py:30 momentum 0.1) */
+int acx_axpby(acx_ctx* ctx, const float* x, float* y, int32_t n, float a, float b, void* stream);
+/* deterministic column sums: part[blk][D] partials over rows_per_block rows each (then acx_reduce_rows) */
+int acx_colsum_partials(acx_ctx* ctx, const float* x, int32_t ld, float* part, int64_t rows, int32_t D,
+                        int32_t rows_per_block, void* stream);
+int acx_text_directions_bwd(acx_ctx* ctx, const float* text, const float* ncentroid, const float* ddirs,
+                            float* dtext, int32_t C, int32_t D, int32_t normal_id, void* stream);
+/* acx_select_idx: selector_model.py:119-158 / 227-266.  logits [B, N*Lg, C1]; masks [B,N] (1 keep, 0 drop);
+ * idx_top [B,ktop] / idx_bot [B,kbot] int64 (first B/2 rows abnormal videos, rest normal).  Ties are broken
+ * towards the LOWER segment index (torch.topk leaves tie order unspecified). */
+int acx_select_idx(acx_ctx* ctx, const float* logits, const int64_t* labels, const float* mask_top,
+                   const float* mask_bot, int64_t* idx_top, int64_t* idx_bot, int32_t B, int32_t N, int32_t Lg,
+                   int32_t C1, int32_t normal_id, int32_t ktop, int32_t kbot, void* stream);
+int acx_gather_segments(acx_ctx* ctx, const float* logits, const int64_t* idx, float* out, int32_t B, int32_t N,
+                        int32_t Lg, int32_t C1, int32_t K, void* stream);
+int acx_scatter_segments(acx_ctx* ctx, const float* dout, const int64_t* idx, float* dlogits, int32_t B, int32_t N,
+                         int32_t Lg, int32_t C1, int32_t K, void* stream);
+/* acx_mil_loss: ComputeLoss.__call__ (loss.py:51-195) forward AND backward in one pass.  losses[8] = (cost,
+ * ldir_abn, ldir_nor, ltopk_abn, lbottomk_abn, ltopk_nor, lsmooth, lsparse); dsim / dsim_topk / dscores are the
+ * gradients of gout*cost.  lambdas[7] = (dir_abn, dir_nor, topk_abn, bottomk_abn, topk_nor, smooth, sparse).
+ * workspace: ceil(B*N*Lg/256)*8 + ceil(B*K*Lg/256) floats. */
+int acx_mil_loss(acx_ctx* ctx, const float* sim, const float* sim_topk, const int64_t* labels, const float* scores,
+                 const int64_t* idx_topk_abn, const int64_t* idx_topk_nor, const int64_t* idx_bottomk_abn,
+                 float* dsim, float* dsim_topk, float* dscores, float* losses, float* workspace,
+                 size_t workspace_floats, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K, int32_t normal_id,
+                 const float* lambdas, const float* gout /* device scalar or NULL (=1) */, void* stream);
+/* acx_adamw: one torch.optim.AdamW step (decoupled weight decay, bias correction; step counts from 1). */
+int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, int32_t step, void* stream);
+int acx_ctx_grad(acx_ctx* ctx, const float* dx, float* dctx, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
+                 int32_t shared_ctx, void* stream);
+int acx_scatter_rows(acx_ctx* ctx, const float* src, const int64_t* idx, float* out, int64_t n, int32_t W,
+                     void* stream);
+
 /* In-library launch timer used by bench.py's roofline leg: when enabled, every kernel launch is
  * bracketed by HIP events on the caller's stream.  kinds: 0 GEMM, 1 attention, 2 norm rows, 3 other.
  * acx_prof_collect synchronises the recorded events and returns per-kind launch counts and summed

@@ -115,26 +115,15 @@ def gen_text(tag, geom, seed, table, key):
 
 # ---------------------------------------------------------------- 5. selector
 def gen_selector(seed=11):
-    g = torch.Generator().manual_seed(seed)
-    B, N, L, D, C, normal_id = 4, 32, 16, 32, 14, 7
-    x = torch.randn(B, N * L, D, generator=g) * 0.3 + 0.1
-    tf = torch.randn(C, D, generator=g) * 0.3 + 0.1
-    nc = x.reshape(-1, D)[B // 2 * N * L:].mean(0)
-    labels = torch.tensor([3, 9, 7, 7])
+    inp = R.selector_inputs(seed)
+    x, tf, nc, labels, rm0, rv0, m1, m2 = (inp[k] for k in ("x", "tf", "nc", "labels", "rm0", "rv0", "topk_mask", "bottomk_mask"))
+    N, L, C, normal_id = 32, 16, 14, 7
     sel = ns.selector_model.SelectorModel([str(i) for i in range(C)], normal_id, torch.nn.Parameter(torch.ones([])),
                                           N, L, 0.7, 0.7, 3, 3)
-    rm0 = torch.randn(C - 1, generator=g) * 0.05
-    rv0 = torch.rand(C - 1, generator=g) * 0.05 + 0.05
     sel.bn_layer.running_mean.copy_(rm0)
     sel.bn_layer.running_var.copy_(rv0)
-    # eval branch
     sel.eval()
     ev = sel(x, tf, labels, nc, True)
-    # train branch with explicit masks (>=3 segments survive in every row -> tie-free top-k)
-    torch.manual_seed(seed)
-    m1 = torch.bernoulli(torch.ones(B, N) * 0.3)
-    m2 = torch.bernoulli(torch.ones(B, N) * 0.3)
-    assert (m1.sum(1) >= 3).all() and (m2.sum(1) >= 3).all()
     masks = [m1, m2]
 
     def fake_mask(logits):
@@ -144,8 +133,7 @@ def gen_selector(seed=11):
     sel.generate_mask = fake_mask
     sel.train()
     lg, lt, lb, ia, in_, ba = sel(x, tf, labels, nc, False)
-    save("selector", x=x, tf=tf, nc=nc, labels=labels, rm0=rm0, rv0=rv0, eval_logits=ev,
-         topk_mask=m1, bottomk_mask=m2, logits=lg, logits_topk=lt, logits_bottomk=lb,
+    save("selector", seed=seed, eval_logits=ev, logits=lg, logits_topk=lt, logits_bottomk=lb,
          idx_topk_abn=ia, idx_topk_nor=in_, idx_bottomk_abn=ba,
          rm1=sel.bn_layer.running_mean, rv1=sel.bn_layer.running_var)
 

@@ -26,3 +26,19 @@ def e2e_inputs(seed: int, D: int):
 def vit_frames(seed: int, n: int, res: int):
     g = torch.Generator().manual_seed(seed + 100)
     return torch.randn(n, 3, res, res, generator=g)
+
+
+def selector_inputs(seed: int = 11):
+    g = torch.Generator().manual_seed(seed)
+    B, N, L, D, C = 4, 32, 16, 64, 14
+    x = torch.randn(B, N * L, D, generator=g) * 0.3 + 0.1
+    tf = torch.randn(C, D, generator=g) * 0.3 + 0.1
+    nc = x.reshape(-1, D)[B // 2 * N * L:].mean(0)
+    labels = torch.tensor([3, 9, 7, 7])
+    rm0 = torch.randn(C - 1, generator=g) * 0.05
+    rv0 = torch.rand(C - 1, generator=g) * 0.05 + 0.05
+    m1 = torch.bernoulli(torch.ones(B, N) * 0.3, generator=g)
+    m2 = torch.bernoulli(torch.ones(B, N) * 0.3, generator=g)
+    m1[:, :3] = 1      # >= 3 surviving segments per video: top-k is tie-free
+    m2[:, 4:7] = 1
+    return dict(x=x, tf=tf, nc=nc, labels=labels, rm0=rm0, rv0=rv0, topk_mask=m1, bottomk_mask=m2)

@@ -1,0 +1,305 @@
+"""-m gpu: training-side kernels and the assembled training step (through the C ABI) against the
+oracle's autograd (torch CPU) and the golden vectors produced by the REFERENCE.  Index outputs are
+compared bit-exactly; floats at fp32 round-off tolerances written per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from anomalyclip_amd import _lib as L
+from anomalyclip_amd import init_weights as IW
+from anomalyclip_amd import ops
+from anomalyclip_amd.components.loss import ComputeLoss
+from anomalyclip_amd.optim import AcxAdamW
+from oracle import anomalyclip_oracle as O
+import recipes as R
+from test_gpu_model import build_net
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N1,N2", [(512, 128, 128), (4096, 64, 256), (1000, 16, 132), (32768, 256, 512)])
+def test_gemm_tn_plain(M, N1, N2):
+    g = torch.Generator().manual_seed(M + N1)
+    a, b = torch.randn(M, N1, generator=g), torch.randn(M, N2, generator=g) + torch.arange(N2) * 0.01
+    sub = torch.randn(N2, generator=g)
+    assert relerr(ops.gemm_tn(a.to(DEV), b.to(DEV)), a.double().t() @ b.double()) < 3e-6
+    assert relerr(ops.gemm_tn(a.to(DEV), b.to(DEV), b_sub=sub.to(DEV)), a.double().t() @ (b - sub).double()) < 3e-6
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 256), (256, 64)])
+def test_conv_grads(cin, cout):
+    """dW (TN implicit GEMM) and dX (NT implicit GEMM with flipped weights) of the 3x3 conv vs autograd."""
+    g = torch.Generator().manual_seed(cin)
+    tiles, N, Lg = 2, 32, 16
+    x = torch.randn(tiles, N, Lg, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    dy = torch.randn(tiles, N, Lg, cout, generator=g)
+    with torch.enable_grad():
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+        y.backward(dy)
+    gw = ops.gemm_tn(dy.reshape(-1, cout).to(DEV), x.reshape(-1, cin).to(DEV), conv=True, gn=N, gl=Lg, cin=cin)
+    gw = gw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    assert relerr(gw, wr.grad) < 1e-5
+    dx = ops.gemm(dy.reshape(-1, cout).to(DEV), ops.conv_weight_dx(w.to(DEV)), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=cout)
+    assert relerr(dx, xr.grad.reshape(-1, cin)) < 1e-5
+
+
+@pytest.mark.parametrize("D", [64, 256, 512])
+@pytest.mark.parametrize("mode", [L.NORM_LAYER, L.NORM_CHAN])
+def test_layernorm_bwd(D, mode):
+    g = torch.Generator().manual_seed(D + mode)
+    x = torch.randn(777, D, generator=g) * 2 + 0.3
+    w, b, dy = torch.randn(D, generator=g), torch.randn(D, generator=g), torch.randn(777, D, generator=g)
+    with torch.enable_grad():
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = O.layer_norm(xr, wr, br) if mode == L.NORM_LAYER else O.chan_layer_norm_last(xr, wr, br)
+        y.backward(dy)
+    dx, dw, db = ops.layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), mode=mode)
+    assert relerr(dx, xr.grad) < 1e-5 and relerr(dw, wr.grad) < 1e-5 and relerr(db, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("axis,e,heads", [(0, 32, 8), (1, 32, 8), (0, 16, 8), (1, 32, 2)])
+def test_axial_attention_bwd(axis, e, heads):
+    g = torch.Generator().manual_seed(axis + e)
+    tiles, N, Lg = 2, 32, 16
+    He = heads * e
+    qkv = torch.randn(tiles * N * Lg, 3 * He, generator=g)
+    dout = torch.randn(tiles * N * Lg, He, generator=g)
+    with torch.enable_grad():
+        t = qkv.clone().double().requires_grad_(True)
+        q, k, v = t.view(tiles, N, Lg, 3, heads, e).permute(3, 0, 1, 2, 4, 5)
+        if axis == 0:
+            q, k, v = (z.transpose(1, 2) for z in (q, k, v))
+        q, k, v = (z.transpose(2, 3) for z in (q, k, v))
+        o = (torch.softmax(q @ k.transpose(-1, -2) * e ** -0.5, -1) @ v).transpose(2, 3)
+        if axis == 0:
+            o = o.transpose(1, 2)
+        o.reshape(-1, He).backward(dout.double())
+    dq = ops.seq_attention_bwd(qkv.to(DEV), dout.to(DEV), tiles, N, Lg, heads, e, axis)
+    assert relerr(dq, t.grad) < 1e-5
+
+
+def test_mha_attention_bwd_causal():
+    g = torch.Generator().manual_seed(1)
+    Bc, Lc, heads = 3, 77, 2
+    W = heads * 64
+    qkv = torch.randn(Bc * Lc, 3 * W, generator=g)
+    dout = torch.randn(Bc * Lc, W, generator=g)
+    with torch.enable_grad():
+        t = qkv.clone().double().requires_grad_(True)
+        q, k, v = t.view(Bc, Lc, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        s = (q * 0.125) @ k.transpose(-1, -2) + torch.full((Lc, Lc), float("-inf"), dtype=torch.float64).triu_(1)
+        (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(Bc * Lc, W).backward(dout.double())
+    dq = ops.seq_attention_bwd(qkv.to(DEV), dout.to(DEV), Bc, 1, Lc, heads, 64, 1, causal=True)
+    assert relerr(dq, t.grad) < 1e-5
+
+
+def test_misc_train_kernels():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1000, 64, generator=g)
+    d = torch.randn(1000, 64, generator=g)
+    assert relerr(ops.act(x.to(DEV), d.to(DEV), 0), d * torch.where(x > 0, 1.0, 0.01)) < 1e-6
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        O.quick_gelu(xr).backward(d)
+    assert relerr(ops.act(x.to(DEV), d.to(DEV), 1), xr.grad) < 1e-5
+    assert relerr(ops.act(x.to(DEV), None, 2), O.quick_gelu(x)) < 1e-5
+    assert torch.equal(ops.transpose(x.to(DEV)).cpu(), x.t())
+    assert relerr(ops.add(x.to(DEV), d.to(DEV)), x + d) == 0
+    assert relerr(ops.colsum(x.to(DEV)), x.double().sum(0)) < 1e-5
+    # cls head backward
+    E, rows = 256, 1024
+    x1, x2 = torch.randn(rows, E, generator=g), torch.randn(rows, E, generator=g)
+    lw, lb = torch.randn(E, generator=g), torch.randn(E, generator=g)
+    w, b = torch.randn(1, E, generator=g) * 0.1, torch.randn(1, generator=g)
+    ds = torch.randn(rows, generator=g)
+    with torch.enable_grad():
+        ps = [t.clone().requires_grad_(True) for t in (x1, x2, lw, lb, w, b)]
+        s = torch.sigmoid(O.layer_norm((ps[0] + ps[1]) / 2, ps[2], ps[3]) @ ps[4].t() + ps[5]).view(-1)
+        s.backward(ds)
+    sc = ops.cls_head(x1.to(DEV), x2.to(DEV), lw.to(DEV), lb.to(DEV), w.to(DEV), b.to(DEV), 32, 16, 0)
+    dx, glw, glb, gw, gb = ops.cls_head_bwd(x1.to(DEV), x2.to(DEV), lw.to(DEV), lb.to(DEV), w.to(DEV), sc, ds.to(DEV))
+    assert relerr(dx, ps[0].grad) < 1e-5 and relerr(dx, ps[1].grad) < 1e-5
+    assert relerr(glw, ps[2].grad) < 1e-5 and relerr(glb, ps[3].grad) < 1e-5
+    assert relerr(gw, ps[4].grad.view(-1)) < 1e-5 and relerr(gb, ps[5].grad) < 1e-5
+
+
+def test_selector_train_golden(golden):
+    """a3/a4 against the REFERENCE's SelectorModel: logits, bit-exact MIL indices, gathered logits, running stats."""
+    from anomalyclip_amd.components.selector_model import SelectorModel
+    g = golden("selector")
+    sel = SelectorModel([str(i) for i in range(14)], 7, 1.0, 32, 16, 0.7, 0.7, 3, 3).to(DEV)
+    inp = R.selector_inputs(int(g["seed"]))
+    sel.bn_layer.running_mean.copy_(inp["rm0"])
+    sel.bn_layer.running_var.copy_(inp["rv0"])
+    x, tf, nc = (inp[k].to(DEV) for k in ("x", "tf", "nc"))
+    masks = (inp["topk_mask"], inp["bottomk_mask"])
+    with torch.enable_grad():
+        tfr = tf.clone().requires_grad_(True)
+        lg, lt, lb, ia, in_, ba = sel(x, tfr, inp["labels"], nc, False, masks=masks)
+        (lg.sum() * 0.5 + (lt ** 2).sum() + lb.sum()).backward()
+    assert torch.equal(ia.cpu(), torch.from_numpy(g["idx_topk_abn"]))
+    assert torch.equal(in_.cpu(), torch.from_numpy(g["idx_topk_nor"]))
+    assert torch.equal(ba.cpu(), torch.from_numpy(g["idx_bottomk_abn"]))
+    assert relerr(lg, g["logits"]) < 1e-4 and relerr(lt, g["logits_topk"]) < 1e-4 and relerr(lb, g["logits_bottomk"]) < 1e-4
+    assert relerr(sel.bn_layer.running_mean, g["rm1"]) < 1e-5 and relerr(sel.bn_layer.running_var, g["rv1"]) < 1e-5
+    # gradient wrt the text features against the oracle's autograd
+    with torch.enable_grad():
+        tfo = inp["tf"].clone().requires_grad_(True)
+        out = O.selector_train(inp["x"], tfo, inp["labels"], inp["nc"], 7, inp["rm0"], inp["rv0"], masks[0], masks[1],
+                               32, 16, 3, 3)
+        (out[0].sum() * 0.5 + (out[1] ** 2).sum() + out[2].sum()).backward()
+    assert relerr(tfr.grad, tfo.grad) < 1e-4
+
+
+def test_select_idx_ties_and_edge_cases():
+    """fewer than k surviving segments => ties at -1e6/+1e6: documented rule = lower index first (== oracle)."""
+    g = torch.Generator().manual_seed(3)
+    B, N, Lg, C1 = 4, 32, 16, 13
+    logits = torch.randn(B, N * Lg, C1, generator=g)
+    labels = torch.tensor([0, 12, 7, 7])
+    mask = torch.zeros(B, N)
+    mask[0, 5] = 1            # one survivor
+    mask[1, :] = 1            # all survive
+    mask[2, [3, 30]] = 1      # two survivors
+    it, ib = ops.select_idx(logits.to(DEV), labels.to(DEV), mask.to(DEV), mask.to(DEV), N, Lg, 7, 3, 3)
+    ia, in_ = O.select_idx(logits, labels, mask, 7, N, Lg, 3, True)
+    ba, bn = O.select_idx(logits, labels, mask, 7, N, Lg, 3, False)
+    assert torch.equal(it.cpu(), torch.cat([ia, in_])) and torch.equal(ib.cpu(), torch.cat([ba, bn]))
+
+
+def test_mil_loss_golden(golden):
+    g = golden("loss")
+    T = lambda k: torch.from_numpy(g[k]).to(DEV)
+    crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    with torch.enable_grad():
+        s1, s2, s3 = T("sim").requires_grad_(True), T("sim_topk").requires_grad_(True), T("scores").requires_grad_(True)
+        outs = crit(s1, s2, T("labels"), s3, T("idx_topk_abn"), T("idx_topk_nor"), T("idx_bottomk_abn"))
+        (outs[0] * 2.0).backward()                 # upstream gradient != 1 exercises the device-side scale
+    assert relerr(torch.stack(outs), g["losses"]) < 1e-5
+    assert relerr(s1.grad, 2 * g["g_sim"]) < 1e-4 and relerr(s2.grad, 2 * g["g_sim_topk"]) < 1e-5
+    assert relerr(s3.grad, 2 * g["g_scores"]) < 1e-4
+
+
+def test_adamw_matches_torch():
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(1000, generator=g)
+    pa, pb = torch.nn.Parameter(p0.clone().to(DEV)), torch.nn.Parameter(p0.clone())
+    oa = AcxAdamW([{"params": [pa], "lr": 1e-3}], weight_decay=0.2)
+    ob = torch.optim.AdamW([{"params": [pb], "lr": 1e-3}], weight_decay=0.2)
+    for _ in range(5):
+        gr = torch.randn(1000, generator=g)
+        pa.grad, pb.grad = gr.to(DEV), gr.clone()
+        oa.step()
+        ob.step()
+    assert relerr(pa, pb) < 1e-6
+
+
+def _train_step_tiny(golden, prompts_table):
+    g = golden("e2e_tiny")
+    seed = int(g["seed"])
+    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1)
+    net, sd, eot = build_net("tiny", hc, "ucf", seed, prompts_table)
+    inp = R.e2e_inputs(seed, IW.TINY.embed_dim)
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(DEV)
+    mod.ncentroid = inp["nc"].to(DEV)
+    net.train()
+    net.selector_model.generate_mask = lambda b: (inp["mask"], inp["mask"])
+    return g, net, mod, inp, sd, eot, hc
+
+
+def test_e2e_train_step_golden(golden, prompts_table):
+    """One full training step (forward, 7-term loss, backward) against the REFERENCE's fixture 8."""
+    g, net, mod, inp, sd, eot, hc = _train_step_tiny(golden, prompts_table)
+    feats, labels = inp["train_feats"].to(DEV), inp["labels"].to(DEV)
+    batch = ((feats[2:], labels[2:]), (feats[:2], labels[:2]))       # (nbatch, abatch) as the datamodule yields
+    with torch.enable_grad():
+        out = mod.training_step(batch)
+        out["loss"].backward()
+    assert relerr(torch.stack(mod.last_losses), g["losses"]) < 1e-4
+    for name in ("temporal_model.projection.weight", "temporal_model.classifier.linear.weight", "prompt_learner.ctx",
+                 "text_encoder.text_projection"):
+        p = dict(net.named_parameters())[name]
+        assert relerr(p.grad, g["grad:" + name]) < 2e-3, name
+    names = [str(n) for n in g["temporal_grad_names"]]
+    params = dict(net.temporal_model.named_parameters())
+    got = np.asarray([float(params[n].grad.double().abs().sum()) for n in names])
+    assert np.allclose(got, g["temporal_grad_abs_sums"], rtol=2e-3), (got, g["temporal_grad_abs_sums"])
+    assert relerr(net.selector_model.bn_layer.running_mean, g["rm1"]) < 1e-4
+    assert relerr(net.selector_model.bn_layer.running_var, g["rv1"]) < 1e-4
+
+
+def test_e2e_train_forward_golden(golden, prompts_table):
+    g, net, mod, inp, sd, eot, hc = _train_step_tiny(golden, prompts_table)
+    with torch.enable_grad():
+        lg, lt, sc, ia, in_, ba = net(inp["train_feats"].to(DEV), inp["labels"].to(DEV), inp["nc"])
+    assert torch.equal(ia.cpu(), torch.from_numpy(g["idx_topk_abn"])) and torch.equal(in_.cpu(), torch.from_numpy(g["idx_topk_nor"]))
+    assert torch.equal(ba.cpu(), torch.from_numpy(g["idx_bottomk_abn"]))
+    assert relerr(lg, g["train_logits"]) < 1e-4 and relerr(lt, g["train_logits_topk"]) < 1e-4 and relerr(sc, g["train_scores"]) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", ["ucf", "sht"])
+def test_full_config_train_step_vs_oracle(prompts_table, cfg):
+    """UCF (E=256, depth 1) and ShanghaiTech (concat on, depth 2) head configs, B=4: loss and every temporal-model
+    gradient against the oracle's autograd on the same seeded inputs."""
+    hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD}[cfg]
+    net, sd, eot = build_net("ViT-B/16", hc, cfg, 11, prompts_table)
+    g = torch.Generator().manual_seed(5)
+    B = 4
+    labels = torch.tensor([1, hc.num_classes - 1, hc.normal_id, hc.normal_id])
+    feats = torch.randn(B, 1, 512, 512, generator=g) * 0.3
+    nc = torch.randn(512, generator=g) * 0.05
+    mask = torch.bernoulli(torch.ones(B, 32) * 0.3, generator=g)
+    mask[:, :3] = 1
+    crit = ComputeLoss(hc.normal_id, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    for p in net.image_encoder.parameters():
+        p.requires_grad = False
+    for p in net.text_encoder.parameters():
+        p.requires_grad = False
+    net.text_encoder.text_projection.requires_grad = True
+    net.token_embedding.weight.requires_grad = False
+    net.train()
+    net.selector_model.generate_mask = lambda b: (mask, mask)
+    with torch.enable_grad():
+        lg, lt, sc, ia, in_, ba = net(feats.to(DEV), labels.to(DEV), nc)
+        losses = crit(lg, lt, labels.to(DEV), sc, ia, in_, ba)
+        losses[0].backward()
+    names = [n for n, p in net.named_parameters() if p.requires_grad and n != "selector_model.logit_scale"]
+    # fp32 oracle: indices and loss values (same arithmetic class as the reference's CPU path)
+    o = O.anomaly_clip_forward_train(sd, hc, feats, labels, nc, eot, 8, mask, mask)
+    ol = O.compute_loss(o[0], o[1], labels, o[2], o[3], o[4], o[5], normal_id=hc.normal_id, num_topk=3, num_segments=32,
+                        frames_per_segment=16)
+    # fp64 oracle: gradient ground truth (an fp32 CPU backward carries ~1e-3 of its own round-off through two
+    # depth levels of 3x3 convs, which would be compared against itself otherwise)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        for n in names:
+            sd64[n] = sd64[n].clone().requires_grad_(True)
+        o64 = O.anomaly_clip_forward_train(sd64, hc, feats.double(), labels, nc.double(), eot, 8, mask.double(), mask.double())
+        ol64 = O.compute_loss(o64[0], o64[1], labels, o64[2], o[3], o[4], o[5], normal_id=hc.normal_id, num_topk=3,
+                              num_segments=32, frames_per_segment=16)
+        ol64[0].backward()
+    sd = sd64
+    assert torch.equal(ia.cpu(), o[3]) and torch.equal(in_.cpu(), o[4]) and torch.equal(ba.cpu(), o[5])
+    assert relerr(torch.stack(losses), torch.stack(ol)) < 1e-4
+    params = dict(net.named_parameters())
+    errs = sorted(((relerr(params[n].grad, sd[n].grad), n) for n in names), reverse=True)
+    print("\n".join(f"{e:.2e} {n}" for e, n in errs[:8]))
+    # LeakyReLU has a kink at 0: an fp32 pre-activation within round-off of 0 can land on the other side than the
+    # fp64 ground truth, which changes that element's derivative from 1 to 0.01 -- a discrete O(1e-3..1e-2)
+    # difference confined to the conv that feeds the activation (`net.1.*`).  The same holds for the reference's
+    # own fp32 CPU path.  Everything else is held to 2e-3 (observed: ~1e-6 when no element sits on the kink).
+    for e, n in errs:
+        tol = 1e-2 if (".net.1.weight" in n or ".net.1.bias" in n) else 2e-3
+        assert e < tol, (e, n)

@@ -61,11 +61,12 @@ def test_text(golden, prompts_table, tag, geom, key):
 
 def test_selector(golden):
     g = golden("selector")
-    x, tf, nc = T(g["x"]), T(g["tf"]), T(g["nc"])
-    ev, _, _ = O.selector_logits(x, tf, nc, 7, T(g["rm0"]), T(g["rv0"]), training=False)
+    inp = R.selector_inputs(int(g["seed"]))
+    x, tf, nc = inp["x"], inp["tf"], inp["nc"]
+    ev, _, _ = O.selector_logits(x, tf, nc, 7, inp["rm0"], inp["rv0"], training=False)
     close(ev, g["eval_logits"])
-    out = O.selector_train(x, tf, T(g["labels"]), nc, 7, T(g["rm0"]), T(g["rv0"]), T(g["topk_mask"]),
-                           T(g["bottomk_mask"]), 32, 16, 3, 3)
+    out = O.selector_train(x, tf, inp["labels"], nc, 7, inp["rm0"], inp["rv0"], inp["topk_mask"],
+                           inp["bottomk_mask"], 32, 16, 3, 3)
     logits, lt, lb, ia, in_, ba, rm, rv = out
     close(logits, g["logits"])
     assert torch.equal(ia, T(g["idx_topk_abn"]))          # bit-exact segment indices
