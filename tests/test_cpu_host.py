@@ -1,0 +1,147 @@
+"""CPU-only (-m "not gpu") checks: the C ABI library loads and exports every symbol include/acx.h declares,
+host-side logic (index tables, LR schedule, mask RNG, sharding, SyncBN statistics combination) and the
+no-fallback rule.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(REPO, "include", "acx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(acx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from anomalyclip_amd import _build, _lib
+    assert os.path.exists(_build.LIB), "libacx.so missing: run python -m anomalyclip_amd._build"
+    lib = ctypes.CDLL(_build.LIB)
+    declared = header_functions()
+    assert len(declared) >= 50
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/acx.h but not exported"
+    # and the ctypes binding covers the same set
+    assert sorted(_lib.declared_symbols()) == declared
+    assert _lib.lib().acx_version() == 100
+
+
+def test_product_path_has_no_cpu_fallback():
+    from anomalyclip_amd import ops, _lib
+    with pytest.raises(_lib.AcxError):
+        ops.gemm(torch.randn(8, 8), torch.randn(8, 8))
+    with pytest.raises(_lib.AcxError):
+        ops.layernorm(torch.randn(4, 64), torch.ones(64), torch.zeros(64))
+    # nothing under anomalyclip_amd/ may import the oracle
+    for root, _, files in os.walk(os.path.join(REPO, "anomalyclip_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib
+    from anomalyclip_amd import _lib
+    monkeypatch.setenv("ACX_LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.AcxError):
+        _lib.lib()
+    monkeypatch.delenv("ACX_LIB_PATH")
+    monkeypatch.setattr(_lib, "_lib", None)
+    _lib.lib()
+
+
+def test_index_tables_match_reference(golden):
+    from anomalyclip_amd import feature_index as FI
+    g = golden("tables")
+    for stride in (1, 2):
+        for T in (1, 511, 512, 513, 1000, 1025, 5000):
+            starts, S = FI.test_start_indices(T, 32, 16, stride)
+            assert np.array_equal(starts, g[f"start_T{T}_s{stride}"].astype(np.int64))
+            assert np.array_equal(FI.frame_index_table(starts, 16, stride, T), g[f"frames_T{T}_s{stride}"])
+    feats = np.arange(1000 * 2 * 4, dtype=np.float32).reshape(1000 * 2, 4)
+    out, S = FI.gather_test_features(feats, 32, 16, 1, ncrops=2)
+    assert out.shape == (2, 512 * S, 4) and S == 2
+    assert np.array_equal(out[1, 5], feats[5 * 2 + 1]) and np.array_equal(out[0, 1000], feats[0])   # wrap-around padding
+
+
+def test_lr_schedule_matches_reference(golden):
+    from anomalyclip_amd.components.scheduler import WarmupCosineAnnealingLR
+    g = golden("tables")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([{"params": [p], "lr": 1e-5}], weight_decay=0.2)
+    sch = WarmupCosineAnnealingLR(optimizer=opt, successor=None, warmup_epochs=5, total_epoch=50)
+    lrs = []
+    for _ in range(55):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert np.allclose(lrs, g["lr_table"], rtol=1e-12, atol=0)
+
+
+def test_mask_rng_matches_reference_draw_order():
+    """generate_mask draws from torch's CPU generator exactly like selector_model.py:101-117."""
+    from anomalyclip_amd.components.selector_model import SelectorModel
+    sel = SelectorModel([str(i) for i in range(14)], 7, 1.0, 32, 16, 0.7, 0.7, 3, 3)
+    torch.manual_seed(123)
+    a, b = sel.generate_mask(6)
+    torch.manual_seed(123)
+    ones = torch.ones((6, 32))
+    t = torch.bernoulli(ones * (1 - 0.7))
+    bt = torch.bernoulli(ones * (1 - 0.7))
+    assert torch.equal(b, bt) and torch.equal(a, bt) and a.shape == (6, 32)    # equal dropouts -> shared mask (:114-115)
+    sel2 = SelectorModel([str(i) for i in range(14)], 7, 1.0, 32, 16, 0.7, 0.5, 3, 3)
+    torch.manual_seed(123)
+    a2, b2 = sel2.generate_mask(6)
+    assert torch.equal(a2, t) and not torch.equal(a2, b2)
+
+
+def test_shard_videos_balanced():
+    from anomalyclip_amd import parallel
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            idx = parallel.shard_videos(64, world, r)
+            half = len(idx) // 2
+            assert all(i < 32 for i in idx[:half]) and all(i >= 32 for i in idx[half:])
+            seen += idx
+        assert sorted(seen) == list(range(64))
+    with pytest.raises(ValueError):
+        parallel.shard_videos(64, 3, 0)
+
+
+def test_combine_bn_stats_equals_global_stats():
+    from anomalyclip_amd import parallel
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1000, 13, generator=g, dtype=torch.float64) * 3 + 1
+    parts = [x[:100], x[100:640], x[640:]]
+    means = torch.stack([p.mean(0) for p in parts])
+    m2s = torch.stack([p.var(0, unbiased=False) * p.shape[0] for p in parts])
+    counts = torch.tensor([float(p.shape[0]) for p in parts], dtype=torch.float64)
+    m, vb, vu, n = parallel.combine_bn_stats(means, m2s, counts)
+    assert torch.allclose(m, x.mean(0)) and torch.allclose(vb, x.var(0, unbiased=False)) and torch.allclose(vu, x.var(0, unbiased=True))
+    assert int(n) == 1000
+
+
+def test_state_dict_keys_match_reference_layout(prompts_table):
+    """module tree == reference AnomalyCLIP.state_dict() key layout (SURVEY section 5 checkpoint row)."""
+    from anomalyclip_amd import init_weights as IW
+    from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP
+    for key, hc in (("ucf", IW.UCF_HEAD), ("sht", IW.SHT_HEAD), ("xd", IW.XD_HEAD)):
+        toks = torch.tensor(prompts_table[key]["tokenized_prompts"], dtype=torch.int32)
+        net = AnomalyCLIP(arch="tiny", labels_key=key, emb_size=hc.emb_size, depth=hc.depth, heads=hc.heads, dim_heads=None,
+                          num_segments=32, seg_length=16, concat_features=hc.concat_features, normal_id=hc.normal_id,
+                          select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, num_topk=3, num_bottomk=3, ncrops=hc.ncrops)
+        sd = IW.init_anomalyclip_state_dict(IW.TINY, hc, toks, 1)
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected
+        assert set(net.state_dict().keys()) == set(sd.keys())
+    # trainable parameter count of the UCF temporal model at the real geometry (10,110,977)
+    tm = IW.init_temporal_state_dict(512, IW.UCF_HEAD, 0)
+    assert sum(v.numel() for v in tm.values()) == 10110977
