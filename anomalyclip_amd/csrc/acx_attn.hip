@@ -15,36 +15,51 @@
 //   * K-permutation trick as in acx_gemm: one ds_read_b128 of K feeds four MFMAs.
 #include "acx_internal.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int KROW = 68;   // floats per K row in LDS (64 + 4 pad = 272 B)
 constexpr int VROW = 64;
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void attn_kernel(const float* __restrict__ qkv, int64_t ldqkv,
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __restrict__ qkv, int64_t ldqkv,
                                                       float* __restrict__ out, int64_t ldo, int L, int heads,
                                                       int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sK = reinterpret_cast<float*>(smem);
   float* sV = sK + NT * 32 * KROW;
-  float* sL = sV + NT * 32 * VROW;   // [4 waves][32] row sums
+  float* sL = sV + NT * 32 * VROW;   // [NW waves][32] row sums
 
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int W = heads * 64;
   const float* base = qkv + (int64_t)b * L * ldqkv + h * 64;
   const int t = threadIdx.x;
 
-  // ---- stage K, V (rows >= L zero-filled)
-  for (int i = t; i < NT * 32 * 16; i += 256) {
+  // ---- stage K, V (rows >= L zero-filled): ALL global loads are issued before the first LDS write so the
+  // staging costs one memory round trip, not one per iteration
+  constexpr int NSTG = (NT * 32 * 16 + NW * 64 - 1) / (NW * 64);
+  float4 stk[NSTG], stv[NSTG];
+#pragma unroll
+  for (int j = 0; j < NSTG; ++j) {
+    const int i = t + j * NW * 64;
     const int row = i >> 4, c4 = i & 15;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (row < L) {
+    stk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    stv[j] = stk[j];
+    if (i < NT * 32 * 16 && row < L) {
       const float* p = base + (int64_t)row * ldqkv + 4 * c4;
-      kv = *reinterpret_cast<const float4*>(p + W);
-      vv = *reinterpret_cast<const float4*>(p + 2 * W);
+      stk[j] = *reinterpret_cast<const float4*>(p + W);
+      stv[j] = *reinterpret_cast<const float4*>(p + 2 * W);
     }
-    *reinterpret_cast<float4*>(sK + row * KROW + 4 * c4) = kv;
-    *reinterpret_cast<float4*>(sV + row * VROW + 4 * c4) = vv;
+  }
+#pragma unroll
+  for (int j = 0; j < NSTG; ++j) {
+    const int i = t + j * NW * 64;
+    const int row = i >> 4, c4 = i & 15;
+    if (i < NT * 32 * 16) {
+      *reinterpret_cast<float4*>(sK + row * KROW + 4 * c4) = stk[j];
+      *reinterpret_cast<float4*>(sV + row * VROW + 4 * c4) = stv[j];
+    }
   }
   __syncthreads();
 
@@ -52,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(const float* __restrict__ 
   const int li = lane & 31, hh = lane >> 5;
   const int nqb = (L + 31) / 32;
 
-  for (int qb = wave; qb < nqb; qb += 4) {
+  for (int qb = wave; qb < nqb; qb += NW) {
     const int q0 = qb * 32;
     // ---- Q fragment (B operand of S^T = K.Q^T): lane (q=li, half hh) holds chunks (2c+hh)
     float4 qf[8];
@@ -154,27 +169,32 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   if (L <= 0 || L > 224 || heads <= 0) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention: need 0 < L <= 224%s");
   if (ldqkv % 4 || ((uintptr_t)qkv & 15)) return acx_fail(ctx, ACX_E_BADARG, "acx_attention: qkv must be 16-byte aligned, ld%%4==0%s");
   const int nt = (L + 31) / 32;
-  const dim3 grid((unsigned)(batch * heads)), block(256);
+  static const bool nw4 = getenv("ACX_ATTN_NW4") != nullptr;
+  const dim3 grid((unsigned)(batch * heads));
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_ATTN, (hipStream_t)stream);
-#define ACX_ATTN(NT)                                                                               \
+#define ACX_ATTN(NT, NW)                                                                           \
   do {                                                                                             \
-    const size_t lds = (size_t)NT * 32 * (KROW + VROW) * 4 + 4 * 32 * 4;                           \
+    const size_t lds = (size_t)NT * 32 * (KROW + VROW) * 4 + NW * 32 * 4;                          \
     static bool done = false;                                                                      \
     if (!done) {                                                                                   \
-      (void)hipFuncSetAttribute((const void*)attn_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void*)attn_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       done = true;                                                                                 \
     }                                                                                              \
-    hipLaunchKernelGGL((attn_kernel<NT>), grid, block, lds, s, qkv, ldqkv, out, ldo, L, heads, causal); \
+    hipLaunchKernelGGL((attn_kernel<NT, NW>), grid, dim3(NW * 64), lds, s, qkv, ldqkv, out, ldo, L, heads, causal); \
   } while (0)
   switch (nt) {
-    case 1: ACX_ATTN(1); break;
-    case 2: ACX_ATTN(2); break;
-    case 3: ACX_ATTN(3); break;
-    case 4: ACX_ATTN(4); break;
-    case 5: ACX_ATTN(5); break;
-    case 6: ACX_ATTN(6); break;
-    default: ACX_ATTN(7); break;
+    // one wave per 32-query block where it fits; >4 blocks -> 8 waves (2 per SIMD: one wave's softmax and
+    // LDS phases overlap the other's MFMAs)
+    case 1: ACX_ATTN(1, 4); break;
+    case 2: ACX_ATTN(2, 4); break;
+    case 3: ACX_ATTN(3, 4); break;
+    case 4: ACX_ATTN(4, 4); break;
+    case 5: ACX_ATTN(5, 8); break;
+    case 6: ACX_ATTN(6, 8); break;
+    default:
+      if (nw4) ACX_ATTN(7, 4); else ACX_ATTN(7, 8);
+      break;
   }
 #undef ACX_ATTN
   ACX_CHECK_LAUNCH(ctx, "acx_attention");

@@ -26,6 +26,15 @@
 //     contiguous run of tiles (n fastest) so the A tile of a row of tiles stays in that XCD's L2.
 #include "acx_internal.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
+#ifndef ACX_DEPHASE
+#define ACX_DEPHASE 1
+#endif
+#ifndef ACX_LOOP_V2
+#define ACX_LOOP_V2 1
+#endif
 #ifndef ACX_STORE_SCHED
 #define ACX_STORE_SCHED 2
 #endif
@@ -40,6 +49,8 @@ constexpr int NTHREADS = 256;
 struct Args {
   acx_gemm_desc d;
   int tiles_n;
+  int tile_order;
+  int dephase_cycles;      // wall_clock64 ticks (100 MHz) the second block of each CU waits at launch
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -70,12 +81,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tm = wg / g.tiles_n, tn = wg % g.tiles_n;
+  int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  if (g.tile_order == 2) wg = bid;
+  int tm = wg / g.tiles_n, tn = wg % g.tiles_n;
+  if (g.tile_order == 1) { const int tiles_m_ = nwg / g.tiles_n; tn = wg / tiles_m_; tm = wg % tiles_m_; }
+  if (g.tile_order == 3) {   // 8-row super-tiles: walk 8 m-tiles down, then next n
+    const int band = wg / (8 * g.tiles_n), rem = wg % (8 * g.tiles_n);
+    const int tiles_m_ = nwg / g.tiles_n;
+    const int bh = min(8, tiles_m_ - band * 8);
+    tm = band * 8 + rem % bh; tn = rem / bh;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int t = threadIdx.x;
   const int chunk = t & 7, rbase = t >> 3;
+
+#if ACX_DEPHASE
+  // Co-resident blocks (2 per CU) start together and do identical work, so their prologue/epilogue bubbles
+  // coincide for the whole launch.  The second block of each CU (dispatch order: blocks 256..511 of the first
+  // wave) is delayed by about half a tile once; successor blocks inherit the phase shift, so one block's
+  // MFMA phases cover the other's loads/stores from then on.
+  if (FAST && g.dephase_cycles > 0 && bid >= 256 && bid < 512) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < g.dephase_cycles) __builtin_amdgcn_s_sleep(64);
+  }
+#endif
 
   // ---- per-thread source rows for the 4 staged A rows and 4 staged W rows
   const int grid_sz = FAST ? 1 : d.gn * d.gl;
@@ -225,6 +255,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int w_off = (wn * 64 + li) * ROWB + hh * 16;
 
   const int nk = (d.K + KE - 1) / KE;
+#if ACX_LOOP_V2
+  // ---- software-pipelined K loop (v2).  Fragment registers are double-buffered by hand (fa/fb sets X and Y);
+  // the ONE barrier of a K-step sits between MFMA phases 2 and 3: by then this wave has written its share of the
+  // next tile and already holds phase 3's fragments, so after the barrier it issues 16 MFMAs immediately and the
+  // ds_reads of the NEXT tile's phase-0 fragments (and the global loads two tiles ahead) ride in their shadow.
+  using frag_t = typename std::conditional<PREC == 0, float4, bf16x8>::type;
+  frag_t xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+#define ACX_RD(SET, stage, q)                                                                             \
+  do {                                                                                                    \
+    const char* sA_ = smem + (stage) * 2 * TILE_B;                                                        \
+    const char* sW_ = sA_ + TILE_B;                                                                       \
+    SET##a0 = *reinterpret_cast<const frag_t*>(sA_ + a_off + (q) * 32);                                   \
+    SET##a1 = *reinterpret_cast<const frag_t*>(sA_ + a_off + 32 * ROWB + (q) * 32);                       \
+    SET##b0 = *reinterpret_cast<const frag_t*>(sW_ + w_off + (q) * 32);                                   \
+    SET##b1 = *reinterpret_cast<const frag_t*>(sW_ + w_off + 32 * ROWB + (q) * 32);                       \
+  } while (0)
+#define ACX_MM(SET)                                                                                       \
+  do {                                                                                                    \
+    if constexpr (PREC == 0) {                                                                            \
+      const float4& A0_ = reinterpret_cast<const float4&>(SET##a0);                                       \
+      const float4& A1_ = reinterpret_cast<const float4&>(SET##a1);                                       \
+      const float4& B0_ = reinterpret_cast<const float4&>(SET##b0);                                       \
+      const float4& B1_ = reinterpret_cast<const float4&>(SET##b1);                                       \
+      const float av_[2][4] = {{A0_.x, A0_.y, A0_.z, A0_.w}, {A1_.x, A1_.y, A1_.z, A1_.w}};               \
+      const float bv_[2][4] = {{B0_.x, B0_.y, B0_.z, B0_.w}, {B1_.x, B1_.y, B1_.z, B1_.w}};               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                  \
+          _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[mi][j], bv_[ni][j], acc[mi][ni], 0, 0, 0); \
+    } else {                                                                                              \
+      const bf16x8& A0_ = reinterpret_cast<const bf16x8&>(SET##a0);                                       \
+      const bf16x8& A1_ = reinterpret_cast<const bf16x8&>(SET##a1);                                       \
+      const bf16x8& B0_ = reinterpret_cast<const bf16x8&>(SET##b0);                                       \
+      const bf16x8& B1_ = reinterpret_cast<const bf16x8&>(SET##b1);                                       \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0_, B0_, acc[0][0], 0, 0, 0);                  \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0_, B1_, acc[0][1], 0, 0, 0);                  \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1_, B0_, acc[1][0], 0, 0, 0);                  \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1_, B1_, acc[1][1], 0, 0, 0);                  \
+    }                                                                                                     \
+  } while (0)
+#define ACX_LOAD_TILE(k0) do { if constexpr (FAST) ACX_FAST_LOAD(k0); else ACX_GEN_LOAD(k0); } while (0)
+
+  ACX_LOAD_TILE(0);
+  ACX_STORE_ROW(0, 0); ACX_STORE_ROW(0, 1); ACX_STORE_ROW(0, 2); ACX_STORE_ROW(0, 3);
+  __syncthreads();
+  if (nk > 1) ACX_LOAD_TILE(KE);
+  ACX_RD(x, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more = kt + 1 < nk;
+    ACX_RD(y, cur, 1);
+    ACX_MM(x);                                   // phase 0
+    ACX_RD(x, cur, 2);
+    if (more) { ACX_STORE_ROW(nxt, 0); ACX_STORE_ROW(nxt, 1); }
+    ACX_MM(y);                                   // phase 1
+    ACX_RD(y, cur, 3);
+    if (more) { ACX_STORE_ROW(nxt, 2); ACX_STORE_ROW(nxt, 3); }
+    ACX_MM(x);                                   // phase 2
+    __syncthreads();                             // next tile complete in LDS; everyone holds its phase-3 fragments
+    if (kt + 2 < nk) ACX_LOAD_TILE((kt + 2) * KE);
+    if (more) ACX_RD(x, nxt, 0);
+    ACX_MM(y);                                   // phase 3
+  }
+#undef ACX_RD
+#undef ACX_MM
+#undef ACX_LOAD_TILE
+#else
   if constexpr (FAST) ACX_FAST_LOAD(0); else ACX_GEN_LOAD(0);
   ACX_STORE_ROW(0, 0); ACX_STORE_ROW(0, 1); ACX_STORE_ROW(0, 2); ACX_STORE_ROW(0, 3);
   __syncthreads();
@@ -287,6 +384,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #endif
     __syncthreads();
   }
+
+#endif
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if constexpr (FAST) {
@@ -365,6 +464,242 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
       }
     }
   }
+}
+
+
+// =====================================================================================================
+// gemm_persistent_kernel -- FAST-path GEMM as a persistent, continuously pipelined tile stream.
+//
+// Measured on the non-persistent kernel: the K loop itself runs at ~99 % of the MFMA rate, but every tile
+// pays ~28 us of un-overlapped prologue (two dependent HBM round trips) and epilogue (64 row-strided stores
+// per lane) -- 24 % of a K=768 tile -- and co-resident blocks stay in lock-step so their bubbles coincide.
+// Here a block owns tiles b, b+G, b+2G, ... (G = 2 blocks per CU) and treats (tile, k-step) as ONE stream:
+//   * global loads run two K-steps ahead and LDS writes one K-step ahead ACROSS tile boundaries, so only the
+//     first tile of a block has a prologue;
+//   * when a tile's K loop ends its 64 accumulators move to a second register set and are written out one
+//     32x64 quadrant per K-step of the NEXT tile, in the shadow of that tile's MFMAs (deferred epilogue).
+template <int PREC, int A_BF16, int C_BF16, int ACT, int RES>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_persistent_kernel(const Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const acx_gemm_desc& d = g.d;
+  constexpr int KE = PREC == 0 ? 32 : 64;
+  constexpr int CE = PREC == 0 ? 4 : 8;
+  constexpr int NLA = (PREC == 1 && !A_BF16) ? 2 : 1;
+  constexpr int WB = PREC == 0 ? 4 : 2;
+  constexpr int AB = A_BF16 ? 2 : 4;
+  using frag_t = typename std::conditional<PREC == 0, float4, bf16x8>::type;
+
+  const int tiles_m = (d.M + BM - 1) / BM;
+  const int total = tiles_m * g.tiles_n;
+  const int G = gridDim.x;
+  const int ntiles = (total - (int)blockIdx.x + G - 1) / G;      // tiles owned by this block (>= 1 by launch)
+  const int nk = d.K / KE;
+  const int S = ntiles * nk;
+
+  const int t = threadIdx.x;
+  const int chunk = t & 7, rbase = t >> 3;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+  const int a_off = (wm * 64 + li) * ROWB + hh * 16;
+  const int w_off = (wn * 64 + li) * ROWB + hh * 16;
+
+  // tile index -> (m0, n0) with the bijective XCD remap on the virtual block id (G % 8 == 0 keeps the XCD)
+  auto tile_origin = [&](int i, int& m0, int& n0) {
+    const int vb = (int)blockIdx.x + i * G;
+    const int xcd = vb & 7, qq = total >> 3, rr = total & 7;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (vb >> 3);
+    const int tm = wg / g.tiles_n;
+    m0 = tm * BM;
+    n0 = (wg - tm * g.tiles_n) * BN;
+  };
+
+  // ---- load stream state: byte pointers of this thread's 4 A rows / 4 W rows at k = 0 of the load tile
+  const char *pa0, *pa1, *pa2, *pa3, *pw0, *pw1, *pw2, *pw3;
+#define PG_SETUP_ROW(r, m0_, n0_)                                                                         \
+  do {                                                                                                    \
+    int m_ = (m0_) + rbase + 32 * (r);                                                                    \
+    m_ = m_ < d.M ? m_ : d.M - 1;                                                                         \
+    pa##r = (const char*)d.A + ((size_t)m_ * d.lda + chunk * CE) * AB;                                    \
+    int n_ = (n0_) + rbase + 32 * (r);                                                                    \
+    n_ = n_ < d.N ? n_ : d.N - 1;                                                                         \
+    pw##r = (const char*)d.W + ((size_t)n_ * d.ldw + chunk * CE) * WB;                                    \
+  } while (0)
+#define PG_SETUP(i_)                                                                                      \
+  do {                                                                                                    \
+    int m0_, n0_;                                                                                         \
+    tile_origin((i_), m0_, n0_);                                                                          \
+    PG_SETUP_ROW(0, m0_, n0_); PG_SETUP_ROW(1, m0_, n0_); PG_SETUP_ROW(2, m0_, n0_); PG_SETUP_ROW(3, m0_, n0_); \
+  } while (0)
+
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  uint4 rw0, rw1, rw2, rw3;
+  rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define PG_LOAD_ROW(r, kb)                                                                                \
+  do {                                                                                                    \
+    if constexpr (A_BF16) {                                                                               \
+      const uint4 v_ = *reinterpret_cast<const uint4*>(pa##r + (size_t)(kb) * AB);                        \
+      ra##r = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
+    } else {                                                                                              \
+      ra##r = *reinterpret_cast<const float4*>(pa##r + (size_t)(kb) * AB);                                \
+      if constexpr (NLA == 2) rb##r = *reinterpret_cast<const float4*>(pa##r + (size_t)(kb) * AB + 16);   \
+    }                                                                                                     \
+    rw##r = *reinterpret_cast<const uint4*>(pw##r + (size_t)(kb) * WB);                                   \
+  } while (0)
+  // loads the load-stream's next K-step and advances the stream (lk, ltile)
+  int lk = 0, ltile = 0;
+#define PG_LOAD_NEXT()                                                                                    \
+  do {                                                                                                    \
+    const int kb_ = lk * KE;                                                                              \
+    PG_LOAD_ROW(0, kb_); PG_LOAD_ROW(1, kb_); PG_LOAD_ROW(2, kb_); PG_LOAD_ROW(3, kb_);                   \
+    if (++lk == nk) {                                                                                     \
+      lk = 0;                                                                                             \
+      if (++ltile < ntiles) PG_SETUP(ltile);                                                              \
+    }                                                                                                     \
+  } while (0)
+
+  frag_t xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+#define PG_RD(SET, stage, q)                                                                              \
+  do {                                                                                                    \
+    const char* sA_ = smem + (stage) * 2 * TILE_B;                                                        \
+    const char* sW_ = sA_ + TILE_B;                                                                       \
+    SET##a0 = *reinterpret_cast<const frag_t*>(sA_ + a_off + (q) * 32);                                   \
+    SET##a1 = *reinterpret_cast<const frag_t*>(sA_ + a_off + 32 * ROWB + (q) * 32);                       \
+    SET##b0 = *reinterpret_cast<const frag_t*>(sW_ + w_off + (q) * 32);                                   \
+    SET##b1 = *reinterpret_cast<const frag_t*>(sW_ + w_off + 32 * ROWB + (q) * 32);                       \
+  } while (0)
+#define PG_MM(SET)                                                                                        \
+  do {                                                                                                    \
+    if constexpr (PREC == 0) {                                                                            \
+      const float4& A0_ = reinterpret_cast<const float4&>(SET##a0);                                       \
+      const float4& A1_ = reinterpret_cast<const float4&>(SET##a1);                                       \
+      const float4& B0_ = reinterpret_cast<const float4&>(SET##b0);                                       \
+      const float4& B1_ = reinterpret_cast<const float4&>(SET##b1);                                       \
+      const float av_[2][4] = {{A0_.x, A0_.y, A0_.z, A0_.w}, {A1_.x, A1_.y, A1_.z, A1_.w}};               \
+      const float bv_[2][4] = {{B0_.x, B0_.y, B0_.z, B0_.w}, {B1_.x, B1_.y, B1_.z, B1_.w}};               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[0][j], bv_[0][j], acc00, 0, 0, 0);               \
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[0][j], bv_[1][j], acc01, 0, 0, 0);               \
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[1][j], bv_[0][j], acc10, 0, 0, 0);               \
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[1][j], bv_[1][j], acc11, 0, 0, 0);               \
+      }                                                                                                   \
+    } else {                                                                                              \
+      const bf16x8& A0_ = reinterpret_cast<const bf16x8&>(SET##a0);                                       \
+      const bf16x8& A1_ = reinterpret_cast<const bf16x8&>(SET##a1);                                       \
+      const bf16x8& B0_ = reinterpret_cast<const bf16x8&>(SET##b0);                                       \
+      const bf16x8& B1_ = reinterpret_cast<const bf16x8&>(SET##b1);                                       \
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0_, B0_, acc00, 0, 0, 0);                          \
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0_, B1_, acc01, 0, 0, 0);                          \
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1_, B0_, acc10, 0, 0, 0);                          \
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1_, B1_, acc11, 0, 0, 0);                          \
+    }                                                                                                     \
+  } while (0)
+#define PG_STORE_ROW(stage, r)                                                                            \
+  do {                                                                                                    \
+    char* sA_ = smem + (stage) * 2 * TILE_B;                                                              \
+    char* sW_ = sA_ + TILE_B;                                                                             \
+    const int off_ = (rbase + 32 * (r)) * ROWB + chunk * 16;                                              \
+    if constexpr (NLA == 2) *reinterpret_cast<uint4*>(sA_ + off_) = pack_bf16x8(ra##r, rb##r);            \
+    else *reinterpret_cast<float4*>(sA_ + off_) = ra##r;                                                  \
+    *reinterpret_cast<uint4*>(sW_ + off_) = rw##r;                                                        \
+  } while (0)
+
+  // ---- accumulators of the running tile and of the tile whose epilogue is pending
+  f32x16 acc00, acc01, acc10, acc11, pnd00, pnd01, pnd10, pnd11;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.f; pnd00[e] = pnd01[e] = pnd10[e] = pnd11[e] = 0.f; }
+  int pm0 = 0, pn0 = 0;      // origin of the pending tile
+  int pend = 0;              // bit q set: quadrant q (mi = q>>1, ni = q&1) still to be written
+
+  // one 32x32 quadrant of the pending tile: bias, activation, residual, store
+#define PG_EPI(Q, REG)                                                                                    \
+  do {                                                                                                    \
+    const int col_ = pn0 + wn * 64 + ((Q) & 1) * 32 + li;                                                 \
+    const bool cok_ = col_ < d.N;                                                                         \
+    const int colc_ = cok_ ? col_ : d.N - 1;                                                              \
+    const float bias_ = d.bias ? d.bias[colc_] : 0.f;                                                     \
+    const int rowb_ = pm0 + wm * 64 + ((Q) >> 1) * 32 + 4 * hh;                                           \
+    float res_[16];                                                                                       \
+    if constexpr (RES) {                                                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+        const int row_ = min(rowb_ + (r & 3) + 8 * (r >> 2), d.M - 1);                                    \
+        res_[r] = d.residual[(size_t)row_ * d.ldr + colc_];                                               \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
+      const int row_ = rowb_ + (r & 3) + 8 * (r >> 2);                                                    \
+      float v_ = REG[r] + bias_;                                                                          \
+      if constexpr (ACT == ACX_ACT_QUICKGELU) v_ = v_ * (1.f / (1.f + __expf(-1.702f * v_)));             \
+      if constexpr (RES) v_ += res_[r];                                                                   \
+      if (cok_ && row_ < d.M) {                                                                           \
+        if constexpr (C_BF16) ((u16*)d.C)[(size_t)row_ * d.ldc + col_] = f2bf(v_);                        \
+        else ((float*)d.C)[(size_t)row_ * d.ldc + col_] = v_;                                             \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+#define PG_EPI_Q(Q)                                                                                       \
+  do {                                                                                                    \
+    if ((Q) == 0) PG_EPI(0, pnd00); else if ((Q) == 1) PG_EPI(1, pnd01);                                  \
+    else if ((Q) == 2) PG_EPI(2, pnd10); else PG_EPI(3, pnd11);                                           \
+  } while (0)
+
+  // ---- prologue (first tile only)
+  PG_SETUP(0);
+  PG_LOAD_NEXT();
+  PG_STORE_ROW(0, 0); PG_STORE_ROW(0, 1); PG_STORE_ROW(0, 2); PG_STORE_ROW(0, 3);
+  __syncthreads();
+  if (S > 1) PG_LOAD_NEXT();
+  PG_RD(x, 0, 0);
+
+  int kt = 0, ti = 0;
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1;
+    const bool more = s + 1 < S;
+    PG_RD(y, cur, 1);
+    PG_MM(x);                                   // phase 0
+    PG_RD(x, cur, 2);
+    if (more) { PG_STORE_ROW(nxt, 0); PG_STORE_ROW(nxt, 1); }
+    PG_MM(y);                                   // phase 1
+    PG_RD(y, cur, 3);
+    if (more) { PG_STORE_ROW(nxt, 2); PG_STORE_ROW(nxt, 3); }
+    if (pend) {                                 // deferred epilogue of the previous tile: one quadrant per K-step
+      if (pend & 1) { PG_EPI(0, pnd00); pend &= ~1; }
+      else if (pend & 2) { PG_EPI(1, pnd01); pend &= ~2; }
+      else if (pend & 4) { PG_EPI(2, pnd10); pend &= ~4; }
+      else { PG_EPI(3, pnd11); pend &= ~8; }
+    }
+    PG_MM(x);                                   // phase 2
+    __syncthreads();
+    if (s + 2 < S) PG_LOAD_NEXT();
+    if (more) PG_RD(x, nxt, 0);
+    PG_MM(y);                                   // phase 3
+    if (++kt == nk) {                           // tile finished: hand the accumulators to the deferred epilogue
+      if (pend & 1) PG_EPI(0, pnd00);
+      if (pend & 2) PG_EPI(1, pnd01);
+      if (pend & 4) PG_EPI(2, pnd10);
+      if (pend & 8) PG_EPI(3, pnd11);
+      pnd00 = acc00; pnd01 = acc01; pnd10 = acc10; pnd11 = acc11;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.f;
+      tile_origin(ti, pm0, pn0);
+      pend = 15;
+      kt = 0;
+      ++ti;
+    }
+  }
+  if (pend & 1) PG_EPI(0, pnd00);
+  if (pend & 2) PG_EPI(1, pnd01);
+  if (pend & 4) PG_EPI(2, pnd10);
+  if (pend & 8) PG_EPI(3, pnd11);
+#undef PG_SETUP_ROW
+#undef PG_SETUP
+#undef PG_LOAD_ROW
+#undef PG_LOAD_NEXT
+#undef PG_RD
+#undef PG_MM
+#undef PG_STORE_ROW
+#undef PG_EPI
+#undef PG_EPI_Q
 }
 
 
@@ -551,6 +886,15 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   g.d = *d;
   const int tiles_m = (d->M + BM - 1) / BM;
   g.tiles_n = (d->N + BN - 1) / BN;
+  {
+    static const int order = getenv("ACX_TILE_ORDER") ? atoi(getenv("ACX_TILE_ORDER")) : 0;
+    g.tile_order = order;
+    // half of one tile's solo K-loop time: nk * 64 MFMA * 64 cycles / 2 at ~2.2 GHz, in 100 MHz wall-clock ticks
+    static const int frac = getenv("ACX_DEPHASE_PCT") ? atoi(getenv("ACX_DEPHASE_PCT")) : 50;
+    const int nk_ = (d->K + (prec == ACX_PREC_F32 ? 32 : 64) - 1) / (prec == ACX_PREC_F32 ? 32 : 64);
+    const double cyc = prec == ACX_PREC_F32 ? 4096.0 : 512.0;
+    g.dephase_cycles = tiles_m * g.tiles_n > 512 ? (int)(nk_ * cyc / 2200.0 * 100.0 * frac / 100.0) : 0;
+  }
   const dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
   const size_t lds = 4 * TILE_B;
   hipStream_t s = (hipStream_t)stream;
@@ -569,9 +913,29 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const bool fast = d->amap == ACX_AMAP_IDENTITY && !d->a_sub && !d->pos0 && d->K % ke == 0 &&
                     d->act != ACX_ACT_LEAKYRELU;
   const int variant = (prec == ACX_PREC_F32 ? 0 : (a_bf16 ? 1 : 2)) * 2 + c_bf16;   // 0..5
+  // persistent tile stream when there are more tiles than resident block slots (2 per CU x 256 CUs)
+  static const int acx_persistent_env = getenv("ACX_GEMM_PERSISTENT") ? atoi(getenv("ACX_GEMM_PERSISTENT")) : 0;
+  const bool persistent = fast && acx_persistent_env && tiles_m * g.tiles_n > 512;
+  const dim3 pgrid(512);
+#define ACX_PLAUNCH(P, AB, CB, ACT, RES)                                                            \
+  do {                                                                                              \
+    static bool attr_done = false;                                                                  \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_persistent_kernel<P, AB, CB, ACT, RES>,           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_persistent_kernel<P, AB, CB, ACT, RES>), pgrid, block, lds, s, g);     \
+  } while (0)
 #define ACX_FAST(P, AB, CB)                                                           \
   do {                                                                                \
-    if (d->act == ACX_ACT_QUICKGELU) {                                                \
+    if (persistent) {                                                                 \
+      if (d->act == ACX_ACT_QUICKGELU) {                                              \
+        if (d->residual) ACX_PLAUNCH(P, AB, CB, 1, 1); else ACX_PLAUNCH(P, AB, CB, 1, 0); \
+      } else {                                                                        \
+        if (d->residual) ACX_PLAUNCH(P, AB, CB, 0, 1); else ACX_PLAUNCH(P, AB, CB, 0, 0); \
+      }                                                                               \
+    } else if (d->act == ACX_ACT_QUICKGELU) {                                         \
       if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 1, 1); else ACX_LAUNCH(P, AB, CB, 1, 1, 0); \
     } else {                                                                          \
       if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 0, 1); else ACX_LAUNCH(P, AB, CB, 1, 0, 0); \
@@ -597,6 +961,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     }
   }
 #undef ACX_FAST
+#undef ACX_PLAUNCH
 #undef ACX_LAUNCH
   ACX_CHECK_LAUNCH(ctx, "acx_gemm");
   return ACX_OK;

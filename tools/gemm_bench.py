@@ -10,12 +10,16 @@ ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--prec", default="f32")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--shapes", default="qkv,out,fc,proj")
+ap.add_argument("--custom", default="")   # e.g. 1536x768,4608x768  (NxK)
 args = ap.parse_args()
 M = 197 * args.frames
 SH = {"qkv": (2304, 768), "out": (768, 768), "fc": (3072, 768), "proj": (768, 3072)}
 dev = "cuda"
 prec = L.PREC_F32 if args.prec == "f32" else L.PREC_BF16
-for name in args.shapes.split(","):
+names = args.shapes.split(",") if not args.custom else []
+for c in filter(None, args.custom.split(",")):
+    n_, k_ = c.split("x"); SH[c] = (int(n_), int(k_)); names.append(c)
+for name in names:
     N, K = SH[name]
     a = torch.randn(M, K, device=dev)
     w = torch.randn(N, K, device=dev) * 0.05
