@@ -4,7 +4,8 @@
 Metric (BASELINE.json): frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2.
 Workload (configs[2] of BASELINE.json / SURVEY.md 8d config 3): one STEP = one synthetic clip of
 512 frames (1,512,3,224,224) f32 already resident in HBM -> `AnomalyCLIP.forward(test_mode=True,
-load_from_features=False)`: CLIP ViT-B/16 encode in chunks of 256 frames (the config's batch 256),
+load_from_features=False)`: CLIP ViT-B/16 encode of the clip (one 512-frame launch by default; --vit-chunk 256
+reproduces the config's batch 256),
 text encoder (recomputed every step like the reference, anomaly_clip.py:136), selector, axial
 temporal transformer (one S=1 tile), classifier, then the eval post-processing
 softmax(similarity)*score (anomaly_clip_module.py:474-477).  Random-init weights of the UCF-Crime
@@ -41,7 +42,7 @@ TEXT_GFLOP_PER_CALL = 83.43           # text encoder at 14 classes
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 
-def build_net(precision, device):
+def build_net(precision, device, vit_chunk=256):
     from anomalyclip_amd import init_weights as IW
     from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP, lookup_prompts
     hc = IW.UCF_HEAD
@@ -51,7 +52,7 @@ def build_net(precision, device):
                       dim_heads=None, num_segments=32, seg_length=16, concat_features=False, normal_id=hc.normal_id,
                       stride=1, load_from_features=False, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7,
                       ncrops=1, num_topk=3, num_bottomk=3, n_ctx=8, shared_context=False, ctx_init="",
-                      precision=precision, vit_chunk=256)
+                      precision=precision, vit_chunk=vit_chunk)
     sd = IW.init_anomalyclip_state_dict(IW.VIT_B16, hc, toks, seed=0)
     net.load_state_dict(sd, strict=True)
     return net.to(device).eval(), sd, toks.argmax(-1), hc
@@ -109,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vit-chunk", type=int, default=512, help="frames per ViT launch (default: the whole 512-frame clip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +130,7 @@ def main():
     from anomalyclip_amd import _lib as L
     from anomalyclip_amd import ops
 
-    net, sd, eot, hc = build_net(args.precision, dev)
+    net, sd, eot, hc = build_net(args.precision, dev, args.vit_chunk)
     g = torch.Generator(device=dev).manual_seed(2 + rank)
     frames = torch.randn(1, FRAMES_PER_CLIP, 3, 224, 224, generator=g, device=dev)      # resident in HBM
     nc = torch.zeros(512, device=dev)
@@ -179,19 +181,29 @@ def main():
         flop_per_launch = gemm_gflop_step * args.steps / max(n_gemm, 1)       # GFLOP per launch (average)
         achieved = flop_per_launch / avg_ms if avg_ms > 0 else 0.0           # GFLOP/ms == TFLOP/s
         peak = PEAK_TFLOPS[args.precision]
+        # HBM traffic of the dominant kernel: PMC counters cannot be read in-process; they are collected by
+        # tools/profile_bench.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/.
+        traffic = None
+        pmc_file = os.path.join(REPO, "profiles", "r01_bench_f32_pmc.json")
+        if args.precision == "f32" and args.vit_chunk == 512 and os.path.exists(pmc_file):
+            try:
+                traffic = round(json.load(open(pmc_file))["gemm"]["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
         out = {
             "metric": "frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "bf16(mfma)/f32(acc,attention)", "data": "synthetic",
-            "config": {"workload": "configs[2]: synthetic 224x224 RGB frames, ViT-B/16 encode (chunks of 256) + "
+            "config": {"workload": "configs[2]: synthetic 224x224 RGB frames, ViT-B/16 encode + "
                                    "text encoder + selector + axial temporal head + eval post-processing; "
                                    "step = one 512-frame clip per GPU, UCF-Crime head config, random-init weights",
-                       "frames_per_step_per_gpu": FRAMES_PER_CLIP, "vit_chunk": 256, "precision": args.precision},
+                       "frames_per_step_per_gpu": FRAMES_PER_CLIP, "vit_chunk": args.vit_chunk, "precision": args.precision},
             "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_kernel, v_mfma_f32_32x32x2_f32)"
                          if args.precision == "f32" else "acx_gemm (gemm_kernel, v_mfma_f32_32x32x16_bf16)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None, "launches": int(n_gemm), "avg_launch_ms": round(avg_ms, 4),
+                         "traffic": traffic, "traffic_source": "profiles/r01_bench_f32_pmc.json (rocprofv3 PMC, bytes per launch)" if traffic else None, "launches": int(n_gemm), "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_gflop_per_launch": round(flop_per_launch, 3)},
             "kernel_time_ms_per_step": {"gemm": round(tot[0] / args.steps, 3), "attention": round(tot[1] / args.steps, 3),
                                         "norm_rows": round(tot[2] / args.steps, 3), "other": round(tot[3] / args.steps, 3)},
