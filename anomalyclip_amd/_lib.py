@@ -62,6 +62,7 @@ _SIGS = {
                                 c_int64, c_int32, c_float, c_int32, c_void_p]),
     "acx_attention": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                 c_int32, c_void_p]),
+    "acx_attention_cls": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_vit_patches": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acx_vit_embed": (C.c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
     "acx_vit_workspace_bytes": (c_size_t, [C.POINTER(VitDesc), c_int32]),
@@ -85,6 +86,7 @@ _SIGS = {
     "acx_add_bcast": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "acx_concat_features": (C.c_int, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_prof_enable": (C.c_int, [c_void_p, C.c_int]),
+    "acx_prof_gemm_flops": (C.c_int, [c_void_p, C.POINTER(C.c_double)]),
     "acx_prof_collect": (C.c_int, [c_void_p, C.POINTER(c_int32), C.POINTER(C.c_double)]),
     "acx_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "acx_gemm_tn": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,

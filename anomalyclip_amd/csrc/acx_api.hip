@@ -4,8 +4,12 @@
 #include "acx_internal.h"
 
 #include <new>
+#include <stdlib.h>
 
 thread_local char acx_tls_err[512] = {0};
+
+extern "C" int acx_attention_cls(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int32_t batch,
+                                 int32_t L, int32_t heads, void* stream);
 
 extern "C" int acx_version(void) { return ACX_VERSION; }
 
@@ -34,6 +38,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->err[0] = 0;
   c->prof_on = false;
   c->prof_n = c->prof_created = 0;
+  c->prof_gemm_flops = 0.0;
   c->prof_ev = new (std::nothrow) hipEvent_t[2 * ACX_PROF_MAX];
   c->prof_kind = new (std::nothrow) unsigned char[ACX_PROF_MAX];
   *out = c;
@@ -51,7 +56,13 @@ extern "C" void acx_destroy(acx_ctx* ctx) {
 extern "C" int acx_prof_enable(acx_ctx* ctx, int on) {
   if (!ctx || !ctx->prof_ev || !ctx->prof_kind) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_enable: no context%s");
   ctx->prof_on = on != 0;
-  if (on) ctx->prof_n = 0;
+  if (on) { ctx->prof_n = 0; ctx->prof_gemm_flops = 0.0; }
+  return ACX_OK;
+}
+
+extern "C" int acx_prof_gemm_flops(acx_ctx* ctx, double* flops) {
+  if (!ctx || !flops) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_gemm_flops: null pointer%s");
+  *flops = ctx->prof_gemm_flops;
   return ACX_OK;
 }
 
@@ -97,7 +108,7 @@ TfWs carve_tf(char* base, int64_t rows, int W) {
 
 int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
            void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
-           hipStream_t s) {
+           hipStream_t s, int ldr = 0) {
   acx_gemm_desc d;
   memset(&d, 0, sizeof(d));
   d.A = A; d.C = C;
@@ -106,17 +117,46 @@ int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const fl
                             prec == ACX_PREC_BF16 ? "bf16" : "f32");
   d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc;
   d.a_dtype = a_dtype; d.c_dtype = c_dtype; d.prec = prec;
-  d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldc;
+  d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
   return acx_gemm(ctx, &d, s);
 }
 
+// cls_ws != nullptr: the LAST layer is evaluated only where its output is consumed (token 0 of every sequence,
+// clip/model.py:285): K and V for all tokens, everything else for `batch` rows.  The final residual stream of
+// the CLS tokens is left COMPACT in cls_ws[0 .. batch*W) instead of x.
 int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int heads, int layers, int causal, int prec,
-                       const acx_block_weights* blk, const TfWs& ws, hipStream_t s) {
+                       const acx_block_weights* blk, const TfWs& ws, hipStream_t s, float* cls_ws = nullptr) {
   const int64_t rows = (int64_t)batch * L;
   const int hdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
+  const size_t esz = prec == ACX_PREC_BF16 ? 2 : 4;
   int rc;
   for (int l = 0; l < layers; ++l) {
     const acx_block_weights& b = blk[l];
+    if (cls_ws && l == layers - 1) {
+      float* xc = cls_ws;                        // [batch, W]  final CLS residual stream
+      float* attc = cls_ws + (size_t)batch * W;  // [batch, W]
+      float* x1 = attc + (size_t)batch * W;      // [batch, W]
+      char* hc = (char*)(x1 + (size_t)batch * W);          // [batch, W]   (f32 or bf16)
+      char* mc = hc + (size_t)batch * W * 4;               // [batch, 4W]  (f32 or bf16)
+      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+      // K | V for every token: rows [W, 3W) of in_proj
+      if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w + (size_t)W * W,
+                       b.in_proj_w_bf16 ? (const char*)b.in_proj_w_bf16 + (size_t)W * W * 2 : nullptr, W,
+                       (float*)ws.qkv + W, ACX_F32, 3 * W, (int)rows, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr, s))) return rc;
+      // Q for the CLS rows only (A rows strided by one sequence)
+      if ((rc = linear(ctx, prec, ws.h, hdt, L * W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, ACX_F32, L * 3 * W, batch, W, W,
+                       b.in_proj_b, ACX_ACT_NONE, nullptr, s))) return rc;
+      if ((rc = acx_attention_cls(ctx, (const float*)ws.qkv, 3 * W, attc, W, batch, L, heads, s))) return rc;
+      if ((rc = linear(ctx, prec, attc, ACX_F32, W, b.out_proj_w, b.out_proj_w_bf16, W, x1, ACX_F32, W, batch, W, W,
+                       b.out_proj_b, ACX_ACT_NONE, x, s, L * W))) return rc;
+      if ((rc = acx_layernorm(ctx, x1, W, b.ln2_w, b.ln2_b, hc, W, hdt, batch, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+      if ((rc = linear(ctx, prec, hc, hdt, W, b.fc_w, b.fc_w_bf16, W, mc, hdt, 4 * W, batch, 4 * W, W, b.fc_b,
+                       ACX_ACT_QUICKGELU, nullptr, s))) return rc;
+      if ((rc = linear(ctx, prec, mc, hdt, 4 * W, b.proj_w, b.proj_w_bf16, 4 * W, xc, ACX_F32, W, batch, W, 4 * W,
+                       b.proj_b, ACX_ACT_NONE, x1, s))) return rc;
+      (void)esz;
+      continue;
+    }
     // x = x + attn(ln_1(x))                                          clip/model.py:215
     if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, ACX_F32, 3 * W, (int)rows, 3 * W, W,
@@ -152,7 +192,7 @@ extern "C" int acx_transformer_forward(acx_ctx* ctx, float* x, int32_t batch, in
 
 namespace {
 struct VitWs {
-  char *patches, *patch_out, *x, *cls;
+  char *patches, *patch_out, *x, *cls, *cls_ws;
   size_t tf_off, total;
 };
 VitWs carve_vit(char* base, const acx_vit_desc* d, int F) {
@@ -164,6 +204,7 @@ VitWs carve_vit(char* base, const acx_vit_desc* d, int F) {
   w.patch_out = base + off; off += al((size_t)F * T * W * 4);
   w.x = base + off;         off += al((size_t)F * (T + 1) * W * 4);
   w.cls = base + off;       off += al((size_t)F * W * 4);
+  w.cls_ws = base + off;    off += al((size_t)F * W * 4 * 8);      // xc, attc, x1, hc, mc(4W)
   w.tf_off = off;
   off += carve_tf(nullptr, (int64_t)F * (T + 1), W).total;
   w.total = off;
@@ -199,10 +240,12 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   if ((rc = acx_vit_embed(ctx, (const float*)ws.patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
                           w->ln_pre_b, (float*)ws.x, F, T, W, s))) return rc;
   const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W);
-  if ((rc = transformer_layers(ctx, (float*)ws.x, F, T + 1, W, d->heads, d->layers, 0, prec, w->blocks, tf, s))) return rc;
+  static const bool prune = !(getenv("ACX_VIT_NO_PRUNE"));
+  if ((rc = transformer_layers(ctx, (float*)ws.x, F, T + 1, W, d->heads, d->layers, 0, prec, w->blocks, tf, s,
+                               prune ? (float*)ws.cls_ws : nullptr))) return rc;
   // ln_post on the CLS rows, then @ proj                                :285-288
-  if ((rc = acx_layernorm(ctx, (const float*)ws.x, (int64_t)(T + 1) * W, w->ln_post_w, w->ln_post_b, ws.cls, W, ACX_F32,
-                          F, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+  if ((rc = acx_layernorm(ctx, prune ? (const float*)ws.cls_ws : (const float*)ws.x, prune ? (int64_t)W : (int64_t)(T + 1) * W,
+                          w->ln_post_w, w->ln_post_b, ws.cls, W, ACX_F32, F, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
   return linear(ctx, prec, ws.cls, ACX_F32, W, w->proj_t, w->proj_t_bf16, W, features, ACX_F32, d->embed_dim, F,
                 d->embed_dim, W, nullptr, ACX_ACT_NONE, nullptr, s);
 }

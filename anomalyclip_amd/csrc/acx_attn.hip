@@ -160,6 +160,57 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __re
   }
 }
 
+
+// CLS-only attention for the LAST ViT layer: only token 0 of every sequence is consumed downstream
+// (clip/model.py:285 takes x[:, 0, :]), so only query row 0 needs softmax(q k^T) v.  One wavefront per
+// (sequence, head): lanes own keys for the scores, then own output dims for the weighted sum of V.
+__global__ __launch_bounds__(256) void attn_cls_kernel(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out,
+                                                       int64_t ldo, int batch, int L, int heads) {
+  const int lane = threadIdx.x & 63;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= (int64_t)batch * heads) return;
+  const int b = (int)(idx / heads), h = (int)(idx % heads);
+  const int W = heads * 64;
+  const float* base = qkv + (int64_t)b * L * ldqkv + h * 64;
+  float q[64];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(base + 4 * c);
+    q[4 * c] = v.x * 0.125f; q[4 * c + 1] = v.y * 0.125f; q[4 * c + 2] = v.z * 0.125f; q[4 * c + 3] = v.w * 0.125f;
+  }
+  float sc[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = lane + 64 * u;
+    float acc = -INFINITY;
+    if (j < L) {
+      const float* kp = base + (int64_t)j * ldqkv + W;
+      acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(kp + 4 * c);
+        acc += q[4 * c] * v.x + q[4 * c + 1] * v.y + q[4 * c + 2] * v.z + q[4 * c + 3] * v.w;
+      }
+    }
+    sc[u] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { sc[u] = __expf(sc[u] - mx); sum += sc[u]; }
+  sum = wave_sum(sum);
+  float o = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const int u_ = j >> 6;
+    const float mine = u_ == 0 ? sc[0] : (u_ == 1 ? sc[1] : (u_ == 2 ? sc[2] : sc[3]));
+    const float p = __shfl(mine, j & 63, 64);
+    o += p * base[(int64_t)j * ldqkv + 2 * W + lane];
+  }
+  out[(int64_t)b * ldo + h * 64 + lane] = o / sum;
+}
+
 }  // namespace
 
 extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
@@ -198,5 +249,19 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   }
 #undef ACX_ATTN
   ACX_CHECK_LAUNCH(ctx, "acx_attention");
+  return ACX_OK;
+}
+
+extern "C" int acx_attention_cls(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int32_t batch,
+                                 int32_t L, int32_t heads, void* stream) {
+  if (!qkv || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_cls: null pointer%s");
+  if (batch <= 0) return ACX_OK;
+  if (L <= 0 || L > 256 || heads <= 0) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention_cls: need 0 < L <= 256%s");
+  if (ldqkv % 4 || ((uintptr_t)qkv & 15)) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_cls: alignment%s");
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_ATTN, s);
+  const int64_t n = (int64_t)batch * heads;
+  hipLaunchKernelGGL(attn_cls_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, qkv, ldqkv, out, ldo, batch, L, heads);
+  ACX_CHECK_LAUNCH(ctx, "acx_attention_cls");
   return ACX_OK;
 }

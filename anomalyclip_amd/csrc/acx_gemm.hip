@@ -899,6 +899,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const size_t lds = 4 * TILE_B;
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM, (hipStream_t)stream);
+  if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * d->M * (double)d->N * d->K;
 #define ACX_LAUNCH(P, AB, CB, F, ACT, RES)                                                          \
   do {                                                                                              \
     static bool attr_done = false;                                                                  \
@@ -997,6 +998,7 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
   const size_t lds = 4 * 32 * TN_ROWF * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM, s);
+  if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -26,6 +26,7 @@ struct acx_ctx {
   int prof_created;    // event pairs created so far
   hipEvent_t* prof_ev; // [2 * ACX_PROF_MAX]
   unsigned char* prof_kind;
+  double prof_gemm_flops;   // 2*M*N*K summed over acx_gemm / acx_gemm_tn launches while recording
 };
 
 struct AcxProfScope {

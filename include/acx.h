@@ -97,6 +97,11 @@ int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const float* w, con
 int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
                   int32_t batch, int32_t L, int32_t heads, int32_t causal, void* stream);
 
+/* acx_attention_cls: same attention, but only for query row 0 of every sequence (out [batch, heads*64]).
+ * Used for the LAST ViT layer, whose output is consumed at the CLS token only (clip/model.py:285). */
+int acx_attention_cls(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                      int32_t batch, int32_t L, int32_t heads, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * acx_vit_patches: im2col of 16x16/16 patches (clip/model.py:246-252,267-269).
  * frames [F,3,R,R] f32 -> patches [F*g*g, 3*P*P] (k = c*P*P + ky*P + kx, token = gy*g+gx). */
@@ -296,6 +301,8 @@ int acx_scatter_rows(acx_ctx* ctx, const float* src, const int64_t* idx, float* 
 #define ACX_PROF_KINDS 4
 int acx_prof_enable(acx_ctx* ctx, int on);
 int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms);
+/* executed GEMM flops (2*M*N*K of every acx_gemm / acx_gemm_tn launch) since acx_prof_enable(ctx, 1) */
+int acx_prof_gemm_flops(acx_ctx* ctx, double* flops);
 
 #ifdef __cplusplus
 }
