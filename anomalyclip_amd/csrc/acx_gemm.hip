@@ -29,6 +29,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef ACX_TRACE
+#define ACX_TRACE 0
+#endif
+#ifndef ACX_PERSISTENT
+#define ACX_PERSISTENT 0   // experimental persistent tile stream (needs a register diet: spills at 256 VGPRs)
+#endif
 #ifndef ACX_DEPHASE
 #define ACX_DEPHASE 1
 #endif
@@ -50,6 +56,7 @@ struct Args {
   acx_gemm_desc d;
   int tiles_n;
   int tile_order;
+  long long* trace;        // debug timeline buffer (ACX_TRACE builds only)
   int dephase_cycles;      // wall_clock64 ticks (100 MHz) the second block of each CU waits at launch
 };
 
@@ -95,6 +102,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 
   const int t = threadIdx.x;
   const int chunk = t & 7, rbase = t >> 3;
+#if ACX_TRACE
+  const long long tr0 = wall_clock64();
+  long long tr1 = 0, tr2 = 0;
+#endif
 
 #if ACX_DEPHASE
   // Co-resident blocks (2 per CU) start together and do identical work, so their prologue/epilogue bubbles
@@ -302,6 +313,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   __syncthreads();
   if (nk > 1) ACX_LOAD_TILE(KE);
   ACX_RD(x, 0, 0);
+#if ACX_TRACE
+  tr1 = wall_clock64();
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
     const bool more = kt + 1 < nk;
@@ -387,86 +401,82 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 
 #endif
 
+#if ACX_TRACE
+  tr2 = wall_clock64();
+#endif
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  if constexpr (FAST) {
+  // Structure matters: every value is fully computed (bias / residual / pos loads consumed) BEFORE the first
+  // store of its group is issued.  A store issued between a pending load and its use makes hipcc wait
+  // vmcnt(0) -- which on CDNA also waits for the previous STORE -- and serialises the 64 stores of a lane
+  // into 64 HBM round trips (measured: 29 us of a 120 us tile).
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 64 + ni * 32 + li;
-      const bool cok = col < d.N;
-      const int colc = cok ? col : d.N - 1;
-      const float bias = d.bias ? d.bias[colc] : 0.f;
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + li;
+    const bool cok = col < d.N;
+    const int colc = cok ? col : d.N - 1;
+    float bias = 0.f;
+    if (d.bias) bias = d.bias[colc];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int rowb = m0 + wm * 64 + mi * 32 + 4 * hh;
-        float resv[16];
-        if constexpr (RES) {
+    for (int mi = 0; mi < 2; ++mi) {
+      const int rowb = m0 + wm * 64 + mi * 32 + 4 * hh;
+      float outv[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
-            resv[r] = d.residual[(size_t)row * d.ldr + colc];
-          }
-        }
+      for (int r = 0; r < 16; ++r) outv[r] = 0.f;
+      const bool has_res = FAST ? (RES != 0) : (d.residual != nullptr);
+      if (has_res) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = rowb + (r & 3) + 8 * (r >> 2);
-          float v = acc[mi][ni][r] + bias;
-          if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
-          if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
-          if constexpr (RES) v += resv[r];
-          if (cok && row < d.M) {
-            if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);
-            else ((float*)d.C)[(size_t)row * d.ldc + col] = v;
+          const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
+          outv[r] = d.residual[(size_t)row * d.ldr + colc];
+        }
+      }
+      if constexpr (!FAST) {
+        if (d.pos0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rc = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
+            const int l = rc % d.gl, n = (rc / d.gl) % d.gn;
+            // reference order: (x + param_0) + param_1, then the residual (none on this GEMM)
+            outv[r] += d.pos0[(size_t)n * d.N + colc] + d.pos1[(size_t)l * d.N + colc];
           }
         }
       }
-    }
-  } else {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 64 + ni * 32 + li;
-      const bool cok = col < d.N;
-      const int colc = cok ? col : d.N - 1;
-      const float bias = d.bias ? d.bias[colc] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[mi][ni][r] + bias;
+        const int act = FAST ? ACT : d.act;
+        if (act == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+        else if (act == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
+        outv[r] += v;
+      }
+      // all loads consumed: make that explicit so the store loop below carries no memory dependencies
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int rowb = m0 + wm * 64 + mi * 32 + 4 * hh;
-        float extra[16];
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(outv[r]));   // pin: computed here, not inside the store's branch
 #pragma unroll
-        for (int r = 0; r < 16; ++r) extra[r] = 0.f;
-        if (d.residual) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
-            extra[r] = d.residual[(size_t)row * d.ldr + colc];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rowb + (r & 3) + 8 * (r >> 2);
-          float v = acc[mi][ni][r] + bias;
-          if (d.act == ACX_ACT_QUICKGELU) {
-            v = v * (1.f / (1.f + __expf(-1.702f * v)));
-          } else if (d.act == ACX_ACT_LEAKYRELU) {
-            v = v > 0.f ? v : 0.01f * v;
-          }
-          if (d.pos0) {
-            const int rc = min(row, d.M - 1);
-            const int l = rc % d.gl, n = (rc / d.gl) % d.gn;
-            v += d.pos0[(size_t)n * d.N + colc];
-            v += d.pos1[(size_t)l * d.N + colc];
-          }
-          v += extra[r];
-          if (cok && row < d.M) {
-            if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);
-            else ((float*)d.C)[(size_t)row * d.ldc + col] = v;
-          }
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowb + (r & 3) + 8 * (r >> 2);
+        if (cok && row < d.M) {
+          if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(outv[r]);
+          else ((float*)d.C)[(size_t)row * d.ldc + col] = outv[r];
         }
       }
     }
   }
+#if ACX_TRACE
+  if (g.trace && t == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* o = g.trace + (size_t)blockIdx.x * 6;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = wall_clock64(); o[4] = hwid; o[5] = xcc;
+  }
+#endif
 }
 
-
+#if ACX_PERSISTENT
 // =====================================================================================================
 // gemm_persistent_kernel -- FAST-path GEMM as a persistent, continuously pipelined tile stream.
 //
@@ -703,6 +713,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_persistent_kernel(const Args
 }
 
 
+#endif  // ACX_PERSISTENT
+
 // =====================================================================================================
 // acx_gemm_tn -- weight-gradient GEMM:  C[N1,N2] = sum_m A[m,n1] * bmap(B)[m,n2]      (exact f32 MFMA)
 //
@@ -889,6 +901,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   {
     static const int order = getenv("ACX_TILE_ORDER") ? atoi(getenv("ACX_TILE_ORDER")) : 0;
     g.tile_order = order;
+    g.trace = getenv("ACX_TRACE_PTR") ? (long long*)strtoull(getenv("ACX_TRACE_PTR"), nullptr, 0) : nullptr;
     // half of one tile's solo K-loop time: nk * 64 MFMA * 64 cycles / 2 at ~2.2 GHz, in 100 MHz wall-clock ticks
     static const int frac = getenv("ACX_DEPHASE_PCT") ? atoi(getenv("ACX_DEPHASE_PCT")) : 50;
     const int nk_ = (d->K + (prec == ACX_PREC_F32 ? 32 : 64) - 1) / (prec == ACX_PREC_F32 ? 32 : 64);
@@ -916,8 +929,9 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const int variant = (prec == ACX_PREC_F32 ? 0 : (a_bf16 ? 1 : 2)) * 2 + c_bf16;   // 0..5
   // persistent tile stream when there are more tiles than resident block slots (2 per CU x 256 CUs)
   static const int acx_persistent_env = getenv("ACX_GEMM_PERSISTENT") ? atoi(getenv("ACX_GEMM_PERSISTENT")) : 0;
-  const bool persistent = fast && acx_persistent_env && tiles_m * g.tiles_n > 512;
+  const bool persistent = ACX_PERSISTENT && fast && acx_persistent_env && tiles_m * g.tiles_n > 512;
   const dim3 pgrid(512);
+#if ACX_PERSISTENT
 #define ACX_PLAUNCH(P, AB, CB, ACT, RES)                                                            \
   do {                                                                                              \
     static bool attr_done = false;                                                                  \
@@ -928,6 +942,9 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     }                                                                                               \
     hipLaunchKernelGGL((gemm_persistent_kernel<P, AB, CB, ACT, RES>), pgrid, block, lds, s, g);     \
   } while (0)
+#else
+#define ACX_PLAUNCH(P, AB, CB, ACT, RES) do { (void)pgrid; } while (0)
+#endif
 #define ACX_FAST(P, AB, CB)                                                           \
   do {                                                                                \
     if (persistent) {                                                                 \
