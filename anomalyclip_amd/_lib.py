@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("a_sub", c_void_p),
         ("amap", c_int32), ("gn", c_int32), ("gl", c_int32), ("cin", c_int32), ("seg", c_int32),
         ("pos0", c_void_p), ("pos1", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
     ]
 
 
@@ -98,7 +99,7 @@ _SIGS = {
     "acx_add": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_transpose": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "acx_conv_weight_dx": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "acx_seq_attention_bwd": (C.c_int, [c_void_p] * 4 + [c_int32] * 7 + [c_void_p]),
+    "acx_seq_attention_bwd": (C.c_int, [c_void_p] * 4 + [c_int32] * 7 + [c_void_p, c_void_p]),
     "acx_pos_grad": (C.c_int, [c_void_p] * 4 + [c_int32] * 4 + [c_void_p]),
     "acx_bn_bwd_stats": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
     "acx_bn_bwd_apply": (C.c_int, [c_void_p] * 6 + [c_int32, c_int64, c_int64, c_int32, c_float, c_void_p]),

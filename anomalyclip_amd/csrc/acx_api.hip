@@ -91,8 +91,8 @@ namespace {
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TfWs {   // transformer scratch carved from the caller's workspace
-  char *h, *qkv, *att, *mlp;
-  size_t total;
+  char *h, *qkv, *att, *mlp, *splitk;
+  size_t splitk_bytes, total;
 };
 
 TfWs carve_tf(char* base, int64_t rows, int W) {
@@ -102,13 +102,16 @@ TfWs carve_tf(char* base, int64_t rows, int W) {
   w.qkv = base + off; off += al((size_t)rows * 3 * W * 4);
   w.att = base + off; off += al((size_t)rows * W * 4);
   w.mlp = base + off; off += al((size_t)rows * 4 * W * 4);
+  // split-K scratch for skinny problems (text tower: 14 x 77 rows): 8 partial copies of the widest output
+  w.splitk_bytes = rows <= 4096 ? (size_t)8 * rows * 4 * W * 4 : 0;
+  w.splitk = base + off; off += al(w.splitk_bytes);
   w.total = off;
   return w;
 }
 
 int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
            void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
-           hipStream_t s, int ldr = 0) {
+           hipStream_t s, int ldr = 0, void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
   acx_gemm_desc d;
   memset(&d, 0, sizeof(d));
   d.A = A; d.C = C;
@@ -118,6 +121,7 @@ int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const fl
   d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc;
   d.a_dtype = a_dtype; d.c_dtype = c_dtype; d.prec = prec;
   d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
+  d.workspace = splitk_bytes ? splitk_ws : nullptr; d.workspace_bytes = splitk_bytes;
   return acx_gemm(ctx, &d, s);
 }
 
@@ -160,16 +164,16 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     // x = x + attn(ln_1(x))                                          clip/model.py:215
     if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, ACX_F32, 3 * W, (int)rows, 3 * W, W,
-                     b.in_proj_b, ACX_ACT_NONE, nullptr, s))) return rc;
+                     b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
     if ((rc = linear(ctx, prec, ws.att, ACX_F32, W, b.out_proj_w, b.out_proj_w_bf16, W, x, ACX_F32, W, (int)rows, W, W,
-                     b.out_proj_b, ACX_ACT_NONE, x, s))) return rc;
+                     b.out_proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     // x = x + mlp(ln_2(x))                                           clip/model.py:216
     if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.fc_w, b.fc_w_bf16, W, ws.mlp, hdt, 4 * W, (int)rows, 4 * W, W, b.fc_b,
-                     ACX_ACT_QUICKGELU, nullptr, s))) return rc;
+                     ACX_ACT_QUICKGELU, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     if ((rc = linear(ctx, prec, ws.mlp, hdt, 4 * W, b.proj_w, b.proj_w_bf16, 4 * W, x, ACX_F32, W, (int)rows, W, 4 * W,
-                     b.proj_b, ACX_ACT_NONE, x, s))) return rc;
+                     b.proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
   }
   return ACX_OK;
 }

@@ -58,6 +58,8 @@ struct Args {
   int tile_order;
   long long* trace;        // debug timeline buffer (ACX_TRACE builds only)
   int dephase_cycles;      // wall_clock64 ticks (100 MHz) the second block of each CU waits at launch
+  int ksplit, kchunk;      // split-K (FAST path, skinny problems): gridDim.y splits of kchunk K-steps each
+  float* partial;          // [ksplit][M][N] raw partial sums (epilogue applied by splitk_reduce_kernel)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -265,7 +267,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int a_off = (wm * 64 + li) * ROWB + hh * 16;
   const int w_off = (wn * 64 + li) * ROWB + hh * 16;
 
-  const int nk = (d.K + KE - 1) / KE;
+  const int nk_total = (d.K + KE - 1) / KE;
+  const int kbeg = (g.ksplit > 1 ? (int)blockIdx.y * g.kchunk : 0) * KE;       // first K element of this split
+  const int nk = g.ksplit > 1 ? min(g.kchunk, nk_total - (int)blockIdx.y * g.kchunk) : nk_total;
 #if ACX_LOOP_V2
   // ---- software-pipelined K loop (v2).  Fragment registers are double-buffered by hand (fa/fb sets X and Y);
   // the ONE barrier of a K-step sits between MFMA phases 2 and 3: by then this wave has written its share of the
@@ -308,10 +312,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   } while (0)
 #define ACX_LOAD_TILE(k0) do { if constexpr (FAST) ACX_FAST_LOAD(k0); else ACX_GEN_LOAD(k0); } while (0)
 
-  ACX_LOAD_TILE(0);
+  ACX_LOAD_TILE(kbeg);
   ACX_STORE_ROW(0, 0); ACX_STORE_ROW(0, 1); ACX_STORE_ROW(0, 2); ACX_STORE_ROW(0, 3);
   __syncthreads();
-  if (nk > 1) ACX_LOAD_TILE(KE);
+  if (nk > 1) ACX_LOAD_TILE(kbeg + KE);
   ACX_RD(x, 0, 0);
 #if ACX_TRACE
   tr1 = wall_clock64();
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
     if (more) { ACX_STORE_ROW(nxt, 2); ACX_STORE_ROW(nxt, 3); }
     ACX_MM(x);                                   // phase 2
     __syncthreads();                             // next tile complete in LDS; everyone holds its phase-3 fragments
-    if (kt + 2 < nk) ACX_LOAD_TILE((kt + 2) * KE);
+    if (kt + 2 < nk) ACX_LOAD_TILE(kbeg + (kt + 2) * KE);
     if (more) ACX_RD(x, nxt, 0);
     ACX_MM(y);                                   // phase 3
   }
@@ -409,6 +413,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   // store of its group is issued.  A store issued between a pending load and its use makes hipcc wait
   // vmcnt(0) -- which on CDNA also waits for the previous STORE -- and serialises the 64 stores of a lane
   // into 64 HBM round trips (measured: 29 us of a 120 us tile).
+  if (g.ksplit > 1) {      // raw partial tile; bias / activation / residual happen in splitk_reduce_kernel
+    float* P = g.partial + (size_t)blockIdx.y * d.M * d.N;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + li;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mi * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+          if (col < d.N && row < d.M) P[(size_t)row * d.N + col] = acc[mi][ni][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + wn * 64 + ni * 32 + li;
@@ -862,6 +881,24 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   reinterpret_cast<float4*>(out)[i] = s;
 }
 
+
+// C = epilogue(sum_s partial[s])  for the split-K path (fixed summation order)
+template <int C_BF16>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, acx_gemm_desc d) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)d.M * d.N;
+  if (i >= total) return;
+  const int row = (int)(i / d.N), col = (int)(i - (int64_t)row * d.N);
+  float v = 0.f;
+  for (int s = 0; s < splits; ++s) v += part[(size_t)s * total + i];
+  if (d.bias) v += d.bias[col];
+  if (d.act == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+  else if (d.act == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
+  if (d.residual) v += d.residual[(size_t)row * d.ldr + col];
+  if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);
+  else ((float*)d.C)[(size_t)row * d.ldc + col] = v;
+}
+
 }  // namespace
 
 extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
@@ -908,7 +945,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     const double cyc = prec == ACX_PREC_F32 ? 4096.0 : 512.0;
     g.dephase_cycles = tiles_m * g.tiles_n > 512 ? (int)(nk_ * cyc / 2200.0 * 100.0 * frac / 100.0) : 0;
   }
-  const dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
+  dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
+  g.ksplit = 1; g.kchunk = 0; g.partial = nullptr;
   const size_t lds = 4 * TILE_B;
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM, (hipStream_t)stream);
@@ -959,6 +997,20 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 0, 1); else ACX_LAUNCH(P, AB, CB, 1, 0, 0); \
     }                                                                                 \
   } while (0)
+  if (fast && !persistent && d->workspace) {
+    // skinny problems (few tiles, long K): split K over gridDim.y so the chip is filled; partial sums are
+    // combined in fixed order by splitk_reduce_kernel together with the epilogue
+    const int tiles = tiles_m * g.tiles_n, nkt = d->K / ke;
+    int split = 1;
+    while (tiles * split * 2 <= 512 && nkt / (split * 2) >= 4 && split < 16) split *= 2;
+    if (split > 1 && (size_t)split * d->M * d->N * sizeof(float) <= d->workspace_bytes) {
+      g.ksplit = split;
+      g.kchunk = (nkt + split - 1) / split;
+      g.ksplit = (nkt + g.kchunk - 1) / g.kchunk;
+      g.partial = (float*)d->workspace;
+      grid.y = g.ksplit;
+    }
+  }
   if (fast) {
     switch (variant) {
       case 0: ACX_FAST(0, 0, 0); break;
@@ -981,6 +1033,12 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
 #undef ACX_FAST
 #undef ACX_PLAUNCH
 #undef ACX_LAUNCH
+  if (g.ksplit > 1) {
+    const int64_t total = (int64_t)d->M * d->N;
+    const dim3 rgrid((unsigned)((total + 255) / 256));
+    if (c_bf16) hipLaunchKernelGGL((splitk_reduce_kernel<1>), rgrid, dim3(256), 0, s, (const float*)g.partial, g.ksplit, *d);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<0>), rgrid, dim3(256), 0, s, (const float*)g.partial, g.ksplit, *d);
+  }
   ACX_CHECK_LAUNCH(ctx, "acx_gemm");
   return ACX_OK;
 }

@@ -370,6 +370,132 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------ sequence attention backward, wave-per-row form
+// For the CLIP text tower (few sequences: classes x heads, T = 77, E = 64) the thread-per-row kernel above leaves
+// the chip empty (9 k threads with 10^4-long serial loops: 0.73 ms per call).  Here ONE WAVEFRONT owns one query
+// row (pass 1) / one key row (pass 2): lanes hold up to KPL keys (queries) each for the dot products, then switch
+// to owning the E output dims for the weighted sums, with the softmax statistics exchanged through a small
+// global scratch ([rows*heads][3] = max, 1/sum, D).  Reads come straight from L2 (K/V/Q/dO of a head are 20 KB).
+template <int E, int KPL>
+__global__ __launch_bounds__(256) void seq_attn_bwd_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                float* __restrict__ dqkv, float* __restrict__ stats,
+                                                                int T, int heads, int causal, float scale, int pass,
+                                                                int64_t nrows) {
+  // row index r = ((seq * heads) + h) * T + i
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  const int i = (int)(r % T);
+  const int64_t sh = r / T;
+  const int h = (int)(sh % heads);
+  const int64_t seq = sh / heads;
+  const int He = heads * E, ld = 3 * He;
+  const float* base = qkv + seq * T * ld + h * E;          // token 0 of this sequence/head (q section)
+  const float* dob = dout + seq * T * He + h * E;
+  float* dqb = dqkv + seq * T * ld + h * E;
+  float* st = stats + sh * T * 3;                          // [T][3] of this (sequence, head)
+  constexpr int EPL = E / 64 > 0 ? E / 64 : 1;             // output dims per lane (E = 64 -> 1)
+  static_assert(E == 64, "rows kernel is built for head dim 64");
+
+  if (pass == 0) {
+    // ---- query row i: s_j, dP_j for this lane's keys
+    float sv[KPL], dp[KPL];
+    float mx = -INFINITY;
+    const int jmax = causal ? i + 1 : T;
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      const int j = lane + 64 * u;
+      sv[u] = -INFINITY;
+      dp[u] = 0.f;
+      if (j < jmax) {
+        float a = 0.f, b = 0.f;
+        const float* kp = base + (int64_t)j * ld + He;
+        const float* vp = base + (int64_t)j * ld + 2 * He;
+        const float* qp = base + (int64_t)i * ld;
+        const float* op = dob + (int64_t)i * He;
+#pragma unroll
+        for (int c = 0; c < E / 4; ++c) {
+          const float4 k4 = *reinterpret_cast<const float4*>(kp + 4 * c), q4 = *reinterpret_cast<const float4*>(qp + 4 * c);
+          const float4 v4 = *reinterpret_cast<const float4*>(vp + 4 * c), o4 = *reinterpret_cast<const float4*>(op + 4 * c);
+          a += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+          b += o4.x * v4.x + o4.y * v4.y + o4.z * v4.z + o4.w * v4.w;
+        }
+        sv[u] = a * scale;
+        dp[u] = b;
+      }
+      mx = fmaxf(mx, sv[u]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f, Di = 0.f;
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      const float p = __expf(sv[u] - mx);     // exp(-inf) = 0 for masked / absent keys
+      sv[u] = p;
+      sum += p;
+      Di += p * dp[u];
+    }
+    sum = wave_sum(sum);
+    Di = wave_sum(Di);
+    const float inv = 1.f / sum;
+    Di *= inv;
+    // dS_j = p_j (dP_j - D) * scale ; dq[e] = sum_j dS_j k[j][e]  (lane = e)
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) sv[u] = sv[u] * inv * (dp[u] - Di) * scale;
+    float dq = 0.f;
+    for (int j = 0; j < jmax; ++j) {
+      const int u_ = j >> 6;
+      float mine = sv[0];
+#pragma unroll
+      for (int u = 1; u < KPL; ++u) mine = u_ == u ? sv[u] : mine;
+      const float ds = __shfl(mine, j & 63, 64);
+      dq += ds * base[(int64_t)j * ld + He + lane];
+    }
+    dqb[(int64_t)i * ld + lane] = dq;
+    if (lane == 0) { st[i * 3] = mx; st[i * 3 + 1] = inv; st[i * 3 + 2] = Di; }
+  } else {
+    // ---- key/value row j = i: lanes hold queries qi = lane + 64u
+    const int j = i;
+    float pv[KPL], dsv[KPL];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      const int qi = lane + 64 * u;
+      pv[u] = 0.f;
+      dsv[u] = 0.f;
+      if (qi < T && (!causal || qi >= j)) {
+        float a = 0.f, b = 0.f;
+        const float* kp = base + (int64_t)j * ld + He;
+        const float* vp = base + (int64_t)j * ld + 2 * He;
+        const float* qp = base + (int64_t)qi * ld;
+        const float* op = dob + (int64_t)qi * He;
+#pragma unroll
+        for (int c = 0; c < E / 4; ++c) {
+          const float4 k4 = *reinterpret_cast<const float4*>(kp + 4 * c), q4 = *reinterpret_cast<const float4*>(qp + 4 * c);
+          const float4 v4 = *reinterpret_cast<const float4*>(vp + 4 * c), o4 = *reinterpret_cast<const float4*>(op + 4 * c);
+          a += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+          b += o4.x * v4.x + o4.y * v4.y + o4.z * v4.z + o4.w * v4.w;
+        }
+        const float p = __expf(a * scale - st[qi * 3]) * st[qi * 3 + 1];
+        pv[u] = p;
+        dsv[u] = p * (b - st[qi * 3 + 2]) * scale;
+      }
+    }
+    float dk = 0.f, dv = 0.f;
+    for (int qi = causal ? j : 0; qi < T; ++qi) {
+      const int u_ = qi >> 6;
+      float mp = pv[0], md = dsv[0];
+#pragma unroll
+      for (int u = 1; u < KPL; ++u) { mp = u_ == u ? pv[u] : mp; md = u_ == u ? dsv[u] : md; }
+      const float p = __shfl(mp, qi & 63, 64), ds = __shfl(md, qi & 63, 64);
+      dk += ds * base[(int64_t)qi * ld + lane];
+      dv += p * dob[(int64_t)qi * He + lane];
+    }
+    dqb[(int64_t)j * ld + He + lane] = dk;
+    dqb[(int64_t)j * ld + 2 * He + lane] = dv;
+  }
+  (void)EPL;
+}
+
 // ------------------------------------------------------------------ positional-embedding gradients
 // d_pos0[n][e] = sum_{tile,l} dx[(tile,n,l)][e];  d_pos1[l][e] = sum_{tile,n} dx[(tile,n,l)][e]
 __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dx, float* __restrict__ d0,
@@ -813,10 +939,25 @@ extern "C" int acx_conv_weight_dx(acx_ctx* ctx, const float* w, float* out, int3
 }
 
 extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int32_t tiles, int32_t gn,
-                                     int32_t gl, int32_t heads, int32_t e, int32_t axis, int32_t causal, void* stream) {
+                                     int32_t gl, int32_t heads, int32_t e, int32_t axis, int32_t causal, float* stats_ws, void* stream) {
   if (!qkv || !dout || !dqkv) return acx_fail(ctx, ACX_E_BADARG, "acx_seq_attention_bwd: null pointer%s");
   if (tiles <= 0) return ACX_OK;
   const int T = axis == 0 ? gn : gl;
+  if (e == 64 && gn == 1 && axis == 1 && T <= 256 && stats_ws) {
+    // text-tower shape: wave-per-row kernel (two launches: rows as queries, then rows as keys)
+    hipStream_t s2 = (hipStream_t)stream;
+    AcxProfScope prof2__(ctx, ACX_K_ATTN, s2);
+    const int64_t nrows = (int64_t)tiles * heads * T;
+    const dim3 grid2((unsigned)((nrows + 3) / 4)), block2(256);
+    const float scale2 = 0.125f;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (T <= 64) hipLaunchKernelGGL((seq_attn_bwd_rows_kernel<64, 1>), grid2, block2, 0, s2, qkv, dout, dqkv, stats_ws, T, heads, causal, scale2, pass, nrows);
+      else if (T <= 128) hipLaunchKernelGGL((seq_attn_bwd_rows_kernel<64, 2>), grid2, block2, 0, s2, qkv, dout, dqkv, stats_ws, T, heads, causal, scale2, pass, nrows);
+      else hipLaunchKernelGGL((seq_attn_bwd_rows_kernel<64, 4>), grid2, block2, 0, s2, qkv, dout, dqkv, stats_ws, T, heads, causal, scale2, pass, nrows);
+    }
+    ACX_CHECK_LAUNCH(ctx, "acx_seq_attention_bwd(rows)");
+    return ACX_OK;
+  }
   if (T <= 0 || T > 256 || (e != 16 && e != 32 && e != 64))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_seq_attention_bwd: need sequence <= 256, head dim in {16,32,64}%s");
   const int64_t nlines = (int64_t)tiles * (axis == 0 ? gl : gn);

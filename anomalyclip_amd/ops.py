@@ -40,6 +40,19 @@ def _dt(t: torch.Tensor) -> int:
     raise L.AcxError(f"unsupported dtype {t.dtype}")
 
 
+_SPLITK_WS: dict = {}
+
+
+def _splitk_workspace(device, nbytes: int) -> torch.Tensor:
+    """one reusable split-K scratch buffer per device (stream-ordered reuse on the current stream)."""
+    key = (device.type, device.index)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _SPLITK_WS[key] = ws
+    return ws
+
+
 def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     src = src.contiguous()
     dst = torch.empty(src.shape, dtype=_BF16, device=src.device)
@@ -72,6 +85,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     d.a_sub = _ptr(a_sub)
     d.amap, d.gn, d.gl, d.cin, d.seg = amap, gn, gl, cin, seg
     d.pos0, d.pos1 = _ptr(pos0), _ptr(pos1)
+    ws = None
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles <= 128 and K >= 256 and amap == L.AMAP_IDENTITY and a_sub is None and pos0 is None:
+        ws = _splitk_workspace(a.device, min(16, 512 // tiles) * M * N * 4)     # skinny problem: let the library split K
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a)
     L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)
     return out
@@ -300,8 +318,9 @@ def conv_weight_dx(w: torch.Tensor) -> torch.Tensor:
 def seq_attention_bwd(qkv, dout, tiles, gn, gl, heads, e, axis, causal=False) -> torch.Tensor:
     dqkv = torch.empty_like(qkv)
     h = _h(qkv)
+    stats = torch.empty(qkv.shape[0] * heads * 3, dtype=torch.float32, device=qkv.device)
     L.check(L.lib().acx_seq_attention_bwd(h, qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), tiles, gn, gl, heads, e, axis,
-                                          int(causal), _stream()), h)
+                                          int(causal), stats.data_ptr(), _stream()), h)
     return dqkv
 
 

@@ -78,6 +78,8 @@ typedef struct acx_gemm_desc {
                              (temporal_model.py:46-53) */
   const float* pos0;      /* [gn, N] axial positional embedding param_0 (or NULL) */
   const float* pos1;      /* [gl, N] axial positional embedding param_1 (or NULL) */
+  void* workspace;        /* optional: enables split-K for skinny problems (few output tiles, long K); */
+  size_t workspace_bytes; /* needs up to 16*M*N*4 bytes, less is fine (fewer splits or none)           */
 } acx_gemm_desc;
 int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
 
@@ -249,7 +251,7 @@ int acx_conv_weight_dx(acx_ctx* ctx, const float* w, float* out, int32_t Cout, i
  * gn=1, gl=L, axis=1, e=64, causal as in the forward): dqkv [rows, 3*heads*e]. */
 int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int32_t tiles,
                           int32_t gn, int32_t gl, int32_t heads, int32_t e, int32_t axis, int32_t causal,
-                          void* stream);
+                          float* stats_ws /* [rows*heads*3] floats or NULL */, void* stream);
 int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, int32_t tiles, int32_t gn, int32_t gl,
                  int32_t E, void* stream);
 /* BatchNorm1d(affine=False) training backward in two steps (so data-parallel SyncBN can all-reduce the

@@ -89,6 +89,20 @@ def test_gemm_bf16():
     assert relerr(out.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(1078, 1536, 512), (1078, 512, 2048), (64, 128, 4096), (300, 200, 1024)])
+def test_gemm_split_k_paths(M, N, K):
+    """skinny problems take the split-K path (workspace handed over by ops.gemm); epilogue applied after the reduce."""
+    g = torch.Generator().manual_seed(K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = O.quick_gelu(a.double() @ w.double().t() + bias.double()) + res.double()
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=L.ACT_QUICKGELU, residual=res.to(DEV))
+    assert relerr(out, ref) < 3e-6
+    x = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), residual=x, out=x)          # in place through the reduce kernel
+    assert relerr(x, a.double() @ w.double().t() + bias.double() + res.double()) < 3e-6
+
+
 def test_gemm_errors():
     a, w = torch.randn(8, 6, device=DEV), torch.randn(4, 6, device=DEV)
     with pytest.raises(L.AcxError):
