@@ -141,7 +141,13 @@ def lib() -> C.CDLL:
             path = os.environ.get("ACX_LIB_PATH") or _build.LIB
             if os.environ.get("ACX_LIB_PATH"):
                 pass
-            elif not os.path.exists(path) or (_build._stale() and os.path.exists(_build.HIPCC)):
+            elif not os.path.exists(path) or (os.environ.get("ACX_AUTOBUILD") == "1" and _build._stale()):
+                # The prebuilt in-tree binary is used as it is (several ranks may import concurrently and file
+                # times do not survive a snapshot copy); rebuilding is explicit: __graft_entry__.build(),
+                # `python -m anomalyclip_amd._build`, or ACX_AUTOBUILD=1 for development.
+                if not os.path.exists(_build.HIPCC):
+                    raise AcxError(f"libacx.so not found at {path} and hipcc is not available to build it; "
+                                   f"there is no fallback compute path")
                 path = _build.build(verbose=False)
             try:
                 L = C.CDLL(path)

@@ -103,15 +103,16 @@ TfWs carve_tf(char* base, int64_t rows, int W) {
   w.att = base + off; off += al((size_t)rows * W * 4);
   w.mlp = base + off; off += al((size_t)rows * 4 * W * 4);
   // split-K scratch for skinny problems (text tower: 14 x 77 rows): 8 partial copies of the widest output
-  w.splitk_bytes = rows <= 4096 ? (size_t)8 * rows * 4 * W * 4 : 0;
+  // ... and for the partial last wave of big problems: <= 256 tiles of 128x128 outputs, 4 splits
+  w.splitk_bytes = rows <= 4096 ? (size_t)8 * rows * 4 * W * 4 : (size_t)4 * 256 * 128 * 128 * 4;
   w.splitk = base + off; off += al(w.splitk_bytes);
   w.total = off;
   return w;
 }
 
-int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
-           void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
-           hipStream_t s, int ldr = 0, void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
+int linear1(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
+            void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
+            hipStream_t s, int ldr, void* splitk_ws, size_t splitk_bytes) {
   acx_gemm_desc d;
   memset(&d, 0, sizeof(d));
   d.A = A; d.C = C;
@@ -123,6 +124,36 @@ int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const fl
   d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
   d.workspace = splitk_bytes ? splitk_ws : nullptr; d.workspace_bytes = splitk_bytes;
   return acx_gemm(ctx, &d, s);
+}
+
+// Linear layer with tail handling: a grid of T tiles runs in ceil(T/512) waves of 128x128 tiles (2 per CU); when
+// the last wave would be mostly empty (e.g. N=768: 9.23 waves -> 10), the rows of that partial wave are issued as a
+// second, split-K launch that fills the chip (9 waves + ~1/3 wave).
+int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
+           void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
+           hipStream_t s, int ldr = 0, void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
+  static const bool tail_split = !getenv("ACX_NO_TAIL_SPLIT");
+  const int tiles_n = (N + 127) / 128, tiles_m = (M + 127) / 128;
+  const long tiles = (long)tiles_m * tiles_n;
+  const long full = tiles / 512;
+  const long rem = tiles - full * 512;
+  if (tail_split && splitk_ws && full >= 2 && rem > 0 && rem <= 256 && !ldr) {
+    const int head_mt = (int)((full * 512) / tiles_n);
+    const int head_rows = head_mt * 128;
+    const int tail_rows = M - head_rows;
+    const size_t need = (size_t)4 * tail_rows * N * sizeof(float);
+    if (head_rows > 0 && tail_rows > 0 && need <= splitk_bytes) {
+      const size_t asz = a_dtype == ACX_BF16 ? 2 : 4, csz = c_dtype == ACX_BF16 ? 2 : 4;
+      int rc = linear1(ctx, prec, A, a_dtype, lda, Wf, Wb, ldw, C, c_dtype, ldc, head_rows, N, K, bias, act, residual, s, 0,
+                       nullptr, 0);
+      if (rc) return rc;
+      return linear1(ctx, prec, (const char*)A + (size_t)head_rows * lda * asz, a_dtype, lda, Wf, Wb, ldw,
+                     (char*)C + (size_t)head_rows * ldc * csz, c_dtype, ldc, tail_rows, N, K, bias, act,
+                     residual ? residual + (size_t)head_rows * ldc : nullptr, s, 0, splitk_ws, splitk_bytes);
+    }
+  }
+  return linear1(ctx, prec, A, a_dtype, lda, Wf, Wb, ldw, C, c_dtype, ldc, M, N, K, bias, act, residual, s, ldr, splitk_ws,
+                 splitk_bytes);
 }
 
 // cls_ws != nullptr: the LAST layer is evaluated only where its output is consumed (token 0 of every sequence,

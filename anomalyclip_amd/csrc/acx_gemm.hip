@@ -33,7 +33,7 @@
 #define ACX_TRACE 0
 #endif
 #ifndef ACX_PERSISTENT
-#define ACX_PERSISTENT 0   // experimental persistent tile stream (needs a register diet: spills at 256 VGPRs)
+#define ACX_PERSISTENT 1   // persistent tile stream for the FAST path (ACX_GEMM_PERSISTENT=0 disables at run time)
 #endif
 #ifndef ACX_DEPHASE
 #define ACX_DEPHASE 1
@@ -505,8 +505,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 // Here a block owns tiles b, b+G, b+2G, ... (G = 2 blocks per CU) and treats (tile, k-step) as ONE stream:
 //   * global loads run two K-steps ahead and LDS writes one K-step ahead ACROSS tile boundaries, so only the
 //     first tile of a block has a prologue;
-//   * when a tile's K loop ends its 64 accumulators move to a second register set and are written out one
-//     32x64 quadrant per K-step of the NEXT tile, in the shadow of that tile's MFMAs (deferred epilogue).
+//   * a finished tile's epilogue is issued inline (compute-then-store, fire-and-forget) and the MFMAs of the
+//     next tile resume immediately: its first K-step is already in LDS, its phase-0 fragments in registers.
+//     (A deferred epilogue from a second accumulator set was tried: 64 extra VGPRs push the kernel into
+//     spills at the 256-register budget of 2 blocks/CU.)
 template <int PREC, int A_BF16, int C_BF16, int ACT, int RES>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_persistent_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -633,43 +635,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_persistent_kernel(const Args
     *reinterpret_cast<uint4*>(sW_ + off_) = rw##r;                                                        \
   } while (0)
 
-  // ---- accumulators of the running tile and of the tile whose epilogue is pending
-  f32x16 acc00, acc01, acc10, acc11, pnd00, pnd01, pnd10, pnd11;
+  // ---- accumulators of the running tile
+  f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.f; pnd00[e] = pnd01[e] = pnd10[e] = pnd11[e] = 0.f; }
-  int pm0 = 0, pn0 = 0;      // origin of the pending tile
-  int pend = 0;              // bit q set: quadrant q (mi = q>>1, ni = q&1) still to be written
+  for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.f;
 
-  // one 32x32 quadrant of the pending tile: bias, activation, residual, store
-#define PG_EPI(Q, REG)                                                                                    \
+  // one 32x32 quadrant of the finished tile: everything computed first, then 16 back-to-back stores
+#define PG_EPI(Q, REG, m0_, n0_)                                                                          \
   do {                                                                                                    \
-    const int col_ = pn0 + wn * 64 + ((Q) & 1) * 32 + li;                                                 \
+    const int col_ = (n0_) + wn * 64 + ((Q) & 1) * 32 + li;                                               \
     const bool cok_ = col_ < d.N;                                                                         \
     const int colc_ = cok_ ? col_ : d.N - 1;                                                              \
-    const float bias_ = d.bias ? d.bias[colc_] : 0.f;                                                     \
-    const int rowb_ = pm0 + wm * 64 + ((Q) >> 1) * 32 + 4 * hh;                                           \
-    float res_[16];                                                                                       \
+    float bias_ = 0.f;                                                                                    \
+    if (d.bias) bias_ = d.bias[colc_];                                                                    \
+    const int rowb_ = (m0_) + wm * 64 + ((Q) >> 1) * 32 + 4 * hh;                                         \
+    float out_[16];                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) out_[r] = 0.f;                                         \
     if constexpr (RES) {                                                                                  \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
         const int row_ = min(rowb_ + (r & 3) + 8 * (r >> 2), d.M - 1);                                    \
-        res_[r] = d.residual[(size_t)row_ * d.ldr + colc_];                                               \
+        out_[r] = d.residual[(size_t)row_ * d.ldr + colc_];                                               \
       }                                                                                                   \
     }                                                                                                     \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-      const int row_ = rowb_ + (r & 3) + 8 * (r >> 2);                                                    \
       float v_ = REG[r] + bias_;                                                                          \
       if constexpr (ACT == ACX_ACT_QUICKGELU) v_ = v_ * (1.f / (1.f + __expf(-1.702f * v_)));             \
-      if constexpr (RES) v_ += res_[r];                                                                   \
+      out_[r] += v_;                                                                                      \
+      REG[r] = 0.f;                                                                                       \
+    }                                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(out_[r]));                      \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
+      const int row_ = rowb_ + (r & 3) + 8 * (r >> 2);                                                    \
       if (cok_ && row_ < d.M) {                                                                           \
-        if constexpr (C_BF16) ((u16*)d.C)[(size_t)row_ * d.ldc + col_] = f2bf(v_);                        \
-        else ((float*)d.C)[(size_t)row_ * d.ldc + col_] = v_;                                             \
+        if constexpr (C_BF16) ((u16*)d.C)[(size_t)row_ * d.ldc + col_] = f2bf(out_[r]);                   \
+        else ((float*)d.C)[(size_t)row_ * d.ldc + col_] = out_[r];                                        \
       }                                                                                                   \
     }                                                                                                     \
-  } while (0)
-#define PG_EPI_Q(Q)                                                                                       \
-  do {                                                                                                    \
-    if ((Q) == 0) PG_EPI(0, pnd00); else if ((Q) == 1) PG_EPI(1, pnd01);                                  \
-    else if ((Q) == 2) PG_EPI(2, pnd10); else PG_EPI(3, pnd11);                                           \
   } while (0)
 
   // ---- prologue (first tile only)
@@ -691,35 +692,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_persistent_kernel(const Args
     PG_MM(y);                                   // phase 1
     PG_RD(y, cur, 3);
     if (more) { PG_STORE_ROW(nxt, 2); PG_STORE_ROW(nxt, 3); }
-    if (pend) {                                 // deferred epilogue of the previous tile: one quadrant per K-step
-      if (pend & 1) { PG_EPI(0, pnd00); pend &= ~1; }
-      else if (pend & 2) { PG_EPI(1, pnd01); pend &= ~2; }
-      else if (pend & 4) { PG_EPI(2, pnd10); pend &= ~4; }
-      else { PG_EPI(3, pnd11); pend &= ~8; }
-    }
     PG_MM(x);                                   // phase 2
     __syncthreads();
     if (s + 2 < S) PG_LOAD_NEXT();
     if (more) PG_RD(x, nxt, 0);
     PG_MM(y);                                   // phase 3
-    if (++kt == nk) {                           // tile finished: hand the accumulators to the deferred epilogue
-      if (pend & 1) PG_EPI(0, pnd00);
-      if (pend & 2) PG_EPI(1, pnd01);
-      if (pend & 4) PG_EPI(2, pnd10);
-      if (pend & 8) PG_EPI(3, pnd11);
-      pnd00 = acc00; pnd01 = acc01; pnd10 = acc10; pnd11 = acc11;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.f;
-      tile_origin(ti, pm0, pn0);
-      pend = 15;
+    if (++kt == nk) {
+      // tile finished: its stores are fire-and-forget; the next tile's first K-step is already in LDS and its
+      // phase-0 fragments are already in registers, so the MFMAs resume right after the last store is issued
+      int em0, en0;
+      tile_origin(ti, em0, en0);
+      PG_EPI(0, acc00, em0, en0);
+      PG_EPI(1, acc01, em0, en0);
+      PG_EPI(2, acc10, em0, en0);
+      PG_EPI(3, acc11, em0, en0);
       kt = 0;
       ++ti;
     }
   }
-  if (pend & 1) PG_EPI(0, pnd00);
-  if (pend & 2) PG_EPI(1, pnd01);
-  if (pend & 4) PG_EPI(2, pnd10);
-  if (pend & 8) PG_EPI(3, pnd11);
 #undef PG_SETUP_ROW
 #undef PG_SETUP
 #undef PG_LOAD_ROW
@@ -728,7 +718,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_persistent_kernel(const Args
 #undef PG_MM
 #undef PG_STORE_ROW
 #undef PG_EPI
-#undef PG_EPI_Q
 }
 
 
@@ -966,7 +955,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
                     d->act != ACX_ACT_LEAKYRELU;
   const int variant = (prec == ACX_PREC_F32 ? 0 : (a_bf16 ? 1 : 2)) * 2 + c_bf16;   // 0..5
   // persistent tile stream when there are more tiles than resident block slots (2 per CU x 256 CUs)
-  static const int acx_persistent_env = getenv("ACX_GEMM_PERSISTENT") ? atoi(getenv("ACX_GEMM_PERSISTENT")) : 0;
+  static const int acx_persistent_env = getenv("ACX_GEMM_PERSISTENT") ? atoi(getenv("ACX_GEMM_PERSISTENT")) : 1;
   const bool persistent = ACX_PERSISTENT && fast && acx_persistent_env && tiles_m * g.tiles_n > 512;
   const dim3 pgrid(512);
 #if ACX_PERSISTENT

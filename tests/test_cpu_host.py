@@ -145,3 +145,38 @@ def test_state_dict_keys_match_reference_layout(prompts_table):
     # trainable parameter count of the UCF temporal model at the real geometry (10,110,977)
     tm = IW.init_temporal_state_dict(512, IW.UCF_HEAD, 0)
     assert sum(v.numel() for v in tm.values()) == 10110977
+
+
+def test_abi_error_behaviour_without_gpu():
+    """argument validation happens before any launch: error codes + acx_last_error text, never an abort."""
+    import ctypes as C
+    from anomalyclip_amd import _lib as L
+    lib = L.lib()
+    h = C.c_void_p()
+    if not torch.cuda.is_available():
+        rc = lib.acx_create(C.byref(h), 0)
+        assert rc in (L_E := (-3, -2))            # ACX_E_HIP (no device) / ACX_E_UNSUPPORTED (not gfx950)
+        assert b"acx_create" in lib.acx_last_error(None)
+    assert lib.acx_gemm(None, None, None) == -1 and b"null" in lib.acx_last_error(None)
+    d = L.GemmDesc()
+    buf = (C.c_float * 64)()
+    d.A = d.W = d.C = C.addressof(buf)
+    d.M, d.N, d.K = 4, 4, 6                       # K % 4 != 0
+    d.lda = d.ldw = 6
+    d.ldc = 4
+    assert lib.acx_gemm(None, C.byref(d), None) == -1
+    d.K = d.lda = d.ldw = 8
+    d.prec = 7
+    assert lib.acx_gemm(None, C.byref(d), None) == -2       # ACX_E_UNSUPPORTED
+    d.prec = 0
+    d.amap = 1                                    # conv3x3 without geometry
+    assert lib.acx_gemm(None, C.byref(d), None) == -1
+    assert lib.acx_layernorm(None, None, 0, None, None, None, 0, 0, 4, 64, 1e-5, 0, None) == -1
+    assert lib.acx_attention(None, C.addressof(buf), 192, C.addressof(buf), 64, 1, 500, 1, 0, None) == -2   # L > 224
+    assert lib.acx_select_idx(None, None, None, None, None, None, None, 4, 32, 16, 13, 7, 3, 3, None) == -1
+    assert lib.acx_adamw(None, C.addressof(buf), C.addressof(buf), C.addressof(buf), C.addressof(buf), 8, 1e-3, 0.9, 0.999,
+                         1e-8, 0.0, 0, None) == -1                                                           # step starts at 1
+    # empty work is a no-op, not an error
+    assert lib.acx_layernorm(None, C.addressof(buf), 64, C.addressof(buf), C.addressof(buf), C.addressof(buf), 64, 0, 0, 64,
+                             1e-5, 0, None) == 0
+    assert lib.acx_gather_rows(None, C.addressof(buf), C.addressof(buf), C.addressof(buf), 0, 64, None) == 0
