@@ -518,3 +518,77 @@ extern "C" int acx_concat_features(acx_ctx* ctx, const float* logits, const floa
   ACX_CHECK_LAUNCH(ctx, "acx_concat_features");
   return ACX_OK;
 }
+
+// =====================================================================================================
+// Frame preprocessing: torchvision Resize(224, BICUBIC) on a PIL image ==
+// PIL.Image.resize (two separable passes over 8-bit data with 22-bit fixed-point coefficients and an 8-bit
+// intermediate image), CenterCrop(224), ToTensor (/255), Normalize(mean, std)
+// (reference src/utils/augmentations.py:21-34, gtransforms.py:89-102,35-40,373-381,479-486).
+// The coefficient tables are computed on the host exactly like PIL's precompute_coeffs/normalize_coeffs_8bpc
+// (anomalyclip_amd/preprocess.py); the kernels reproduce ImagingResampleHorizontal_8bpc / Vertical_8bpc bit for bit,
+// restricted to the rows/columns the centre crop keeps.  HBM-bound: one pass over the uint8 frames.
+namespace {
+
+__device__ __forceinline__ unsigned char clip8_22(int v) {
+  v >>= 22;
+  return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// tmp[f][y][xo][c] = clip8(0.5 + sum_x in[f][y][xmin+x][c] * k[xo][x])   for the `ocols` kept output columns
+__global__ __launch_bounds__(256) void resample_h_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ tmp,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                         int64_t total, int H, int W, int ocols) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % 3);
+  const int xo = (int)((i / 3) % ocols);
+  const int64_t fy = i / (3 * (int64_t)ocols);          // f*H + y
+  const int xmin = bounds[2 * xo], xn = bounds[2 * xo + 1];
+  const unsigned char* row = in + (fy * W + xmin) * 3 + c;
+  const int* k = kk + (size_t)xo * ksize;
+  int ss = 1 << 21;
+  for (int x = 0; x < xn; ++x) ss += (int)row[3 * x] * k[x];
+  tmp[i] = clip8_22(ss);
+}
+
+// out[f][c][yo][xo] = (clip8(0.5 + sum_y tmp[f][ymin+y][xo][c] * k[yo][y]) / 255 - mean[c]) / std[c]
+__global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned char* __restrict__ tmp, float* __restrict__ out,
+                                                              const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                              int ksize, int64_t total, int H, int ocols, int orows,
+                                                              float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xo = (int)(i % ocols);
+  const int yo = (int)((i / ocols) % orows);
+  const int c = (int)((i / ((int64_t)ocols * orows)) % 3);
+  const int64_t f = i / ((int64_t)ocols * orows * 3);
+  const int ymin = bounds[2 * yo], yn = bounds[2 * yo + 1];
+  const unsigned char* col = tmp + ((f * H + ymin) * ocols + xo) * 3 + c;
+  const int* k = kk + (size_t)yo * ksize;
+  int ss = 1 << 21;
+  for (int y = 0; y < yn; ++y) ss += (int)col[(size_t)y * ocols * 3] * k[y];
+  const float v = (float)clip8_22(ss) / 255.f;           // ToTensor: uint8 -> float32 / 255
+  const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+  out[i] = (v - mean) / sd;
+}
+
+}  // namespace
+
+extern "C" int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, float* out, unsigned char* tmp,
+                                     const int32_t* hbounds, const int32_t* hcoef, int32_t hksize, const int32_t* vbounds,
+                                     const int32_t* vcoef, int32_t vksize, int32_t F, int32_t H, int32_t W, int32_t orows,
+                                     int32_t ocols, const float* mean3, const float* std3, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  if (!frames || !out || !tmp || !hbounds || !hcoef || !vbounds || !vcoef || !mean3 || !std3)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_preprocess_frames: null pointer%s");
+  if (F <= 0) return ACX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t t1 = (int64_t)F * H * ocols * 3;
+  hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, frames, tmp, hbounds, hcoef, hksize, t1,
+                     H, W, ocols);
+  const int64_t t2 = (int64_t)F * 3 * orows * ocols;
+  hipLaunchKernelGGL(resample_v_norm_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, (const unsigned char*)tmp, out,
+                     vbounds, vcoef, vksize, t2, H, ocols, orows, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  ACX_CHECK_LAUNCH(ctx, "acx_preprocess_frames");
+  return ACX_OK;
+}

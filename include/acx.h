@@ -213,6 +213,17 @@ int acx_add_bcast(acx_ctx* ctx, const float* x, const float* p, float* out, int6
 int acx_concat_features(acx_ctx* ctx, const float* logits, const float* x, const float* ncentroid,
                         float* out, int64_t rows, int32_t C1, int32_t D, int32_t Kp, void* stream);
 
+/* acx_preprocess_frames: decoded uint8 RGB frames [F,H,W,3] -> CLIP input [F,3,orows,ocols] f32:
+ * Resize(shorter side, BICUBIC as PIL does it) + CenterCrop + /255 + Normalize (reference
+ * src/utils/augmentations.py:21-34 and gtransforms.py GroupScale/GroupCenterCrop/GroupToTensor/GroupNormalize).
+ * hbounds/hcoef: for each kept output column (xmin, n) and hksize 22-bit fixed-point coefficients (PIL's
+ * precompute_coeffs + normalize_coeffs_8bpc, computed by anomalyclip_amd/preprocess.py); vbounds/vcoef likewise for
+ * the kept output rows.  tmp: [F,H,ocols,3] uint8 scratch.  mean3/std3 are HOST pointers. */
+int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, float* out, unsigned char* tmp,
+                          const int32_t* hbounds, const int32_t* hcoef, int32_t hksize, const int32_t* vbounds,
+                          const int32_t* vcoef, int32_t vksize, int32_t F, int32_t H, int32_t W, int32_t orows,
+                          int32_t ocols, const float* mean3, const float* std3, void* stream);
+
 /* utility: f32 -> bf16 (round-to-nearest-even) copy, used to prepare bf16 weight copies. */
 int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* stream);
 /* utility: column sums of x[rows, D] accumulated into acc[D] (ncentroid, anomaly_clip_module.py:145-171). */

@@ -404,7 +404,34 @@ def start_indices(num_frames: int, num_segments: int, seg_length: int, stride: i
     return (np.arange(total, dtype=np.float64) * seg_length * stride).astype(np.int64), seg_size
 
 
-def warmup_cosine_lr(base_lr: float, epoch: int, warmup_epochs: int, total_epoch: int, max_epochs: float):
-    """scheduler.py:46-68 WarmupCosineAnnealingLR(successor=CosineAnnealingLR(T_max=max_epochs)):
-    linear warm-up from base_lr/warmup... handled in tests against the golden lr table."""
-    raise NotImplementedError("pinned by tests/golden/scheduler.npz through the host class")
+def warmup_cosine_lr(base_lr: float, epoch: int, warmup_epochs: int, total_epoch: int):
+    """scheduler.py:21-68 WarmupCosineAnnealingLR (warmup_powers=1, warmup_lrs=0, final_factor=0), lr after `epoch`
+    scheduler steps."""
+    if epoch < warmup_epochs:
+        return base_lr * epoch / warmup_epochs
+    prog = min((epoch - warmup_epochs) / (total_epoch - warmup_epochs), 1.0)
+    return base_lr * (math.cos(math.pi * prog) + 1) / 2
+
+
+# --------------------------------------------------------------------------- frame preprocessing (row f2)
+def preprocess_frames_ref(frames_u8, size: int = 224):
+    """src/utils/augmentations.py:21-34 with PIL directly (torchvision is not installed in this image; on PIL
+    images torchvision's Resize IS `Image.resize` and CenterCrop is `Image.crop` at int(round((h-s)/2)))."""
+    import numpy as np
+    from PIL import Image
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    out = []
+    for f in np.asarray(frames_u8):
+        img = Image.fromarray(f)
+        w, h = img.size
+        if w <= h:
+            ow, oh = size, int(size * h / w)
+        else:
+            oh, ow = size, int(size * w / h)
+        img = img.resize((ow, oh), Image.BICUBIC)                        # gtransforms.py:89-102
+        top, left = int(round((oh - size) / 2.0)), int(round((ow - size) / 2.0))
+        img = img.crop((left, top, left + size, top + size))             # gtransforms.py:35-40
+        t = torch.from_numpy(np.asarray(img).astype(np.float32) / np.float32(255.0)).permute(2, 0, 1)   # :373-381
+        out.append((t - torch.from_numpy(mean).view(3, 1, 1)) / torch.from_numpy(std).view(3, 1, 1))    # :479-486
+    return torch.stack(out)

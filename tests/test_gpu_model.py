@@ -147,3 +147,22 @@ def test_head_vs_oracle_full_configs(prompts_table, cfg):
         sim, sc = net(feats.to(DEV), None, nc, S, True)
         rs, rc = O.anomaly_clip_forward_test(sd, hc, feats, nc, eot, 8, S)
     assert relerr(sim, rs) < TOL and relerr(sc, rc) < TOL
+
+
+@pytest.mark.parametrize("hw", [(240, 320), (480, 360), (224, 224), (120, 160), (720, 1280)])
+def test_frame_preprocessing_matches_pil(hw):
+    """row f2: uint8 frames -> CLIP input; the 8-bit resample stages are bit-exact with Pillow, the float tail
+    (/255, normalise) within one ulp-class tolerance."""
+    from anomalyclip_amd.preprocess import preprocess_frames
+    g = torch.Generator().manual_seed(hw[0])
+    frames = torch.randint(0, 256, (3, hw[0], hw[1], 3), generator=g, dtype=torch.uint8)
+    frames[0, : hw[0] // 2] = 255           # saturated / flat regions exercise the clip8 path
+    frames[1, :, : hw[1] // 3] = 0
+    ref = O.preprocess_frames_ref(frames.numpy())
+    out = preprocess_frames(frames.to(DEV))
+    assert out.shape == (3, 3, 224, 224)
+    assert (out.cpu() - ref).abs().max().item() < 2e-6
+    # recover the uint8 image exactly: v = round((out*std + mean) * 255)
+    from anomalyclip_amd.preprocess import CLIP_MEAN, CLIP_STD
+    m, s = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    assert torch.equal(((out.cpu() * s + m) * 255).round(), ((ref * s + m) * 255).round())

@@ -146,3 +146,13 @@ def test_e2e_tiny(golden, prompts_table):
         ref = T(g["grad:" + n])
         scale = ref.abs().max().item()
         close(sd[n].grad, ref, rtol=2e-3, atol=2e-4 * scale)
+
+
+def test_tables(golden):
+    g = golden("tables")
+    for stride in (1, 2):
+        for T_ in (1, 511, 512, 513, 1000, 1025, 5000):
+            si, S = O.start_indices(T_, 32, 16, stride)
+            assert np.array_equal(si, g[f"start_T{T_}_s{stride}"].astype(np.int64)) and S == len(si) // 32
+    lrs = [O.warmup_cosine_lr(1e-5, ep, 5, 50) for ep in range(55)]
+    assert np.allclose(lrs, g["lr_table"], rtol=1e-12, atol=0)
