@@ -180,3 +180,27 @@ def test_abi_error_behaviour_without_gpu():
     assert lib.acx_layernorm(None, C.addressof(buf), 64, C.addressof(buf), C.addressof(buf), C.addressof(buf), 64, 0, 0, 64,
                              1e-5, 0, None) == 0
     assert lib.acx_gather_rows(None, C.addressof(buf), C.addressof(buf), C.addressof(buf), 0, 64, None) == 0
+
+
+def test_lightning_checkpoint_round_trip(tmp_path, prompts_table):
+    from anomalyclip_amd import checkpoint, init_weights as IW
+    from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP
+    kw = dict(arch="tiny", labels_key="ucf", emb_size=64, depth=1, heads=2, dim_heads=None, num_segments=32, seg_length=16,
+              concat_features=False, normal_id=7, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, num_topk=3,
+              num_bottomk=3)
+    a, b = AnomalyCLIP(**kw), AnomalyCLIP(**kw)
+    toks = torch.tensor(prompts_table["ucf"]["tokenized_prompts"], dtype=torch.int32)
+    a.load_state_dict(IW.init_anomalyclip_state_dict(IW.TINY, IW.HeadConfig(emb_size=64, heads=2), toks, 5), strict=True)
+    ck = {"state_dict": {**checkpoint.to_lightning_state_dict(a), "train_loss.mean_value": torch.zeros(1)},
+          "epoch": 3, "hyper_parameters": {}}
+    # CLIP towers are stored in half precision by some exports: must be up-cast on load
+    ck["state_dict"]["net.image_encoder.proj"] = ck["state_dict"]["net.image_encoder.proj"].half()
+    path = str(tmp_path / "last.ckpt")
+    torch.save(ck, path)
+    checkpoint.load_into(b, path)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb
+        if ka == "image_encoder.proj":
+            assert torch.equal(vb, va.half().float())
+        else:
+            assert torch.equal(va, vb), ka

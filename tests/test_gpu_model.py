@@ -166,3 +166,63 @@ def test_frame_preprocessing_matches_pil(hw):
     from anomalyclip_amd.preprocess import CLIP_MEAN, CLIP_STD
     m, s = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
     assert torch.equal(((out.cpu() * s + m) * 255).round(), ((ref * s + m) * 255).round())
+
+
+def test_shared_context_and_stride_and_long_segments(prompts_table):
+    """edge configurations the reference supports: shared (2-D) CoOp context (coop.py:37-39,76-77), stride 2
+    (repeat_interleave, anomaly_clip.py:149-150) and a long video (S = 16 tiles, XD head)."""
+    import dataclasses
+    hc = dataclasses.replace(IW.XD_HEAD, shared_context=True, stride=2, ncrops=1)
+    toks = torch.tensor(prompts_table["xd"]["tokenized_prompts"], dtype=torch.int32)
+    net = AnomalyCLIP(arch="ViT-B/16", labels_key="xd", emb_size=hc.emb_size, depth=hc.depth, heads=hc.heads, dim_heads=None,
+                      num_segments=32, seg_length=16, concat_features=False, normal_id=hc.normal_id, stride=2,
+                      load_from_features=True, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, ncrops=1,
+                      num_topk=3, num_bottomk=3, n_ctx=8, shared_context=True)
+    sd = IW.init_anomalyclip_state_dict(IW.VIT_B16, hc, toks, 3)
+    assert sd["prompt_learner.ctx"].dim() == 2
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    S = 16
+    feats = torch.randn(1, 1, 512 * S, 512, generator=g) * 0.3
+    nc = torch.randn(512, generator=g) * 0.05
+    with torch.no_grad():
+        sim, sc = net(feats.to(DEV), None, nc, S, True)
+        rs, rc = O.anomaly_clip_forward_test(sd, hc, feats, nc, toks.argmax(-1), 8, S)
+    assert sim.shape == (512 * S * 2, 6) and sc.shape == (512 * S * 2,)
+    assert relerr(sim, rs) < TOL and relerr(sc, rc) < TOL
+
+
+def test_frames_path_with_crops_tiny(prompts_table):
+    """test mode from FRAMES with ncrops = 2 and S = 2: the "(b ncrops n s l) d" view of anomaly_clip.py:124-131."""
+    import dataclasses
+    hc = dataclasses.replace(IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1), ncrops=2)
+    net, sd, eot = build_net("tiny", hc, "ucf", 9, prompts_table)
+    net.load_from_features = False
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randn(1, 2 * 512 * 2, 3, 32, 32, generator=g)        # b=1, ncrops*n*s*l frames
+    nc = torch.randn(128, generator=g) * 0.1
+    with torch.no_grad():
+        sim, sc = net(frames.to(DEV), None, nc, 2, True)
+        rs, rc = O.anomaly_clip_forward_test(sd, hc, None, nc, eot, 2, 2, frames=frames)
+    assert relerr(sim, rs) < TOL and relerr(sc, rc) < TOL
+
+
+def test_ncentroid_and_module_test_step(prompts_table):
+    """a10 (mean of normal features) and a11 (class probabilities, padded frames stripped) through the module mirror."""
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1)
+    net, sd, eot = build_net("tiny", hc, "ucf", 4, prompts_table)
+    mod = AnomalyCLIPModule(net, None, None, None, num_classes=14, solver={"lr": 1e-5}).to(DEV)
+    g = torch.Generator().manual_seed(6)
+    vids = [torch.randn(1, 1, 512 * s, 128, generator=g) * 0.3 + 0.05 for s in (1, 2, 1)]
+    lens = [300, 1000, 512]
+    loader = [(v, torch.zeros(1, n), 7, s) for v, n, s in zip(vids, lens, (1, 2, 1))]
+    nc = mod.compute_ncentroid(loader)
+    ref = O.ncentroid_from_features([v.reshape(-1, 128)[:n] for v, n in zip(vids, lens)])
+    assert relerr(nc, ref) < 1e-5
+    out = mod.test_step((vids[1], torch.zeros(1, 1000), 7, 2, "x"))
+    rs, rc = O.anomaly_clip_forward_test(sd, hc, vids[1], ref, eot, 2, 2)
+    cp, sc = O.eval_postprocess(rs, rc, 1000)
+    assert out["class_probs"].shape == (1000, 13) and out["abnormal_scores"].shape == (1000,)
+    assert relerr(out["class_probs"], cp) < TOL and relerr(out["abnormal_scores"], sc) < TOL
