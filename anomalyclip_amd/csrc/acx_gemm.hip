@@ -15,8 +15,16 @@
 //     MFMA (q,j) supplies k = 4*(2q+h)+j for A and B alike (a dot product does not care about
 //     the order of k as long as both operands agree).
 //   * ACX_PREC_BF16: v_mfma_f32_32x32x16_bf16, one ds_read_b128 (8 bf16) per operand per MFMA.
-//   * register-staged double buffering (guide T14): global loads of K-step t+1 are issued before
-//     the MFMAs of step t and written to the other LDS buffer after them; one barrier per step.
+//   * register-staged double buffering (guide T14) as a hand-scheduled 4-phase K-step: fragments are
+//     double-buffered in registers, the next tile's LDS writes ride in the shadow of MFMA phases 1-2,
+//     the ONE barrier of the step sits between phases 2 and 3 (every wave already holds its phase-3
+//     fragments), and the global loads two K-steps ahead plus the next tile's phase-0 fragment reads
+//     are issued right after it, under phase 3's MFMAs.
+//   * staging values live in NAMED registers and the epilogue computes every value before the first
+//     store is issued (both are measured necessities with hipcc: arrays get demoted to scratch, and
+//     a load pending across a predicated store makes every store wait for the previous one).
+//   * skinny problems (few output tiles, long K) are split along K over gridDim.y with a fused
+//     reduce+epilogue kernel (fixed summation order).
 //   * A-operand prologue fused into the staging pass: f32->bf16 conversion, re-centring
 //     (a - ncentroid[k]), the 3x3-conv row gather (implicit GEMM over the (gn,gl) token grid,
 //     zero padding) and the reference's test-mode tiling gather.
@@ -32,18 +40,6 @@
 #ifndef ACX_TRACE
 #define ACX_TRACE 0
 #endif
-#ifndef ACX_PERSISTENT
-#define ACX_PERSISTENT 1   // persistent tile stream for the FAST path (ACX_GEMM_PERSISTENT=0 disables at run time)
-#endif
-#ifndef ACX_DEPHASE
-#define ACX_DEPHASE 1
-#endif
-#ifndef ACX_LOOP_V2
-#define ACX_LOOP_V2 1
-#endif
-#ifndef ACX_STORE_SCHED
-#define ACX_STORE_SCHED 2
-#endif
 
 namespace {
 
@@ -55,9 +51,7 @@ constexpr int NTHREADS = 256;
 struct Args {
   acx_gemm_desc d;
   int tiles_n;
-  int tile_order;
   long long* trace;        // debug timeline buffer (ACX_TRACE builds only)
-  int dephase_cycles;      // wall_clock64 ticks (100 MHz) the second block of each CU waits at launch
   int ksplit, kchunk;      // split-K (FAST path, skinny problems): gridDim.y splits of kchunk K-steps each
   float* partial;          // [ksplit][M][N] raw partial sums (epilogue applied by splitk_reduce_kernel)
 };
@@ -90,16 +84,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  if (g.tile_order == 2) wg = bid;
-  int tm = wg / g.tiles_n, tn = wg % g.tiles_n;
-  if (g.tile_order == 1) { const int tiles_m_ = nwg / g.tiles_n; tn = wg / tiles_m_; tm = wg % tiles_m_; }
-  if (g.tile_order == 3) {   // 8-row super-tiles: walk 8 m-tiles down, then next n
-    const int band = wg / (8 * g.tiles_n), rem = wg % (8 * g.tiles_n);
-    const int tiles_m_ = nwg / g.tiles_n;
-    const int bh = min(8, tiles_m_ - band * 8);
-    tm = band * 8 + rem % bh; tn = rem / bh;
-  }
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = wg / g.tiles_n, tn = wg % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int t = threadIdx.x;
@@ -107,17 +93,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #if ACX_TRACE
   const long long tr0 = wall_clock64();
   long long tr1 = 0, tr2 = 0;
-#endif
-
-#if ACX_DEPHASE
-  // Co-resident blocks (2 per CU) start together and do identical work, so their prologue/epilogue bubbles
-  // coincide for the whole launch.  The second block of each CU (dispatch order: blocks 256..511 of the first
-  // wave) is delayed by about half a tile once; successor blocks inherit the phase shift, so one block's
-  // MFMA phases cover the other's loads/stores from then on.
-  if (FAST && g.dephase_cycles > 0 && bid >= 256 && bid < 512) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < g.dephase_cycles) __builtin_amdgcn_s_sleep(64);
-  }
 #endif
 
   // ---- per-thread source rows for the 4 staged A rows and 4 staged W rows
@@ -270,7 +245,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int nk_total = (d.K + KE - 1) / KE;
   const int kbeg = (g.ksplit > 1 ? (int)blockIdx.y * g.kchunk : 0) * KE;       // first K element of this split
   const int nk = g.ksplit > 1 ? min(g.kchunk, nk_total - (int)blockIdx.y * g.kchunk) : nk_total;
-#if ACX_LOOP_V2
   // ---- software-pipelined K loop (v2).  Fragment registers are double-buffered by hand (fa/fb sets X and Y);
   // the ONE barrier of a K-step sits between MFMA phases 2 and 3: by then this wave has written its share of the
   // next tile and already holds phase 3's fragments, so after the barrier it issues 16 MFMAs immediately and the
@@ -339,71 +313,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #undef ACX_RD
 #undef ACX_MM
 #undef ACX_LOAD_TILE
-#else
-  if constexpr (FAST) ACX_FAST_LOAD(0); else ACX_GEN_LOAD(0);
-  ACX_STORE_ROW(0, 0); ACX_STORE_ROW(0, 1); ACX_STORE_ROW(0, 2); ACX_STORE_ROW(0, 3);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) { if constexpr (FAST) ACX_FAST_LOAD((kt + 1) * KE); else ACX_GEN_LOAD((kt + 1) * KE); }
-    const char* sA = smem + cur * 2 * TILE_B;
-    const char* sW = sA + TILE_B;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if constexpr (PREC == 0) {
-        float4 a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[i] = *reinterpret_cast<const float4*>(sA + a_off + i * 32 * ROWB + q * 32);
-          b[i] = *reinterpret_cast<const float4*>(sW + w_off + i * 32 * ROWB + q * 32);
-        }
-        const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
-        const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-      } else {
-        bf16x8 a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[i] = *reinterpret_cast<const bf16x8*>(sA + a_off + i * 32 * ROWB + q * 32);
-          b[i] = *reinterpret_cast<const bf16x8*>(sW + w_off + i * 32 * ROWB + q * 32);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-      }
-      // stage the next K-step into the other LDS buffer in the shadow of this phase's MFMAs:
-      // one quarter of the rows after each of the 4 phases (the loads were issued a phase or
-      // more ago; the write costs issue slots while the matrix pipe is busy, not pipe time)
-#if ACX_STORE_SCHED == 1
-      if (more) {
-        if (q == 0) ACX_STORE_ROW(cur ^ 1, 0);
-        if (q == 1) ACX_STORE_ROW(cur ^ 1, 1);
-        if (q == 2) ACX_STORE_ROW(cur ^ 1, 2);
-        if (q == 3) ACX_STORE_ROW(cur ^ 1, 3);
-      }
-#elif ACX_STORE_SCHED == 2
-      if (more) {
-        if (q == 2) { ACX_STORE_ROW(cur ^ 1, 0); ACX_STORE_ROW(cur ^ 1, 1); }
-        if (q == 3) { ACX_STORE_ROW(cur ^ 1, 2); ACX_STORE_ROW(cur ^ 1, 3); }
-      }
-#endif
-    }
-#if ACX_STORE_SCHED == 0
-    if (more) { ACX_STORE_ROW(cur ^ 1, 0); ACX_STORE_ROW(cur ^ 1, 1); ACX_STORE_ROW(cur ^ 1, 2); ACX_STORE_ROW(cur ^ 1, 3); }
-#endif
-    __syncthreads();
-  }
-
-#endif
 
 #if ACX_TRACE
   tr2 = wall_clock64();
@@ -495,233 +404,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #endif
 }
 
-#if ACX_PERSISTENT
-// =====================================================================================================
-// gemm_persistent_kernel -- FAST-path GEMM as a persistent, continuously pipelined tile stream.
-//
-// Measured on the non-persistent kernel: the K loop itself runs at ~99 % of the MFMA rate, but every tile
-// pays ~28 us of un-overlapped prologue (two dependent HBM round trips) and epilogue (64 row-strided stores
-// per lane) -- 24 % of a K=768 tile -- and co-resident blocks stay in lock-step so their bubbles coincide.
-// Here a block owns tiles b, b+G, b+2G, ... (G = 2 blocks per CU) and treats (tile, k-step) as ONE stream:
-//   * global loads run two K-steps ahead and LDS writes one K-step ahead ACROSS tile boundaries, so only the
-//     first tile of a block has a prologue;
-//   * a finished tile's epilogue is issued inline (compute-then-store, fire-and-forget) and the MFMAs of the
-//     next tile resume immediately: its first K-step is already in LDS, its phase-0 fragments in registers.
-//     (A deferred epilogue from a second accumulator set was tried: 64 extra VGPRs push the kernel into
-//     spills at the 256-register budget of 2 blocks/CU.)
-template <int PREC, int A_BF16, int C_BF16, int ACT, int RES>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_persistent_kernel(const Args g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const acx_gemm_desc& d = g.d;
-  constexpr int KE = PREC == 0 ? 32 : 64;
-  constexpr int CE = PREC == 0 ? 4 : 8;
-  constexpr int NLA = (PREC == 1 && !A_BF16) ? 2 : 1;
-  constexpr int WB = PREC == 0 ? 4 : 2;
-  constexpr int AB = A_BF16 ? 2 : 4;
-  using frag_t = typename std::conditional<PREC == 0, float4, bf16x8>::type;
-
-  const int tiles_m = (d.M + BM - 1) / BM;
-  const int total = tiles_m * g.tiles_n;
-  const int G = gridDim.x;
-  const int ntiles = (total - (int)blockIdx.x + G - 1) / G;      // tiles owned by this block (>= 1 by launch)
-  const int nk = d.K / KE;
-  const int S = ntiles * nk;
-
-  const int t = threadIdx.x;
-  const int chunk = t & 7, rbase = t >> 3;
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, hh = lane >> 5;
-  const int a_off = (wm * 64 + li) * ROWB + hh * 16;
-  const int w_off = (wn * 64 + li) * ROWB + hh * 16;
-
-  // tile index -> (m0, n0) with the bijective XCD remap on the virtual block id (G % 8 == 0 keeps the XCD)
-  auto tile_origin = [&](int i, int& m0, int& n0) {
-    const int vb = (int)blockIdx.x + i * G;
-    const int xcd = vb & 7, qq = total >> 3, rr = total & 7;
-    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (vb >> 3);
-    const int tm = wg / g.tiles_n;
-    m0 = tm * BM;
-    n0 = (wg - tm * g.tiles_n) * BN;
-  };
-
-  // ---- load stream state: byte pointers of this thread's 4 A rows / 4 W rows at k = 0 of the load tile
-  const char *pa0, *pa1, *pa2, *pa3, *pw0, *pw1, *pw2, *pw3;
-#define PG_SETUP_ROW(r, m0_, n0_)                                                                         \
-  do {                                                                                                    \
-    int m_ = (m0_) + rbase + 32 * (r);                                                                    \
-    m_ = m_ < d.M ? m_ : d.M - 1;                                                                         \
-    pa##r = (const char*)d.A + ((size_t)m_ * d.lda + chunk * CE) * AB;                                    \
-    int n_ = (n0_) + rbase + 32 * (r);                                                                    \
-    n_ = n_ < d.N ? n_ : d.N - 1;                                                                         \
-    pw##r = (const char*)d.W + ((size_t)n_ * d.ldw + chunk * CE) * WB;                                    \
-  } while (0)
-#define PG_SETUP(i_)                                                                                      \
-  do {                                                                                                    \
-    int m0_, n0_;                                                                                         \
-    tile_origin((i_), m0_, n0_);                                                                          \
-    PG_SETUP_ROW(0, m0_, n0_); PG_SETUP_ROW(1, m0_, n0_); PG_SETUP_ROW(2, m0_, n0_); PG_SETUP_ROW(3, m0_, n0_); \
-  } while (0)
-
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-  uint4 rw0, rw1, rw2, rw3;
-  rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define PG_LOAD_ROW(r, kb)                                                                                \
-  do {                                                                                                    \
-    if constexpr (A_BF16) {                                                                               \
-      const uint4 v_ = *reinterpret_cast<const uint4*>(pa##r + (size_t)(kb) * AB);                        \
-      ra##r = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
-    } else {                                                                                              \
-      ra##r = *reinterpret_cast<const float4*>(pa##r + (size_t)(kb) * AB);                                \
-      if constexpr (NLA == 2) rb##r = *reinterpret_cast<const float4*>(pa##r + (size_t)(kb) * AB + 16);   \
-    }                                                                                                     \
-    rw##r = *reinterpret_cast<const uint4*>(pw##r + (size_t)(kb) * WB);                                   \
-  } while (0)
-  // loads the load-stream's next K-step and advances the stream (lk, ltile)
-  int lk = 0, ltile = 0;
-#define PG_LOAD_NEXT()                                                                                    \
-  do {                                                                                                    \
-    const int kb_ = lk * KE;                                                                              \
-    PG_LOAD_ROW(0, kb_); PG_LOAD_ROW(1, kb_); PG_LOAD_ROW(2, kb_); PG_LOAD_ROW(3, kb_);                   \
-    if (++lk == nk) {                                                                                     \
-      lk = 0;                                                                                             \
-      if (++ltile < ntiles) PG_SETUP(ltile);                                                              \
-    }                                                                                                     \
-  } while (0)
-
-  frag_t xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
-#define PG_RD(SET, stage, q)                                                                              \
-  do {                                                                                                    \
-    const char* sA_ = smem + (stage) * 2 * TILE_B;                                                        \
-    const char* sW_ = sA_ + TILE_B;                                                                       \
-    SET##a0 = *reinterpret_cast<const frag_t*>(sA_ + a_off + (q) * 32);                                   \
-    SET##a1 = *reinterpret_cast<const frag_t*>(sA_ + a_off + 32 * ROWB + (q) * 32);                       \
-    SET##b0 = *reinterpret_cast<const frag_t*>(sW_ + w_off + (q) * 32);                                   \
-    SET##b1 = *reinterpret_cast<const frag_t*>(sW_ + w_off + 32 * ROWB + (q) * 32);                       \
-  } while (0)
-#define PG_MM(SET)                                                                                        \
-  do {                                                                                                    \
-    if constexpr (PREC == 0) {                                                                            \
-      const float4& A0_ = reinterpret_cast<const float4&>(SET##a0);                                       \
-      const float4& A1_ = reinterpret_cast<const float4&>(SET##a1);                                       \
-      const float4& B0_ = reinterpret_cast<const float4&>(SET##b0);                                       \
-      const float4& B1_ = reinterpret_cast<const float4&>(SET##b1);                                       \
-      const float av_[2][4] = {{A0_.x, A0_.y, A0_.z, A0_.w}, {A1_.x, A1_.y, A1_.z, A1_.w}};               \
-      const float bv_[2][4] = {{B0_.x, B0_.y, B0_.z, B0_.w}, {B1_.x, B1_.y, B1_.z, B1_.w}};               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[0][j], bv_[0][j], acc00, 0, 0, 0);               \
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[0][j], bv_[1][j], acc01, 0, 0, 0);               \
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[1][j], bv_[0][j], acc10, 0, 0, 0);               \
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[1][j], bv_[1][j], acc11, 0, 0, 0);               \
-      }                                                                                                   \
-    } else {                                                                                              \
-      const bf16x8& A0_ = reinterpret_cast<const bf16x8&>(SET##a0);                                       \
-      const bf16x8& A1_ = reinterpret_cast<const bf16x8&>(SET##a1);                                       \
-      const bf16x8& B0_ = reinterpret_cast<const bf16x8&>(SET##b0);                                       \
-      const bf16x8& B1_ = reinterpret_cast<const bf16x8&>(SET##b1);                                       \
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0_, B0_, acc00, 0, 0, 0);                          \
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0_, B1_, acc01, 0, 0, 0);                          \
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1_, B0_, acc10, 0, 0, 0);                          \
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1_, B1_, acc11, 0, 0, 0);                          \
-    }                                                                                                     \
-  } while (0)
-#define PG_STORE_ROW(stage, r)                                                                            \
-  do {                                                                                                    \
-    char* sA_ = smem + (stage) * 2 * TILE_B;                                                              \
-    char* sW_ = sA_ + TILE_B;                                                                             \
-    const int off_ = (rbase + 32 * (r)) * ROWB + chunk * 16;                                              \
-    if constexpr (NLA == 2) *reinterpret_cast<uint4*>(sA_ + off_) = pack_bf16x8(ra##r, rb##r);            \
-    else *reinterpret_cast<float4*>(sA_ + off_) = ra##r;                                                  \
-    *reinterpret_cast<uint4*>(sW_ + off_) = rw##r;                                                        \
-  } while (0)
-
-  // ---- accumulators of the running tile
-  f32x16 acc00, acc01, acc10, acc11;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.f;
-
-  // one 32x32 quadrant of the finished tile: everything computed first, then 16 back-to-back stores
-#define PG_EPI(Q, REG, m0_, n0_)                                                                          \
-  do {                                                                                                    \
-    const int col_ = (n0_) + wn * 64 + ((Q) & 1) * 32 + li;                                               \
-    const bool cok_ = col_ < d.N;                                                                         \
-    const int colc_ = cok_ ? col_ : d.N - 1;                                                              \
-    float bias_ = 0.f;                                                                                    \
-    if (d.bias) bias_ = d.bias[colc_];                                                                    \
-    const int rowb_ = (m0_) + wm * 64 + ((Q) >> 1) * 32 + 4 * hh;                                         \
-    float out_[16];                                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) out_[r] = 0.f;                                         \
-    if constexpr (RES) {                                                                                  \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
-        const int row_ = min(rowb_ + (r & 3) + 8 * (r >> 2), d.M - 1);                                    \
-        out_[r] = d.residual[(size_t)row_ * d.ldr + colc_];                                               \
-      }                                                                                                   \
-    }                                                                                                     \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-      float v_ = REG[r] + bias_;                                                                          \
-      if constexpr (ACT == ACX_ACT_QUICKGELU) v_ = v_ * (1.f / (1.f + __expf(-1.702f * v_)));             \
-      out_[r] += v_;                                                                                      \
-      REG[r] = 0.f;                                                                                       \
-    }                                                                                                     \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(out_[r]));                      \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-      const int row_ = rowb_ + (r & 3) + 8 * (r >> 2);                                                    \
-      if (cok_ && row_ < d.M) {                                                                           \
-        if constexpr (C_BF16) ((u16*)d.C)[(size_t)row_ * d.ldc + col_] = f2bf(out_[r]);                   \
-        else ((float*)d.C)[(size_t)row_ * d.ldc + col_] = out_[r];                                        \
-      }                                                                                                   \
-    }                                                                                                     \
-  } while (0)
-
-  // ---- prologue (first tile only)
-  PG_SETUP(0);
-  PG_LOAD_NEXT();
-  PG_STORE_ROW(0, 0); PG_STORE_ROW(0, 1); PG_STORE_ROW(0, 2); PG_STORE_ROW(0, 3);
-  __syncthreads();
-  if (S > 1) PG_LOAD_NEXT();
-  PG_RD(x, 0, 0);
-
-  int kt = 0, ti = 0;
-  for (int s = 0; s < S; ++s) {
-    const int cur = s & 1, nxt = cur ^ 1;
-    const bool more = s + 1 < S;
-    PG_RD(y, cur, 1);
-    PG_MM(x);                                   // phase 0
-    PG_RD(x, cur, 2);
-    if (more) { PG_STORE_ROW(nxt, 0); PG_STORE_ROW(nxt, 1); }
-    PG_MM(y);                                   // phase 1
-    PG_RD(y, cur, 3);
-    if (more) { PG_STORE_ROW(nxt, 2); PG_STORE_ROW(nxt, 3); }
-    PG_MM(x);                                   // phase 2
-    __syncthreads();
-    if (s + 2 < S) PG_LOAD_NEXT();
-    if (more) PG_RD(x, nxt, 0);
-    PG_MM(y);                                   // phase 3
-    if (++kt == nk) {
-      // tile finished: its stores are fire-and-forget; the next tile's first K-step is already in LDS and its
-      // phase-0 fragments are already in registers, so the MFMAs resume right after the last store is issued
-      int em0, en0;
-      tile_origin(ti, em0, en0);
-      PG_EPI(0, acc00, em0, en0);
-      PG_EPI(1, acc01, em0, en0);
-      PG_EPI(2, acc10, em0, en0);
-      PG_EPI(3, acc11, em0, en0);
-      kt = 0;
-      ++ti;
-    }
-  }
-#undef PG_SETUP_ROW
-#undef PG_SETUP
-#undef PG_LOAD_ROW
-#undef PG_LOAD_NEXT
-#undef PG_RD
-#undef PG_MM
-#undef PG_STORE_ROW
-#undef PG_EPI
-}
-
-
-#endif  // ACX_PERSISTENT
 
 // =====================================================================================================
 // acx_gemm_tn -- weight-gradient GEMM:  C[N1,N2] = sum_m A[m,n1] * bmap(B)[m,n2]      (exact f32 MFMA)
@@ -924,16 +606,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   g.d = *d;
   const int tiles_m = (d->M + BM - 1) / BM;
   g.tiles_n = (d->N + BN - 1) / BN;
-  {
-    static const int order = getenv("ACX_TILE_ORDER") ? atoi(getenv("ACX_TILE_ORDER")) : 0;
-    g.tile_order = order;
-    g.trace = getenv("ACX_TRACE_PTR") ? (long long*)strtoull(getenv("ACX_TRACE_PTR"), nullptr, 0) : nullptr;
-    // half of one tile's solo K-loop time: nk * 64 MFMA * 64 cycles / 2 at ~2.2 GHz, in 100 MHz wall-clock ticks
-    static const int frac = getenv("ACX_DEPHASE_PCT") ? atoi(getenv("ACX_DEPHASE_PCT")) : 50;
-    const int nk_ = (d->K + (prec == ACX_PREC_F32 ? 32 : 64) - 1) / (prec == ACX_PREC_F32 ? 32 : 64);
-    const double cyc = prec == ACX_PREC_F32 ? 4096.0 : 512.0;
-    g.dephase_cycles = tiles_m * g.tiles_n > 512 ? (int)(nk_ * cyc / 2200.0 * 100.0 * frac / 100.0) : 0;
-  }
+  g.trace = getenv("ACX_TRACE_PTR") ? (long long*)strtoull(getenv("ACX_TRACE_PTR"), nullptr, 0) : nullptr;   // ACX_TRACE builds only
   dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
   g.ksplit = 1; g.kchunk = 0; g.partial = nullptr;
   const size_t lds = 4 * TILE_B;
@@ -954,39 +627,15 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const bool fast = d->amap == ACX_AMAP_IDENTITY && !d->a_sub && !d->pos0 && d->K % ke == 0 &&
                     d->act != ACX_ACT_LEAKYRELU;
   const int variant = (prec == ACX_PREC_F32 ? 0 : (a_bf16 ? 1 : 2)) * 2 + c_bf16;   // 0..5
-  // persistent tile stream when there are more tiles than resident block slots (2 per CU x 256 CUs)
-  static const int acx_persistent_env = getenv("ACX_GEMM_PERSISTENT") ? atoi(getenv("ACX_GEMM_PERSISTENT")) : 1;
-  const bool persistent = ACX_PERSISTENT && fast && acx_persistent_env && tiles_m * g.tiles_n > 512;
-  const dim3 pgrid(512);
-#if ACX_PERSISTENT
-#define ACX_PLAUNCH(P, AB, CB, ACT, RES)                                                            \
-  do {                                                                                              \
-    static bool attr_done = false;                                                                  \
-    if (!attr_done) {                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_persistent_kernel<P, AB, CB, ACT, RES>,           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-      attr_done = true;                                                                             \
-    }                                                                                               \
-    hipLaunchKernelGGL((gemm_persistent_kernel<P, AB, CB, ACT, RES>), pgrid, block, lds, s, g);     \
-  } while (0)
-#else
-#define ACX_PLAUNCH(P, AB, CB, ACT, RES) do { (void)pgrid; } while (0)
-#endif
 #define ACX_FAST(P, AB, CB)                                                           \
   do {                                                                                \
-    if (persistent) {                                                                 \
-      if (d->act == ACX_ACT_QUICKGELU) {                                              \
-        if (d->residual) ACX_PLAUNCH(P, AB, CB, 1, 1); else ACX_PLAUNCH(P, AB, CB, 1, 0); \
-      } else {                                                                        \
-        if (d->residual) ACX_PLAUNCH(P, AB, CB, 0, 1); else ACX_PLAUNCH(P, AB, CB, 0, 0); \
-      }                                                                               \
-    } else if (d->act == ACX_ACT_QUICKGELU) {                                         \
+    if (d->act == ACX_ACT_QUICKGELU) {                                                \
       if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 1, 1); else ACX_LAUNCH(P, AB, CB, 1, 1, 0); \
     } else {                                                                          \
       if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 0, 1); else ACX_LAUNCH(P, AB, CB, 1, 0, 0); \
     }                                                                                 \
   } while (0)
-  if (fast && !persistent && d->workspace) {
+  if (fast && d->workspace) {
     // skinny problems (few tiles, long K): split K over gridDim.y so the chip is filled; partial sums are
     // combined in fixed order by splitk_reduce_kernel together with the epilogue
     const int tiles = tiles_m * g.tiles_n, nkt = d->K / ke;
@@ -1020,7 +669,6 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     }
   }
 #undef ACX_FAST
-#undef ACX_PLAUNCH
 #undef ACX_LAUNCH
   if (g.ksplit > 1) {
     const int64_t total = (int64_t)d->M * d->N;
