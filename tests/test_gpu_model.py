@@ -226,3 +226,30 @@ def test_ncentroid_and_module_test_step(prompts_table):
     cp, sc = O.eval_postprocess(rs, rc, 1000)
     assert out["class_probs"].shape == (1000, 13) and out["abnormal_scores"].shape == (1000,)
     assert relerr(out["class_probs"], cp) < TOL and relerr(out["abnormal_scores"], sc) < TOL
+
+
+def test_feature_stream_matches_reference_loop(tmp_path, prompts_table):
+    """row f1: .npy files -> HBM tiles (pinned + async copy) equal the reference's per-frame loop, and scoring a
+    stream of videos equals scoring them one by one."""
+    from anomalyclip_amd.feature_stream import FeatureStream
+    rng = np.random.default_rng(0)
+    paths, raws = [], []
+    for i, T_ in enumerate((300, 513, 1000)):
+        a = (rng.standard_normal((T_, 128)) * 0.3).astype(np.float32)
+        p = str(tmp_path / f"v{i}.npy")
+        np.save(p, a)
+        paths.append(p)
+        raws.append(a)
+    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1)
+    net, sd, eot = build_net("tiny", hc, "ucf", 2, prompts_table)
+    nc = torch.zeros(128)
+    for (feats, T_, S, path), raw in zip(FeatureStream(paths, device=torch.device(DEV)), raws):
+        # the reference's loop (feature_dataset.py:359-367), literally
+        starts = np.arange(np.ceil(T_ / 512) * 512 / 16) * 16
+        ref = np.stack([raw[(int(s) + i) % T_] for s in starts for i in range(16)])
+        assert S == len(starts) // 32 and feats.shape == (1, 1, 512 * S, 128)
+        assert np.array_equal(feats[0, 0].cpu().numpy(), ref)
+        with torch.no_grad():
+            sim, sc = net(feats, None, nc, S, True)
+            rs, rc = O.anomaly_clip_forward_test(sd, hc, torch.from_numpy(ref).view(1, 1, -1, 128), nc, eot, 2, S)
+        assert relerr(sc[:T_], rc[:T_]) < TOL
