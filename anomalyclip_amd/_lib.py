@@ -49,6 +49,11 @@ class VitWeights(C.Structure):
     ]
 
 
+class CurveResult(C.Structure):          # == struct acx_curve_result (56 bytes, device memory)
+    _fields_ = [("auroc", C.c_double), ("ap", C.c_double), ("n_pos", c_int64), ("n_neg", c_int64),
+                ("n_distinct", c_int64), ("opt_index", c_int64), ("opt_threshold", c_float), ("pad", c_float)]
+
+
 class VitDesc(C.Structure):
     _fields_ = [(n, c_int32) for n in ("resolution", "patch", "width", "layers", "heads", "embed_dim", "prec")]
 
@@ -117,6 +122,14 @@ _SIGS = {
                               [C.POINTER(c_float), C.POINTER(c_float), c_void_p]),
     "acx_cast_bf16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_colsum": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "acx_sort_workspace_bytes": (c_int64, [c_int64]),
+    "acx_sort_pairs": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64,
+                                 c_void_p]),
+    "acx_clf_curve_workspace_bytes": (c_int64, [c_int64]),
+    "acx_clf_curve": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_int64, c_void_p]),
+    "acx_test_counts": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
 }
 
 # entry points added by later translation units register themselves here (name -> signature)

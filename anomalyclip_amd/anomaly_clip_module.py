@@ -6,7 +6,9 @@ loss, **kwargs` with kwargs = num_classes / solver / save_dir), same hook names 
 pytorch_lightning is not part of this image; the class derives from LightningModule when it is importable
 and from torch.nn.Module otherwise, and `fit_epoch` / `test_epoch` provide the minimal loop the reference
 gets from `Trainer` (one process per GPU; gradients exchanged through parallel.GradBuckets).
-Metrics (torchmetrics AUROC/AP/...) and plotting are out of scope."""
+`test_epoch_end` / `on_validation_epoch_end` compute the reference's metrics.json numbers (AUROC, AP, mAUC, mAP,
+top-1/5, optimal threshold; :339-404, :501-626) with libacx's sort/scan kernels (metrics.py); plots are out of
+scope."""
 from __future__ import annotations
 
 from pathlib import Path
@@ -114,6 +116,38 @@ class AnomalyCLIPModule(_Base):
         return {"abnormal_scores": abnormal_scores[:n], "labels": labels, "class_probs": class_probs[:n]}
 
     validation_step = test_step
+
+    # ------------------------------------------------------------------ metrics epilogue (:339-404, :501-626)
+    def test_epoch_end(self, outputs, save_dir: Optional[str] = None, epoch: int = 0):
+        """outputs = list of test_step dicts.  Returns (and optionally writes `metrics.json` with) the reference's
+        keys; rank-zero only in the reference (@rank_zero_only, :500)."""
+        import json
+        from . import metrics as M
+        scores = torch.cat([o["abnormal_scores"] for o in outputs])
+        labels = torch.cat([o["labels"] for o in outputs])
+        probs = torch.cat([o["class_probs"] for o in outputs])
+        C = int(self.hparams_.get("num_classes", probs.shape[1] + 1))
+        r = M.evaluate(scores, labels, probs, int(self.net.normal_id), C)
+        keys = ("auc_roc", "auc_pr", "mean_mc_auroc", "mean_mc_aupr", "mc_auroc", "mc_aupr", "top1_accuracy",
+                "top5_accuracy", "optimal_threshold")
+        metrics = {"epoch": epoch, **{k: r[k] for k in keys}}
+        if save_dir is not None:
+            Path(save_dir).mkdir(parents=True, exist_ok=True)
+            with open(Path(save_dir) / "metrics.json", "w") as fp:
+                json.dump(metrics, fp, indent=4, sort_keys=True)
+        self.last_metrics = r
+        return metrics
+
+    def on_validation_epoch_end(self, outputs, save_dir: Optional[str] = None, epoch: int = 0):
+        """:339-404 -- same numbers minus the per-frame predictions."""
+        m = self.test_epoch_end(outputs, None, epoch)
+        m = {k: v for k, v in m.items() if k not in ("top1_accuracy", "top5_accuracy")}
+        if save_dir is not None:
+            import json
+            Path(save_dir).mkdir(parents=True, exist_ok=True)
+            with open(Path(save_dir) / f"metrics_{epoch}.json", "w") as fp:
+                json.dump(m, fp, indent=4, sort_keys=True)
+        return m
 
     # ------------------------------------------------------------------ optimizer (:693-746)
     def configure_optimizers(self, max_epochs: int = 50):

@@ -446,3 +446,55 @@ def scatter_rows(src, idx, rows) -> torch.Tensor:
     h = _h(src)
     L.check(L.lib().acx_scatter_rows(h, src.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), src.shape[1], _stream()), h)
     return out
+
+
+# ---------------------------------------------------------------------------------- metrics epilogue (section 8f rank 3)
+CURVE_RESULT_BYTES = 56
+
+
+def sort_pairs(keys: torch.Tensor, vals: torch.Tensor, descending: bool = True):
+    """Stable radix sort of (f32 key, int32 payload) pairs -> (sorted keys, payload in that order)."""
+    assert keys.dtype == torch.float32 and vals.dtype == torch.int32 and keys.is_contiguous() and vals.is_contiguous()
+    n = keys.numel()
+    assert vals.numel() == n
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    if n == 0:
+        return ko, vo
+    lib = L.lib()
+    ws = torch.empty(int(lib.acx_sort_workspace_bytes(n)), dtype=torch.uint8, device=keys.device)
+    h = _h(keys)
+    L.check(lib.acx_sort_pairs(h, keys.data_ptr(), vals.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, int(descending),
+                               ws.data_ptr(), ws.numel(), _stream()), h)
+    return ko, vo
+
+
+def clf_curve(sorted_scores: torch.Tensor, sorted_labels: torch.Tensor, cls: int, negate: bool,
+              result: torch.Tensor, curves: bool = False):
+    """Fills one 56-byte acx_curve_result record (`result`: uint8[56] device view); optionally returns the
+    (tps, fps, thresholds) arrays (capacity n; the first n_distinct entries are valid)."""
+    n = sorted_scores.numel()
+    lib = L.lib()
+    dev = sorted_scores.device
+    ws = torch.empty(int(lib.acx_clf_curve_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    tps = fps = thr = None
+    if curves:
+        tps = torch.empty(n, dtype=torch.int32, device=dev)
+        fps = torch.empty(n, dtype=torch.int32, device=dev)
+        thr = torch.empty(n, dtype=torch.float32, device=dev)
+    h = _h(sorted_scores)
+    L.check(lib.acx_clf_curve(h, sorted_scores.data_ptr(), sorted_labels.data_ptr(), n, cls, int(negate),
+                              result.data_ptr(), _ptr(tps), _ptr(fps), _ptr(thr), ws.data_ptr(), ws.numel(),
+                              _stream()), h)
+    return tps, fps, thr
+
+
+def eval_counts(scores, probs, labels, C: int, normal_idx: int, threshold_dev: torch.Tensor):
+    """-> (y_pred int32 [n], counts int64 [3C + C*C + 30]); `threshold_dev` is a device f32 scalar view."""
+    n = scores.numel()
+    assert probs.shape == (n, C - 1) and probs.is_contiguous() and labels.dtype == torch.int64
+    y = torch.empty(n, dtype=torch.int32, device=scores.device)
+    counts = torch.empty(3 * C + C * C + 30, dtype=torch.int64, device=scores.device)
+    h = _h(scores)
+    L.check(L.lib().acx_test_counts(h, scores.data_ptr(), probs.data_ptr(), labels.data_ptr(), n, C, normal_idx,
+                                    threshold_dev.data_ptr(), y.data_ptr(), counts.data_ptr(), _stream()), h)
+    return y, counts

@@ -307,6 +307,42 @@ int acx_ctx_grad(acx_ctx* ctx, const float* dx, float* dctx, int32_t C, int32_t 
 int acx_scatter_rows(acx_ctx* ctx, const float* src, const int64_t* idx, float* out, int64_t n, int32_t W,
                      void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Metrics epilogue: anomaly_clip_module.py:501-626 and the torchmetrics==0.11.0
+ * curve functions it calls (requirements.txt:6; functional/classification/{precision_recall_curve,roc,auroc,
+ * average_precision}.py).  All results are exact-integer or fixed-order f64 -- run-to-run deterministic.
+ * --------------------------------------------------------------------------------------------------------- */
+/* Stable LSD radix sort (4 passes of 8 bits) of (f32 key, u32 payload) pairs; replaces
+ * `torch.argsort(preds, descending=True)` + gathers of _binary_clf_curve.  Not in place.  -0.0 < +0.0. */
+int64_t acx_sort_workspace_bytes(int64_t n);
+int acx_sort_pairs(acx_ctx* ctx, const float* keys, const uint32_t* vals, float* keys_out, uint32_t* vals_out,
+                   int64_t n, int32_t descending, void* workspace, int64_t workspace_bytes, void* stream);
+
+typedef struct acx_curve_result {   /* written to DEVICE memory */
+  double auroc;          /* trapz(tpr, fpr) over the distinct thresholds; 0 when a class is absent (torchmetrics) */
+  double ap;             /* sum (R_k - R_{k-1}) P_k; NaN without positives */
+  int64_t n_pos, n_neg, n_distinct;
+  int64_t opt_index;     /* sorted index of argmax(tpr - fpr) (first maximum, exact integer compare), -1 = the
+                            prepended (0,0) point */
+  float opt_threshold;   /* thresholds[argmax(tpr - fpr)] (anomaly_clip_module.py:526-527); 1.0 for the (0,0) point */
+  float pad;
+} acx_curve_result;
+/* From pairs sorted by score DESCENDING: target_i = (label_i == cls) (negate=0) or (label_i != cls) (negate=1,
+ * the reference's labels_binary, :520).  Optional curve_* arrays (capacity n) receive the n_distinct points
+ * (tps, fps, threshold) of _binary_clf_curve; pass NULL to skip. */
+int64_t acx_clf_curve_workspace_bytes(int64_t n);
+int acx_clf_curve(acx_ctx* ctx, const float* sorted_scores, const uint32_t* sorted_labels, int64_t n, int32_t cls,
+                  int32_t negate, acx_curve_result* result, int32_t* curve_tps, int32_t* curve_fps,
+                  float* curve_thresholds, void* workspace, int64_t workspace_bytes, void* stream);
+/* anomaly_clip_module.py:538-581, 621-626, 673: y_pred and the integer counters behind top-1 / top-5 accuracy,
+ * the confusion matrix and F1@{0.1..1.0}.  probs [n, C-1] (class_probs without the normal column), labels int64,
+ * threshold = DEVICE pointer to the optimal threshold (e.g. &result->opt_threshold).  counts (int64, device,
+ * 3C + C*C + 30 entries): top1_hit[C] | top5_hit[C] | class_n[C] | confusion[C][C] (row = true) | f1_tp[10] |
+ * f1_fp[10] | f1_fn[10].  Probability ties rank the lower class index first (torch.topk leaves it unspecified). */
+int acx_test_counts(acx_ctx* ctx, const float* scores, const float* probs, const int64_t* labels, int64_t n,
+                    int32_t C, int32_t normal_idx, const float* threshold, int32_t* y_pred, int64_t* counts,
+                    void* stream);
+
 /* In-library launch timer used by bench.py's roofline leg: when enabled, every kernel launch is
  * bracketed by HIP events on the caller's stream.  kinds: 0 GEMM, 1 attention, 2 norm rows, 3 other.
  * acx_prof_collect synchronises the recorded events and returns per-kind launch counts and summed
