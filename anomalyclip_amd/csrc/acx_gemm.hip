@@ -156,6 +156,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   // generic-path staging (runtime row map / a_sub / bounds): per-step uniforms then one macro per row
   int g_dn = 0, g_dl = 0, g_kc = 0, g_kw = 0;
   bool g_kin = true;
+  unsigned g_ok = 0;           // generic loader predicates of the staged rows: bit r = A row, bit 4+r = W row
   float4 g_sub0 = make_float4(0.f, 0.f, 0.f, 0.f), g_sub1 = g_sub0;
 #define ACX_GEN_SETUP(k0)                                                                          \
   do {                                                                                             \
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
       if constexpr (NLA == 2) g_sub1 = ld4(d.a_sub + g_kc + 4);                                    \
     }                                                                                              \
   } while (0)
-#define ACX_GEN_LOAD_ROW(r)                                                                        \
+#define ACX_GEN_LOAD_ROW(r)   /* issues the loads only; masking / a_sub happen in ACX_STORE_ROW (no vmcnt wait here) */ \
   do {                                                                                             \
     bool ok_ = a_ok[r] && g_kin;                                                                   \
     long srow_ = a_row[r];                                                                         \
@@ -189,25 +190,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
       srow_ += (long)nn_ * d.gl + ll_;                                                             \
     }                                                                                              \
     if constexpr (A_BF16) {                                                                        \
-      uint4 v_ = *reinterpret_cast<const uint4*>((const u16*)d.A + (size_t)srow_ * d.lda + g_kc);  \
-      if (!ok_) v_ = make_uint4(0, 0, 0, 0);                                                       \
+      const uint4 v_ = *reinterpret_cast<const uint4*>((const u16*)d.A + (size_t)srow_ * d.lda + g_kc); \
       ra##r = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
     } else {                                                                                       \
       const float* p_ = (const float*)d.A + (size_t)srow_ * d.lda + g_kc;                          \
-      float4 v_ = ld4(p_);                                                                         \
-      v_.x -= g_sub0.x; v_.y -= g_sub0.y; v_.z -= g_sub0.z; v_.w -= g_sub0.w;                      \
-      if (!ok_) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
-      ra##r = v_;                                                                                  \
-      if constexpr (NLA == 2) {                                                                    \
-        float4 u_ = ld4(p_ + 4);                                                                   \
-        u_.x -= g_sub1.x; u_.y -= g_sub1.y; u_.z -= g_sub1.z; u_.w -= g_sub1.w;                    \
-        if (!ok_) u_ = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
-        rb##r = u_;                                                                                \
-      }                                                                                            \
+      ra##r = ld4(p_);                                                                             \
+      if constexpr (NLA == 2) rb##r = ld4(p_ + 4);                                                 \
     }                                                                                              \
-    uint4 w_ = *reinterpret_cast<const uint4*>(w_ptr[r] + (size_t)g_kw * WB);                     \
-    if (!(w_ok[r] && g_kin)) w_ = make_uint4(0, 0, 0, 0);                                          \
-    rw##r = w_;                                                                                    \
+    rw##r = *reinterpret_cast<const uint4*>(w_ptr[r] + (size_t)g_kw * WB);                        \
+    g_ok = (g_ok & ~(0x11u << (r))) | (ok_ ? (1u << (r)) : 0u) | ((w_ok[r] && g_kin) ? (0x10u << (r)) : 0u); \
   } while (0)
 #define ACX_GEN_LOAD(k0) \
   do { ACX_GEN_SETUP(k0); ACX_GEN_LOAD_ROW(0); ACX_GEN_LOAD_ROW(1); ACX_GEN_LOAD_ROW(2); ACX_GEN_LOAD_ROW(3); } while (0)
@@ -219,12 +210,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
     char* sA_ = smem + (stage) * 2 * TILE_B;                                           \
     char* sW_ = sA_ + TILE_B;                                                          \
     const int off_ = (rbase + 32 * (r)) * ROWB + chunk * 16;                           \
-    if constexpr (NLA == 2) {                                                          \
-      *reinterpret_cast<uint4*>(sA_ + off_) = pack_bf16x8(ra##r, rb##r);               \
-    } else {                                                                           \
-      *reinterpret_cast<float4*>(sA_ + off_) = ra##r;                                  \
+    float4 va_ = ra##r, vb_ = rb##r;                                                   \
+    uint4 w_ = rw##r;                                                                  \
+    if constexpr (!FAST) {   /* generic loader: recentre + zero-fill, one K-step after the loads were issued */ \
+      if constexpr (!A_BF16) {                                                         \
+        va_.x -= g_sub0.x; va_.y -= g_sub0.y; va_.z -= g_sub0.z; va_.w -= g_sub0.w;    \
+        if constexpr (NLA == 2) { vb_.x -= g_sub1.x; vb_.y -= g_sub1.y; vb_.z -= g_sub1.z; vb_.w -= g_sub1.w; } \
+      }                                                                                \
+      if (!(g_ok & (1u << (r)))) { va_ = make_float4(0.f, 0.f, 0.f, 0.f); vb_ = va_; } \
+      if (!(g_ok & (0x10u << (r)))) w_ = make_uint4(0, 0, 0, 0);                       \
     }                                                                                  \
-    *reinterpret_cast<uint4*>(sW_ + off_) = rw##r;                                     \
+    if constexpr (NLA == 2) {                                                          \
+      *reinterpret_cast<uint4*>(sA_ + off_) = pack_bf16x8(va_, vb_);                   \
+    } else {                                                                           \
+      *reinterpret_cast<float4*>(sA_ + off_) = va_;                                    \
+    }                                                                                  \
+    *reinterpret_cast<uint4*>(sW_ + off_) = w_;                                        \
   } while (0)
 
   // ---- accumulators
@@ -424,6 +425,7 @@ struct TnArgs {
   const float* b_sub;
   int conv, gn, gl, cin;
   int m_per_split;
+  int sh_gl, sh_grid;      // log2(gl), log2(gn*gl) when both are powers of two, else -1
 };
 
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const TnArgs g) {
@@ -453,35 +455,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const TnArgs g) {
   if (g.b_sub && b_cok) bsub = *reinterpret_cast<const float4*>(g.b_sub + cb);
   const int grid_sz = g.conv ? g.gn * g.gl : 1;
 
+  // TN_LOAD_ROW only ISSUES the two 16-byte loads of staging row r and records their predicates; masking and
+  // the b_sub recentre happen in TN_STORE_ROW, a whole K-step later, so nothing waits on memory in between.
   float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+  unsigned ok_a = 0, ok_b = 0;
 #define TN_LOAD_ROW(r, mbase)                                                                      \
   do {                                                                                             \
     const int m_ = (mbase) + r0 + 8 * (r);                                                         \
     const bool mok_ = m_ < m_end;                                                                  \
     const int mc_ = mok_ ? m_ : m_end - 1;                                                         \
-    float4 va_ = *reinterpret_cast<const float4*>(g.A + (size_t)mc_ * g.lda + (a_cok ? ca : 0));   \
-    if (!(mok_ && a_cok)) va_ = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-    sa##r = va_;                                                                                   \
+    sa##r = *reinterpret_cast<const float4*>(g.A + (size_t)mc_ * g.lda + (a_cok ? ca : 0));        \
     long srow_ = mc_;                                                                              \
     bool bok_ = mok_ && b_cok;                                                                     \
     if (g.conv) {                                                                                  \
-      const int tile_ = mc_ / grid_sz, rem_ = mc_ - tile_ * grid_sz;                               \
-      int nn_ = rem_ / g.gl + tap_dn, ll_ = rem_ % g.gl + tap_dl;                                  \
+      int tile_, rem_, nn_, ll_;                                                                   \
+      if (g.sh_gl >= 0) { /* power-of-two grid (every shipped config: 32 x 16): shifts, no division */ \
+        tile_ = mc_ >> g.sh_grid; rem_ = mc_ & (grid_sz - 1);                                      \
+        nn_ = (rem_ >> g.sh_gl) + tap_dn; ll_ = (rem_ & (g.gl - 1)) + tap_dl;                      \
+      } else {                                                                                     \
+        tile_ = mc_ / grid_sz; rem_ = mc_ - tile_ * grid_sz;                                       \
+        nn_ = rem_ / g.gl + tap_dn; ll_ = rem_ % g.gl + tap_dl;                                    \
+      }                                                                                            \
       bok_ = bok_ && nn_ >= 0 && nn_ < g.gn && ll_ >= 0 && ll_ < g.gl;                             \
       nn_ = min(max(nn_, 0), g.gn - 1);                                                            \
       ll_ = min(max(ll_, 0), g.gl - 1);                                                            \
       srow_ = (long)tile_ * grid_sz + (long)nn_ * g.gl + ll_;                                      \
     }                                                                                              \
-    float4 vb_ = *reinterpret_cast<const float4*>(g.B + (size_t)srow_ * g.ldb + (b_cok ? b_col : 0)); \
-    vb_.x -= bsub.x; vb_.y -= bsub.y; vb_.z -= bsub.z; vb_.w -= bsub.w;                             \
-    if (!bok_) vb_ = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
-    sb##r = vb_;                                                                                   \
+    sb##r = *reinterpret_cast<const float4*>(g.B + (size_t)srow_ * g.ldb + (b_cok ? b_col : 0));   \
+    ok_a = (ok_a & ~(1u << (r))) | ((mok_ && a_cok) ? (1u << (r)) : 0u);                            \
+    ok_b = (ok_b & ~(1u << (r))) | (bok_ ? (1u << (r)) : 0u);                                       \
   } while (0)
 #define TN_STORE_ROW(stage, r)                                                                     \
   do {                                                                                             \
     float* pa_ = sm + (stage) * 2 * TILE_F + (r0 + 8 * (r)) * TN_ROWF + 4 * c16;                   \
-    *reinterpret_cast<float4*>(pa_) = sa##r;                                                       \
-    *reinterpret_cast<float4*>(pa_ + TILE_F) = sb##r;                                              \
+    float4 va_ = sa##r, vb_ = sb##r;                                                               \
+    vb_.x -= bsub.x; vb_.y -= bsub.y; vb_.z -= bsub.z; vb_.w -= bsub.w;                             \
+    if (!(ok_a & (1u << (r)))) va_ = make_float4(0.f, 0.f, 0.f, 0.f);                              \
+    if (!(ok_b & (1u << (r)))) vb_ = make_float4(0.f, 0.f, 0.f, 0.f);                              \
+    *reinterpret_cast<float4*>(pa_) = va_;                                                         \
+    *reinterpret_cast<float4*>(pa_ + TILE_F) = vb_;                                                \
   } while (0)
 
   f32x16 acc[2][2];
@@ -505,21 +517,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const TnArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
-    if (more) {
-      const int mb = m_begin + (kt + 1) * 32;
-      TN_LOAD_ROW(0, mb); TN_LOAD_ROW(1, mb); TN_LOAD_ROW(2, mb); TN_LOAD_ROW(3, mb);
-    }
     const float* pa = sm + cur * 2 * TILE_F + hh * TN_ROWF + wm * 64 + li;
     const float* pb = sm + cur * 2 * TILE_F + TILE_F + hh * TN_ROWF + wn * 64 + li;
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-      const float a0 = pa[2 * s2 * TN_ROWF], a1 = pa[2 * s2 * TN_ROWF + 32];
-      const float b0 = pb[2 * s2 * TN_ROWF], b1 = pb[2 * s2 * TN_ROWF + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
+    // operand fragments run two MFMA groups (~512 pipe cycles) ahead of their use in a 4-deep register ring,
+    // and the next tile's global loads (with their conv index arithmetic) are spread between the groups, so
+    // neither an LDS round trip nor the address VALU work ever sits in front of an idle matrix pipe.
+    float fa0A, fa1A, fb0A, fb1A, fa0B, fa1B, fb0B, fb1B, fa0C, fa1C, fb0C, fb1C, fa0D, fa1D, fb0D, fb1D;
+#define TN_RD(S, s2)                                                                               \
+  do {                                                                                             \
+    fa0##S = pa[2 * (s2) * TN_ROWF]; fa1##S = pa[2 * (s2) * TN_ROWF + 32];                          \
+    fb0##S = pb[2 * (s2) * TN_ROWF]; fb1##S = pb[2 * (s2) * TN_ROWF + 32];                          \
+  } while (0)
+#define TN_MM(S)                                                                                   \
+  do {                                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0##S, fb0##S, acc[0][0], 0, 0, 0);          \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0##S, fb1##S, acc[0][1], 0, 0, 0);          \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1##S, fb0##S, acc[1][0], 0, 0, 0);          \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1##S, fb1##S, acc[1][1], 0, 0, 0);          \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+    const int mb = m_begin + (kt + 1) * 32;
+    TN_RD(A, 0); TN_RD(B, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    TN_RD(C, 2);  TN_MM(A);
+    TN_RD(D, 3);  TN_MM(B);
+    TN_LOAD_ROW(0, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(A, 4);  TN_MM(C);
+    TN_RD(B, 5);  TN_MM(D);
+    TN_RD(C, 6);  TN_MM(A);
+    TN_LOAD_ROW(1, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(D, 7);  TN_MM(B);
+    TN_RD(A, 8);  TN_MM(C);
+    TN_RD(B, 9);  TN_MM(D);
+    TN_LOAD_ROW(2, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(C, 10); TN_MM(A);
+    TN_RD(D, 11); TN_MM(B);
+    TN_RD(A, 12); TN_MM(C);
+    TN_LOAD_ROW(3, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(B, 13); TN_MM(D);
+    TN_RD(C, 14); TN_MM(A);
+    TN_RD(D, 15); TN_MM(B);
+    TN_MM(C);
+    TN_MM(D);
+#undef TN_RD
+#undef TN_MM
     if (more) { TN_STORE_ROW(cur ^ 1, 0); TN_STORE_ROW(cur ^ 1, 1); TN_STORE_ROW(cur ^ 1, 2); TN_STORE_ROW(cur ^ 1, 3); }
     __syncthreads();
   }
@@ -680,10 +721,28 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   return ACX_OK;
 }
 
+// Split count of the M reduction: a pure function of the shape (so results are run-to-run identical).
+// Cost model in units of "rows of m streamed by one resident block": rounds(s) * (rows per split + fixed
+// per-block overhead) + the partial-tile traffic of s splits; 512 = 256 CUs x 2 resident blocks.  A power-of-two
+// rule leaves e.g. 144 tiles x 4 = 576 blocks = 2 rounds at 56 % occupancy; 7 splits give 1008 blocks (98 %).
+static int tn_choose_splits(int64_t M, int64_t N1, int64_t N2) {
+  const int64_t tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+  const double row_us = 0.106;                                   // one 32-row K-step per ~3.4 us with 2 blocks/CU
+  const double part_us = (double)N1 * N2 * 8.0 / 4.0e6;           // write + read of one partial image at ~4 TB/s
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 64; ++s) {
+    const int64_t mps = ((M + s - 1) / s + 31) / 32 * 32;
+    if (s > 1 && (mps < 256 || mps * (s - 1) >= M)) continue;      // too short, or a split would be empty
+    const int64_t rounds = (tiles * s + 511) / 512;
+    const double cost = (double)rounds * (double)(mps + 64) * row_us + (s > 1 ? s * part_us + 4.0 : 0.0);
+    if (cost < best_cost * 0.995) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
 extern "C" size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2) {
-  const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
-  int splits = 1;
-  while (tiles * splits < 512 && splits < 64 && (int64_t)M / (splits * 2) >= 256) splits *= 2;
+  const int splits = tn_choose_splits(M, N1, N2);
   return splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;
 }
 
@@ -698,8 +757,7 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
     return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: bad conv geometry%s");
   if (b_sub && ((uintptr_t)b_sub & 15)) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: b_sub alignment%s");
   const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
-  int splits = 1;
-  while (tiles * splits < 512 && splits < 64 && (int64_t)M / (splits * 2) >= 256) splits *= 2;
+  const int splits = tn_choose_splits(M, N1, N2);
   const size_t need = splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;
   if (need > workspace_bytes || (need && !workspace)) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_gemm_tn: workspace too small%s");
   TnArgs g;
@@ -707,6 +765,11 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
   g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.b_sub = b_sub; g.conv = conv; g.gn = gn; g.gl = gl; g.cin = cin;
   g.m_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
+  g.sh_gl = g.sh_grid = -1;
+  if (conv && !(gl & (gl - 1)) && !((gn * gl) & (gn * gl - 1))) {
+    g.sh_gl = __builtin_ctz((unsigned)gl);
+    g.sh_grid = __builtin_ctz((unsigned)(gn * gl));
+  }
   const size_t lds = 4 * 32 * TN_ROWF * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM, s);

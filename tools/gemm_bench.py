@@ -10,6 +10,8 @@ ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--prec", default="f32")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--shapes", default="qkv,out,fc,proj")
+ap.add_argument("--epi", type=int, default=0)   # 1: the in-model epilogues (residual on out/proj, QuickGELU on fc)
+ap.add_argument("--rounds", type=int, default=1)
 ap.add_argument("--custom", default="")   # e.g. 1536x768,4608x768  (NxK)
 args = ap.parse_args()
 M = 197 * args.frames
@@ -19,7 +21,7 @@ prec = L.PREC_F32 if args.prec == "f32" else L.PREC_BF16
 names = args.shapes.split(",") if not args.custom else []
 for c in filter(None, args.custom.split(",")):
     n_, k_ = c.split("x"); SH[c] = (int(n_), int(k_)); names.append(c)
-for name in names:
+for name in names * args.rounds:
     N, K = SH[name]
     a = torch.randn(M, K, device=dev)
     w = torch.randn(N, K, device=dev) * 0.05
@@ -28,13 +30,18 @@ for name in names:
         w = ops.cast_bf16(w)
         a = ops.cast_bf16(a)
     out = torch.empty(M, N, device=dev)
+    kw = {}
+    if args.epi and name in ("out", "proj"):
+        kw["residual"] = torch.randn(M, N, device=dev)
+    if args.epi and name == "fc":
+        kw["act"] = L.ACT_QUICKGELU
     for _ in range(2):
-        ops.gemm(a, w, bias=b, out=out, prec=prec)
+        ops.gemm(a, w, bias=b, out=out, prec=prec, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(args.iters):
-        ops.gemm(a, w, bias=b, out=out, prec=prec)
+        ops.gemm(a, w, bias=b, out=out, prec=prec, **kw)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
