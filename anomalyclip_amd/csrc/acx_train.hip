@@ -9,11 +9,22 @@ namespace {
 // out[c] = sum_p part[p][c]   (fixed order; part is [nparts][width])
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int nparts, int width) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= width) return;
+  // 16 columns x 16 slices of the parts per block: slice s sums parts s, s+16, ... in order, then the 16 slice
+  // sums are added in order -- a fixed summation tree, with width/16 blocks instead of width/256
+  __shared__ float red[16][17];
+  const int ci = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + ci;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * width + c];
-  out[c] = s;
+  if (c < width)
+    for (int p = sl; p < nparts; p += 16) s += part[(size_t)p * width + c];
+  red[sl][ci] = s;
+  __syncthreads();
+  if (sl == 0 && c < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][ci];
+    out[c] = t;
+  }
 }
 
 // block-level sum of a per-thread value (256 threads), result valid in thread 0
@@ -498,21 +509,34 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_rows_kernel(const float* __r
 
 // ------------------------------------------------------------------ positional-embedding gradients
 // d_pos0[n][e] = sum_{tile,l} dx[(tile,n,l)][e];  d_pos1[l][e] = sum_{tile,n} dx[(tile,n,l)][e]
-__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dx, float* __restrict__ d0,
-                                                       float* __restrict__ d1, int tiles, int gn, int gl, int E) {
-  // blockIdx.x < gn : row n of d0 ; else row l of d1.  thread = column(s)
-  const int b = blockIdx.x;
+// stage 1: block (tile, group of 4 segment rows n): p0[tile][n][e] = sum_l dx, p1[tile*ng + g][l][e] = sum_{n in group} dx;
+// stage 2: acx_reduce_rows over the tiles (p0) and over the tiles x groups (p1).  Fixed order throughout.
+__global__ __launch_bounds__(256) void pos_grad_part_kernel(const float* __restrict__ dx, float* __restrict__ p0,
+                                                            float* __restrict__ p1, int gn, int gl, int E) {
+  const int ng = (gn + 3) / 4;
+  const int tile = blockIdx.x / ng, g = blockIdx.x - tile * ng;
   for (int e = threadIdx.x; e < E; e += 256) {
-    float s = 0.f;
-    if (b < gn) {
-      for (int tl = 0; tl < tiles; ++tl)
-        for (int l = 0; l < gl; ++l) s += dx[(((size_t)tl * gn + b) * gl + l) * E + e];
-      d0[(size_t)b * E + e] = s;
-    } else {
-      const int l = b - gn;
-      for (int tl = 0; tl < tiles; ++tl)
-        for (int n = 0; n < gn; ++n) s += dx[(((size_t)tl * gn + n) * gl + l) * E + e];
-      d1[(size_t)l * E + e] = s;
+    for (int l0 = 0; l0 < gl; l0 += 16) {            // 16 l-accumulators in registers per pass
+      float a1[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a1[j] = 0.f;
+      for (int n = 4 * g; n < min(4 * g + 4, gn); ++n) {
+        float a0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int l = l0 + j;
+          if (l < gl) {
+            const float v = dx[(((size_t)tile * gn + n) * gl + l) * E + e];
+            a0 += v;
+            a1[j] += v;
+          }
+        }
+        float* o = p0 + ((size_t)tile * gn + n) * E + e;
+        *o = (l0 ? *o : 0.f) + a0;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (l0 + j < gl) p1[((size_t)blockIdx.x * gl + l0 + j) * E + e] = a1[j];
     }
   }
 }
@@ -564,6 +588,30 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     float s = 0.f;
     for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
     part[(size_t)blockIdx.x * D + c] = s;
+  }
+}
+// the same partials for D % 4 == 0, 16-byte aligned rows: 64 float4 columns x 4 row slices per block, grid
+// (row blocks, 256-column blocks); slice k sums rows r0+k, r0+k+4, ... and the four slices are added in order
+__global__ __launch_bounds__(256) void colsum_part4_kernel(const float* __restrict__ x, float* __restrict__ part, int64_t rows,
+                                                           int D, int ld, int rows_per_block) {
+  __shared__ float4 red[4][64];
+  const int q = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + 4 * q;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < D)
+    for (int64_t r = r0 + sl; r < r1; r += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[sl][q] = s;
+  __syncthreads();
+  if (sl == 0 && c < D) {
+    float4 t = red[0][q];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * D + c) = t;
   }
 }
 
@@ -870,7 +918,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 extern "C" int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int32_t nparts, int32_t width, void* stream) {
   if (!part || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_reduce_rows: null pointer%s");
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
-  hipLaunchKernelGGL(reduce_rows_kernel, GRID1(width), dim3(256), 0, (hipStream_t)stream, part, out, nparts, width);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((width + 15) / 16)), dim3(256), 0, (hipStream_t)stream, part, out, nparts, width);
   ACX_CHECK_LAUNCH(ctx, "acx_reduce_rows");
   return ACX_OK;
 }
@@ -982,11 +1030,19 @@ extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float
   return ACX_OK;
 }
 
-extern "C" int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, int32_t tiles, int32_t gn, int32_t gl,
-                            int32_t E, void* stream) {
-  if (!dx || !d0 || !d1) return acx_fail(ctx, ACX_E_BADARG, "acx_pos_grad: null pointer%s");
-  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
-  hipLaunchKernelGGL(pos_grad_kernel, dim3(gn + gl), dim3(256), 0, (hipStream_t)stream, dx, d0, d1, tiles, gn, gl, E);
+extern "C" int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, float* part, int32_t tiles, int32_t gn,
+                            int32_t gl, int32_t E, void* stream) {
+  if (!dx || !d0 || !d1 || !part) return acx_fail(ctx, ACX_E_BADARG, "acx_pos_grad: null pointer%s");
+  if (tiles <= 0 || gn <= 0 || gl <= 0 || E <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_pos_grad: empty shape%s");
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+  const int ng = (gn + 3) / 4;
+  float* p0 = part;                                   // [tiles][gn*E]
+  float* p1 = part + (size_t)tiles * gn * E;          // [tiles*ng][gl*E]
+  hipLaunchKernelGGL(pos_grad_part_kernel, dim3((unsigned)(tiles * ng)), dim3(256), 0, s, dx, p0, p1, gn, gl, E);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((gn * E + 15) / 16)), dim3(256), 0, s, (const float*)p0, d0, tiles, gn * E);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((gl * E + 15) / 16)), dim3(256), 0, s, (const float*)p1, d1, tiles * ng,
+                     gl * E);
   ACX_CHECK_LAUNCH(ctx, "acx_pos_grad");
   return ACX_OK;
 }
@@ -1031,7 +1087,11 @@ extern "C" int acx_colsum_partials(acx_ctx* ctx, const float* x, int32_t ld, flo
   if (rows <= 0) return ACX_OK;
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   const unsigned nb = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
-  hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, rows, D, ld, rows_per_block);
+  if (D % 4 == 0 && ld % 4 == 0 && !(((uintptr_t)x | (uintptr_t)part) & 15))
+    hipLaunchKernelGGL(colsum_part4_kernel, dim3(nb, (unsigned)((D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, part, rows, D,
+                       ld, rows_per_block);
+  else
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, rows, D, ld, rows_per_block);
   ACX_CHECK_LAUNCH(ctx, "acx_colsum_partials");
   return ACX_OK;
 }

@@ -328,8 +328,9 @@ def pos_grad(dx, tiles, gn, gl):
     E = dx.shape[1]
     d0 = torch.empty(gn, E, dtype=torch.float32, device=dx.device)
     d1 = torch.empty(gl, E, dtype=torch.float32, device=dx.device)
+    part = torch.empty(tiles * gn * E + tiles * ((gn + 3) // 4) * gl * E, dtype=torch.float32, device=dx.device)
     h = _h(dx)
-    L.check(L.lib().acx_pos_grad(h, dx.data_ptr(), d0.data_ptr(), d1.data_ptr(), tiles, gn, gl, E, _stream()), h)
+    L.check(L.lib().acx_pos_grad(h, dx.data_ptr(), d0.data_ptr(), d1.data_ptr(), part.data_ptr(), tiles, gn, gl, E, _stream()), h)
     return d0, d1
 
 

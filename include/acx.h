@@ -263,8 +263,10 @@ int acx_conv_weight_dx(acx_ctx* ctx, const float* w, float* out, int32_t Cout, i
 int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int32_t tiles,
                           int32_t gn, int32_t gl, int32_t heads, int32_t e, int32_t axis, int32_t causal,
                           float* stats_ws /* [rows*heads*3] floats or NULL */, void* stream);
-int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, int32_t tiles, int32_t gn, int32_t gl,
-                 int32_t E, void* stream);
+/* gradients of the axial positional embeddings (pos0 [gn,E], pos1 [gl,E]) from dx [(tile,n,l), E]; `part` is a
+ * scratch buffer of tiles*gn*E + tiles*ceil(gn/4)*gl*E floats (two-stage fixed-order reduction). */
+int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, float* part, int32_t tiles, int32_t gn,
+                 int32_t gl, int32_t E, void* stream);
 /* BatchNorm1d(affine=False) training backward in two steps (so data-parallel SyncBN can all-reduce the
  * sums in between): stats -> sums[2*C1] = (sum dl, sum dl*xhat) per column over this rank's rows; apply ->
  * draw[r*ldo + c] with total_rows = rows of ALL ranks. */
