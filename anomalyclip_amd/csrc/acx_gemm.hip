@@ -407,6 +407,167 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 
 
 // =====================================================================================================
+// bf16 GEMM with LDS-DMA staging:  C = epilogue(A[M,K] W[N,K]^T), A and W bf16 in global, K % 64 == 0.
+//
+// At the bf16 MFMA rate a 128x128x64 K-step is 16 x v_mfma_f32_32x32x16_bf16 = 512 matrix-pipe cycles per wave,
+// an eighth of the f32 kernel's -- the register-staged loop above then spends its time in ds_write_b128 (79 B/clk)
+// and staging VGPR traffic.  Here both operands go global -> LDS directly (global_load_lds_dwordx4: no staging
+// registers, no LDS write instructions): a wave instruction moves 8 rows x 128 B = 1 KB to wave-uniform
+// LDS base + lane*16, so the LDS image is row-linear [row][128 B] and the bank swizzle is applied on the SOURCE
+// side: LDS position p of row r holds global 16-B chunk p ^ ((r >> 1) & 7); the reader of chunk c of row r
+// looks at position c ^ ((r >> 1) & 7) -- conflict-free for every ds_read_b128 lane group, and the 8 lanes of
+// a row still cover one full 128-B line.  Two 32 KB stages per block, two blocks per CU; per K-step: issue the
+// DMA of the next tile, wait for this tile's (counted vmcnt, never 0 inside the loop), raw s_barrier, 16
+// ds_read_b128 + 16 MFMA, raw s_barrier (the stage is overwritten by the DMA issued in the next iteration).
+constexpr int DMA_ROWB = 128;                    // LDS row = one K-step of bf16
+constexpr int DMA_OP_B = 128 * DMA_ROWB;         // one operand tile: 16 KB
+constexpr int DMA_STAGE_B = 2 * DMA_OP_B;        // A | W
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int C_BF16, int ACT, int RES>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(const Args g) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const acx_gemm_desc& d = g.d;
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = wg / g.tiles_n, tn = wg % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+
+  // ---- DMA sources: instruction j (0..3) of wave w moves tile rows (4w + j)*8 .. +7; lane -> (row, position)
+  const char* ga0; const char* ga1; const char* ga2; const char* ga3;
+  const char* gw0; const char* gw1; const char* gw2; const char* gw3;
+#define DMA_SRC(j)                                                                                 \
+  do {                                                                                             \
+    const int row_ = (4 * wave + (j)) * 8 + (lane >> 3);                                           \
+    const int c_ = (lane & 7) ^ ((row_ >> 1) & 7);                                                 \
+    ga##j = (const char*)d.A + ((size_t)min(m0 + row_, d.M - 1) * d.lda) * 2 + c_ * 16;            \
+    gw##j = (const char*)d.W + ((size_t)min(n0 + row_, d.N - 1) * d.ldw) * 2 + c_ * 16;            \
+  } while (0)
+  DMA_SRC(0); DMA_SRC(1); DMA_SRC(2); DMA_SRC(3);
+#undef DMA_SRC
+  const int dma_off = 4 * wave * 1024;             // this wave's 4 KB slice of each operand image
+#define DMA_ISSUE(stage, kt_)                                                                      \
+  do {                                                                                             \
+    char* sA_ = smem + (stage) * DMA_STAGE_B + dma_off;                                            \
+    char* sW_ = sA_ + DMA_OP_B;                                                                    \
+    const size_t ko_ = (size_t)(kt_) * 128;                                                        \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga0 + ko_), (lds_void_t*)(sA_), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga1 + ko_), (lds_void_t*)(sA_ + 1024), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga2 + ko_), (lds_void_t*)(sA_ + 2048), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga3 + ko_), (lds_void_t*)(sA_ + 3072), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw0 + ko_), (lds_void_t*)(sW_), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw1 + ko_), (lds_void_t*)(sW_ + 1024), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw2 + ko_), (lds_void_t*)(sW_ + 2048), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw3 + ko_), (lds_void_t*)(sW_ + 3072), 16, 0, 0); \
+  } while (0)
+
+  // ---- fragment addresses: row (wm*64 + mi*32 + li), chunk 2*kk + hh at position chunk ^ ((li >> 1) & 7)
+  const int sw = (li >> 1) & 7;
+  const int a_base = (wm * 64 + li) * DMA_ROWB;
+  const int w_base = DMA_OP_B + (wn * 64 + li) * DMA_ROWB;
+  const int o0 = ((0 + hh) ^ sw) * 16, o1 = ((2 + hh) ^ sw) * 16, o2 = ((4 + hh) ^ sw) * 16, o3 = ((6 + hh) ^ sw) * 16;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = d.K / 64;
+  DMA_ISSUE(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      DMA_ISSUE(cur ^ 1, kt + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 8 DMAs of tile kt have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                            // ... and everybody else's
+    const char* sS = smem + cur * DMA_STAGE_B;
+#define DMA_FRAG(base, o) (*reinterpret_cast<const bf16x8*>(sS + (base) + (o)))
+#define DMA_RD(S, o)                                                                               \
+  do {                                                                                             \
+    fA0##S = DMA_FRAG(a_base, o); fA1##S = DMA_FRAG(a_base + 32 * DMA_ROWB, o);                    \
+    fB0##S = DMA_FRAG(w_base, o); fB1##S = DMA_FRAG(w_base + 32 * DMA_ROWB, o);                    \
+  } while (0)
+#define DMA_MM(S)                                                                                  \
+  do {                                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA0##S, fB0##S, acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA0##S, fB1##S, acc[0][1], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA1##S, fB0##S, acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA1##S, fB1##S, acc[1][1], 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+    // fragment reads run two k-substeps ahead of their MFMAs (4 named register sets): the matrix pipe does not
+    // wait on an LDS round trip between the four k-substeps
+    bf16x8 fA0P, fA1P, fB0P, fB1P, fA0Q, fA1Q, fB0Q, fB1Q, fA0R, fA1R, fB0R, fB1R, fA0S, fA1S, fB0S, fB1S;
+    DMA_RD(P, o0); DMA_RD(Q, o1);
+    __builtin_amdgcn_sched_barrier(0);
+    DMA_RD(R, o2); DMA_MM(P);
+    DMA_RD(S, o3); DMA_MM(Q);
+    DMA_MM(R); DMA_MM(S);
+#undef DMA_MM
+#undef DMA_RD
+#undef DMA_FRAG
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // stage `cur` is free for the DMA of tile kt + 2
+  }
+#undef DMA_ISSUE
+
+  // ---- epilogue (same structure as gemm_kernel's: compute everything, then store)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + li;
+    const bool cok = col < d.N;
+    const int colc = cok ? col : d.N - 1;
+    float bias = 0.f;
+    if (d.bias) bias = d.bias[colc];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int rowb = m0 + wm * 64 + mi * 32 + 4 * hh;
+      float outv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) outv[r] = 0.f;
+      if constexpr (RES != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
+          outv[r] = d.residual[(size_t)row * d.ldr + colc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[mi][ni][r] + bias;
+        if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+        outv[r] += v;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(outv[r]));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowb + (r & 3) + 8 * (r >> 2);
+        if (cok && row < d.M) {
+          if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(outv[r]);
+          else ((float*)d.C)[(size_t)row * d.ldc + col] = outv[r];
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================
 // acx_gemm_tn -- weight-gradient GEMM:  C[N1,N2] = sum_m A[m,n1] * bmap(B)[m,n2]      (exact f32 MFMA)
 //
 // Both operands are stored with the REDUCTION index m as the slow (row) index -- dY [M,N1] and
@@ -690,7 +851,33 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       grid.y = g.ksplit;
     }
   }
-  if (fast) {
+  // bf16 operands already in global memory, no split: the LDS-DMA kernel (ACX_NO_DMA=1 keeps the register-staged one)
+  static const bool no_dma = getenv("ACX_NO_DMA") != nullptr;
+  if (fast && g.ksplit == 1 && prec == ACX_PREC_BF16 && a_bf16 && !no_dma && d->lda % 8 == 0 && d->ldw % 8 == 0) {
+    const size_t dlds = 2 * DMA_STAGE_B;
+#define ACX_DMA(CB, ACT, RES)                                                                       \
+  do {                                                                                              \
+    static bool attr_done = false;                                                                  \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<CB, ACT, RES>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);             \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<CB, ACT, RES>), grid, block, dlds, s, g);              \
+  } while (0)
+    const int sel = (c_bf16 ? 4 : 0) + (d->act == ACX_ACT_QUICKGELU ? 2 : 0) + (d->residual ? 1 : 0);
+    switch (sel) {
+      case 0: ACX_DMA(0, 0, 0); break;
+      case 1: ACX_DMA(0, 0, 1); break;
+      case 2: ACX_DMA(0, 1, 0); break;
+      case 3: ACX_DMA(0, 1, 1); break;
+      case 4: ACX_DMA(1, 0, 0); break;
+      case 5: ACX_DMA(1, 0, 1); break;
+      case 6: ACX_DMA(1, 1, 0); break;
+      default: ACX_DMA(1, 1, 1); break;
+    }
+#undef ACX_DMA
+  } else if (fast) {
     switch (variant) {
       case 0: ACX_FAST(0, 0, 0); break;
       case 1: ACX_FAST(0, 0, 1); break;
