@@ -568,6 +568,204 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(const Args g
 }
 
 // =====================================================================================================
+// bf16 GEMM, 256x256 block tile, persistent, LDS-DMA double buffer  (the large-M ViT shapes in bf16 mode)
+//
+// One 512-thread block per CU walks its share of the output tiles.  K-step = 64 bf16 = one full 128-B line per
+// row (a 64-B half line per step re-fetches every line twice: measured 5.1 TB/s of fill traffic, DMA-bound).
+// A stage = A[256][128 B] | W[256][128 B] = 64 KB, two stages.  8 waves as 2(M) x 4(N); a wave owns 128 x 64 of
+// C = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 and issues 32 MFMAs per K-step (1024 pipe cycles, 2048 per
+// SIMD: about one L2 round trip, which is the lead the DMA of the next step gets).  Per K-step:
+//     s_waitcnt vmcnt(0); s_barrier      -> DMA(s) complete for every wave, stage of step s-1 free
+//     issue DMA(s+1)                      -> 8 x global_load_lds_dwordx4 per wave; s+1 may belong to the NEXT tile,
+//                                            so its first lines land while this tile's epilogue runs
+//     4 x { 6 ds_read_b128 || 8 MFMA }    -> fragment sets alternate between two named register sets
+//     [last K-step of a tile: epilogue through 8 x 4 KB of wave-private LDS -> full-line 16-byte stores]
+// Source-side swizzle as in gemm_bf16_dma_kernel (position p of row r <- chunk p ^ ((r >> 1) & 7)).
+constexpr int RG_TM = 256, RG_TN = 256;
+constexpr int RG_ROWB = 128;
+constexpr int RG_OP_B = 256 * RG_ROWB;      // 32 KB per operand image
+constexpr int RG_STAGE_B = 2 * RG_OP_B;     // 64 KB
+
+#define RG_GLDS(a, la) __builtin_amdgcn_global_load_lds((gbl_void_t*)(a), (lds_void_t*)(la), 16, 0, 0)
+
+template <int C_BF16, int ACT, int RES>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(const Args g) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const acx_gemm_desc& d = g.d;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, hh = lane >> 5;
+  const int tiles_n = (d.N + RG_TN - 1) / RG_TN, tiles_m = (d.M + RG_TM - 1) / RG_TM;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  // XCD-aware start: within a round of G tiles each XCD (blockIdx & 7) owns a contiguous chunk
+  const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
+  const int b0 = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + ((int)blockIdx.x >> 3);
+  const int my_tiles = b0 < ntiles ? (ntiles - b0 + G - 1) / G : 0;
+  if (my_tiles == 0) return;
+  const int nk = d.K / 64;
+  const int S = my_tiles * nk;
+
+  // ---- DMA cursor: (tile jd, K-step hd) of the next stage to issue, source pointers of tile jd at k = 0.
+  // instruction i (0..3) of wave w moves tile rows (4w + i)*8 .. +7 of each operand; lane -> (row, position)
+  const int dr = (4 * wave) * 8 + (lane >> 3);
+  const char *pa0, *pa1, *pa2, *pa3, *pw0, *pw1, *pw2, *pw3;
+  int jd = 0, hd = 0, std_ = 0;
+#define RG_SRC1(i, m0_, n0_)                                                                       \
+  do {                                                                                             \
+    const int row_ = dr + 8 * (i);                                                                 \
+    const int c_ = (lane & 7) ^ ((row_ >> 1) & 7);                                                 \
+    pa##i = (const char*)d.A + ((size_t)min((m0_) + row_, d.M - 1) * d.lda) * 2 + c_ * 16;         \
+    pw##i = (const char*)d.W + ((size_t)min((n0_) + row_, d.N - 1) * d.ldw) * 2 + c_ * 16;         \
+  } while (0)
+#define RG_SET_SRC(j)                                                                              \
+  do {                                                                                             \
+    const int L_ = b0 + min((j), my_tiles - 1) * G;    /* past the end: re-read the last tile (never consumed) */ \
+    const int tm_ = L_ / tiles_n, tn_ = L_ - tm_ * tiles_n;                                        \
+    RG_SRC1(0, tm_ * RG_TM, tn_ * RG_TN); RG_SRC1(1, tm_ * RG_TM, tn_ * RG_TN);                    \
+    RG_SRC1(2, tm_ * RG_TM, tn_ * RG_TN); RG_SRC1(3, tm_ * RG_TM, tn_ * RG_TN);                    \
+  } while (0)
+#define RG_DMA()                                                                                   \
+  do {                                                                                             \
+    char* sA_ = smem + std_ * RG_STAGE_B + (4 * wave) * 1024;                                      \
+    char* sW_ = sA_ + RG_OP_B;                                                                     \
+    const size_t ko_ = (size_t)hd * 128;                                                           \
+    RG_GLDS(pa0 + ko_, sA_);        RG_GLDS(pa1 + ko_, sA_ + 1024);                          \
+    RG_GLDS(pa2 + ko_, sA_ + 2048); RG_GLDS(pa3 + ko_, sA_ + 3072);                          \
+    RG_GLDS(pw0 + ko_, sW_);        RG_GLDS(pw1 + ko_, sW_ + 1024);                          \
+    RG_GLDS(pw2 + ko_, sW_ + 2048); RG_GLDS(pw3 + ko_, sW_ + 3072);                          \
+    std_ ^= 1;                                                                                     \
+    if (++hd == nk) { hd = 0; ++jd; RG_SET_SRC(jd); }                                              \
+  } while (0)
+  RG_SET_SRC(0);
+
+  // ---- fragment addresses inside a stage: row, chunk 2*kk + hh at position chunk ^ ((li >> 1) & 7)
+  const int sw = (li >> 1) & 7;
+  const int fa = (wm * 128 + li) * RG_ROWB;                 // + mi * 32 * RG_ROWB
+  const int fw = RG_OP_B + (wn * 64 + li) * RG_ROWB;        // + ni * 32 * RG_ROWB
+  const int oK0 = ((0 + hh) ^ sw) * 16, oK1 = ((2 + hh) ^ sw) * 16, oK2 = ((4 + hh) ^ sw) * 16, oK3 = ((6 + hh) ^ sw) * 16;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+  bf16x8 pA0, pA1, pA2, pA3, pB0, pB1, qA0, qA1, qA2, qA3, qB0, qB1;
+#define RG_FRAG(stage, base, o) (*reinterpret_cast<const bf16x8*>(smem + (stage) * RG_STAGE_B + (base) + (o)))
+#define RG_RD(S, stage, o)                                                                         \
+  do {                                                                                             \
+    S##A0 = RG_FRAG(stage, fa, o);                    S##A1 = RG_FRAG(stage, fa + 32 * RG_ROWB, o); \
+    S##A2 = RG_FRAG(stage, fa + 64 * RG_ROWB, o);     S##A3 = RG_FRAG(stage, fa + 96 * RG_ROWB, o); \
+    S##B0 = RG_FRAG(stage, fw, o);                    S##B1 = RG_FRAG(stage, fw + 32 * RG_ROWB, o); \
+    __builtin_amdgcn_sched_barrier(0);   /* keep the reads AHEAD of the MFMAs they overlap with */   \
+  } while (0)
+// Operands are SWAPPED (W fragment first): the accumulator then holds C^T, i.e. a lane owns ONE row of C and 4 x 4
+// consecutive columns per 32x32 tile, so the epilogue stores (and the residual loads) are 16-byte accesses -- a
+// quarter of the store instructions of the natural layout (narrow stores cost up to 46 % of this kernel).
+// The first MFMA of a fragment set is issued BEFORE the next set's reads: hipcc waits lgkmcnt(0) (never a partial
+// count) in front of the first use of a set, and at that point only reads issued >= 7 MFMAs earlier are outstanding.
+#define RG_MM_HEAD(S)                                                                              \
+  do {                                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B0, S##A0, acc[0][0], 0, 0, 0);         \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#define RG_MM_TAIL(S)                                                                              \
+  do {                                                                                             \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B1, S##A0, acc[0][1], 0, 0, 0);         \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B0, S##A1, acc[1][0], 0, 0, 0);         \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B1, S##A1, acc[1][1], 0, 0, 0);         \
+    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B0, S##A2, acc[2][0], 0, 0, 0);         \
+    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B1, S##A2, acc[2][1], 0, 0, 0);         \
+    acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B0, S##A3, acc[3][0], 0, 0, 0);         \
+    acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##B1, S##A3, acc[3][1], 0, 0, 0);         \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+
+  RG_DMA();                         // DMA(0)
+  int cur = 0, h = 0, j = 0;
+  for (int s = 0; s < S; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA(s) (and older stores) are done
+    __builtin_amdgcn_s_barrier();                            // everybody's; the other stage is free
+    RG_DMA();                                                // DMA(s + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    RG_RD(p, cur, oK0);
+    RG_MM_HEAD(p); RG_RD(q, cur, oK1); RG_MM_TAIL(p);
+    RG_MM_HEAD(q); RG_RD(p, cur, oK2); RG_MM_TAIL(q);
+    RG_MM_HEAD(p); RG_RD(q, cur, oK3); RG_MM_TAIL(p);
+    RG_MM_HEAD(q); RG_MM_TAIL(q);
+    if (++h == nk) {
+      // ---- epilogue of tile j (rows >= M / cols >= N masked), then restart the accumulators
+      const int L = b0 + j * G;
+      const int tm = L / tiles_n, tn = L - tm * tiles_n;
+      const int m0 = tm * RG_TM, n0 = tn * RG_TN;
+      // Each 32x32 accumulator tile goes through this wave's private 4 KB of LDS (XOR-swizzled 128-B rows) and
+      // comes back row-major: lane l then owns 4 consecutive columns (l & 7) of row (l >> 3) + 8*pass, and one
+      // store instruction writes 8 complete 128-B lines (narrow or per-row-scattered stores cost 30-46 % here).
+      char* scr = smem + 2 * RG_STAGE_B + wave * 4096;
+      const int rl = lane >> 3, cj = lane & 7;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn * 64 + ni * 32 + 4 * cj;                  // 4 consecutive columns (N % 4 == 0)
+        const bool cok = col < d.N;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias) b4 = *reinterpret_cast<const float4*>(d.bias + (cok ? col : 0));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int row0 = m0 + wm * 128 + mi * 32 + rl;
+          float4 res[4];
+          if constexpr (RES != 0) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+              res[ps] = *reinterpret_cast<const float4*>(d.residual + (size_t)min(row0 + 8 * ps, d.M - 1) * d.ldr + (cok ? col : 0));
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)       // accumulator (C^T layout): row li, columns 8k + 4hh .. +3 = chunk 2k + hh
+            *reinterpret_cast<float4*>(scr + li * 128 + (((2 * k + hh) ^ (li & 7)) * 16)) =
+                make_float4(acc[mi][ni][4 * k], acc[mi][ni][4 * k + 1], acc[mi][ni][4 * k + 2], acc[mi][ni][4 * k + 3]);
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int rr_ = rl + 8 * ps;
+            float4 v = *reinterpret_cast<const float4*>(scr + rr_ * 128 + ((cj ^ (rr_ & 7)) * 16));
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            if constexpr (ACT == ACX_ACT_QUICKGELU) {
+              v.x = v.x * (1.f / (1.f + __expf(-1.702f * v.x))); v.y = v.y * (1.f / (1.f + __expf(-1.702f * v.y)));
+              v.z = v.z * (1.f / (1.f + __expf(-1.702f * v.z))); v.w = v.w * (1.f / (1.f + __expf(-1.702f * v.w)));
+            }
+            if constexpr (RES != 0) { v.x += res[ps].x; v.y += res[ps].y; v.z += res[ps].z; v.w += res[ps].w; }
+            const int row = row0 + 8 * ps;
+            if (cok && row < d.M) {
+              if constexpr (C_BF16) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                *reinterpret_cast<uint2*>((u16*)d.C + (size_t)row * d.ldc + col) = pk;
+              } else {
+                *reinterpret_cast<float4*>((float*)d.C + (size_t)row * d.ldc + col) = v;
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        }
+      }
+      h = 0; ++j;
+    }
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may still be writing this block's LDS at exit
+#undef RG_MM_HEAD
+#undef RG_MM_TAIL
+#undef RG_RD
+#undef RG_FRAG
+#undef RG_DMA
+#undef RG_SET_SRC
+#undef RG_SRC1
+}
+
+// =====================================================================================================
 // acx_gemm_tn -- weight-gradient GEMM:  C[N1,N2] = sum_m A[m,n1] * bmap(B)[m,n2]      (exact f32 MFMA)
 //
 // Both operands are stored with the REDUCTION index m as the slow (row) index -- dY [M,N1] and
@@ -851,8 +1049,41 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       grid.y = g.ksplit;
     }
   }
-  // bf16 operands already in global memory, no split: the LDS-DMA kernel (ACX_NO_DMA=1 keeps the register-staged one)
+  // bf16 operands already in global memory, no split: the LDS-DMA kernels (ACX_NO_DMA=1 keeps the register-staged
+  // one, ACX_NO_RING=1 the 128x128 DMA kernel).  Large problems take the persistent 256x256 ring kernel.
   static const bool no_dma = getenv("ACX_NO_DMA") != nullptr;
+  static const bool no_ring = getenv("ACX_NO_RING") != nullptr;
+  const int rtiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+  const int ring_min = getenv("ACX_RING_MIN_TILES") ? atoi(getenv("ACX_RING_MIN_TILES")) : 512;   // (tests lower it)
+  if (fast && g.ksplit == 1 && prec == ACX_PREC_BF16 && a_bf16 && !no_dma && !no_ring && d->lda % 8 == 0 && d->ldw % 8 == 0 &&
+      d->K % 64 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
+      !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && rtiles >= ring_min && !(d->act == ACX_ACT_QUICKGELU && d->residual)) {
+    int ncu = 256;
+    { hipDeviceProp_t prop; int dev = 0;
+      static int cached = 0;
+      if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
+      if (cached > 0) ncu = cached; }
+    const dim3 rgrid((unsigned)(rtiles < ncu ? rtiles : ncu));
+#define ACX_RING_L(CB, ACT, RES)                                                                    \
+  do {                                                                                              \
+    static bool attr_done = false;                                                                  \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<CB, ACT, RES>,                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * RG_STAGE_B + 8 * 4096)); \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<CB, ACT, RES>), rgrid, dim3(512), (size_t)(2 * RG_STAGE_B + 8 * 4096), s, g); \
+  } while (0)
+#define ACX_RING_SEL()                                                                              \
+  do {                                                                                              \
+    if (d->residual) { if (c_bf16) ACX_RING_L(1, 0, 1); else ACX_RING_L(0, 0, 1); }                 \
+    else if (d->act == ACX_ACT_QUICKGELU) { if (c_bf16) ACX_RING_L(1, 1, 0); else ACX_RING_L(0, 1, 0); } \
+    else { if (c_bf16) ACX_RING_L(1, 0, 0); else ACX_RING_L(0, 0, 0); }                             \
+  } while (0)
+    ACX_RING_SEL();
+#undef ACX_RING_SEL
+#undef ACX_RING_L
+  } else
   if (fast && g.ksplit == 1 && prec == ACX_PREC_BF16 && a_bf16 && !no_dma && d->lda % 8 == 0 && d->ldw % 8 == 0) {
     const size_t dlds = 2 * DMA_STAGE_B;
 #define ACX_DMA(CB, ACT, RES)                                                                       \

@@ -108,6 +108,26 @@ def test_gemm_bf16_lds_dma_path(M, N, K, act, res, obf):
     assert relerr(out.float(), ref) < (1e-2 if obf else 1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,act,res,obf", [(3001, 600, 768, 0, 0, 0), (2500, 512, 128, 0, 1, 0), (5000, 300, 3072, 1, 0, 1),
+                                               (777, 1000, 64, 0, 1, 1), (256, 256, 64, 0, 0, 0), (70000, 520, 192, 0, 1, 0)])
+def test_gemm_bf16_ring_kernel(M, N, K, act, res, obf, monkeypatch):
+    """persistent 256x256 LDS-DMA kernel (normally only for >= 512 tiles; forced here): ragged tiles, tile counts
+    below / above the CU count (several tiles per block), single-step K, residual-as-accumulator-init."""
+    monkeypatch.setenv("ACX_RING_MIN_TILES", "1")
+    g = torch.Generator().manual_seed(M + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = a.bfloat16().double() @ w.bfloat16().double().t() + bias.double()
+    if act:
+        ref = O.quick_gelu(ref)
+    if res:
+        ref = ref + r.double()
+    out = ops.gemm(ops.cast_bf16(a.to(DEV)), ops.cast_bf16(w.to(DEV)), bias=bias.to(DEV), prec=L.PREC_BF16,
+                   act=L.ACT_QUICKGELU if act else L.ACT_NONE, residual=r.to(DEV) if res else None,
+                   out_dtype=torch.bfloat16 if obf else torch.float32)
+    assert relerr(out.float(), ref) < (1e-2 if obf else 1e-5)
+
+
 @pytest.mark.parametrize("M,N,K", [(1078, 1536, 512), (1078, 512, 2048), (64, 128, 4096), (300, 200, 1024)])
 def test_gemm_split_k_paths(M, N, K):
     """skinny problems take the split-K path (workspace handed over by ops.gemm); epilogue applied after the reduce."""
