@@ -423,6 +423,7 @@ constexpr int DMA_ROWB = 128;                    // LDS row = one K-step of bf16
 constexpr int DMA_OP_B = 128 * DMA_ROWB;         // one operand tile: 16 KB
 constexpr int DMA_STAGE_B = 2 * DMA_OP_B;        // A | W
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
@@ -575,10 +576,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(const Args g
 // A stage = A[256][128 B] | W[256][128 B] = 64 KB, two stages.  8 waves as 2(M) x 4(N); a wave owns 128 x 64 of
 // C = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 and issues 32 MFMAs per K-step (1024 pipe cycles, 2048 per
 // SIMD: about one L2 round trip, which is the lead the DMA of the next step gets).  Per K-step:
-//     s_waitcnt vmcnt(0); s_barrier      -> DMA(s) complete for every wave, stage of step s-1 free
+//     s_barrier                           -> DMA(s) complete for every wave, stage of step s-1 free
 //     issue DMA(s+1)                      -> 8 x global_load_lds_dwordx4 per wave; s+1 may belong to the NEXT tile,
 //                                            so its first lines land while this tile's epilogue runs
 //     4 x { 6 ds_read_b128 || 8 MFMA }    -> fragment sets alternate between two named register sets
+//     s_waitcnt vmcnt(0)                  -> this wave's DMA(s+1) landed (before any epilogue store is issued)
 //     [last K-step of a tile: epilogue through 8 x 4 KB of wave-private LDS -> full-line 16-byte stores]
 // Source-side swizzle as in gemm_bf16_dma_kernel (position p of row r <- chunk p ^ ((r >> 1) & 7)).
 constexpr int RG_TM = 256, RG_TN = 256;
@@ -686,9 +688,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(const Args g) {
 
   RG_DMA();                         // DMA(0)
   int cur = 0, h = 0, j = 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int s = 0; s < S; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA(s) (and older stores) are done
-    __builtin_amdgcn_s_barrier();                            // everybody's; the other stage is free
+    __builtin_amdgcn_s_barrier();                            // everybody's DMA(s) is complete; the other stage is free
     RG_DMA();                                                // DMA(s + 1)
     __builtin_amdgcn_sched_barrier(0);
     RG_RD(p, cur, oK0);
@@ -696,6 +698,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(const Args g) {
     RG_MM_HEAD(q); RG_RD(p, cur, oK2); RG_MM_TAIL(q);
     RG_MM_HEAD(p); RG_RD(q, cur, oK3); RG_MM_TAIL(p);
     RG_MM_HEAD(q); RG_MM_TAIL(q);
+    // this wave's DMA(s+1) has had the whole K-step to land.  Waiting for it HERE, before the epilogue's stores are
+    // issued, keeps those stores out of the wait (vmcnt cannot tell loads from stores): they get the next K-step to
+    // drain instead of stalling it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (++h == nk) {
       // ---- epilogue of tile j (rows >= M / cols >= N masked), then restart the accumulators
       const int L = b0 + j * G;
@@ -704,23 +710,37 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(const Args g) {
       // Each 32x32 accumulator tile goes through this wave's private 4 KB of LDS (XOR-swizzled 128-B rows) and
       // comes back row-major: lane l then owns 4 consecutive columns (l & 7) of row (l >> 3) + 8*pass, and one
       // store instruction writes 8 complete 128-B lines (narrow or per-row-scattered stores cost 30-46 % here).
+      // No global load may sit between stores and its use (vmcnt cannot tell them apart and the wait would cover
+      // the stores' full round trip): both bias vectors are fetched first, and the residual of two 32 x 32 tiles
+      // (8 float4 per lane) is requested in one batch before those tiles' stores.
       char* scr = smem + 2 * RG_STAGE_B + wave * 4096;
       const int rl = lane >> 3, cj = lane & 7;
+      const int col0 = n0 + wn * 64 + 4 * cj, col1 = col0 + 32;           // 4 consecutive columns (N % 4 == 0)
+      float4 bb0 = make_float4(0.f, 0.f, 0.f, 0.f), bb1 = bb0;
+      if (d.bias) {
+        bb0 = *reinterpret_cast<const float4*>(d.bias + (col0 < d.N ? col0 : 0));
+        bb1 = *reinterpret_cast<const float4*>(d.bias + (col1 < d.N ? col1 : 0));
+      }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn * 64 + ni * 32 + 4 * cj;                  // 4 consecutive columns (N % 4 == 0)
+        const int col = ni ? col1 : col0;
         const bool cok = col < d.N;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias) b4 = *reinterpret_cast<const float4*>(d.bias + (cok ? col : 0));
+        const float4 b4 = ni ? bb1 : bb0;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const int row0 = m0 + wm * 128 + mi * 32 + rl;
-          float4 res[4];
-          if constexpr (RES != 0) {
+        for (int mp = 0; mp < 2; ++mp) {
+        float4 res[2][4];
+        if constexpr (RES != 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
-              res[ps] = *reinterpret_cast<const float4*>(d.residual + (size_t)min(row0 + 8 * ps, d.M - 1) * d.ldr + (cok ? col : 0));
-          }
+              res[u][ps] = *reinterpret_cast<const float4*>(
+                  d.residual + (size_t)min(m0 + wm * 128 + (2 * mp + u) * 32 + rl + 8 * ps, d.M - 1) * d.ldr + (cok ? col : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int mi = 2 * mp + u;
+          const int row0 = m0 + wm * 128 + mi * 32 + rl;
 #pragma unroll
           for (int k = 0; k < 4; ++k)       // accumulator (C^T layout): row li, columns 8k + 4hh .. +3 = chunk 2k + hh
             *reinterpret_cast<float4*>(scr + li * 128 + (((2 * k + hh) ^ (li & 7)) * 16)) =
@@ -734,21 +754,26 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(const Args g) {
               v.x = v.x * (1.f / (1.f + __expf(-1.702f * v.x))); v.y = v.y * (1.f / (1.f + __expf(-1.702f * v.y)));
               v.z = v.z * (1.f / (1.f + __expf(-1.702f * v.z))); v.w = v.w * (1.f / (1.f + __expf(-1.702f * v.w)));
             }
-            if constexpr (RES != 0) { v.x += res[ps].x; v.y += res[ps].y; v.z += res[ps].z; v.w += res[ps].w; }
+            if constexpr (RES != 0) { v.x += res[u][ps].x; v.y += res[u][ps].y; v.z += res[u][ps].z; v.w += res[u][ps].w; }
             const int row = row0 + 8 * ps;
             if (cok && row < d.M) {
               if constexpr (C_BF16) {
                 uint2 pk;
                 pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
                 pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-                *reinterpret_cast<uint2*>((u16*)d.C + (size_t)row * d.ldc + col) = pk;
+                u32x2* dst = reinterpret_cast<u32x2*>((u16*)d.C + (size_t)row * d.ldc + col);
+                if constexpr (RES != 0) *dst = *reinterpret_cast<const u32x2*>(&pk);     // residual stream: re-read soon
+                else __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pk), dst);   // streamed: keep A / W in L2
               } else {
-                *reinterpret_cast<float4*>((float*)d.C + (size_t)row * d.ldc + col) = v;
+                f32x4* dst = reinterpret_cast<f32x4*>((float*)d.C + (size_t)row * d.ldc + col);
+                if constexpr (RES != 0) *dst = *reinterpret_cast<const f32x4*>(&v);
+                else __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&v), dst);
               }
             }
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        }
         }
       }
       h = 0; ++j;
