@@ -194,10 +194,19 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     }
     // x = x + attn(ln_1(x))                                          clip/model.py:215
     if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
-    if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, ACX_F32, 3 * W, (int)rows, 3 * W, W,
+    // bf16 mode, non-causal (the ViT): q/k/v, the attention and its output stay bf16 end to end -- half the
+    // QKV store traffic, bf16-MFMA attention, and a bf16 A operand (LDS-DMA kernels) for the out-projection
+    static const bool attn_f32 = getenv("ACX_ATTN_F32") != nullptr;
+    const bool ab = prec == ACX_PREC_BF16 && !causal && L <= 224 && !attn_f32;
+    const int qdt = ab ? ACX_BF16 : ACX_F32;
+    if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, qdt, 3 * W, (int)rows, 3 * W, W,
                      b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
-    if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
-    if ((rc = linear(ctx, prec, ws.att, ACX_F32, W, b.out_proj_w, b.out_proj_w_bf16, W, x, ACX_F32, W, (int)rows, W, W,
+    if (ab) {
+      if ((rc = acx_attention_bf16(ctx, ws.qkv, 3 * W, ws.att, W, batch, L, heads, s))) return rc;
+    } else {
+      if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
+    }
+    if ((rc = linear(ctx, prec, ws.att, qdt, W, b.out_proj_w, b.out_proj_w_bf16, W, x, ACX_F32, W, (int)rows, W, W,
                      b.out_proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     // x = x + mlp(ln_2(x))                                           clip/model.py:216
     if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;

@@ -252,6 +252,192 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   return ACX_OK;
 }
 
+namespace {
+// =====================================================================================================
+// acx_attention_bf16 -- the same attention with bf16 operands (bf16 mode of the ViT, not a parity path):
+// qkv and the output are bf16 in global memory, QK^T and PV run on v_mfma_f32_32x32x16_bf16, softmax in f32.
+//   * K of the head in LDS as bf16 rows of 128 B padded to 144 B (conflict-free ds_read_b128 A fragments);
+//     V TRANSPOSED, Vt[e][key] with 520-B rows, because the bf16 MFMA packs 8 contraction indices (keys) per
+//     lane -- the transposition happens while staging (16-byte global loads, 2-byte LDS writes).
+//     K + Vt = 64 KB -> two workgroups per CU (the f32 kernel needs 112 KB and runs one).
+//   * S^T = K Q^T exactly as in the f32 kernel (lane = query column, registers = keys), so softmax is
+//     in-register + one cross-half exchange, and register group 8c..8c+7 of a key tile, packed to bf16, IS the
+//     B operand of O^T = V^T P^T for key chunk c.  The keys a lane half holds there are
+//     {16c + 4h + (0..3)} u {16c + 8 + 4h + (0..3)}: the Vt fragment is two ds_read_b64 at those offsets.
+//   * O^T's C layout has lane = query again: 1/rowsum is a per-lane scalar and a lane stores 4 x 8 bytes per
+//     32-wide slice of its row.
+constexpr int BK_ROWB = 144;       // bytes per K row in LDS
+constexpr int BV_ROWB = 520;       // bytes per Vt row (224 keys * 2 B = 448, +72: stride/4 = 130 = 2 mod 64)
+
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) { return f2bf2(a, b); }
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict__ qkv, int64_t ldqkv, u16* __restrict__ out,
+                                                          int64_t ldo, int L, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                                  // [NT*32][144 B]
+  char* sV = smem + NT * 32 * BK_ROWB;              // [64][520 B]
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int W = heads * 64;
+  const u16* base = qkv + (int64_t)b * L * ldqkv + h * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+
+  // ---- stage K (row copy) and V (transposed); 8 lanes cover one 128-byte row; rows >= L are zero
+  constexpr int NP = NT * 32 * 8;                   // 16-byte pieces per operand
+  constexpr int NSTG = (NP + 255) / 256;
+  uint4 stk[NSTG], stv[NSTG];
+#pragma unroll
+  for (int j = 0; j < NSTG; ++j) {
+    const int i = t + j * 256;
+    const int row = i >> 3, pc = i & 7;
+    stk[j] = make_uint4(0, 0, 0, 0);
+    stv[j] = stk[j];
+    if (i < NP && row < L) {
+      const u16* p = base + (int64_t)row * ldqkv + 8 * pc;
+      stk[j] = *reinterpret_cast<const uint4*>(p + W);
+      stv[j] = *reinterpret_cast<const uint4*>(p + 2 * W);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NSTG; ++j) {
+    const int i = t + j * 256;
+    const int row = i >> 3, pc = i & 7;
+    if (i < NP) {
+      *reinterpret_cast<uint4*>(sK + row * BK_ROWB + pc * 16) = stk[j];
+      const uint32_t w4[4] = {stv[j].x, stv[j].y, stv[j].z, stv[j].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        *reinterpret_cast<u16*>(sV + (8 * pc + e) * BV_ROWB + row * 2) = (u16)(w4[e >> 1] >> (16 * (e & 1)));
+    }
+  }
+  __syncthreads();
+
+  const int nqb = (L + 31) / 32;
+  for (int qb = wave; qb < nqb; qb += 4) {
+    // ---- Q fragments (B operand): query row qb*32 + li, d = 8*(2kk + hh) .. +7
+    const int q = min(qb * 32 + li, L - 1);
+    const u16* qp = base + (int64_t)q * ldqkv + 8 * hh;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint4 v = *reinterpret_cast<const uint4*>(qp + 16 * kk);
+      qf[kk] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    // ---- S^T tiles: keys x queries
+    f32x16 st[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[kt][e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 32 + li) * BK_ROWB + (2 * kk + hh) * 16);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one key tile of fragments in flight, not all 28 (register spills)
+    }
+    // ---- softmax over the keys of this lane's query: register r of tile kt is key kt*32 + (r&3) + 8(r>>2) + 4hh
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        st[kt][r] = key < L ? st[kt][r] * 0.125f : -3.0e38f;
+        m = fmaxf(m, st[kt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(st[kt][r] - m);
+        st[kt][r] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    // ---- O^T = V^T P^T : two 32-wide e tiles
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        uint4 pk;
+        pk.x = pack2_bf16(st[kt][8 * c + 0], st[kt][8 * c + 1]);
+        pk.y = pack2_bf16(st[kt][8 * c + 2], st[kt][8 * c + 3]);
+        pk.z = pack2_bf16(st[kt][8 * c + 4], st[kt][8 * c + 5]);
+        pk.w = pack2_bf16(st[kt][8 * c + 6], st[kt][8 * c + 7]);
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pk);
+        const int kb = (kt * 32 + 16 * c + 4 * hh) * 2;
+        const char* v0 = sV + li * BV_ROWB + kb;
+        uint4 va, vb;
+        {
+          const uint2 x0 = *reinterpret_cast<const uint2*>(v0), x1 = *reinterpret_cast<const uint2*>(v0 + 16);
+          va = make_uint4(x0.x, x0.y, x1.x, x1.y);
+          const uint2 y0 = *reinterpret_cast<const uint2*>(v0 + 32 * BV_ROWB), y1 = *reinterpret_cast<const uint2*>(v0 + 32 * BV_ROWB + 16);
+          vb = make_uint4(y0.x, y0.y, y1.x, y1.y);
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&va), pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&vb), pf, o1, 0, 0, 0);
+      }
+    // ---- store: lane = query, register r of tile et is column e = et*32 + (r&3) + 8(r>>2) + 4hh
+    const int qrow = qb * 32 + li;
+    if (qrow < L) {
+      u16* op = out + ((int64_t)b * L + qrow) * ldo + h * 64 + 4 * hh;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 w0, w1;
+        w0.x = pack2_bf16(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv); w0.y = pack2_bf16(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
+        w1.x = pack2_bf16(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv); w1.y = pack2_bf16(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
+        *reinterpret_cast<uint2*>(op + 8 * g4) = w0;
+        *reinterpret_cast<uint2*>(op + 32 + 8 * g4) = w1;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int acx_attention_bf16(acx_ctx* ctx, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int32_t batch,
+                                  int32_t L, int32_t heads, void* stream) {
+  if (!qkv || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_bf16: null pointer%s");
+  if (batch <= 0) return ACX_OK;
+  if (L <= 0 || L > 224 || heads <= 0) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention_bf16: need 0 < L <= 224%s");
+  if (ldqkv % 8 || ldo % 4 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_attention_bf16: qkv 16-byte aligned with ld%%8==0, out 8-byte aligned with ld%%4==0%s");
+  const int nt = (L + 31) / 32;
+  const dim3 grid((unsigned)(batch * heads));
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_ATTN, s);
+#define ACX_ATTNB(NT)                                                                              \
+  do {                                                                                             \
+    const size_t lds = (size_t)NT * 32 * BK_ROWB + 64 * BV_ROWB;                                   \
+    static bool done = false;                                                                      \
+    if (!done) {                                                                                   \
+      (void)hipFuncSetAttribute((const void*)attn_bf16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      done = true;                                                                                 \
+    }                                                                                              \
+    hipLaunchKernelGGL((attn_bf16_kernel<NT>), grid, dim3(256), lds, s, (const u16*)qkv, ldqkv, (u16*)out, ldo, L, heads); \
+  } while (0)
+  switch (nt) {
+    case 1: ACX_ATTNB(1); break;
+    case 2: ACX_ATTNB(2); break;
+    case 3: ACX_ATTNB(3); break;
+    case 4: ACX_ATTNB(4); break;
+    case 5: ACX_ATTNB(5); break;
+    case 6: ACX_ATTNB(6); break;
+    default: ACX_ATTNB(7); break;
+  }
+#undef ACX_ATTNB
+  ACX_CHECK_LAUNCH(ctx, "acx_attention_bf16");
+  return ACX_OK;
+}
+
 extern "C" int acx_attention_cls(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo, int32_t batch,
                                  int32_t L, int32_t heads, void* stream) {
   if (!qkv || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_cls: null pointer%s");

@@ -60,10 +60,10 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 
 __device__ __forceinline__ uint4 pack_bf16x8(float4 a, float4 b) {
   uint4 r;
-  r.x = (uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16);
-  r.y = (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16);
-  r.z = (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16);
-  r.w = (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16);
+  r.x = f2bf2(a.x, a.y);
+  r.y = f2bf2(a.z, a.w);
+  r.z = f2bf2(b.x, b.y);
+  r.w = f2bf2(b.z, b.w);
   return r;
 }
 
@@ -759,8 +759,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(const Args g) {
             if (cok && row < d.M) {
               if constexpr (C_BF16) {
                 uint2 pk;
-                pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-                pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                pk.x = f2bf2(v.x, v.y);
+                pk.y = f2bf2(v.z, v.w);
                 u32x2* dst = reinterpret_cast<u32x2*>((u16*)d.C + (size_t)row * d.ldc + col);
                 if constexpr (RES != 0) *dst = *reinterpret_cast<const u32x2*>(&pk);     // residual stream: re-read soon
                 else __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pk), dst);   // streamed: keep A / W in L2

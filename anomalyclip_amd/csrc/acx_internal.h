@@ -82,12 +82,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// f32 -> bf16 round-to-nearest-even (same rounding torch uses for .to(torch.bfloat16))
+// f32 -> bf16 round-to-nearest-even (same rounding torch uses for .to(torch.bfloat16)): gfx950 has the
+// conversion in hardware (v_cvt_pk_bf16_f32), reached through the native __bf16 type
+typedef __bf16 acx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float acx_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16 f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(u16, b);
+}
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {   // two values -> one packed dword
+  const acx_f32x2 v = {lo, hi};
+  const acx_bf16x2 r = __builtin_convertvector(v, acx_bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 

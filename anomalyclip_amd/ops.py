@@ -117,6 +117,16 @@ def attention(qkv: torch.Tensor, batch: int, L_: int, heads: int, causal: bool) 
     return out
 
 
+def attention_bf16(qkv: torch.Tensor, batch: int, L_: int, heads: int) -> torch.Tensor:
+    """bf16 attention (bf16 mode only): qkv [batch*L, 3*heads*64] bf16 -> [batch*L, heads*64] bf16."""
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+    W = heads * 64
+    out = torch.empty(batch * L_, W, dtype=torch.bfloat16, device=qkv.device)
+    h = _h(qkv)
+    L.check(L.lib().acx_attention_bf16(h, qkv.data_ptr(), qkv.stride(0), out.data_ptr(), W, batch, L_, heads, _stream()), h)
+    return out
+
+
 def text_directions(text: torch.Tensor, ncentroid: torch.Tensor, normal_id: int) -> torch.Tensor:
     Cc, D = text.shape
     dirs = torch.empty(Cc - 1, D, dtype=torch.float32, device=text.device)

@@ -99,6 +99,10 @@ int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const float* w, con
 int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
                   int32_t batch, int32_t L, int32_t heads, int32_t causal, void* stream);
 
+/* bf16 variant of acx_attention for the bf16 mode of the ViT (NOT a parity path): qkv [batch*L, ldqkv] and out
+ * [batch*L, ldo] are bf16, QK^T and PV run on the bf16 MFMA, softmax in f32.  Non-causal only. */
+int acx_attention_bf16(acx_ctx* ctx, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int32_t batch,
+                       int32_t L, int32_t heads, void* stream);
 /* acx_attention_cls: same attention, but only for query row 0 of every sequence (out [batch, heads*64]).
  * Used for the LAST ViT layer, whose output is consumed at the CLS token only (clip/model.py:285). */
 int acx_attention_cls(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,

@@ -251,3 +251,17 @@ def test_cls_head_class_probs_misc():
     acc = torch.zeros(E, device=DEV)
     ops.colsum_(acc, x1.to(DEV))
     assert relerr(acc, x1.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("batch,L,heads", [(3, 197, 12), (2, 77, 8), (5, 32, 2), (1, 224, 1), (4, 50, 3)])
+def test_attention_bf16(batch, L, heads):
+    """bf16 attention kernel (bf16 mode) vs fp64 softmax attention on the bf16-rounded inputs."""
+    g = torch.Generator().manual_seed(L)
+    W = heads * 64
+    qkv = (torch.randn(batch * L, 3 * W, generator=g) * 0.8).bfloat16()
+    x = qkv.double().view(batch, L, 3, heads, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(batch * L, W)
+    out = ops.attention_bf16(qkv.to(DEV), batch, L, heads)
+    assert out.dtype == torch.bfloat16
+    assert relerr(out.float(), ref) < 1.5e-2
