@@ -2,7 +2,7 @@
 Usage: python tools/bench_metrics.py [n_frames]"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from anomalyclip_amd import metrics as M, ops
 from oracle import metrics_oracle as MO
 
