@@ -206,7 +206,7 @@ def main():
                                    "text encoder + selector + axial temporal head + eval post-processing; "
                                    "step = one 512-frame clip per GPU, UCF-Crime head config, random-init weights",
                        "frames_per_step_per_gpu": FRAMES_PER_CLIP, "vit_chunk": args.vit_chunk, "precision": args.precision},
-            "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_kernel, v_mfma_f32_32x32x2_f32)"
+            "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_f32_w8_kernel / gemm_kernel, v_mfma_f32_32x32x2_f32)"
                          if args.precision == "f32" else "acx_gemm (gemm_bf16_ring_kernel / gemm_bf16_dma_kernel / gemm_kernel, v_mfma_f32_32x32x16_bf16)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": "profiles/r01_bench_f32_pmc.json (rocprofv3 PMC, bytes per launch)" if traffic else None, "launches": int(n_gemm), "avg_launch_ms": round(avg_ms, 4),
