@@ -413,7 +413,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 // instead of 4 waves of 64 x 64: two co-resident blocks then put FOUR waves on every SIMD (<= 128 VGPRs each), so
 // a wave that sits at the K-step barrier or on an LDS round trip leaves three others to feed the matrix pipe
 // instead of one.  Costs 1.5x the LDS fragment reads per flop (still < 10 % of the LDS port).
-template <int ACT, int RES>
+// CONV = 1: the implicit-GEMM 3x3 convolution of the axial feed-forwards (A rows are token rows shifted by the tap of
+// the current K-step, zero outside the (gn, gl) grid; cin % 32 == 0 so a K-step never straddles two taps).
+template <int ACT, int RES, int CONV>
 __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -431,12 +433,42 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
   const float* pw0 = (const float*)d.W + (size_t)min(n0 + rbase, d.N - 1) * d.ldw + chunk * 4;
   const float* pw1 = (const float*)d.W + (size_t)min(n0 + rbase + 64, d.N - 1) * d.ldw + chunk * 4;
   float4 ra0, ra1, rw0, rw1;
-#define W8_LOAD(k0) do { ra0 = ld4(pa0 + (k0)); ra1 = ld4(pa1 + (k0)); rw0 = ld4(pw0 + (k0)); rw1 = ld4(pw1 + (k0)); } while (0)
+  // conv: grid coordinates of the two staged token rows, base row of their tile, validity of the staged taps
+  int cn0 = 0, cl0 = 0, cn1 = 0, cl1 = 0;
+  long cb0 = 0, cb1 = 0;
+  bool ok0 = true, ok1 = true;
+  if constexpr (CONV != 0) {
+    const int gsz = d.gn * d.gl;
+    const int r0_ = min(m0 + rbase, d.M - 1), r1_ = min(m0 + rbase + 64, d.M - 1);
+    const int t0_ = r0_ / gsz, t1_ = r1_ / gsz;
+    cb0 = (long)t0_ * gsz; cb1 = (long)t1_ * gsz;
+    cn0 = (r0_ - t0_ * gsz) / d.gl; cl0 = (r0_ - t0_ * gsz) - cn0 * d.gl;
+    cn1 = (r1_ - t1_ * gsz) / d.gl; cl1 = (r1_ - t1_ * gsz) - cn1 * d.gl;
+  }
+#define W8_LOAD(k0)                                                                                \
+  do {                                                                                             \
+    if constexpr (CONV != 0) {                                                                     \
+      const int tap_ = (k0) / d.cin;                    /* uniform */                             \
+      const int dn_ = tap_ / 3 - 1, dl_ = tap_ - (tap_ / 3) * 3 - 1, kc_ = (k0) - tap_ * d.cin + chunk * 4; \
+      const int n0_ = cn0 + dn_, l0_ = cl0 + dl_, n1_ = cn1 + dn_, l1_ = cl1 + dl_;                 \
+      ok0 = (unsigned)n0_ < (unsigned)d.gn && (unsigned)l0_ < (unsigned)d.gl;                      \
+      ok1 = (unsigned)n1_ < (unsigned)d.gn && (unsigned)l1_ < (unsigned)d.gl;                      \
+      const long s0_ = cb0 + (long)min(max(n0_, 0), d.gn - 1) * d.gl + min(max(l0_, 0), d.gl - 1); \
+      const long s1_ = cb1 + (long)min(max(n1_, 0), d.gn - 1) * d.gl + min(max(l1_, 0), d.gl - 1); \
+      ra0 = ld4((const float*)d.A + (size_t)s0_ * d.lda + kc_);                                    \
+      ra1 = ld4((const float*)d.A + (size_t)s1_ * d.lda + kc_);                                    \
+    } else {                                                                                       \
+      ra0 = ld4(pa0 + (k0)); ra1 = ld4(pa1 + (k0));                                                \
+    }                                                                                              \
+    rw0 = ld4(pw0 + (k0)); rw1 = ld4(pw1 + (k0));                                                  \
+  } while (0)
 #define W8_STORE(stage, r)                                                             \
   do {                                                                                 \
     char* sA_ = smem + (stage) * 2 * TILE_B;                                           \
     const int off_ = (rbase + 64 * (r)) * ROWB + chunk * 16;                           \
-    *reinterpret_cast<float4*>(sA_ + off_) = ra##r;                                    \
+    float4 va_ = ra##r;                                                                \
+    if constexpr (CONV != 0) { if (!ok##r) va_ = make_float4(0.f, 0.f, 0.f, 0.f); }    \
+    *reinterpret_cast<float4*>(sA_ + off_) = va_;                                      \
     *reinterpret_cast<float4*>(sA_ + TILE_B + off_) = rw##r;                           \
   } while (0)
 
@@ -520,6 +552,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
     for (int r = 0; r < 16; ++r) {
       float v = acc[mi][r] + bias;
       if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+      if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
       outv[r] += v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1203,19 +1236,26 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   }
   // f32 FAST problems without split-K: the 8-wave variant (ACX_W8=0 keeps the 4-wave kernel)
   static const bool w8 = getenv("ACX_W8") ? atoi(getenv("ACX_W8")) != 0 : true;
-  if (w8 && fast && g.ksplit == 1 && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16) {
-#define ACX_W8L(ACT, RES)                                                                           \
+  const bool w8_conv = d->amap == ACX_AMAP_CONV3X3 && !d->a_sub && !d->pos0 && d->K % 32 == 0 && d->cin % 32 == 0;
+  if (w8 && (fast || w8_conv) && g.ksplit == 1 && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16) {
+#define ACX_W8L(ACT, RES, CV)                                                                       \
   do {                                                                                              \
     static bool attr_done = false;                                                                  \
     if (!attr_done) {                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_f32_w8_kernel<ACT, RES>,                          \
+      (void)hipFuncSetAttribute((const void*)gemm_f32_w8_kernel<ACT, RES, CV>,                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
       attr_done = true;                                                                             \
     }                                                                                               \
-    hipLaunchKernelGGL((gemm_f32_w8_kernel<ACT, RES>), grid, dim3(512), lds, s, g);                 \
+    hipLaunchKernelGGL((gemm_f32_w8_kernel<ACT, RES, CV>), grid, dim3(512), lds, s, g);             \
   } while (0)
-    if (d->act == ACX_ACT_QUICKGELU) { if (d->residual) ACX_W8L(1, 1); else ACX_W8L(1, 0); }
-    else { if (d->residual) ACX_W8L(0, 1); else ACX_W8L(0, 0); }
+    if (w8_conv) {
+      if (d->act == ACX_ACT_LEAKYRELU) { if (d->residual) ACX_W8L(2, 1, 1); else ACX_W8L(2, 0, 1); }
+      else if (d->act == ACX_ACT_QUICKGELU) { if (d->residual) ACX_W8L(1, 1, 1); else ACX_W8L(1, 0, 1); }
+      else { if (d->residual) ACX_W8L(0, 1, 1); else ACX_W8L(0, 0, 1); }
+    } else {
+      if (d->act == ACX_ACT_QUICKGELU) { if (d->residual) ACX_W8L(1, 1, 0); else ACX_W8L(1, 0, 0); }
+      else { if (d->residual) ACX_W8L(0, 1, 0); else ACX_W8L(0, 0, 0); }
+    }
 #undef ACX_W8L
     ACX_CHECK_LAUNCH(ctx, "acx_gemm");
     return ACX_OK;
