@@ -1,0 +1,337 @@
+// acx_gemm_tn -- weight-gradient GEMM kernels (4-wave and 8-wave) and their fixed-order reduce
+// (included by acx_gemm.hip inside its anonymous namespace; shares Args / tile constants / helpers defined there)
+// =====================================================================================================
+// acx_gemm_tn -- weight-gradient GEMM:  C[N1,N2] = sum_m A[m,n1] * bmap(B)[m,n2]      (exact f32 MFMA)
+//
+// Both operands are stored with the REDUCTION index m as the slow (row) index -- dY [M,N1] and
+// X [M,N2] exactly as the forward pass left them -- so no transposes are materialised.  A K-step is
+// 32 rows of m; the LDS image is [32 m][128 n] (+pad), a lane of the 32x32x2 MFMA reads its operand
+// with ds_read_b32 (32 consecutive floats per half-wave: conflict free for any row stride).
+// bmap: identity, or the 3x3-conv gather (column k = tap*cin + ci reads row shift_tap(m), zero outside
+// the (gn,gl) grid) for the conv weight gradient, optionally minus a per-column vector (b_sub) for the
+// selector's direction gradient.  The M reduction is split over gridDim.y; partial tiles go to a
+// workspace and are summed in fixed order by tn_reduce_kernel (deterministic, no atomics).
+constexpr int TN_ROWF = 132;   // floats per LDS row (128 + 4 pad keeps 16-B alignment of the b128 writes)
+
+struct TnArgs {
+  const float* A; const float* B; float* C;   // C: [splits][N1][ldc] partials (or the result when splits == 1)
+  int M, N1, N2, lda, ldb, ldc;
+  const float* b_sub;
+  int conv, gn, gl, cin;
+  int m_per_split;
+  int sh_gl, sh_grid;      // log2(gl), log2(gn*gl) when both are powers of two, else -1
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const TnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem);           // [stage][A|B][32][TN_ROWF]
+  constexpr int TILE_F = 32 * TN_ROWF;
+  const int tiles_n2 = (g.N2 + 127) / 128;
+  const int tm = blockIdx.x / tiles_n2, tn = blockIdx.x % tiles_n2;
+  const int n1_0 = tm * 128, n2_0 = tn * 128;
+  const int split = blockIdx.y;
+  const int m_begin = split * g.m_per_split;
+  const int m_end = min(g.M, m_begin + g.m_per_split);
+
+  const int t = threadIdx.x;
+  const int c16 = t & 31, r0 = t >> 5;                  // chunk column (4 floats), base row (0..7) + 8*r
+  // column validity / conv tap of this thread's chunk (fixed over the K loop)
+  const int ca = n1_0 + 4 * c16, cb = n2_0 + 4 * c16;
+  const bool a_cok = ca < g.N1, b_cok = cb < g.N2;      // N1, N2 multiples of 4 (checked on the host)
+  int tap_dn = 0, tap_dl = 0, b_col = cb;
+  if (g.conv && b_cok) {
+    const int tap = cb / g.cin;
+    tap_dn = tap / 3 - 1;
+    tap_dl = tap - (tap / 3) * 3 - 1;
+    b_col = cb - tap * g.cin;
+  }
+  float4 bsub = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.b_sub && b_cok) bsub = *reinterpret_cast<const float4*>(g.b_sub + cb);
+  const int grid_sz = g.conv ? g.gn * g.gl : 1;
+
+  // TN_LOAD_ROW only ISSUES the two 16-byte loads of staging row r and records their predicates; masking and
+  // the b_sub recentre happen in TN_STORE_ROW, a whole K-step later, so nothing waits on memory in between.
+  float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+  unsigned ok_a = 0, ok_b = 0;
+#define TN_LOAD_ROW(r, mbase)                                                                      \
+  do {                                                                                             \
+    const int m_ = (mbase) + r0 + 8 * (r);                                                         \
+    const bool mok_ = m_ < m_end;                                                                  \
+    const int mc_ = mok_ ? m_ : m_end - 1;                                                         \
+    sa##r = *reinterpret_cast<const float4*>(g.A + (size_t)mc_ * g.lda + (a_cok ? ca : 0));        \
+    long srow_ = mc_;                                                                              \
+    bool bok_ = mok_ && b_cok;                                                                     \
+    if (g.conv) {                                                                                  \
+      int tile_, rem_, nn_, ll_;                                                                   \
+      if (g.sh_gl >= 0) { /* power-of-two grid (every shipped config: 32 x 16): shifts, no division */ \
+        tile_ = mc_ >> g.sh_grid; rem_ = mc_ & (grid_sz - 1);                                      \
+        nn_ = (rem_ >> g.sh_gl) + tap_dn; ll_ = (rem_ & (g.gl - 1)) + tap_dl;                      \
+      } else {                                                                                     \
+        tile_ = mc_ / grid_sz; rem_ = mc_ - tile_ * grid_sz;                                       \
+        nn_ = rem_ / g.gl + tap_dn; ll_ = rem_ % g.gl + tap_dl;                                    \
+      }                                                                                            \
+      bok_ = bok_ && nn_ >= 0 && nn_ < g.gn && ll_ >= 0 && ll_ < g.gl;                             \
+      nn_ = min(max(nn_, 0), g.gn - 1);                                                            \
+      ll_ = min(max(ll_, 0), g.gl - 1);                                                            \
+      srow_ = (long)tile_ * grid_sz + (long)nn_ * g.gl + ll_;                                      \
+    }                                                                                              \
+    sb##r = *reinterpret_cast<const float4*>(g.B + (size_t)srow_ * g.ldb + (b_cok ? b_col : 0));   \
+    ok_a = (ok_a & ~(1u << (r))) | ((mok_ && a_cok) ? (1u << (r)) : 0u);                            \
+    ok_b = (ok_b & ~(1u << (r))) | (bok_ ? (1u << (r)) : 0u);                                       \
+  } while (0)
+#define TN_STORE_ROW(stage, r)                                                                     \
+  do {                                                                                             \
+    float* pa_ = sm + (stage) * 2 * TILE_F + (r0 + 8 * (r)) * TN_ROWF + 4 * c16;                   \
+    float4 va_ = sa##r, vb_ = sb##r;                                                               \
+    vb_.x -= bsub.x; vb_.y -= bsub.y; vb_.z -= bsub.z; vb_.w -= bsub.w;                             \
+    if (!(ok_a & (1u << (r)))) va_ = make_float4(0.f, 0.f, 0.f, 0.f);                              \
+    if (!(ok_b & (1u << (r)))) vb_ = make_float4(0.f, 0.f, 0.f, 0.f);                              \
+    *reinterpret_cast<float4*>(pa_) = va_;                                                         \
+    *reinterpret_cast<float4*>(pa_ + TILE_F) = vb_;                                                \
+  } while (0)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+
+  const int nk = (m_end - m_begin + 31) / 32;
+  if (nk > 0) {
+    TN_LOAD_ROW(0, m_begin); TN_LOAD_ROW(1, m_begin); TN_LOAD_ROW(2, m_begin); TN_LOAD_ROW(3, m_begin);
+    TN_STORE_ROW(0, 0); TN_STORE_ROW(0, 1); TN_STORE_ROW(0, 2); TN_STORE_ROW(0, 3);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    const float* pa = sm + cur * 2 * TILE_F + hh * TN_ROWF + wm * 64 + li;
+    const float* pb = sm + cur * 2 * TILE_F + TILE_F + hh * TN_ROWF + wn * 64 + li;
+    // operand fragments run two MFMA groups (~512 pipe cycles) ahead of their use in a 4-deep register ring,
+    // and the next tile's global loads (with their conv index arithmetic) are spread between the groups, so
+    // neither an LDS round trip nor the address VALU work ever sits in front of an idle matrix pipe.
+    float fa0A, fa1A, fb0A, fb1A, fa0B, fa1B, fb0B, fb1B, fa0C, fa1C, fb0C, fb1C, fa0D, fa1D, fb0D, fb1D;
+#define TN_RD(S, s2)                                                                               \
+  do {                                                                                             \
+    fa0##S = pa[2 * (s2) * TN_ROWF]; fa1##S = pa[2 * (s2) * TN_ROWF + 32];                          \
+    fb0##S = pb[2 * (s2) * TN_ROWF]; fb1##S = pb[2 * (s2) * TN_ROWF + 32];                          \
+  } while (0)
+#define TN_MM(S)                                                                                   \
+  do {                                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0##S, fb0##S, acc[0][0], 0, 0, 0);          \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0##S, fb1##S, acc[0][1], 0, 0, 0);          \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1##S, fb0##S, acc[1][0], 0, 0, 0);          \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1##S, fb1##S, acc[1][1], 0, 0, 0);          \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+    const int mb = m_begin + (kt + 1) * 32;
+    TN_RD(A, 0); TN_RD(B, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    TN_RD(C, 2);  TN_MM(A);
+    TN_RD(D, 3);  TN_MM(B);
+    TN_LOAD_ROW(0, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(A, 4);  TN_MM(C);
+    TN_RD(B, 5);  TN_MM(D);
+    TN_RD(C, 6);  TN_MM(A);
+    TN_LOAD_ROW(1, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(D, 7);  TN_MM(B);
+    TN_RD(A, 8);  TN_MM(C);
+    TN_RD(B, 9);  TN_MM(D);
+    TN_LOAD_ROW(2, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(C, 10); TN_MM(A);
+    TN_RD(D, 11); TN_MM(B);
+    TN_RD(A, 12); TN_MM(C);
+    TN_LOAD_ROW(3, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(B, 13); TN_MM(D);
+    TN_RD(C, 14); TN_MM(A);
+    TN_RD(D, 15); TN_MM(B);
+    TN_MM(C);
+    TN_MM(D);
+#undef TN_RD
+#undef TN_MM
+    if (more) { TN_STORE_ROW(cur ^ 1, 0); TN_STORE_ROW(cur ^ 1, 1); TN_STORE_ROW(cur ^ 1, 2); TN_STORE_ROW(cur ^ 1, 3); }
+    __syncthreads();
+  }
+  float* Cs = g.C + (size_t)split * g.N1 * g.ldc;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n2_0 + wn * 64 + ni * 32 + li;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n1_0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < g.N1 && col < g.N2) Cs[(size_t)row * g.ldc + col] = acc[mi][ni][r];
+      }
+  }
+#undef TN_LOAD_ROW
+#undef TN_STORE_ROW
+}
+
+// 8-wave variant (64 x 32 of C per wave, four waves per SIMD with two resident blocks): same LDS image and K-step.
+__global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem);           // [stage][A|B][32][TN_ROWF]
+  constexpr int TILE_F = 32 * TN_ROWF;
+  const int tiles_n2 = (g.N2 + 127) / 128;
+  const int tm = blockIdx.x / tiles_n2, tn = blockIdx.x % tiles_n2;
+  const int n1_0 = tm * 128, n2_0 = tn * 128;
+  const int split = blockIdx.y;
+  const int m_begin = split * g.m_per_split;
+  const int m_end = min(g.M, m_begin + g.m_per_split);
+
+  const int t = threadIdx.x;
+  const int c16 = t & 31, r0 = t >> 5;                  // chunk column (4 floats), base row (0..15) + 16*r
+  // column validity / conv tap of this thread's chunk (fixed over the K loop)
+  const int ca = n1_0 + 4 * c16, cb = n2_0 + 4 * c16;
+  const bool a_cok = ca < g.N1, b_cok = cb < g.N2;      // N1, N2 multiples of 4 (checked on the host)
+  int tap_dn = 0, tap_dl = 0, b_col = cb;
+  if (g.conv && b_cok) {
+    const int tap = cb / g.cin;
+    tap_dn = tap / 3 - 1;
+    tap_dl = tap - (tap / 3) * 3 - 1;
+    b_col = cb - tap * g.cin;
+  }
+  float4 bsub = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.b_sub && b_cok) bsub = *reinterpret_cast<const float4*>(g.b_sub + cb);
+  const int grid_sz = g.conv ? g.gn * g.gl : 1;
+
+  // TN_LOAD_ROW only ISSUES the two 16-byte loads of staging row r and records their predicates; masking and
+  // the b_sub recentre happen in TN_STORE_ROW, a whole K-step later, so nothing waits on memory in between.
+  float4 sa0, sa1, sb0, sb1;
+  unsigned ok_a = 0, ok_b = 0;
+#define TN_LOAD_ROW(r, mbase)                                                                      \
+  do {                                                                                             \
+    const int m_ = (mbase) + r0 + 16 * (r);                                                         \
+    const bool mok_ = m_ < m_end;                                                                  \
+    const int mc_ = mok_ ? m_ : m_end - 1;                                                         \
+    sa##r = *reinterpret_cast<const float4*>(g.A + (size_t)mc_ * g.lda + (a_cok ? ca : 0));        \
+    long srow_ = mc_;                                                                              \
+    bool bok_ = mok_ && b_cok;                                                                     \
+    if (g.conv) {                                                                                  \
+      int tile_, rem_, nn_, ll_;                                                                   \
+      if (g.sh_gl >= 0) { /* power-of-two grid (every shipped config: 32 x 16): shifts, no division */ \
+        tile_ = mc_ >> g.sh_grid; rem_ = mc_ & (grid_sz - 1);                                      \
+        nn_ = (rem_ >> g.sh_gl) + tap_dn; ll_ = (rem_ & (g.gl - 1)) + tap_dl;                      \
+      } else {                                                                                     \
+        tile_ = mc_ / grid_sz; rem_ = mc_ - tile_ * grid_sz;                                       \
+        nn_ = rem_ / g.gl + tap_dn; ll_ = rem_ % g.gl + tap_dl;                                    \
+      }                                                                                            \
+      bok_ = bok_ && nn_ >= 0 && nn_ < g.gn && ll_ >= 0 && ll_ < g.gl;                             \
+      nn_ = min(max(nn_, 0), g.gn - 1);                                                            \
+      ll_ = min(max(ll_, 0), g.gl - 1);                                                            \
+      srow_ = (long)tile_ * grid_sz + (long)nn_ * g.gl + ll_;                                      \
+    }                                                                                              \
+    sb##r = *reinterpret_cast<const float4*>(g.B + (size_t)srow_ * g.ldb + (b_cok ? b_col : 0));   \
+    ok_a = (ok_a & ~(1u << (r))) | ((mok_ && a_cok) ? (1u << (r)) : 0u);                            \
+    ok_b = (ok_b & ~(1u << (r))) | (bok_ ? (1u << (r)) : 0u);                                       \
+  } while (0)
+#define TN_STORE_ROW(stage, r)                                                                     \
+  do {                                                                                             \
+    float* pa_ = sm + (stage) * 2 * TILE_F + (r0 + 16 * (r)) * TN_ROWF + 4 * c16;                   \
+    float4 va_ = sa##r, vb_ = sb##r;                                                               \
+    vb_.x -= bsub.x; vb_.y -= bsub.y; vb_.z -= bsub.z; vb_.w -= bsub.w;                             \
+    if (!(ok_a & (1u << (r)))) va_ = make_float4(0.f, 0.f, 0.f, 0.f);                              \
+    if (!(ok_b & (1u << (r)))) vb_ = make_float4(0.f, 0.f, 0.f, 0.f);                              \
+    *reinterpret_cast<float4*>(pa_) = va_;                                                         \
+    *reinterpret_cast<float4*>(pa_ + TILE_F) = vb_;                                                \
+  } while (0)
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, hh = lane >> 5;
+
+  const int nk = (m_end - m_begin + 31) / 32;
+  if (nk > 0) {
+    TN_LOAD_ROW(0, m_begin); TN_LOAD_ROW(1, m_begin);
+    TN_STORE_ROW(0, 0); TN_STORE_ROW(0, 1);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    const float* pa = sm + cur * 2 * TILE_F + hh * TN_ROWF + wm * 64 + li;
+    const float* pb = sm + cur * 2 * TILE_F + TILE_F + hh * TN_ROWF + wn * 32 + li;
+    // operand fragments run two MFMA groups (~512 pipe cycles) ahead of their use in a 4-deep register ring,
+    // and the next tile's global loads (with their conv index arithmetic) are spread between the groups, so
+    // neither an LDS round trip nor the address VALU work ever sits in front of an idle matrix pipe.
+    float fa0A, fa1A, fb0A, fa0B, fa1B, fb0B, fa0C, fa1C, fb0C, fa0D, fa1D, fb0D;
+#define TN_RD(S, s2)                                                                               \
+  do {                                                                                             \
+    fa0##S = pa[2 * (s2) * TN_ROWF]; fa1##S = pa[2 * (s2) * TN_ROWF + 32];                          \
+    fb0##S = pb[2 * (s2) * TN_ROWF];                                                               \
+  } while (0)
+#define TN_MM(S)                                                                                   \
+  do {                                                                                             \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0##S, fb0##S, acc[0], 0, 0, 0);                \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1##S, fb0##S, acc[1], 0, 0, 0);                \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+    const int mb = m_begin + (kt + 1) * 32;
+    TN_RD(A, 0); TN_RD(B, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    TN_RD(C, 2);  TN_MM(A);
+    TN_RD(D, 3);  TN_MM(B);
+    TN_LOAD_ROW(0, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(A, 4);  TN_MM(C);
+    TN_RD(B, 5);  TN_MM(D);
+    TN_RD(C, 6);  TN_MM(A);
+    TN_LOAD_ROW(1, mb);          // unconditional (rows clamp to m_end-1): straight-line code keeps vmcnt exact
+    TN_RD(D, 7);  TN_MM(B);
+    TN_RD(A, 8);  TN_MM(C);
+    TN_RD(B, 9);  TN_MM(D);
+    TN_RD(C, 10); TN_MM(A);
+    TN_RD(D, 11); TN_MM(B);
+    TN_RD(A, 12); TN_MM(C);
+    TN_RD(B, 13); TN_MM(D);
+    TN_RD(C, 14); TN_MM(A);
+    TN_RD(D, 15); TN_MM(B);
+    TN_MM(C);
+    TN_MM(D);
+#undef TN_RD
+#undef TN_MM
+    if (more) { TN_STORE_ROW(cur ^ 1, 0); TN_STORE_ROW(cur ^ 1, 1); }
+    __syncthreads();
+  }
+  float* Cs = g.C + (size_t)split * g.N1 * g.ldc;
+  {
+    const int col = n2_0 + wn * 32 + li;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n1_0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < g.N1 && col < g.N2) Cs[(size_t)row * g.ldc + col] = acc[mi][r];
+      }
+  }
+#undef TN_LOAD_ROW
+#undef TN_STORE_ROW
+}
+
+// out[i] = sum_s part[s][i]   (fixed order)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                        int64_t n4, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = reinterpret_cast<const float4*>(part)[i];
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)k * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = s;
+}
+
+
+// C = epilogue(sum_s partial[s])  for the split-K path (fixed summation order)

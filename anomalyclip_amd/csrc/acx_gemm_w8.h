@@ -1,0 +1,162 @@
+// acx_gemm -- 8-wave f32 kernel (FAST problems and the implicit-GEMM 3x3 convolutions)
+// (included by acx_gemm.hip inside its anonymous namespace; shares Args / tile constants / helpers defined there)
+// =====================================================================================================
+// f32 GEMM, 8 waves per 128x128 tile (FAST problems only: identity rows, K % 32 == 0, f32 in / out)
+//
+// Same LDS image, K-permutation and K-step schedule as gemm_kernel, but the tile is shared by 8 waves of 64 x 32
+// instead of 4 waves of 64 x 64: two co-resident blocks then put FOUR waves on every SIMD (<= 128 VGPRs each), so
+// a wave that sits at the K-step barrier or on an LDS round trip leaves three others to feed the matrix pipe
+// instead of one.  Costs 1.5x the LDS fragment reads per flop (still < 10 % of the LDS port).
+// CONV = 1: the implicit-GEMM 3x3 convolution of the axial feed-forwards (A rows are token rows shifted by the tap of
+// the current K-step, zero outside the (gn, gl) grid; cin % 32 == 0 so a K-step never straddles two taps).
+template <int ACT, int RES, int CONV>
+__global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const acx_gemm_desc& d = g.d;
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = wg / g.tiles_n, tn = wg % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int t = threadIdx.x;
+  const int chunk = t & 7, rbase = t >> 3;                  // 64 staged rows per pass, 2 passes per operand
+  const float* pa0 = (const float*)d.A + (size_t)min(m0 + rbase, d.M - 1) * d.lda + chunk * 4;
+  const float* pa1 = (const float*)d.A + (size_t)min(m0 + rbase + 64, d.M - 1) * d.lda + chunk * 4;
+  const float* pw0 = (const float*)d.W + (size_t)min(n0 + rbase, d.N - 1) * d.ldw + chunk * 4;
+  const float* pw1 = (const float*)d.W + (size_t)min(n0 + rbase + 64, d.N - 1) * d.ldw + chunk * 4;
+  float4 ra0, ra1, rw0, rw1;
+  // conv: grid coordinates of the two staged token rows, base row of their tile, validity of the staged taps
+  int cn0 = 0, cl0 = 0, cn1 = 0, cl1 = 0;
+  long cb0 = 0, cb1 = 0;
+  bool ok0 = true, ok1 = true;
+  if constexpr (CONV != 0) {
+    const int gsz = d.gn * d.gl;
+    const int r0_ = min(m0 + rbase, d.M - 1), r1_ = min(m0 + rbase + 64, d.M - 1);
+    const int t0_ = r0_ / gsz, t1_ = r1_ / gsz;
+    cb0 = (long)t0_ * gsz; cb1 = (long)t1_ * gsz;
+    cn0 = (r0_ - t0_ * gsz) / d.gl; cl0 = (r0_ - t0_ * gsz) - cn0 * d.gl;
+    cn1 = (r1_ - t1_ * gsz) / d.gl; cl1 = (r1_ - t1_ * gsz) - cn1 * d.gl;
+  }
+#define W8_LOAD(k0)                                                                                \
+  do {                                                                                             \
+    if constexpr (CONV != 0) {                                                                     \
+      const int tap_ = (k0) / d.cin;                    /* uniform */                             \
+      const int dn_ = tap_ / 3 - 1, dl_ = tap_ - (tap_ / 3) * 3 - 1, kc_ = (k0) - tap_ * d.cin + chunk * 4; \
+      const int n0_ = cn0 + dn_, l0_ = cl0 + dl_, n1_ = cn1 + dn_, l1_ = cl1 + dl_;                 \
+      ok0 = (unsigned)n0_ < (unsigned)d.gn && (unsigned)l0_ < (unsigned)d.gl;                      \
+      ok1 = (unsigned)n1_ < (unsigned)d.gn && (unsigned)l1_ < (unsigned)d.gl;                      \
+      const long s0_ = cb0 + (long)min(max(n0_, 0), d.gn - 1) * d.gl + min(max(l0_, 0), d.gl - 1); \
+      const long s1_ = cb1 + (long)min(max(n1_, 0), d.gn - 1) * d.gl + min(max(l1_, 0), d.gl - 1); \
+      ra0 = ld4((const float*)d.A + (size_t)s0_ * d.lda + kc_);                                    \
+      ra1 = ld4((const float*)d.A + (size_t)s1_ * d.lda + kc_);                                    \
+    } else {                                                                                       \
+      ra0 = ld4(pa0 + (k0)); ra1 = ld4(pa1 + (k0));                                                \
+    }                                                                                              \
+    rw0 = ld4(pw0 + (k0)); rw1 = ld4(pw1 + (k0));                                                  \
+  } while (0)
+#define W8_STORE(stage, r)                                                             \
+  do {                                                                                 \
+    char* sA_ = smem + (stage) * 2 * TILE_B;                                           \
+    const int off_ = (rbase + 64 * (r)) * ROWB + chunk * 16;                           \
+    float4 va_ = ra##r;                                                                \
+    if constexpr (CONV != 0) { if (!ok##r) va_ = make_float4(0.f, 0.f, 0.f, 0.f); }    \
+    *reinterpret_cast<float4*>(sA_ + off_) = va_;                                      \
+    *reinterpret_cast<float4*>(sA_ + TILE_B + off_) = rw##r;                           \
+  } while (0)
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, hh = lane >> 5;
+  const int a_off = (wm * 64 + li) * ROWB + hh * 16;
+  const int w_off = (wn * 32 + li) * ROWB + hh * 16;
+  float4 xa0, xa1, xb, ya0, ya1, yb;
+#define W8_RD(SET, stage, q)                                                                              \
+  do {                                                                                                    \
+    const char* sA_ = smem + (stage) * 2 * TILE_B;                                                        \
+    SET##a0 = *reinterpret_cast<const float4*>(sA_ + a_off + (q) * 32);                                   \
+    SET##a1 = *reinterpret_cast<const float4*>(sA_ + a_off + 32 * ROWB + (q) * 32);                       \
+    SET##b = *reinterpret_cast<const float4*>(sA_ + TILE_B + w_off + (q) * 32);                           \
+  } while (0)
+#define W8_MM(SET)                                                                                        \
+  do {                                                                                                    \
+    const float a0_[4] = {SET##a0.x, SET##a0.y, SET##a0.z, SET##a0.w};                                    \
+    const float a1_[4] = {SET##a1.x, SET##a1.y, SET##a1.z, SET##a1.w};                                    \
+    const float b_[4] = {SET##b.x, SET##b.y, SET##b.z, SET##b.w};                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[j], b_[j], acc[0], 0, 0, 0);                      \
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[j], b_[j], acc[1], 0, 0, 0);                      \
+    }                                                                                                     \
+  } while (0)
+
+  const int nk = d.K / 32;
+  W8_LOAD(0);
+  W8_STORE(0, 0); W8_STORE(0, 1);
+  __syncthreads();
+  if (nk > 1) W8_LOAD(32);
+  W8_RD(x, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more = kt + 1 < nk;
+    W8_RD(y, cur, 1);
+    W8_MM(x);                                    // phase 0
+    W8_RD(x, cur, 2);
+    if (more) W8_STORE(nxt, 0);
+    W8_MM(y);                                    // phase 1
+    W8_RD(y, cur, 3);
+    if (more) W8_STORE(nxt, 1);
+    W8_MM(x);                                    // phase 2
+    __syncthreads();                             // next tile complete in LDS; everyone holds its phase-3 fragments
+    if (kt + 2 < nk) W8_LOAD((kt + 2) * 32);
+    if (more) W8_RD(x, nxt, 0);
+    W8_MM(y);                                    // phase 3
+  }
+#undef W8_MM
+#undef W8_RD
+#undef W8_STORE
+#undef W8_LOAD
+
+  // ---- epilogue (structure of gemm_kernel's: everything computed, then stored)
+  const int col = n0 + wn * 32 + li;
+  const bool cok = col < d.N;
+  const int colc = cok ? col : d.N - 1;
+  float bias = 0.f;
+  if (d.bias) bias = d.bias[colc];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int rowb = m0 + wm * 64 + mi * 32 + 4 * hh;
+    float outv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) outv[r] = 0.f;
+    if constexpr (RES != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
+        outv[r] = d.residual[(size_t)row * d.ldr + colc];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[mi][r] + bias;
+      if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+      if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
+      outv[r] += v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(outv[r]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rowb + (r & 3) + 8 * (r >> 2);
+      if (cok && row < d.M) ((float*)d.C)[(size_t)row * d.ldc + col] = outv[r];
+    }
+  }
+}
+
