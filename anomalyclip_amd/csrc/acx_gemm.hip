@@ -498,7 +498,10 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 0, 1); else ACX_LAUNCH(P, AB, CB, 1, 0, 0); \
     }                                                                                 \
   } while (0)
-  if (fast && d->workspace) {
+  const bool w8_conv = d->amap == ACX_AMAP_CONV3X3 && !d->a_sub && !d->pos0 && d->K % 32 == 0 && d->cin % 32 == 0 &&
+                       prec == ACX_PREC_F32 && !c_bf16 && !a_bf16;
+  static const bool w8 = getenv("ACX_W8") ? atoi(getenv("ACX_W8")) != 0 : true;   // ACX_W8=0 keeps the 4-wave kernels
+  if ((fast || (w8_conv && w8)) && d->workspace) {
     // skinny problems (few tiles, long K): split K over gridDim.y so the chip is filled; partial sums are
     // combined in fixed order by splitk_reduce_kernel together with the epilogue
     const int tiles = tiles_m * g.tiles_n, nkt = d->K / ke;
@@ -513,9 +516,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     }
   }
   // f32 FAST problems without split-K: the 8-wave variant (ACX_W8=0 keeps the 4-wave kernel)
-  static const bool w8 = getenv("ACX_W8") ? atoi(getenv("ACX_W8")) != 0 : true;
-  const bool w8_conv = d->amap == ACX_AMAP_CONV3X3 && !d->a_sub && !d->pos0 && d->K % 32 == 0 && d->cin % 32 == 0;
-  if (w8 && (fast || w8_conv) && g.ksplit == 1 && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16) {
+  // (short split-K pieces of identity-map problems stay on the 4-wave kernel: no measurable difference)
+  if (w8 && (w8_conv || (fast && g.ksplit == 1)) && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16) {
 #define ACX_W8L(ACT, RES, CV)                                                                       \
   do {                                                                                              \
     static bool attr_done = false;                                                                  \
@@ -535,6 +537,11 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       else { if (d->residual) ACX_W8L(0, 1, 0); else ACX_W8L(0, 0, 0); }
     }
 #undef ACX_W8L
+    if (g.ksplit > 1) {
+      const int64_t total = (int64_t)d->M * d->N;
+      hipLaunchKernelGGL((splitk_reduce_kernel<0>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)g.partial,
+                         g.ksplit, *d);
+    }
     ACX_CHECK_LAUNCH(ctx, "acx_gemm");
     return ACX_OK;
   }

@@ -96,11 +96,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
     }                                                                                                     \
   } while (0)
 
-  const int nk = d.K / 32;
-  W8_LOAD(0);
+  // split-K (skinny problems): gridDim.y splits of kchunk K-steps; raw partial tiles, epilogue in splitk_reduce_kernel
+  const int nk_total = d.K / 32;
+  const int kbeg = (g.ksplit > 1 ? (int)blockIdx.y * g.kchunk : 0) * 32;
+  const int nk = g.ksplit > 1 ? min(g.kchunk, nk_total - (int)blockIdx.y * g.kchunk) : nk_total;
+  W8_LOAD(kbeg);
   W8_STORE(0, 0); W8_STORE(0, 1);
   __syncthreads();
-  if (nk > 1) W8_LOAD(32);
+  if (nk > 1) W8_LOAD(kbeg + 32);
   W8_RD(x, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
     if (more) W8_STORE(nxt, 1);
     W8_MM(x);                                    // phase 2
     __syncthreads();                             // next tile complete in LDS; everyone holds its phase-3 fragments
-    if (kt + 2 < nk) W8_LOAD((kt + 2) * 32);
+    if (kt + 2 < nk) W8_LOAD(kbeg + (kt + 2) * 32);
     if (more) W8_RD(x, nxt, 0);
     W8_MM(y);                                    // phase 3
   }
@@ -123,9 +126,20 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
 #undef W8_STORE
 #undef W8_LOAD
 
-  // ---- epilogue (structure of gemm_kernel's: everything computed, then stored)
   const int col = n0 + wn * 32 + li;
   const bool cok = col < d.N;
+  if (g.ksplit > 1) {
+    float* P = g.partial + (size_t)blockIdx.y * d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mi * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+        if (cok && row < d.M) P[(size_t)row * d.N + col] = acc[mi][r];
+      }
+    return;
+  }
+  // ---- epilogue (structure of gemm_kernel's: everything computed, then stored)
   const int colc = cok ? col : d.N - 1;
   float bias = 0.f;
   if (d.bias) bias = d.bias[colc];

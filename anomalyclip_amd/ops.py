@@ -87,7 +87,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     d.pos0, d.pos1 = _ptr(pos0), _ptr(pos1)
     ws = None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles <= 128 and K >= 256 and amap == L.AMAP_IDENTITY and a_sub is None and pos0 is None:
+    if tiles <= 128 and K >= 256 and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and a_sub is None and pos0 is None:
         ws = _splitk_workspace(a.device, min(16, 512 // tiles) * M * N * 4)     # skinny problem: let the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a)

@@ -265,3 +265,25 @@ def test_attention_bf16(batch, L, heads):
     out = ops.attention_bf16(qkv.to(DEV), batch, L, heads)
     assert out.dtype == torch.bfloat16
     assert relerr(out.float(), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,cin,cout,act,res", [(512, 256, 1024, L.ACT_LEAKYRELU, False), (512, 1024, 256, L.ACT_NONE, True),
+                                                (1024, 64, 128, L.ACT_NONE, False)])
+def test_conv_gemm_split_k(M, cin, cout, act, res):
+    """single-video conv GEMMs (8-16 output tiles, K up to 9216) take the split-K path of the 8-wave kernel;
+    LeakyReLU / residual are applied by the reduce kernel."""
+    g = torch.Generator().manual_seed(M + cin)
+    N, Lg = 32, 16
+    x = torch.randn(M, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5
+    b, r = torch.randn(cout, generator=g), torch.randn(M, cout, generator=g)
+    xi = x.view(-1, N, Lg, cin).permute(0, 3, 1, 2).double()
+    ref = torch.nn.functional.conv2d(xi, w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+    if act == L.ACT_LEAKYRELU:
+        ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    if res:
+        ref = ref + r.double()
+    wk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = ops.gemm(x.to(DEV), wk.to(DEV), bias=b.to(DEV), act=act, residual=r.to(DEV) if res else None,
+                   amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=cin)
+    assert relerr(out, ref) < 1e-5
