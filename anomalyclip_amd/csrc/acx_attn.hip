@@ -30,6 +30,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __re
   float* sK = reinterpret_cast<float*>(smem);
   float* sV = sK + NT * 32 * KROW;
   float* sL = sV + NT * 32 * VROW;   // [NW waves][32] row sums
+  int* vflag = reinterpret_cast<int*>(sL + NW * 32);   // STAGGER: number of waves that have finished staging V
 
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int W = heads * 64;
@@ -37,37 +38,70 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __re
   const int t = threadIdx.x;
 
   // ---- stage K, V (rows >= L zero-filled): ALL global loads are issued before the first LDS write so the
-  // staging costs one memory round trip, not one per iteration
+  // staging costs one memory round trip, not one per iteration.
+  // STAGGER (8 waves, one query block each): only K is staged up front; the second wave of every SIMD (waves 4-7)
+  // then stages V while the first (waves 0-3) is already in QK^T, and one barrier in front of P.V publishes V.
+  // The two waves of a SIMD thereby run out of phase -- one's softmax (VALU) under the other's MFMAs -- instead of
+  // both doing QK^T, then both softmax with the matrix pipe idle, then both P.V.  V is published through an LDS
+  // counter, not a barrier, so the phase shift survives until the end of the block.
+  constexpr bool STAGGER = NW == 8;
   constexpr int NSTG = (NT * 32 * 16 + NW * 64 - 1) / (NW * 64);
-  float4 stk[NSTG], stv[NSTG];
+  {
+    float4 stk[NSTG], stv[NSTG];
 #pragma unroll
-  for (int j = 0; j < NSTG; ++j) {
-    const int i = t + j * NW * 64;
-    const int row = i >> 4, c4 = i & 15;
-    stk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    stv[j] = stk[j];
-    if (i < NT * 32 * 16 && row < L) {
-      const float* p = base + (int64_t)row * ldqkv + 4 * c4;
-      stk[j] = *reinterpret_cast<const float4*>(p + W);
-      stv[j] = *reinterpret_cast<const float4*>(p + 2 * W);
+    for (int j = 0; j < NSTG; ++j) {
+      const int i = t + j * NW * 64;
+      const int row = i >> 4, c4 = i & 15;
+      stk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      stv[j] = stk[j];
+      if (i < NT * 32 * 16 && row < L) {
+        const float* p = base + (int64_t)row * ldqkv + 4 * c4;
+        stk[j] = *reinterpret_cast<const float4*>(p + W);
+        if constexpr (!STAGGER) stv[j] = *reinterpret_cast<const float4*>(p + 2 * W);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NSTG; ++j) {
+      const int i = t + j * NW * 64;
+      const int row = i >> 4, c4 = i & 15;
+      if (i < NT * 32 * 16) {
+        *reinterpret_cast<float4*>(sK + row * KROW + 4 * c4) = stk[j];
+        if constexpr (!STAGGER) *reinterpret_cast<float4*>(sV + row * VROW + 4 * c4) = stv[j];
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < NSTG; ++j) {
-    const int i = t + j * NW * 64;
-    const int row = i >> 4, c4 = i & 15;
-    if (i < NT * 32 * 16) {
-      *reinterpret_cast<float4*>(sK + row * KROW + 4 * c4) = stk[j];
-      *reinterpret_cast<float4*>(sV + row * VROW + 4 * c4) = stv[j];
-    }
-  }
+  if constexpr (STAGGER) { if (t == 0) *vflag = 0; }
   __syncthreads();
+  if constexpr (STAGGER) {
+    if (t >= 256) {
+      constexpr int NSV = (NT * 32 * 16 + 255) / 256;
+      float4 stv[NSV];
+#pragma unroll
+      for (int j = 0; j < NSV; ++j) {
+        const int i = (t - 256) + j * 256;
+        const int row = i >> 4, c4 = i & 15;
+        stv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < NT * 32 * 16 && row < L) stv[j] = *reinterpret_cast<const float4*>(base + (int64_t)row * ldqkv + 4 * c4 + 2 * W);
+      }
+#pragma unroll
+      for (int j = 0; j < NSV; ++j) {
+        const int i = (t - 256) + j * 256;
+        if (i < NT * 32 * 16) *reinterpret_cast<float4*>(sV + (i >> 4) * VROW + 4 * (i & 15)) = stv[j];
+      }
+      // publish (LDS ops of a wave complete in order; the counter is bumped after this wave's V writes) and
+      // fall behind the first wave of this SIMD by about one QK^T phase
+      __threadfence_block();
+      if ((t & 63) == 0) atomicAdd(vflag, 1);
+      __builtin_amdgcn_s_sleep(100);     // ~6.4k cycles; measured optimum (0 / 6.4k / 12.8k / 19.2k: -2.5 / -3.9 / -2.4 / 0 %)
+    }
+  }
 
   const int lane = t & 63, wave = t >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int nqb = (L + 31) / 32;
 
-  for (int qb = wave; qb < nqb; qb += NW) {
+  for (int qb = wave; qb < (STAGGER ? NW : nqb); qb += NW) {      // STAGGER: exactly one trip per wave (nqb <= 8)
+    const bool has = qb < nqb;
     const int q0 = qb * 32;
     // ---- Q fragment (B operand of S^T = K.Q^T): lane (q=li, half hh) holds chunks (2c+hh)
     float4 qf[8];
@@ -81,7 +115,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __re
         qf[c] = v;
       }
     }
-    const int t_hi = causal ? min(NT, (q0 + 31) / 32 + 1) : NT;   // key tiles that can be visible
+    const int t_hi = !has ? 0 : (causal ? min(NT, (q0 + 31) / 32 + 1) : NT);   // key tiles that can be visible (none: idle wave)
 
     f32x16 st[NT];
 #pragma unroll
@@ -127,6 +161,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __re
     sum += __shfl_xor(sum, 32, 64);
     if (hh == 0) sL[wave * 32 + li] = sum;
 
+    if constexpr (STAGGER) {                     // V (staged by waves 4-7 meanwhile) is complete: no barrier, the waves stay out of phase
+      while (*reinterpret_cast<volatile int*>(vflag) < 4) __builtin_amdgcn_s_sleep(2);
+    }
     // ---- O = P.V : A operand = P^T registers as they are, B operand = V rows from LDS
     f32x16 o[2];
 #pragma unroll
@@ -226,7 +263,7 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   AcxProfScope prof__(ctx, ACX_K_ATTN, (hipStream_t)stream);
 #define ACX_ATTN(NT, NW)                                                                           \
   do {                                                                                             \
-    const size_t lds = (size_t)NT * 32 * (KROW + VROW) * 4 + NW * 32 * 4;                          \
+    const size_t lds = (size_t)NT * 32 * (KROW + VROW) * 4 + NW * 32 * 4 + 16;                          \
     static bool done = false;                                                                      \
     if (!done) {                                                                                   \
       (void)hipFuncSetAttribute((const void*)attn_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
