@@ -507,6 +507,136 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_rows_kernel(const float* __r
   (void)EPL;
 }
 
+// One WORKGROUP per (sequence, head) for the text tower (T <= 128, E = 64): q, k, v, dO of the head are staged
+// ONCE in LDS (4 x T x 272 B) instead of being re-read from L2 by every row (77 x 20 KB per row-wave: the rows
+// kernel above moves 0.67 GB per launch), both passes run in the same launch with the softmax statistics in LDS,
+// and a wave walks the rows r = wave, wave + NWV, ...  Same arithmetic and summation order per row as the rows
+// kernel.
+constexpr int SB_ROWF = 68;            // floats per staged row (64 + 4: conflict-free ds_read_b128 across rows)
+template <int KPL>
+__global__ __launch_bounds__(512) void seq_attn_bwd_block_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                 float* __restrict__ dqkv, int T, int heads, int causal,
+                                                                 float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_sb[];
+  float* sQ = reinterpret_cast<float*>(smem_sb);
+  float* sK = sQ + T * SB_ROWF;
+  float* sV = sK + T * SB_ROWF;
+  float* sO = sV + T * SB_ROWF;
+  float* sS = sO + T * SB_ROWF;        // [T][3] max, 1/sum, D
+  const int TP = (T + 3) & ~3;
+  float* sW = sS + 3 * T + ((4 - (3 * T) % 4) % 4);      // per-wave rows [nwv][2][TP] (16-byte aligned): dS / P of the current row
+  const int h = blockIdx.x % heads;
+  const int64_t seq = blockIdx.x / heads;
+  const int He = heads * 64, ld = 3 * He;
+  const float* base = qkv + seq * T * ld + h * 64;
+  const float* dob = dout + seq * T * He + h * 64;
+  float* dqb = dqkv + seq * T * ld + h * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwv = blockDim.x >> 6;
+  float* wA = sW + (size_t)wave * 2 * TP;                 // dS (pass 0) / dS^T (pass 1) of this wave's current row
+  float* wB = wA + TP;                                    // P^T (pass 1)
+  for (int i = t; i < T * 16; i += blockDim.x) {
+    const int row = i >> 4, c4 = i & 15;
+    const float* p = base + (int64_t)row * ld + 4 * c4;
+    *reinterpret_cast<float4*>(sQ + row * SB_ROWF + 4 * c4) = *reinterpret_cast<const float4*>(p);
+    *reinterpret_cast<float4*>(sK + row * SB_ROWF + 4 * c4) = *reinterpret_cast<const float4*>(p + He);
+    *reinterpret_cast<float4*>(sV + row * SB_ROWF + 4 * c4) = *reinterpret_cast<const float4*>(p + 2 * He);
+    *reinterpret_cast<float4*>(sO + row * SB_ROWF + 4 * c4) = *reinterpret_cast<const float4*>(dob + (int64_t)row * He + 4 * c4);
+  }
+  __syncthreads();
+  // ---- pass 0: query rows
+  for (int i = wave; i < T; i += nwv) {
+    float sv[KPL], dp[KPL];
+    float mx = -INFINITY;
+    const int jmax = causal ? i + 1 : T;
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      const int j = lane + 64 * u;
+      sv[u] = -INFINITY;
+      dp[u] = 0.f;
+      if (j < jmax) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float4 k4 = *reinterpret_cast<const float4*>(sK + j * SB_ROWF + 4 * c), q4 = *reinterpret_cast<const float4*>(sQ + i * SB_ROWF + 4 * c);
+          const float4 v4 = *reinterpret_cast<const float4*>(sV + j * SB_ROWF + 4 * c), o4 = *reinterpret_cast<const float4*>(sO + i * SB_ROWF + 4 * c);
+          a += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+          b += o4.x * v4.x + o4.y * v4.y + o4.z * v4.z + o4.w * v4.w;
+        }
+        sv[u] = a * scale;
+        dp[u] = b;
+      }
+      mx = fmaxf(mx, sv[u]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f, Di = 0.f;
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      const float p = __expf(sv[u] - mx);
+      sv[u] = p;
+      sum += p;
+      Di += p * dp[u];
+    }
+    sum = wave_sum(sum);
+    Di = wave_sum(Di);
+    const float inv = 1.f / sum;
+    Di *= inv;
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) sv[u] = sv[u] * inv * (dp[u] - Di) * scale;
+    // dq[e] = sum_j dS_j k[j][e] (lane = e): the row of dS goes through this wave's LDS scratch, so the loop is a
+    // broadcast float4 read + 4 K reads per 4 keys instead of a cross-lane shuffle per key
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) { const int j = lane + 64 * u; if (j < TP) wA[j] = j < jmax ? sv[u] : 0.f; }
+    float dq = 0.f;
+    for (int j = 0; j < jmax; j += 4) {
+      const float4 d4 = *reinterpret_cast<const float4*>(wA + j);
+      dq += d4.x * sK[j * SB_ROWF + lane];
+      if (j + 1 < jmax) dq += d4.y * sK[(j + 1) * SB_ROWF + lane];
+      if (j + 2 < jmax) dq += d4.z * sK[(j + 2) * SB_ROWF + lane];
+      if (j + 3 < jmax) dq += d4.w * sK[(j + 3) * SB_ROWF + lane];
+    }
+    dqb[(int64_t)i * ld + lane] = dq;
+    if (lane == 0) { sS[i * 3] = mx; sS[i * 3 + 1] = inv; sS[i * 3 + 2] = Di; }
+  }
+  __syncthreads();
+  // ---- pass 1: key / value rows
+  for (int j = wave; j < T; j += nwv) {
+    float pv[KPL], dsv[KPL];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      const int qi = lane + 64 * u;
+      pv[u] = 0.f;
+      dsv[u] = 0.f;
+      if (qi < T && (!causal || qi >= j)) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float4 k4 = *reinterpret_cast<const float4*>(sK + j * SB_ROWF + 4 * c), q4 = *reinterpret_cast<const float4*>(sQ + qi * SB_ROWF + 4 * c);
+          const float4 v4 = *reinterpret_cast<const float4*>(sV + j * SB_ROWF + 4 * c), o4 = *reinterpret_cast<const float4*>(sO + qi * SB_ROWF + 4 * c);
+          a += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+          b += o4.x * v4.x + o4.y * v4.y + o4.z * v4.z + o4.w * v4.w;
+        }
+        const float p = __expf(a * scale - sS[qi * 3]) * sS[qi * 3 + 1];
+        pv[u] = p;
+        dsv[u] = p * (b - sS[qi * 3 + 2]) * scale;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) { const int qi = lane + 64 * u; if (qi < TP) { wA[qi] = dsv[u]; wB[qi] = pv[u]; } }
+    float dk = 0.f, dv = 0.f;
+    const int q0 = causal ? (j & ~3) : 0;                 // entries below j are zero (masked above)
+    for (int qi = q0; qi < T; qi += 4) {
+      const float4 d4 = *reinterpret_cast<const float4*>(wA + qi), p4 = *reinterpret_cast<const float4*>(wB + qi);
+      dk += d4.x * sQ[qi * SB_ROWF + lane];
+      dv += p4.x * sO[qi * SB_ROWF + lane];
+      if (qi + 1 < T) { dk += d4.y * sQ[(qi + 1) * SB_ROWF + lane]; dv += p4.y * sO[(qi + 1) * SB_ROWF + lane]; }
+      if (qi + 2 < T) { dk += d4.z * sQ[(qi + 2) * SB_ROWF + lane]; dv += p4.z * sO[(qi + 2) * SB_ROWF + lane]; }
+      if (qi + 3 < T) { dk += d4.w * sQ[(qi + 3) * SB_ROWF + lane]; dv += p4.w * sO[(qi + 3) * SB_ROWF + lane]; }
+    }
+    dqb[(int64_t)j * ld + He + lane] = dk;
+    dqb[(int64_t)j * ld + 2 * He + lane] = dv;
+  }
+}
+
 // ------------------------------------------------------------------ positional-embedding gradients
 // d_pos0[n][e] = sum_{tile,l} dx[(tile,n,l)][e];  d_pos1[l][e] = sum_{tile,n} dx[(tile,n,l)][e]
 // stage 1: block (tile, group of 4 segment rows n): p0[tile][n][e] = sum_l dx, p1[tile*ng + g][l][e] = sum_{n in group} dx;
@@ -991,6 +1121,23 @@ extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float
   if (!qkv || !dout || !dqkv) return acx_fail(ctx, ACX_E_BADARG, "acx_seq_attention_bwd: null pointer%s");
   if (tiles <= 0) return ACX_OK;
   const int T = axis == 0 ? gn : gl;
+  static const bool sab_rows = getenv("ACX_SAB_ROWS") != nullptr;    // keep the two-launch rows kernel (A/B)
+  if (e == 64 && gn == 1 && axis == 1 && T <= 128 && !sab_rows) {
+    // text-tower shape: one workgroup per (sequence, head), operands staged once in LDS, both passes in one launch
+    hipStream_t s3 = (hipStream_t)stream;
+    AcxProfScope prof3__(ctx, ACX_K_ATTN, s3);
+    const size_t lds3 = ((size_t)4 * T * SB_ROWF + 3 * T + 4 + 8 * 2 * ((T + 3) & ~3)) * sizeof(float);
+    const dim3 grid3((unsigned)(tiles * heads)), block3(512);
+    if (T <= 64) {
+      (void)hipFuncSetAttribute((const void*)seq_attn_bwd_block_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      hipLaunchKernelGGL((seq_attn_bwd_block_kernel<1>), grid3, block3, lds3, s3, qkv, dout, dqkv, T, heads, causal, 0.125f);
+    } else {
+      (void)hipFuncSetAttribute((const void*)seq_attn_bwd_block_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      hipLaunchKernelGGL((seq_attn_bwd_block_kernel<2>), grid3, block3, lds3, s3, qkv, dout, dqkv, T, heads, causal, 0.125f);
+    }
+    ACX_CHECK_LAUNCH(ctx, "acx_seq_attention_bwd(block)");
+    return ACX_OK;
+  }
   if (e == 64 && gn == 1 && axis == 1 && T <= 256 && stats_ws) {
     // text-tower shape: wave-per-row kernel (two launches: rows as queries, then rows as keys)
     hipStream_t s2 = (hipStream_t)stream;
