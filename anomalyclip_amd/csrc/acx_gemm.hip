@@ -500,6 +500,28 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   } while (0)
   const bool w8_conv = d->amap == ACX_AMAP_CONV3X3 && !d->a_sub && !d->pos0 && d->K % 32 == 0 && d->cin % 32 == 0 &&
                        prec == ACX_PREC_F32 && !c_bf16 && !a_bf16;
+  // small branch-free f32 problems (text tower): 64x64 tiles, four blocks per CU, no split-K
+  static const bool s64 = getenv("ACX_S64") ? atoi(getenv("ACX_S64")) != 0 : true;
+  const int st_m = (d->M + 63) / 64, st_n = (d->N + 63) / 64;
+  if (s64 && fast && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16 && tiles_m * g.tiles_n <= 256 && st_m * st_n >= 96) {
+    const size_t lds_s = 4 * TILE_S;
+    const dim3 sgrid((unsigned)(st_m * st_n));
+#define ACX_S64L(ACT, RES)                                                                          \
+  do {                                                                                              \
+    static bool attr_done = false;                                                                  \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_f32_s64_kernel<ACT, RES>,                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);            \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_f32_s64_kernel<ACT, RES>), sgrid, dim3(256), lds_s, s, g);             \
+  } while (0)
+    if (d->act == ACX_ACT_QUICKGELU) { if (d->residual) ACX_S64L(1, 1); else ACX_S64L(1, 0); }
+    else { if (d->residual) ACX_S64L(0, 1); else ACX_S64L(0, 0); }
+#undef ACX_S64L
+    ACX_CHECK_LAUNCH(ctx, "acx_gemm");
+    return ACX_OK;
+  }
   static const bool w8 = getenv("ACX_W8") ? atoi(getenv("ACX_W8")) != 0 : true;   // ACX_W8=0 keeps the 4-wave kernels
   if ((fast || (w8_conv && w8)) && d->workspace) {
     // skinny problems (few tiles, long K): split K over gridDim.y so the chip is filled; partial sums are

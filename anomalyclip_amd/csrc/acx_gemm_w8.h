@@ -174,3 +174,115 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
   }
 }
 
+
+// =====================================================================================================
+// f32 GEMM for SMALL problems (text tower: M = classes x 77 rows): 64 x 64 tiles, 4 waves of 32 x 32, 36 KB of
+// LDS -> four blocks (16 waves) per CU.  A 1309 x 512 output is 44 tiles of 128 x 128 -- a sixth of the chip, which
+// split-K fills only by adding partial-sum traffic and a reduce launch -- but 168 tiles of 64 x 64.  Same LDS row
+// format, K-permutation and K-step schedule as gemm_f32_w8_kernel; FAST problems only.
+constexpr int TILE_S = 64 * ROWB;          // 9216 B per operand image
+template <int ACT, int RES>
+__global__ __launch_bounds__(256, 4) void gemm_f32_s64_kernel(const Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const acx_gemm_desc& d = g.d;
+  const int tiles_n = (d.N + 63) / 64;
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = wg / tiles_n, tn = wg % tiles_n;
+  const int m0 = tm * 64, n0 = tn * 64;
+  const int t = threadIdx.x;
+  const int chunk = t & 7, rbase = t >> 3;                  // 32 staged rows per pass, 2 passes per operand
+  const float* pa0 = (const float*)d.A + (size_t)min(m0 + rbase, d.M - 1) * d.lda + chunk * 4;
+  const float* pa1 = (const float*)d.A + (size_t)min(m0 + rbase + 32, d.M - 1) * d.lda + chunk * 4;
+  const float* pw0 = (const float*)d.W + (size_t)min(n0 + rbase, d.N - 1) * d.ldw + chunk * 4;
+  const float* pw1 = (const float*)d.W + (size_t)min(n0 + rbase + 32, d.N - 1) * d.ldw + chunk * 4;
+  float4 ra0, ra1, rw0, rw1;
+#define S64_LOAD(k0) do { ra0 = ld4(pa0 + (k0)); ra1 = ld4(pa1 + (k0)); rw0 = ld4(pw0 + (k0)); rw1 = ld4(pw1 + (k0)); } while (0)
+#define S64_STORE(stage, r)                                                            \
+  do {                                                                                 \
+    char* sA_ = smem + (stage) * 2 * TILE_S;                                           \
+    const int off_ = (rbase + 32 * (r)) * ROWB + chunk * 16;                           \
+    *reinterpret_cast<float4*>(sA_ + off_) = ra##r;                                    \
+    *reinterpret_cast<float4*>(sA_ + TILE_S + off_) = rw##r;                           \
+  } while (0)
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+  const int a_off = (wm * 32 + li) * ROWB + hh * 16;
+  const int w_off = TILE_S + (wn * 32 + li) * ROWB + hh * 16;
+  float4 xa, xb, ya, yb;
+#define S64_RD(SET, stage, q)                                                                             \
+  do {                                                                                                    \
+    const char* sA_ = smem + (stage) * 2 * TILE_S;                                                        \
+    SET##a = *reinterpret_cast<const float4*>(sA_ + a_off + (q) * 32);                                    \
+    SET##b = *reinterpret_cast<const float4*>(sA_ + w_off + (q) * 32);                                    \
+  } while (0)
+#define S64_MM(SET)                                                                                       \
+  do {                                                                                                    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(SET##a.x, SET##b.x, acc, 0, 0, 0);                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(SET##a.y, SET##b.y, acc, 0, 0, 0);                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(SET##a.z, SET##b.z, acc, 0, 0, 0);                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(SET##a.w, SET##b.w, acc, 0, 0, 0);                         \
+  } while (0)
+  const int nk = d.K / 32;
+  S64_LOAD(0);
+  S64_STORE(0, 0); S64_STORE(0, 1);
+  __syncthreads();
+  if (nk > 1) S64_LOAD(32);
+  S64_RD(x, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more = kt + 1 < nk;
+    S64_RD(y, cur, 1);
+    S64_MM(x);
+    S64_RD(x, cur, 2);
+    if (more) S64_STORE(nxt, 0);
+    S64_MM(y);
+    S64_RD(y, cur, 3);
+    if (more) S64_STORE(nxt, 1);
+    S64_MM(x);
+    __syncthreads();
+    if (kt + 2 < nk) S64_LOAD((kt + 2) * 32);
+    if (more) S64_RD(x, nxt, 0);
+    S64_MM(y);
+  }
+#undef S64_MM
+#undef S64_RD
+#undef S64_STORE
+#undef S64_LOAD
+  const int col = n0 + wn * 32 + li;
+  const bool cok = col < d.N;
+  const int colc = cok ? col : d.N - 1;
+  float bias = 0.f;
+  if (d.bias) bias = d.bias[colc];
+  const int rowb = m0 + wm * 32 + 4 * hh;
+  float outv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) outv[r] = 0.f;
+  if constexpr (RES != 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rowb + (r & 3) + 8 * (r >> 2), d.M - 1);
+      outv[r] = d.residual[(size_t)row * d.ldr + colc];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = acc[r] + bias;
+    if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+    outv[r] += v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(outv[r]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rowb + (r & 3) + 8 * (r >> 2);
+    if (cok && row < d.M) ((float*)d.C)[(size_t)row * d.ldc + col] = outv[r];
+  }
+}

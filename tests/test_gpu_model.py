@@ -44,11 +44,15 @@ def test_vit_b16_golden(golden):
     frames = R.vit_frames(int(g["seed"]), 2, 224)
     out = vit(frames.to(DEV))
     assert relerr(out, g["out"]) < TOL
-    # more frames than one chunk / ragged chunking gives the same rows
+    # more frames than one chunk / ragged chunking gives the same rows.  Rows inside ONE launch are bit-identical
+    # wherever they sit; across chunk sizes the library may pick a different K split for the GEMMs (64x64 tiles,
+    # split-K for skinny problems and for the tail round of tiles), i.e. a different summation order: round-off only.
     vit.chunk = 3
     f5 = torch.cat([frames, frames.flip(0), frames[:1]], 0)
     out5 = vit(f5.to(DEV))
-    assert torch.equal(out5[:2], out) and torch.equal(out5[4], out[0]) and torch.equal(out5[2], out[1])
+    assert torch.equal(out5[1], out5[2])            # same frame twice inside the 3-frame launch
+    assert torch.equal(out5[4], out[0])             # 2-frame launches: slot 1 of the second chunk == slot 0 of `out`
+    assert relerr(out5[:2], out) < 2e-6             # 3-frame vs 2-frame launch: summation order only
 
 
 def test_vit_b16_bf16_mode(golden):
