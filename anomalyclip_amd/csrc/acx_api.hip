@@ -128,7 +128,8 @@ int linear1(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const f
 
 // Linear layer with tail handling: a grid of T tiles runs in ceil(T/512) waves of 128x128 tiles (2 per CU); when
 // the last wave would be mostly empty (e.g. N=768: 9.23 waves -> 10), the rows of that partial wave are issued as a
-// second, split-K launch that fills the chip (9 waves + ~1/3 wave).
+// second launch that fills the chip (9 waves + ~1/3 wave): acx_gemm runs it on 64x64 tiles (f32, four blocks per CU)
+// or splits K over the workspace handed in here (other precisions).
 int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
            void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
            hipStream_t s, int ldr = 0, void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
