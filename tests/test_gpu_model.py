@@ -55,6 +55,38 @@ def test_vit_b16_golden(golden):
     assert relerr(out5[:2], out) < 2e-6             # 3-frame vs 2-frame launch: summation order only
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_vit_b16_full_clip_properties(golden, precision):
+    """BASELINE.json's full size (512 frames in ONE launch: 8-wave kernels, the 64x64-tile tail launch, CLS-only last
+    layer, 256x256 ring kernels in bf16 mode) through size-independent properties: identical frames give bit-identical
+    rows wherever they sit in the launch, and the rows agree with the golden-pinned 2-frame launch to round-off."""
+    g = golden("vit_b16")
+    vit, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision=precision)
+    vit.chunk = 512
+    base = R.vit_frames(int(g["seed"]), 2, 224)
+    extra = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    eight = torch.cat([base, extra], 0)
+    idx = torch.arange(512) % 8
+    idx[500:] = torch.tensor([7, 3, 0, 1, 5, 5, 2, 6, 4, 0, 1, 7])          # break the period near the tail rows
+    out = vit(eight[idx].to(DEV))
+    assert out.shape == (512, 512) and torch.isfinite(out).all()
+    for k in range(8):
+        rows = out[idx == k]
+        if precision == "f32":
+            assert torch.equal(rows, rows[:1].expand_as(rows)), k              # bit-identical across ALL slots
+        else:
+            # bf16 mode: the tail round of tiles runs through another kernel (other f32 summation order), and a
+            # last-bit difference before a bf16 rounding is a bf16 ulp after it -- bit-identical inside the main
+            # launch, bf16 round-off for the last frames
+            head = out[:480][idx[:480] == k]
+            assert torch.equal(head, head[:1].expand_as(head)), k
+            assert relerr(rows, rows[:1].expand_as(rows)) < 3e-2, k
+    small = vit(base.to(DEV))                                                  # 2-frame launch (other kernels)
+    assert relerr(out[:2], small) < (2e-6 if precision == "f32" else 3e-2)
+    if precision == "f32":
+        assert relerr(out[:2], g["out"]) < TOL
+
+
 def test_vit_b16_bf16_mode(golden):
     """bf16 MFMA mode: NOT the parity path; documents its distance from the f32 reference."""
     g = golden("vit_b16")
