@@ -15,6 +15,7 @@ PREC_F32, PREC_BF16 = 0, 1
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE = 0, 1, 2
 NORM_LAYER, NORM_CHAN = 0, 1
+OPT_RING_MIN_TILES = 1
 
 
 class GemmDesc(C.Structure):
@@ -63,6 +64,7 @@ _SIGS = {
     "acx_create": (C.c_int, [C.POINTER(c_void_p), C.c_int]),
     "acx_destroy": (None, [c_void_p]),
     "acx_last_error": (C.c_char_p, [c_void_p]),
+    "acx_set_option": (C.c_int, [c_void_p, c_int32, c_int64]),
     "acx_gemm": (C.c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
     "acx_layernorm": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                 c_int64, c_int32, c_float, c_int32, c_void_p]),

@@ -117,12 +117,22 @@ class AnomalyCLIP(nn.Module):
         from . import functional as Fn
         if torch.is_grad_enabled() and (self.prompt_learner.ctx.requires_grad or self.text_encoder.text_projection.requires_grad):
             return Fn.text_features_train(self)
-        if self.cache_text_features and self._text_cache is not None:
-            return self._text_cache
+        key = None
+        if self.cache_text_features:
+            # every input of the text path: optimizer steps through raw pointers bump WEIGHT_EPOCH, load_state_dict /
+            # in-place edits bump _version, .to(device) changes data_ptr -- any of them invalidates the cache
+            key = (ops.WEIGHT_EPOCH[0],) + tuple(
+                (t.data_ptr(), t._version) for t in (self.prompt_learner.ctx, self.prompt_learner.token_prefix,
+                                                     self.prompt_learner.token_suffix,
+                                                     self.text_encoder.text_projection,
+                                                     self.text_encoder.positional_embedding)
+            ) + tuple((p.data_ptr(), p._version) for p in self.text_encoder.transformer.parameters())
+            if self._text_cache is not None and self._text_cache[0] == key:
+                return self._text_cache[1]
         x = self.prompt_learner(self.text_encoder.positional_embedding)
         tf = self.text_encoder.encode(x, self.eot_index)
         if self.cache_text_features:
-            self._text_cache = tf
+            self._text_cache = (key, tf)
         return tf
 
     def get_temporal_model_input(self, image_features, similarity, ncentroid):

@@ -161,6 +161,11 @@ class TemporalModel(nn.Module):
         caller's re-centring (anomaly_clip.py:143,201) into the projection GEMM's A staging."""
         from . import functional as Fn
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if test_mode:
+                # TemporalFn implements the TRAIN tiling "(b n l) d" only; the reference evaluates under Lightning's
+                # no_grad (validation_step / test_step), so a differentiable test-mode pass is not part of the path.
+                raise RuntimeError("TemporalModel(test_mode=True) must run under torch.no_grad(): the differentiable "
+                                   "path implements the training tiling only (temporal_model.py:55-60)")
             return Fn.temporal_train(self, features, a_sub)
         P = self.prepared()
         N, Lg, E = self.num_segments, self.seg_length, self.emb_size

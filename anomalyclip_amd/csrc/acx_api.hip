@@ -35,6 +35,8 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   acx_ctx* c = new (std::nothrow) acx_ctx;
   if (!c) return acx_fail(nullptr, ACX_E_HIP, "acx_create: out of host memory%s");
   c->device = device;
+  c->multiprocessors = prop.multiProcessorCount;
+  c->opt_ring_min_tiles = 512;
   c->err[0] = 0;
   c->prof_on = false;
   c->prof_n = c->prof_created = 0;
@@ -82,6 +84,18 @@ extern "C" int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms)
   }
   ctx->prof_n = 0;
   return ACX_OK;
+}
+
+extern "C" int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value) {
+  if (!ctx) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: no context%s");
+  switch (option) {
+    case ACX_OPT_RING_MIN_TILES:
+      if (value < 1) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: ring_min_tiles must be >= 1%s");
+      ctx->opt_ring_min_tiles = (int)value;
+      return ACX_OK;
+    default:
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_set_option: unknown option %s%ld", "", (long)option);
+  }
 }
 
 extern "C" const char* acx_last_error(acx_ctx* ctx) { return ctx ? ctx->err : acx_tls_err; }
@@ -133,7 +147,7 @@ int linear1(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const f
 int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
            void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
            hipStream_t s, int ldr = 0, void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
-  static const bool tail_split = !getenv("ACX_NO_TAIL_SPLIT");
+  const bool tail_split = ACX_DBG_SWITCH("TAIL_SPLIT", true);
   const int tiles_n = (N + 127) / 128, tiles_m = (M + 127) / 128;
   const long tiles = (long)tiles_m * tiles_n;
   const long full = tiles / 512;
@@ -197,8 +211,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     // bf16 mode, non-causal (the ViT): q/k/v, the attention and its output stay bf16 end to end -- half the
     // QKV store traffic, bf16-MFMA attention, and a bf16 A operand (LDS-DMA kernels) for the out-projection
-    static const bool attn_f32 = getenv("ACX_ATTN_F32") != nullptr;
-    const bool ab = prec == ACX_PREC_BF16 && !causal && L <= 224 && !attn_f32;
+    const bool ab = prec == ACX_PREC_BF16 && !causal && L <= 224 && ACX_DBG_SWITCH("ATTN_BF16", true);
     const int qdt = ab ? ACX_BF16 : ACX_F32;
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, qdt, 3 * W, (int)rows, 3 * W, W,
                      b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
@@ -285,7 +298,7 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   if ((rc = acx_vit_embed(ctx, (const float*)ws.patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
                           w->ln_pre_b, (float*)ws.x, F, T, W, s))) return rc;
   const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W);
-  static const bool prune = !(getenv("ACX_VIT_NO_PRUNE"));
+  const bool prune = ACX_DBG_SWITCH("VIT_PRUNE", true);
   if ((rc = transformer_layers(ctx, (float*)ws.x, F, T + 1, W, d->heads, d->layers, 0, prec, w->blocks, tf, s,
                                prune ? (float*)ws.cls_ws : nullptr))) return rc;
   // ln_post on the CLS rows, then @ proj                                :285-288

@@ -257,7 +257,7 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   if (L <= 0 || L > 224 || heads <= 0) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention: need 0 < L <= 224%s");
   if (ldqkv % 4 || ((uintptr_t)qkv & 15)) return acx_fail(ctx, ACX_E_BADARG, "acx_attention: qkv must be 16-byte aligned, ld%%4==0%s");
   const int nt = (L + 31) / 32;
-  static const bool nw4 = getenv("ACX_ATTN_NW4") != nullptr;
+  const bool nw4 = ACX_DBG_SWITCH("ATTN_NW4", false);
   const dim3 grid((unsigned)(batch * heads));
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_ATTN, (hipStream_t)stream);

@@ -469,7 +469,11 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   g.d = *d;
   const int tiles_m = (d->M + BM - 1) / BM;
   g.tiles_n = (d->N + BN - 1) / BN;
-  g.trace = getenv("ACX_TRACE_PTR") ? (long long*)strtoull(getenv("ACX_TRACE_PTR"), nullptr, 0) : nullptr;   // ACX_TRACE builds only
+#if ACX_TRACE
+  g.trace = getenv("ACX_TRACE_PTR") ? (long long*)strtoull(getenv("ACX_TRACE_PTR"), nullptr, 0) : nullptr;
+#else
+  g.trace = nullptr;
+#endif
   dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
   g.ksplit = 1; g.kchunk = 0; g.partial = nullptr;
   const size_t lds = 4 * TILE_B;
@@ -501,7 +505,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const bool w8_conv = d->amap == ACX_AMAP_CONV3X3 && !d->a_sub && !d->pos0 && d->K % 32 == 0 && d->cin % 32 == 0 &&
                        prec == ACX_PREC_F32 && !c_bf16 && !a_bf16;
   // small branch-free f32 problems (text tower): 64x64 tiles, four blocks per CU, no split-K
-  static const bool s64 = getenv("ACX_S64") ? atoi(getenv("ACX_S64")) != 0 : true;
+  const bool s64 = ACX_DBG_SWITCH("S64", true);
   const int st_m = (d->M + 63) / 64, st_n = (d->N + 63) / 64;
   if (s64 && fast && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16 && tiles_m * g.tiles_n <= 256 && st_m * st_n >= 96) {
     const size_t lds_s = 4 * TILE_S;
@@ -522,7 +526,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     ACX_CHECK_LAUNCH(ctx, "acx_gemm");
     return ACX_OK;
   }
-  static const bool w8 = getenv("ACX_W8") ? atoi(getenv("ACX_W8")) != 0 : true;   // ACX_W8=0 keeps the 4-wave kernels
+  const bool w8 = ACX_DBG_SWITCH("W8", true);   // ACX_W8=0 (debug builds) keeps the 4-wave kernels
   if ((fast || (w8_conv && w8)) && d->workspace) {
     // skinny problems (few tiles, long K): split K over gridDim.y so the chip is filled; partial sums are
     // combined in fixed order by splitk_reduce_kernel together with the epilogue
@@ -569,18 +573,14 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   }
   // bf16 operands already in global memory, no split: the LDS-DMA kernels (ACX_NO_DMA=1 keeps the register-staged
   // one, ACX_NO_RING=1 the 128x128 DMA kernel).  Large problems take the persistent 256x256 ring kernel.
-  static const bool no_dma = getenv("ACX_NO_DMA") != nullptr;
-  static const bool no_ring = getenv("ACX_NO_RING") != nullptr;
+  const bool no_dma = !ACX_DBG_SWITCH("DMA", true);
+  const bool no_ring = !ACX_DBG_SWITCH("RING", true);
   const int rtiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
-  const int ring_min = getenv("ACX_RING_MIN_TILES") ? atoi(getenv("ACX_RING_MIN_TILES")) : 512;   // (tests lower it)
+  const int ring_min = ctx ? ctx->opt_ring_min_tiles : 512;   // acx_set_option(ACX_OPT_RING_MIN_TILES); tests lower it
   if (fast && g.ksplit == 1 && prec == ACX_PREC_BF16 && a_bf16 && !no_dma && !no_ring && d->lda % 8 == 0 && d->ldw % 8 == 0 &&
       d->K % 64 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
       !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && rtiles >= ring_min && !(d->act == ACX_ACT_QUICKGELU && d->residual)) {
-    int ncu = 256;
-    { hipDeviceProp_t prop; int dev = 0;
-      static int cached = 0;
-      if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
-      if (cached > 0) ncu = cached; }
+    const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     const dim3 rgrid((unsigned)(rtiles < ncu ? rtiles : ncu));
 #define ACX_RING_L(CB, ACT, RES)                                                                    \
   do {                                                                                              \
@@ -715,7 +715,7 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  static const bool tn_w8 = getenv("ACX_TN_W8") ? atoi(getenv("ACX_TN_W8")) != 0 : true;
+  const bool tn_w8 = ACX_DBG_SWITCH("TN_W8", true);
   if (tn_w8) {
     static bool attr8_done = false;
     if (!attr8_done) {

@@ -18,8 +18,23 @@ typedef unsigned short u16;
 enum { ACX_K_GEMM = 0, ACX_K_ATTN = 1, ACX_K_NORM = 2, ACX_K_OTHER = 3, ACX_K_COUNT = 4 };
 constexpr int ACX_PROF_MAX = 32768;
 
+// Development A/B switches.  The product library compiles them to their constant defaults; only a tools build with
+// -DACX_DEBUG_SWITCHES (tools/ab_gemm.sh) reads them from the environment (ACX_<NAME>=0/1), once per process.
+#ifdef ACX_DEBUG_SWITCHES
+#include <stdlib.h>
+static inline bool acx_dbg_switch_env(const char* env, bool dflt) {
+  const char* v = getenv(env);
+  return v ? atoi(v) != 0 : dflt;
+}
+#define ACX_DBG_SWITCH(name, dflt) ([] { static const bool v_ = acx_dbg_switch_env("ACX_" name, dflt); return v_; }())
+#else
+#define ACX_DBG_SWITCH(name, dflt) (dflt)
+#endif
+
 struct acx_ctx {
   int device;
+  int multiprocessors;      // CUs of the device (persistent-kernel grid size)
+  int opt_ring_min_tiles;   // ACX_OPT_RING_MIN_TILES
   char err[512];
   bool prof_on;
   int prof_n;          // recorded pairs

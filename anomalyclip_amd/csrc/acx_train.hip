@@ -1121,7 +1121,7 @@ extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float
   if (!qkv || !dout || !dqkv) return acx_fail(ctx, ACX_E_BADARG, "acx_seq_attention_bwd: null pointer%s");
   if (tiles <= 0) return ACX_OK;
   const int T = axis == 0 ? gn : gl;
-  static const bool sab_rows = getenv("ACX_SAB_ROWS") != nullptr;    // keep the two-launch rows kernel (A/B)
+  const bool sab_rows = ACX_DBG_SWITCH("SAB_ROWS", false);    // keep the two-launch rows kernel (A/B, debug builds)
   if (e == 64 && gn == 1 && axis == 1 && T <= 128 && !sab_rows) {
     // text-tower shape: one workgroup per (sequence, head), operands staged once in LDS, both passes in one launch
     hipStream_t s3 = (hipStream_t)stream;

@@ -25,6 +25,7 @@ class FeatureStream:
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._pinned = [None, None]
+        self._copied = [None, None]      # per slot: event recorded after the last H2D copy that READ the pinned buffer
         self.max_tiles = max_tiles
 
     def _host_tile(self, path: str, slot: int):
@@ -35,6 +36,12 @@ class FeatureStream:
         idx = FI.frame_index_table(starts, self.L, self.stride, T)
         rows = idx.shape[0]
         need = self.ncrops * rows * D
+        # The pinned buffer of this slot was the source of an asynchronous copy two videos ago: that copy must have
+        # finished reading it before the host overwrites it (the device-side wait_event below orders the CONSUMER
+        # stream only, not the host).
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()
+            self._copied[slot] = None
         buf = self._pinned[slot]
         if buf is None or buf.numel() < need:
             buf = torch.empty(max(need, self.ncrops * 512 * D), dtype=torch.float32).pin_memory()
@@ -54,6 +61,7 @@ class FeatureStream:
                 dev = view.to(self.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self._copy_stream)
+            self._copied[slot] = ev
             if pending is not None:
                 yield pending
             torch.cuda.current_stream().wait_event(ev)          # consumer stream waits for this copy only

@@ -105,6 +105,7 @@ class GradBuckets:
         self._bucket_of = {i: b for b, idxs in enumerate(self.buckets) for i in idxs}
         self._pending = [len(b) for b in self.buckets]
         self._handles = []
+        self._fired = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
 
     def _make_hook(self, i):
@@ -114,6 +115,7 @@ class GradBuckets:
                 # autograd replaced the view (first accumulation into a None grad): copy back and re-point
                 self.flat[lo:hi].copy_(p.grad.reshape(-1))
                 p.grad = self.flat[lo:hi].view_as(p)
+            self._fired.add(i)
             b = self._bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0 and is_distributed():
@@ -125,10 +127,22 @@ class GradBuckets:
         self.flat.zero_()
         self._pending = [len(b) for b in self.buckets]
         self._handles = []
+        self._fired = set()
+        for i, p in enumerate(self.params):          # finish() detaches the grads of unused parameters
+            if p.grad is None:
+                lo, hi = self._views[i]
+                p.grad = self.flat[lo:hi].view_as(p)
 
     def finish(self):
         """Wait for the in-flight all-reduces, reduce buckets whose gradients never arrived (unused
         parameters, e.g. selector_model.logit_scale), and average."""
+        # A parameter that received no gradient keeps grad = None, as under the reference's DDP
+        # (find_unused_parameters: a globally unused parameter's .grad is left untouched), so AdamW skips it --
+        # no weight decay on the never-used selector_model.logit_scale (selector_model.py:22).  The autograd graph
+        # is the same on every rank, hence so is the set of unused parameters.
+        for i, p in enumerate(self.params):
+            if i not in self._fired:
+                p.grad = None
         if not is_distributed():
             return
         for b, pend in enumerate(self._pending):

@@ -48,6 +48,12 @@ int acx_create(acx_ctx** out, int device);
 void acx_destroy(acx_ctx* ctx);
 const char* acx_last_error(acx_ctx* ctx);
 
+/* Per-context tuning options (dispatch thresholds; results never depend on them beyond summation order).
+ *   ACX_OPT_RING_MIN_TILES  bf16 GEMMs with at least this many 256x256 output tiles take the persistent
+ *                           256x256 LDS-DMA kernel instead of the 128x128 one (default 512). */
+enum { ACX_OPT_RING_MIN_TILES = 1 };
+int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value);
+
 /* ------------------------------------------------------------------------------------------
  * acx_gemm: C[M,N] = epilogue( amap(A)[M,K] . W[N,K]^T )            (MFMA-bound workhorse)
  * replaces every nn.Linear / F.linear / `@` / nn.Conv2d on the path:

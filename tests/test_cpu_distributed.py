@@ -25,13 +25,15 @@ def _worker(rank, world, port, q):
     loss.backward()
     gb.finish()
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params[:4]))
-    ok &= bool(torch.all(params[4].grad == 0))
+    ok &= params[4].grad is None                   # unused parameter: grad stays None (the reference's DDP semantics)
     ok &= len(gb.buckets) >= 2
     # second step reuses the flat buffer
     gb.zero()
     sum((p * (rank + 3)).sum() for p in params[:4]).backward()
     gb.finish()
     ok &= all(torch.allclose(p.grad, torch.full_like(p, 3.5)) for p in params[:4])
+    ok &= all(p.grad.data_ptr() == gb.flat[gb._views[i][0]:].data_ptr() for i, p in enumerate(params[:4]))   # still views
+    ok &= params[4].grad is None
     # --- SyncBN statistics: each rank holds a different slab of rows
     g = torch.Generator().manual_seed(1)
     x = torch.randn(700, 13, generator=g) * 2 + 0.5

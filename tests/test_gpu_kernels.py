@@ -108,12 +108,19 @@ def test_gemm_bf16_lds_dma_path(M, N, K, act, res, obf):
     assert relerr(out.float(), ref) < (1e-2 if obf else 1e-5)
 
 
+@pytest.fixture
+def ring_everywhere():
+    h = L.ctx(0)
+    L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 1), h)
+    yield
+    L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 512), h)
+
+
 @pytest.mark.parametrize("M,N,K,act,res,obf", [(3001, 600, 768, 0, 0, 0), (2500, 512, 128, 0, 1, 0), (5000, 300, 3072, 1, 0, 1),
                                                (777, 1000, 64, 0, 1, 1), (256, 256, 64, 0, 0, 0), (70000, 520, 192, 0, 1, 0)])
-def test_gemm_bf16_ring_kernel(M, N, K, act, res, obf, monkeypatch):
+def test_gemm_bf16_ring_kernel(M, N, K, act, res, obf, ring_everywhere):
     """persistent 256x256 LDS-DMA kernel (normally only for >= 512 tiles; forced here): ragged tiles, tile counts
     below / above the CU count (several tiles per block), single-step K, residual-as-accumulator-init."""
-    monkeypatch.setenv("ACX_RING_MIN_TILES", "1")
     g = torch.Generator().manual_seed(M + K)
     a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
     bias, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
