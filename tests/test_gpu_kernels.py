@@ -89,6 +89,61 @@ def test_gemm_bf16():
     assert relerr(out.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(33001, 2300, 768, 1, 0), (33001, 2300, 768, 0, 1), (70000, 768, 3072, 0, 1),
+                                           (100864, 768, 768, 1, 1), (20000, 3072, 768, 0, 0)])
+def test_gemm_f32_w8_benchmark_shapes(M, N, K, act, res):
+    """The kernel the frame benchmark spends 87 % of its time in -- gemm_f32_w8_kernel<ACT,RES,0> (8 waves, identity rows,
+    no split-K: > 256 output tiles, K % 32 == 0) -- at ViT-B/16 sizes with ragged M / N tails, every compile-time
+    epilogue, against an fp64 CPU product of the same operands.  (test_gemm_f32_plain's shapes dispatch to the
+    64x64-tile / 4-wave kernels.)  Element-wise check: |err| <= 2e-6 * (|a|.|w| + |bias| + |res|) row/col bound."""
+    assert ((M + 127) // 128) * ((N + 127) // 128) > 256 and K % 32 == 0
+    g = torch.Generator().manual_seed(M + N + K + act + 2 * res)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).view(-1, 1) * 1e-4     # asymmetric (rule 16)
+    bias = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=L.ACT_QUICKGELU if act else L.ACT_NONE,
+                   residual=r.to(DEV) if res else None).cpu()
+    pre = a.double() @ w.double().t() + bias.double()
+    ref = O.quick_gelu(pre) if act else pre
+    if res:
+        ref = ref + r.double()
+    # magnitude bound of the f32 accumulation per element: sum_k |a||w| (Cauchy-Schwarz upper bound per row/col pair)
+    scale = a.double().norm(dim=1, keepdim=True) * w.double().norm(dim=1).view(1, -1) + bias.double().abs() + 1.0
+    err = ((out.double() - ref).abs() / scale).max().item()
+    assert err < 2e-6, err
+    assert relerr(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("cin,cout,act,res", [(256, 1024, 2, 0), (1024, 256, 0, 1)])
+def test_gemm_conv3x3_benchmark_rows(cin, cout, act, res):
+    """The implicit-GEMM 3x3 convolutions of the UCF head at benchmark row counts: 33 tiles of 512 tokens = 16 896 rows
+    -> 264 / 1056 output tiles, so NO split-K: gemm_f32_w8_kernel<2,0,1> (conv1 + LeakyReLU) and <0,1,1> (conv2 +
+    residual), the kernels behind the features/s numbers (the B = 4 training test runs its convs through split-K).
+    Reference: nine shifted fp64 matmuls on the CPU."""
+    tiles, N, Lg = 33, 32, 16
+    M = tiles * N * Lg
+    assert ((M + 127) // 128) * ((cout + 127) // 128) > 256
+    g = torch.Generator().manual_seed(cin + act)
+    x = torch.randn(tiles, N, Lg, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(M, cout, generator=g) if res else None
+    xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1))            # zero halo on the (N, L) grid
+    ref = b.double().expand(M, cout).clone()
+    for kh in range(3):
+        for kw in range(3):
+            ref += xp[:, kh:kh + N, kw:kw + Lg, :].reshape(M, cin) @ w[:, :, kh, kw].double().t()
+    if act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    if res:
+        ref = ref + r.double()
+    wk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = ops.gemm(x.reshape(-1, cin).to(DEV), wk.to(DEV), bias=b.to(DEV), act=act, residual=r.to(DEV) if res else None,
+                   amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=cin)
+    assert relerr(out, ref) < 3e-6
+
+
 @pytest.mark.parametrize("M,N,K,act,res,obf", [(20011, 320, 768, 0, 0, 0), (33000, 256, 128, 1, 1, 0),
                                                (16500, 768, 3072, 0, 1, 1), (70000, 128, 64, 1, 0, 1)])
 def test_gemm_bf16_lds_dma_path(M, N, K, act, res, obf):

@@ -289,3 +289,35 @@ def test_feature_stream_matches_reference_loop(tmp_path, prompts_table):
             sim, sc = net(feats, None, nc, S, True)
             rs, rc = O.anomaly_clip_forward_test(sd, hc, torch.from_numpy(ref).view(1, 1, -1, 128), nc, eot, 2, S)
         assert relerr(sc[:T_], rc[:T_]) < TOL
+
+
+def test_lightning_checkpoint_load_then_score(tmp_path, prompts_table):
+    """f4 on the device: a Lightning-shaped `last.ckpt` (`state_dict` keyed `net.*`, torchmetrics state, CLIP towers
+    exported in half precision) + the `ncentroid.pt` side-car -> checkpoint.load_into a fresh module -> test-mode
+    scores equal the oracle evaluated on the SAME (half-rounded) weights."""
+    from anomalyclip_amd import checkpoint
+    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1)
+    src, sd, eot = build_net("tiny", hc, "ucf", 31, prompts_table)
+    lsd = checkpoint.to_lightning_state_dict(src)
+    for k in list(lsd):
+        if k.startswith(("net.image_encoder.", "net.text_encoder.transformer.")):
+            lsd[k] = lsd[k].half()
+    lsd["train_loss.mean_value"] = torch.zeros(1)
+    lsd["auroc.confmat"] = torch.zeros(2, 2)
+    path = tmp_path / "logs" / "last.ckpt"
+    path.parent.mkdir(parents=True)
+    torch.save({"state_dict": lsd, "epoch": 7, "global_step": 123, "hyper_parameters": {"num_classes": 14}}, str(path))
+    nc = torch.randn(IW.TINY.embed_dim, generator=torch.Generator().manual_seed(2)) * 0.1
+    torch.save(nc, str(path.parent / "ncentroid.pt"))
+
+    dst, _, _ = build_net("tiny", hc, "ucf", 99, prompts_table)          # other weights: everything must come from the file
+    missing, unexpected = checkpoint.load_into(dst, str(path))
+    assert not missing and not unexpected
+    ncl = torch.load(str(path.parent / "ncentroid.pt"))
+    feats = torch.randn(1, 1, 2 * 512, IW.TINY.embed_dim, generator=torch.Generator().manual_seed(3)) * 0.3
+    dst.eval()
+    with torch.no_grad():
+        sim, sc = dst(feats.to(DEV), None, ncl, 2, True)
+    sd_half = {k[4:]: (v.float() if v.is_floating_point() else v) for k, v in lsd.items() if k.startswith("net.")}
+    rsim, rsc = O.anomaly_clip_forward_test(sd_half, hc, feats, ncl, eot, IW.TINY.transformer_heads, 2)
+    assert relerr(sim, rsim) < TOL and relerr(sc, rsc) < TOL

@@ -249,15 +249,17 @@ def test_e2e_train_forward_golden(golden, prompts_table):
     assert relerr(lg, g["train_logits"]) < 1e-4 and relerr(lt, g["train_logits_topk"]) < 1e-4 and relerr(sc, g["train_scores"]) < 1e-4
 
 
-@pytest.mark.parametrize("cfg", ["ucf", "sht"])
-def test_full_config_train_step_vs_oracle(prompts_table, cfg):
-    """UCF (E=256, depth 1) and ShanghaiTech (concat on, depth 2) head configs, B=4: loss and every temporal-model
-    gradient against the oracle's autograd on the same seeded inputs."""
+@pytest.mark.parametrize("cfg,B", [("ucf", 4), ("sht", 4), ("ucf", 64), ("sht", 16)])
+def test_full_config_train_step_vs_oracle(prompts_table, cfg, B):
+    """UCF (E=256, depth 1) and ShanghaiTech (concat on, depth 2) head configs: loss and every trainable gradient
+    against the oracle's autograd on the same seeded inputs.  B = 4 runs the single-video-sized GEMMs (split-K convs,
+    64x64 tiles); B = 64 is BASELINE.json configs[1] itself (32 768 features per step: the 8-wave conv / GEMM kernels
+    and the cost-model split counts of the weight-gradient GEMMs that the features/s numbers are measured on)."""
     hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD}[cfg]
     net, sd, eot = build_net("ViT-B/16", hc, cfg, 11, prompts_table)
     g = torch.Generator().manual_seed(5)
-    B = 4
-    labels = torch.tensor([1, hc.num_classes - 1, hc.normal_id, hc.normal_id])
+    abn = [c for c in range(hc.num_classes) if c != hc.normal_id]
+    labels = torch.tensor(([1, hc.num_classes - 1] + abn * 3)[:B // 2] + [hc.normal_id] * (B // 2))
     feats = torch.randn(B, 1, 512, 512, generator=g) * 0.3
     nc = torch.randn(512, generator=g) * 0.05
     mask = torch.bernoulli(torch.ones(B, 32) * 0.3, generator=g)
@@ -305,3 +307,145 @@ def test_full_config_train_step_vs_oracle(prompts_table, cfg):
     for e, n in errs:
         tol = 2.5e-2 if (".net.1.weight" in n or ".net.1.bias" in n) else 2e-3
         assert e < tol, (e, n)
+
+
+# ====================================================================================================== data parallel glue
+def _dp_module(prompts_table, seed=21, geom="tiny"):
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1) if geom == "tiny" else IW.UCF_HEAD
+    net, sd, eot = build_net(geom if geom == "tiny" else "ViT-B/16", hc, "ucf", seed, prompts_table)
+    crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-3}).to(DEV)
+    net.train()
+    return mod, net
+
+
+def _dp_batch(B, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, 1, 512, D, generator=g) * 0.3
+    labels = torch.tensor([1 + (i % 6) for i in range(B // 2)] + [7] * (B // 2))
+    masks = [torch.bernoulli(torch.ones(B, 32) * 0.3, generator=g) for _ in range(2)]
+    for m in masks:
+        m[:, :3] = 1
+    return feats, labels, masks
+
+
+@pytest.mark.parametrize("geom", ["tiny", "ViT-B/16"])
+def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom):
+    """AnomalyCLIPModule.train_batch with parallel.GradBuckets fed by LIBACX-produced gradients (autograd.Function
+    backward outputs accumulated into views of the flat buffer): two optimisation steps must leave exactly the same
+    parameters as plain `loss.backward(); opt.step()` without buckets, every p.grad must still alias the flat
+    buffer afterwards, and the never-used logit_scale must keep grad None (no weight decay on it, like the
+    reference's DDP)."""
+    D = IW.TINY.embed_dim if geom == "tiny" else 512
+    B = 4
+    mods = [_dp_module(prompts_table, geom=geom) for _ in range(2)]
+    opts = [m.configure_optimizers()["optimizer"] for m, _ in mods]
+    for step in range(2):
+        feats, labels, masks = _dp_batch(B, D, 100 + step)
+        f, l = feats.to(DEV), labels.to(DEV)
+        batch = ((f[B // 2:], l[B // 2:]), (f[:B // 2], l[:B // 2]))
+        for (mod, net), opt, bucketed in zip(mods, opts, (True, False)):
+            mod.ncentroid = torch.zeros(D, device=DEV)
+            net.selector_model.generate_mask = lambda b, m=masks: (m[0], m[1])
+            if bucketed:
+                mod.train_batch(batch, opt)
+            else:
+                opt.zero_grad(set_to_none=True)
+                with torch.enable_grad():
+                    mod.training_step(batch)["loss"].backward()
+                opt.step()
+        gb = mods[0][0]._buckets
+        for i, p in enumerate(gb.params):
+            lo, hi = gb._views[i]
+            if p is mods[0][1].selector_model.logit_scale:
+                assert p.grad is None
+            else:
+                assert p.grad is not None and p.grad.data_ptr() == gb.flat[lo:hi].data_ptr(), i
+        pa, pb = dict(mods[0][1].named_parameters()), dict(mods[1][1].named_parameters())
+        for n in pa:
+            if pa[n].requires_grad:
+                assert torch.equal(pa[n], pb[n]), (step, n)
+                if pb[n].grad is not None:
+                    assert torch.equal(pa[n].grad, pb[n].grad), (step, n)
+        assert torch.equal(mods[0][0].last_losses[0], mods[1][0].last_losses[0])
+    assert float(mods[0][1].selector_model.logit_scale) == float(np.float32(2.6592601))      # untouched by weight decay
+
+
+def _nccl_worker(rank, world, port, q):
+    import os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        import json
+        from anomalyclip_amd import parallel
+        global DEV
+        DEV = f"cuda:{rank}"
+        import test_gpu_model
+        test_gpu_model.DEV = DEV
+        table = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anomalyclip_amd",
+                                            "data", "prompts.json")))
+        B, D = 8, IW.TINY.embed_dim
+        (ma, na), (mb, nb) = _dp_module(table), _dp_module(table)
+        oa = ma.configure_optimizers()["optimizer"]
+        ok = True
+        for step in range(2):
+            feats, labels, masks = _dp_batch(B, D, 300 + step)
+            idx = parallel.shard_videos(B, world, rank)
+            f, l = feats[idx].to(DEV), labels[idx].to(DEV)
+            mk = [m[idx] for m in masks]
+            h = len(idx) // 2
+            batch = ((f[h:], l[h:]), (f[:h], l[:h]))
+            for mod, net in ((ma, na), (mb, nb)):
+                mod.ncentroid = torch.zeros(D, device=DEV)
+                net.selector_model.generate_mask = lambda b, m=mk: (m[0], m[1])
+            # reference for the exchange: module B's LOCAL gradients (SyncBN statistics exchanged inside, as in A),
+            # summed over ranks and divided by the world size by hand.  lr = 0: both modules keep identical weights.
+            for p in nb.parameters():
+                p.grad = None
+            with torch.enable_grad():
+                mb.training_step(batch)["loss"].backward()
+            want = {}
+            for n, p in nb.named_parameters():
+                if p.grad is not None:
+                    gsum = p.grad.clone()
+                    dist.all_reduce(gsum)
+                    want[n] = gsum / world
+            for gr in oa.param_groups:
+                gr["lr"], gr["weight_decay"] = 0.0, 0.0
+            ma.train_batch(batch, oa)
+            got = {n: p.grad for n, p in na.named_parameters() if p.grad is not None}
+            ok &= set(got) == set(want)
+            for n in want:
+                e = ((got[n] - want[n]).abs().max() / (want[n].abs().max() + 1e-30)).item()
+                ok &= e < 1e-5
+            flat = ma._buckets.flat.clone()
+            dist.broadcast(flat, 0)
+            ok &= bool(torch.equal(flat, ma._buckets.flat))           # identical averaged gradients on every rank
+        q.put((rank, bool(ok)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL); the single-GPU box covers the same code with world 1")
+def test_train_batch_gradbuckets_rccl_world2():
+    """two ranks over RCCL: the bucketed asynchronous all-reduce of libacx-produced gradients equals the hand-averaged
+    per-rank gradients, SyncBN statistics are exchanged, and every rank ends with bit-identical gradient buffers."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)], res
