@@ -1,18 +1,35 @@
 """AnomalyCLIPModule -- host-side mirror of the reference's LightningModule
-(src/models/anomaly_clip_module.py:31-750) for the hot path: same constructor (`net, optimizer, scheduler,
-loss, **kwargs` with kwargs = num_classes / solver / save_dir), same hook names and batch layouts
-(`model_step`, `training_step`, `validation_step`, `test_step`, `on_train_start`, `configure_optimizers`).
+(src/models/anomaly_clip_module.py:31-750) for the hot path.  Same constructor (`net, optimizer, scheduler, loss,
+**kwargs` with kwargs = num_classes / solver / save_dir, configs/model/*.yaml:2,63-68) and the SAME Trainer-called
+hook signatures:
 
-pytorch_lightning is not part of this image; the class derives from LightningModule when it is importable
-and from torch.nn.Module otherwise, and `fit_epoch` / `test_epoch` provide the minimal loop the reference
-gets from `Trainer` (one process per GPU; gradients exchanged through parallel.GradBuckets).
-`test_epoch_end` / `on_validation_epoch_end` compute the reference's metrics.json numbers (AUROC, AP, mAUC, mAP,
-top-1/5, optimal threshold; :339-404, :501-626) with libacx's sort/scan kernels (metrics.py); plots are out of
-scope."""
+    on_train_start(self)                    :134   ncentroid.pt under hparams.save_dir, else computed from
+                                                   self.trainer.datamodule.train_dataloader_test_mode()
+    training_step(self, batch, batch_idx)   :203   8 loss terms -> running means + self.log("train/*")
+    validation_step(self, batch, batch_idx) :301   4- or 5-tuple batches, results ACCUMULATED on self
+    on_validation_epoch_end(self)           :339   metrics_{epoch}.json under hparams.save_dir, lists cleared
+    on_test_start(self)                     :406   ncentroid next to the checkpoint's run directory
+    test_step(self, batch, batch_idx)       :458   @rank_zero_only, returns the per-video dict
+    test_epoch_end(self, outputs)           :501   @rank_zero_only, metrics.json under <logs>/eval/runs/<run>
+    configure_optimizers(self)              :693   4 param groups, CosineAnnealingLR(T_max = trainer.max_epochs) successor
+
+`self.trainer` is whatever drives the module: pytorch_lightning's Trainer when that package is importable (the
+class then derives from LightningModule), otherwise anomalyclip_amd.trainer.Trainer -- a thin loop that calls
+exactly these hooks in Lightning's order (one process per GPU; gradients through parallel.GradBuckets).  Both are
+read through the same attributes: `trainer.datamodule` (`.train_dataloader_test_mode()`, `.num_classes`,
+`.hparams.{load_from_features, normal_id, labels_file, visualize}`), `trainer.current_epoch`, `trainer.max_epochs`,
+`trainer.ckpt_path`.
+
+The metric numbers (AUROC, AP, mAUC, mAP, top-1/5, optimal threshold; :339-404, :501-626) come from libacx's sort /
+scan kernels (metrics.py) instead of torchmetrics; plots and the Visualizer are out of scope.
+The reference hard-codes /usr/src/app/logs/{train,eval}/runs/<run> (:409,:596); the same layout is used under
+`hparams.logs_root` (default "/usr/src/app/logs")."""
 from __future__ import annotations
 
+import json
+import os
 from pathlib import Path
-from typing import Any, Optional
+from typing import Any, List, Optional
 
 import torch
 
@@ -21,18 +38,84 @@ from .optim import AcxAdamW
 
 try:  # pragma: no cover - not installed in the build image
     from pytorch_lightning import LightningModule as _Base
+    _HAVE_LIGHTNING = True
 except Exception:  # noqa: BLE001
     _Base = torch.nn.Module
+    _HAVE_LIGHTNING = False
+
+
+class AttrDict(dict):
+    """`self.hparams` without Lightning: attribute + item access, nested dicts wrapped on the way out."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _get(obj, key, default=None):
+    """hparams / solver blocks arrive as dict, AttrDict, DictConfig or Namespace."""
+    if obj is None:
+        return default
+    if isinstance(obj, dict):
+        return obj.get(key, default)
+    try:
+        return getattr(obj, key)
+    except Exception:  # noqa: BLE001
+        try:
+            return obj[key]
+        except Exception:  # noqa: BLE001
+            return default
+
+
+class MeanMetric:
+    """torchmetrics.MeanMetric as the module uses it (:77-84): running mean of scalars, kept on the device (no host
+    sync per step); under data parallelism `compute()` averages over ranks like torchmetrics' epoch-end sync."""
+
+    def __init__(self):
+        self.total: Optional[torch.Tensor] = None
+        self.count = 0
+
+    def __call__(self, value):
+        self.update(value)
+
+    def update(self, value):
+        v = torch.as_tensor(value).detach().float().reshape(())
+        self.total = v.clone() if self.total is None else self.total + v
+        self.count += 1
+
+    def compute(self) -> torch.Tensor:
+        if self.total is None:
+            return torch.tensor(float("nan"))
+        t = torch.stack([self.total, self.total.new_tensor(float(self.count))])
+        if parallel.is_distributed():
+            parallel.all_reduce_sum_(t)
+        return t[0] / t[1]
+
+    def reset(self):
+        self.total, self.count = None, 0
+
+
+_LOSS_NAMES = ("train_loss", "dir_abn_loss", "dir_nor_loss", "topk_abn_loss", "bottomk_abn_loss", "topk_nor_loss",
+               "smooth_loss", "sparse_loss")
 
 
 class AnomalyCLIPModule(_Base):
     def __init__(self, net: torch.nn.Module, optimizer=None, scheduler=None, loss=None, **kwargs):
         super().__init__()
+        if _HAVE_LIGHTNING:  # pragma: no cover
+            self.save_hyperparameters(logger=False, ignore=["net"])
+        else:
+            self.hparams = AttrDict(kwargs)
         self.net = net
         self.criterion = loss
         self.optimizer = optimizer
         self.scheduler = scheduler
-        self.hparams_ = dict(kwargs)
         # freezing backbone (anomaly_clip_module.py:68-74)
         for p in self.net.image_encoder.parameters():
             p.requires_grad = False
@@ -41,26 +124,53 @@ class AnomalyCLIPModule(_Base):
         self.net.text_encoder.text_projection.requires_grad = True
         for p in self.net.token_embedding.parameters():
             p.requires_grad = False
+        # for averaging loss across batches (:77-84)
+        for n in _LOSS_NAMES:
+            object.__setattr__(self, n, MeanMetric())
         self.ncentroid: Optional[torch.Tensor] = None
-        self.labels, self.abnormal_scores, self.class_probs = [], [], []
+        self.labels: List[torch.Tensor] = []
+        self.abnormal_scores: List[torch.Tensor] = []
+        self.class_probs: List[torch.Tensor] = []
+        self.visualizer = None
+        self.logged: dict = {}                    # last value per self.log() name (the fallback logger)
         self._buckets: Optional[parallel.GradBuckets] = None
+        if not _HAVE_LIGHTNING:
+            object.__setattr__(self, "trainer", None)
+
+    # ------------------------------------------------------------------ small Lightning stand-ins
+    if not _HAVE_LIGHTNING:
+        @property
+        def device(self) -> torch.device:
+            return next(self.net.temporal_model.parameters()).device
+
+        def log(self, name, value, **kw):
+            self.logged[name] = value
+
+    def _datamodule(self):
+        tr = getattr(self, "trainer", None)
+        return getattr(tr, "datamodule", None) if tr is not None else None
+
+    def _logs_root(self) -> str:
+        return str(_get(self.hparams, "logs_root", "/usr/src/app/logs"))
 
     # ------------------------------------------------------------------ forward (anomaly_clip_module.py:118-132)
     def forward(self, image_features, labels, ncentroid, segment_size: int = 1, test_mode: bool = False):
         return self.net(image_features, labels, ncentroid, segment_size, test_mode)
 
-    # ------------------------------------------------------------------ ncentroid (:134-171, :406-445)
+    # ------------------------------------------------------------------ ncentroid (:145-171, :419-445)
     @torch.no_grad()
     def compute_ncentroid(self, loader, load_from_features: bool = True) -> torch.Tensor:
-        """mean feature over every frame of every normal training video; under data parallelism each rank
-        scans its shard and (sum, count) is all-reduced."""
-        dev = next(self.net.temporal_model.parameters()).device
+        """mean feature over every frame of every normal training video.  Batches are the test-mode datasets' 4- or
+        5-tuples (features, labels, label, segment_size[, path]) -- both arities occur in the reference (:153,:427).
+        Under data parallelism a rank may be handed a shard of the loader: (sum, count) is all-reduced; handing every
+        rank the full loader (what the reference does, SURVEY section 5 "DDP quirks") gives the same mean."""
+        dev = self.device
         D = self.net.embedding_dim
         acc = torch.zeros(D, dtype=torch.float32, device=dev)
         count = 0
         for batch in loader:
             feats, nlabels = batch[0], batch[1]
-            n = int(torch.as_tensor(nlabels).reshape(-1).shape[0])
+            n = int(torch.as_tensor(nlabels).reshape(-1).shape[0])                   # len(nlabels.squeeze())
             if load_from_features:
                 f = feats.reshape(-1, feats.shape[-1])[:n].to(dev, torch.float32).contiguous()
             else:
@@ -75,20 +185,26 @@ class AnomalyCLIPModule(_Base):
         self.ncentroid = acc / cnt
         return self.ncentroid
 
-    def on_train_start(self, loader=None, load_from_features: bool = True):
-        save_dir = self.hparams_.get("save_dir")
-        f = Path(save_dir) / "ncentroid.pt" if save_dir else None
-        if f is not None and f.is_file():
+    def _load_or_compute_ncentroid(self, save_dir: Path):
+        save_dir.mkdir(parents=True, exist_ok=True)
+        f = save_dir / "ncentroid.pt"
+        if f.is_file():
             self.ncentroid = torch.load(f)
-        elif loader is not None:
-            self.compute_ncentroid(loader, load_from_features)
-            if f is not None and parallel.rank() == 0:
-                f.parent.mkdir(parents=True, exist_ok=True)
-                torch.save(self.ncentroid.cpu(), f)
+            return
+        dm = self._datamodule()
+        if dm is None:
+            raise RuntimeError(f"{f} does not exist and there is no trainer.datamodule to compute it from")
+        loader = dm.train_dataloader_test_mode()
+        self.compute_ncentroid(loader, bool(_get(_get(dm, "hparams"), "load_from_features", True)))
+        if parallel.rank() == 0:                 # the reference lets every rank write the same file
+            torch.save(self.ncentroid.cpu(), f)
 
-    # ------------------------------------------------------------------ steps
+    def on_train_start(self):
+        self._load_or_compute_ncentroid(Path(_get(self.hparams, "save_dir")))
+
+    # ------------------------------------------------------------------ training (:173-293)
     def model_step(self, batch: Any):
-        nbatch, abatch = batch                                        # anomaly_clip_module.py:173-178
+        nbatch, abatch = batch
         nimage_features, nlabel = nbatch
         aimage_features, alabel = abatch
         image_features = torch.cat((aimage_features, nimage_features), 0)
@@ -101,71 +217,122 @@ class AnomalyCLIPModule(_Base):
         sim, sim_topk, labels, scores, ia, in_, ba = self.model_step(batch)
         losses = self.criterion(sim, sim_topk, labels, scores, ia, in_, ba)
         self.last_losses = losses
+        for name, value in zip(_LOSS_NAMES, losses):                                # :244-293
+            meter = getattr(self, name)
+            meter(value)
+            self.log("train/" + ("loss" if name == "train_loss" else name), meter, on_step=False, on_epoch=True, prog_bar=True)
         return {"loss": losses[0]}
 
-    @torch.no_grad()
-    def test_step(self, batch: Any, batch_idx: int = 0):
-        image_features, labels = batch[0], batch[1]
-        segment_size = batch[3]
-        dev = next(self.net.temporal_model.parameters()).device
+    def on_train_epoch_end(self):
+        pass
+
+    # ------------------------------------------------------------------ evaluation (:301-337, :458-498)
+    def _score_video(self, batch):
+        image_features, labels, segment_size = batch[0], batch[1], batch[3]        # 4-tuple (:302) or 5-tuple (:460)
+        dev = self.device
         image_features = image_features.to(dev)
         labels = torch.as_tensor(labels).squeeze(0).to(dev)
-        similarity, abnormal_scores = self.forward(image_features, labels, self.ncentroid, int(segment_size), test_mode=True)
-        class_probs = ops.class_probs(similarity.contiguous(), abnormal_scores.contiguous())   # :474-477
-        n = labels.shape[0]                                           # remove padded frames (:480-483)
-        return {"abnormal_scores": abnormal_scores[:n], "labels": labels, "class_probs": class_probs[:n]}
+        with torch.no_grad():
+            similarity, abnormal_scores = self.forward(image_features, labels, self.ncentroid, int(segment_size), test_mode=True)
+            class_probs = ops.class_probs(similarity.contiguous(), abnormal_scores.contiguous())   # softmax * score
+        n = labels.shape[0]                                                          # remove padded frames
+        return abnormal_scores[:n], labels, class_probs[:n]
 
-    validation_step = test_step
+    def validation_step(self, batch: Any, batch_idx: int = 0):
+        save_dir = _get(self.hparams, "save_dir")
+        f = Path(save_dir) / "ncentroid.pt" if save_dir else None
+        if f is not None and f.is_file():
+            self.ncentroid = torch.load(f)
+        elif self.ncentroid is None:
+            raise FileNotFoundError(f"ncentroid file {f} not found")
+        scores, labels, probs = self._score_video(batch)
+        # the reference extends its lists frame by frame and stacks at epoch end; one tensor per video is the same data
+        self.labels.append(labels)
+        self.class_probs.append(probs)
+        self.abnormal_scores.append(scores)
 
-    # ------------------------------------------------------------------ metrics epilogue (:339-404, :501-626)
-    def test_epoch_end(self, outputs, save_dir: Optional[str] = None, epoch: int = 0):
-        """outputs = list of test_step dicts.  Returns (and optionally writes `metrics.json` with) the reference's
-        keys; rank-zero only in the reference (@rank_zero_only, :500)."""
-        import json
+    def _evaluate(self, scores, labels, probs, per_frame: bool):
         from . import metrics as M
-        scores = torch.cat([o["abnormal_scores"] for o in outputs])
-        labels = torch.cat([o["labels"] for o in outputs])
-        probs = torch.cat([o["class_probs"] for o in outputs])
-        C = int(self.hparams_.get("num_classes", probs.shape[1] + 1))
-        r = M.evaluate(scores, labels, probs, int(self.net.normal_id), C)
-        keys = ("auc_roc", "auc_pr", "mean_mc_auroc", "mean_mc_aupr", "mc_auroc", "mc_aupr", "top1_accuracy",
-                "top5_accuracy", "optimal_threshold")
-        metrics = {"epoch": epoch, **{k: r[k] for k in keys}}
-        if save_dir is not None:
-            Path(save_dir).mkdir(parents=True, exist_ok=True)
-            with open(Path(save_dir) / "metrics.json", "w") as fp:
-                json.dump(metrics, fp, indent=4, sort_keys=True)
+        dm = self._datamodule()
+        C = int(_get(dm, "num_classes", None) or _get(self.hparams, "num_classes", probs.shape[1] + 1))
+        normal_idx = int(_get(_get(dm, "hparams"), "normal_id", self.net.normal_id))
+        r = M.evaluate(scores, labels, probs, normal_idx, C, per_frame=per_frame)
         self.last_metrics = r
-        return metrics
+        return r
 
-    def on_validation_epoch_end(self, outputs, save_dir: Optional[str] = None, epoch: int = 0):
-        """:339-404 -- same numbers minus the per-frame predictions."""
-        m = self.test_epoch_end(outputs, None, epoch)
-        m = {k: v for k, v in m.items() if k not in ("top1_accuracy", "top5_accuracy")}
-        if save_dir is not None:
-            import json
+    def on_validation_epoch_end(self):
+        if not self.labels:
+            return None
+        r = self._evaluate(torch.cat(self.abnormal_scores), torch.cat(self.labels), torch.cat(self.class_probs), False)
+        self.log("test/AUC", r["auc_roc"], on_step=False, on_epoch=True, prog_bar=True)
+        self.log("test/AP", r["auc_pr"], on_step=False, on_epoch=True, prog_bar=True)
+        self.log("test/mAUC", r["mean_mc_auroc"], on_step=False, on_epoch=True, prog_bar=True)
+        self.log("test/mAP", r["mean_mc_aupr"], on_step=False, on_epoch=True, prog_bar=True)
+        epoch = int(getattr(getattr(self, "trainer", None), "current_epoch", 0) or 0)
+        keys = ("auc_roc", "auc_pr", "mean_mc_auroc", "mean_mc_aupr", "mc_auroc", "mc_aupr", "optimal_threshold")
+        metrics = {"epoch": epoch, **{k: r[k] for k in keys}}
+        save_dir = _get(self.hparams, "save_dir")
+        if save_dir:
             Path(save_dir).mkdir(parents=True, exist_ok=True)
             with open(Path(save_dir) / f"metrics_{epoch}.json", "w") as fp:
-                json.dump(m, fp, indent=4, sort_keys=True)
-        return m
+                json.dump(metrics, fp, indent=4, sort_keys=True)
+        self.labels.clear()
+        self.class_probs.clear()
+        self.abnormal_scores.clear()
+        return metrics
+
+    def _run_dir(self, kind: str) -> Path:
+        """<logs_root>/<kind>/runs/<name of the checkpoint's parent directory> (:407-409, :594-596)."""
+        ckpt_path = Path(str(getattr(getattr(self, "trainer", None), "ckpt_path", None) or "ckpt/last.ckpt"))
+        run = os.path.normpath(ckpt_path.parent).split(os.path.sep)[-1]
+        d = Path(os.path.join(self._logs_root(), kind, "runs", str(run)))
+        d.mkdir(parents=True, exist_ok=True)
+        return d
+
+    def on_test_start(self):
+        self._load_or_compute_ncentroid(self._run_dir("train"))
+        dm = self._datamodule()
+        if bool(_get(_get(dm, "hparams"), "visualize", False)):
+            raise NotImplementedError("data.visualize=True: the qualitative Visualizer is out of scope of this path")
+        self.visualizer = None
+
+    @parallel.rank_zero_only
+    def test_step(self, batch: Any, batch_idx: int = 0):
+        scores, labels, probs = self._score_video(batch)
+        return {"abnormal_scores": scores, "labels": labels, "class_probs": probs}
+
+    @parallel.rank_zero_only
+    def test_epoch_end(self, outputs: List[Any]):
+        outputs = [o for o in outputs if o is not None]
+        r = self._evaluate(torch.cat([o["abnormal_scores"] for o in outputs]), torch.cat([o["labels"] for o in outputs]),
+                           torch.cat([o["class_probs"] for o in outputs]), True)
+        keys = ("auc_roc", "auc_pr", "mean_mc_auroc", "mean_mc_aupr", "mc_auroc", "mc_aupr", "top1_accuracy",
+                "top5_accuracy", "optimal_threshold")
+        epoch = int(getattr(getattr(self, "trainer", None), "current_epoch", 0) or 0)
+        metrics = {"epoch": epoch, **{k: r[k] for k in keys}}
+        with open(self._run_dir("eval") / "metrics.json", "w") as fp:
+            json.dump(metrics, fp, indent=4, sort_keys=True)
+        return metrics
 
     # ------------------------------------------------------------------ optimizer (:693-746)
-    def configure_optimizers(self, max_epochs: int = 50):
-        s = self.hparams_.get("solver", {})
-        lr = s.get("lr", 1e-5)
+    def configure_optimizers(self):
+        s = _get(self.hparams, "solver", {})
+        lr = _get(s, "lr", 1e-5)
         groups = [
-            {"params": list(self.net.selector_model.parameters()), "lr": lr * s.get("selector_model_ratio", 1), "name": "selector_model"},
-            {"params": list(self.net.temporal_model.parameters()), "lr": lr * s.get("temporal_model_ratio", 1), "name": "temporal_model"},
-            {"params": list(self.net.prompt_learner.parameters()), "lr": lr * s.get("prompt_learner_ratio", 1), "name": "prompt_learner"},
-            {"params": [self.net.text_encoder.text_projection], "lr": lr * s.get("text_projection_ratio", 1), "name": "text_projection"},
+            {"params": list(self.net.selector_model.parameters()), "lr": lr * _get(s, "selector_model_ratio", 1), "name": "selector_model"},
+            {"params": list(self.net.temporal_model.parameters()), "lr": lr * _get(s, "temporal_model_ratio", 1), "name": "temporal_model"},
+            {"params": list(self.net.prompt_learner.parameters()), "lr": lr * _get(s, "prompt_learner_ratio", 1), "name": "prompt_learner"},
+            {"params": [self.net.text_encoder.text_projection], "lr": lr * _get(s, "text_projection_ratio", 1), "name": "text_projection"},
         ]
         opt = self.optimizer(params=groups) if self.optimizer is not None else AcxAdamW(groups, weight_decay=0.2)
         if self.scheduler is None:
             return {"optimizer": opt}
+        max_epochs = getattr(getattr(self, "trainer", None), "max_epochs", None) or 50
         successor = torch.optim.lr_scheduler.CosineAnnealingLR(opt, float(max_epochs))
         sch = self.scheduler(optimizer=opt, successor=successor)
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sch, "monitor": "train/loss", "interval": "epoch", "frequency": 1}}
 
+    # ------------------------------------------------------------------ one optimisation step of the built-in loop
     def trainable_parameters(self):
         seen, out = set(), []
         for mod in (self.net.selector_model, self.net.temporal_model, self.net.prompt_learner):
@@ -176,16 +343,18 @@ class AnomalyCLIPModule(_Base):
         out.append(self.net.text_encoder.text_projection)
         return out
 
-    def train_batch(self, batch, optimizer) -> torch.Tensor:
-        """one optimisation step: forward, loss, backward (+ bucketed gradient all-reduce), AdamW."""
+    def train_batch(self, batch, optimizer, batch_idx: int = 0) -> torch.Tensor:
+        """forward, loss, backward (+ bucketed gradient all-reduce overlapped with it), AdamW: what Lightning's
+        automatic optimisation + DDP do around `training_step` (configs/trainer/ddp.yaml)."""
         if self._buckets is None:
             # forward order: prompt/text first ... temporal last; buckets fill in reverse
             order = [self.net.prompt_learner.ctx, self.net.text_encoder.text_projection, self.net.selector_model.logit_scale]
             order += list(self.net.temporal_model.parameters())
             self._buckets = parallel.GradBuckets(order)
         self._buckets.zero()
-        loss = self.training_step(batch)["loss"]
-        loss.backward()
+        with torch.enable_grad():
+            loss = self.training_step(batch, batch_idx)["loss"]
+            loss.backward()
         self._buckets.finish()
         optimizer.step()
         return loss.detach()

@@ -84,7 +84,13 @@ class AnomalyCLIP(nn.Module):
             if self.labels_file and os.path.isfile(self.labels_file):
                 classnames = _read_classnames(self.labels_file)
             else:
-                classnames = lookup_prompts(key=g("labels_key", "ucf"))["classnames"]
+                # the reference's label files are data/{ucf,sht,xd}_labels.csv (configs/data/*.yaml `labels_file`);
+                # when the configured path does not exist on this machine their class names ship in prompts.json
+                key = g("labels_key")
+                if key is None and self.labels_file:
+                    stem = os.path.basename(str(self.labels_file)).split("_")[0].lower()
+                    key = stem if stem in ("ucf", "sht", "xd") else None
+                classnames = lookup_prompts(key=key or "ucf")["classnames"]
         if tokenized is None:
             tokenized = torch.tensor(lookup_prompts(classnames)["tokenized_prompts"], dtype=torch.int32)
         self.classnames = classnames
@@ -109,6 +115,9 @@ class AnomalyCLIP(nn.Module):
         self.temporal_model = TemporalModel(input_size, self.emb_size, 1, self.heads, self.dim_heads, self.depth,
                                             self.num_segments, self.seg_length)
         self.cache_text_features = bool(g("cache_text_features", False))
+        # under data parallelism the (replicated) text encoder is evaluated class-parallel: every rank runs its block
+        # of classes and the (C, E) features / their gradients are exchanged (functional.TextFeaturesFn)
+        self.text_class_parallel = bool(g("text_class_parallel", True))
         self._text_cache = None
 
     # ------------------------------------------------------------------------------------------

@@ -26,64 +26,108 @@ def _parallel():
 
 
 # ====================================================================================================== text path
+def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int):
+    """Text features of classes [lo, hi) (coop.py:74-90, text_encoder.py:14-25): prompt assembly, the 12 frozen CLIP
+    text layers, EOT gather, ln_final, @ text_projection.  Returns (features [hi-lo, E], state for the backward)."""
+    te, pl = net.text_encoder, net.prompt_learner
+    tr = te.transformer
+    W, heads, Lc = tr.width, tr.heads, te.positional_embedding.shape[0]
+    shared = ctx_param.dim() == 2
+    cp = ctx_param.detach() if shared else ctx_param.detach()[lo:hi]
+    x0 = ops.prompt_embed(pl.token_prefix[lo:hi], cp, pl.token_suffix[lo:hi], te.positional_embedding.detach(), pl.n_ctx)
+    C = x0.shape[0]
+    x = x0.view(C * Lc, W)
+    saved = []
+    for blk in tr.resblocks:
+        h1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+        qkv = ops.gemm(h1, blk.attn.in_proj_weight.detach(), bias=blk.attn.in_proj_bias.detach())
+        att = ops.attention(qkv, C, Lc, heads, True)
+        x_mid = ops.gemm(att, blk.attn.out_proj.weight.detach(), bias=blk.attn.out_proj.bias.detach(), residual=x)
+        h2 = ops.layernorm(x_mid, blk.ln_2.weight, blk.ln_2.bias)
+        pre = ops.gemm(h2, blk.mlp.c_fc.weight.detach(), bias=blk.mlp.c_fc.bias.detach())
+        act = ops.act(pre, None, 2)
+        x_next = ops.gemm(act, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid)
+        saved.append((x, qkv, x_mid, pre))
+        x = x_next
+    rows_idx = torch.arange(C, device=x.device, dtype=torch.int64) * Lc + net.eot_index[lo:hi]
+    eot = ops.gather_rows(x, rows_idx)
+    eln = ops.layernorm(eot, te.ln_final.weight, te.ln_final.bias)
+    tf = ops.gemm(eln, text_projection.detach().t().contiguous())
+    return tf, (saved, rows_idx, eot, eln, C, Lc, W, heads, shared)
+
+
+def _text_backward_rows(net, text_projection, state, d_tf):
+    """d(features of the local classes) -> (d ctx for those classes [C_loc, n_ctx, W] (or [n_ctx, W] when shared),
+    d text_projection [W, E]); dX only through the frozen layers."""
+    te, pl = net.text_encoder, net.prompt_learner
+    saved, rows_idx, eot, eln, C, Lc, W, heads, shared = state
+    d_tf = d_tf.contiguous()
+    d_P = ops.gemm_tn(eln, d_tf)                                             # [W, E]
+    d_eln = ops.gemm(d_tf, text_projection.detach().contiguous())            # d_tf @ P^T  (W_op = P [W,E])
+    d_eot, _, _ = ops.layernorm_bwd(eot, te.ln_final.weight, d_eln, need_params=False)
+    d_x = ops.scatter_rows(d_eot, rows_idx, C * Lc)
+    wt = _frozen_transposes(te)
+    for li in range(len(saved) - 1, -1, -1):
+        blk = te.transformer.resblocks[li]
+        x, qkv, x_mid, pre = saved[li]
+        t_in, t_out, t_fc, t_proj = wt[li]
+        d_act = ops.gemm(d_x, t_proj)                                        # [rows,4W] = d_x @ proj_w
+        d_pre = ops.act(pre, d_act, 1)
+        d_h2 = ops.gemm(d_pre, t_fc)                                         # [rows,W]
+        d_ln, _, _ = ops.layernorm_bwd(x_mid, blk.ln_2.weight, d_h2, need_params=False)
+        d_x_mid = ops.add(d_x, d_ln)
+        d_att = ops.gemm(d_x_mid, t_out)
+        d_qkv = ops.seq_attention_bwd(qkv, d_att, C, 1, Lc, heads, 64, 1, causal=True)
+        d_h1 = ops.gemm(d_qkv, t_in)
+        d_ln, _, _ = ops.layernorm_bwd(x, blk.ln_1.weight, d_h1, need_params=False)
+        d_x = ops.add(d_x_mid, d_ln)
+    d_ctx = ops.ctx_grad(d_x, C, pl.n_ctx, Lc, W, shared)
+    return d_ctx, d_P
+
+
 class TextFeaturesFn(torch.autograd.Function):
+    """Text features of ALL classes on this rank, or -- class-parallel under data parallelism -- of this rank's
+    contiguous block of classes followed by an exchange (the text encoder is the one part
+    of the step that plain DP replicates; 83 GFLOP forward + dX backward at 14 classes do not shrink with more GPUs).
+
+    class_parallel: forward  = local rows written into a zero (C, E) buffer, ONE all-reduce (sum with zeros is exact);
+                    backward = ONE all-reduce of d_features (every rank holds the gradient of ITS videos w.r.t. ALL
+                    classes), then the local classes' rows go through the local backward.  The returned d_ctx is
+                    non-zero only in the local class block and d_text_projection is the local classes' partial sum --
+                    both already summed over ranks' videos -- so the gradient all-reduce (sum / world) that follows
+                    (parallel.GradBuckets) yields exactly the data-parallel mean the reference's DDP produces."""
+
     @staticmethod
-    def forward(ctx, ctx_param, text_projection, net):
-        te, pl = net.text_encoder, net.prompt_learner
-        tr = te.transformer
-        W, heads, Lc = tr.width, tr.heads, te.positional_embedding.shape[0]
-        x0 = ops.prompt_embed(pl.token_prefix, ctx_param.detach(), pl.token_suffix, te.positional_embedding.detach(), pl.n_ctx)
-        C = x0.shape[0]
-        x = x0.view(C * Lc, W)
-        saved = []
-        for blk in tr.resblocks:
-            h1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
-            qkv = ops.gemm(h1, blk.attn.in_proj_weight.detach(), bias=blk.attn.in_proj_bias.detach())
-            att = ops.attention(qkv, C, Lc, heads, True)
-            x_mid = ops.gemm(att, blk.attn.out_proj.weight.detach(), bias=blk.attn.out_proj.bias.detach(), residual=x)
-            h2 = ops.layernorm(x_mid, blk.ln_2.weight, blk.ln_2.bias)
-            pre = ops.gemm(h2, blk.mlp.c_fc.weight.detach(), bias=blk.mlp.c_fc.bias.detach())
-            act = ops.act(pre, None, 2)
-            x_next = ops.gemm(act, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid)
-            saved.append((x, qkv, x_mid, pre))
-            x = x_next
-        rows_idx = torch.arange(C, device=x.device, dtype=torch.int64) * Lc + net.eot_index
-        eot = ops.gather_rows(x, rows_idx)
-        eln = ops.layernorm(eot, te.ln_final.weight, te.ln_final.bias)
-        tf = ops.gemm(eln, text_projection.detach().t().contiguous())
-        ctx.net, ctx.saved_acts, ctx.misc = net, saved, (rows_idx, eot, eln, C, Lc, W, heads)
-        ctx.save_for_backward(text_projection)
+    def forward(ctx, ctx_param, text_projection, net, class_parallel):
+        par = _parallel()
+        C_all = net.prompt_learner.n_cls
+        cp = bool(class_parallel) and par.is_distributed()
+        lo, hi = par.shard_range(C_all, par.world_size(), par.rank()) if cp else (0, C_all)
+        tf_loc, state = _text_forward_rows(net, ctx_param, text_projection, lo, hi)
+        if cp:
+            tf = par.assemble_rows(tf_loc, lo, C_all)
+        else:
+            tf = tf_loc
+        ctx.net, ctx.state, ctx.rows, ctx.cp = net, state, (lo, hi, C_all), cp
+        ctx.save_for_backward(text_projection, ctx_param)
         return tf
 
     @staticmethod
     def backward(ctx, d_tf):
         net = ctx.net
-        te, pl = net.text_encoder, net.prompt_learner
-        rows_idx, eot, eln, C, Lc, W, heads = ctx.misc
-        (P,) = ctx.saved_tensors
+        lo, hi, C_all = ctx.rows
+        P, ctx_param = ctx.saved_tensors
         d_tf = d_tf.contiguous()
-        d_P = ops.gemm_tn(eln, d_tf)                                             # [W, E]
-        d_eln = ops.gemm(d_tf, P.detach().contiguous())                          # d_tf @ P^T  (W_op = P [W,E])
-        d_eot, _, _ = ops.layernorm_bwd(eot, te.ln_final.weight, d_eln, need_params=False)
-        d_x = ops.scatter_rows(d_eot, rows_idx, C * Lc)
-        wt = _frozen_transposes(te)
-        for li in range(len(ctx.saved_acts) - 1, -1, -1):
-            blk = te.transformer.resblocks[li]
-            x, qkv, x_mid, pre = ctx.saved_acts[li]
-            t_in, t_out, t_fc, t_proj = wt[li]
-            d_act = ops.gemm(d_x, t_proj)                                        # [rows,4W] = d_x @ proj_w
-            d_pre = ops.act(pre, d_act, 1)
-            d_h2 = ops.gemm(d_pre, t_fc)                                         # [rows,W]
-            d_ln, _, _ = ops.layernorm_bwd(x_mid, blk.ln_2.weight, d_h2, need_params=False)
-            d_x_mid = ops.add(d_x, d_ln)
-            d_att = ops.gemm(d_x_mid, t_out)
-            d_qkv = ops.seq_attention_bwd(qkv, d_att, C, 1, Lc, heads, 64, 1, causal=True)
-            d_h1 = ops.gemm(d_qkv, t_in)
-            d_ln, _, _ = ops.layernorm_bwd(x, blk.ln_1.weight, d_h1, need_params=False)
-            d_x = ops.add(d_x_mid, d_ln)
-        d_ctx = ops.ctx_grad(d_x, C, pl.n_ctx, Lc, W, pl.ctx.dim() == 2)
-        ctx.saved_acts = None
-        return d_ctx, d_P, None
+        if ctx.cp:
+            d_tf = _parallel().all_reduce_sum_(d_tf.clone())[lo:hi]
+        d_ctx_loc, d_P = _text_backward_rows(net, P, ctx.state, d_tf)
+        if ctx.cp and ctx_param.dim() == 3:
+            d_ctx = torch.zeros_like(ctx_param)
+            d_ctx[lo:hi] = d_ctx_loc
+        else:
+            d_ctx = d_ctx_loc
+        ctx.state = None
+        return d_ctx, d_P, None, None
 
 
 def _frozen_transposes(te):
@@ -101,7 +145,8 @@ def _frozen_transposes(te):
 
 
 def text_features_train(net):
-    return TextFeaturesFn.apply(net.prompt_learner.ctx, net.text_encoder.text_projection, net)
+    return TextFeaturesFn.apply(net.prompt_learner.ctx, net.text_encoder.text_projection, net,
+                                getattr(net, "text_class_parallel", True))
 
 
 # ====================================================================================================== selector

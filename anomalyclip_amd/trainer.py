@@ -1,0 +1,107 @@
+"""Minimal stand-in for `pytorch_lightning.Trainer` (not installed in this image): drives an AnomalyCLIPModule through
+the SAME hooks, in Lightning 1.8's order, that `src/train.py:71-105` / `src/eval.py:73` reach through `trainer.fit` /
+`trainer.test`.  One process per GPU (launch with torch.distributed.run for data parallelism: gradients are exchanged
+by AnomalyCLIPModule.train_batch through parallel.GradBuckets, SyncBN statistics inside the selector).  Nothing here is
+arithmetic -- it is the thin loop SURVEY.md section 7 step 3 asks for so that the module's hooks can keep the
+reference's Trainer-called signatures.
+
+Attributes the module reads: `datamodule`, `current_epoch`, `max_epochs`, `ckpt_path`."""
+from __future__ import annotations
+
+import os
+from typing import Any, Optional
+
+import torch
+
+from . import checkpoint, parallel
+
+
+def _to_device(x: Any, dev):
+    if torch.is_tensor(x):
+        return x.to(dev, non_blocking=True)
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_device(v, dev) for v in x)
+    return x
+
+
+class Trainer:
+    def __init__(self, max_epochs: int = 50, min_epochs: int = 1, check_val_every_n_epoch: int = 1,
+                 default_root_dir: Optional[str] = None, limit_train_batches: Optional[int] = None, **ignored):
+        # accepted and ignored like any Trainer kwarg that has no meaning here: accelerator, devices, strategy,
+        # sync_batchnorm (always on under DP), num_sanity_val_steps, deterministic, callbacks, logger ...
+        self.max_epochs, self.min_epochs = int(max_epochs), int(min_epochs)
+        self.check_val_every_n_epoch = int(check_val_every_n_epoch)
+        self.default_root_dir = default_root_dir
+        self.limit_train_batches = limit_train_batches
+        self.datamodule = None
+        self.current_epoch = 0
+        self.global_step = 0
+        self.ckpt_path: Optional[str] = None
+        self.callback_metrics: dict = {}
+
+    # ------------------------------------------------------------------------------------------------------
+    def _attach(self, model, datamodule, stage):
+        self.datamodule = datamodule
+        object.__setattr__(model, "trainer", self)
+        if hasattr(datamodule, "setup"):
+            datamodule.setup(stage)
+
+    def _validate(self, model, dev):
+        model.net.eval()
+        loader = self.datamodule.val_dataloader()
+        for i, batch in enumerate(loader):
+            model.validation_step(_to_device(batch, dev), i)
+        m = model.on_validation_epoch_end()
+        if m:
+            self.callback_metrics.update({k: v for k, v in m.items() if isinstance(v, (int, float))})
+
+    def save_checkpoint(self, model, path: str):
+        """Lightning-shaped `.ckpt` (configs/callbacks/default.yaml:8-14: save_last) on rank 0."""
+        if parallel.rank() != 0:
+            return
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"state_dict": checkpoint.to_lightning_state_dict(model.net), "epoch": self.current_epoch,
+                    "global_step": self.global_step, "hyper_parameters": dict(getattr(model, "hparams", {}) or {}),
+                    "pytorch-lightning_version": "1.8.3"}, path)
+
+    def fit(self, model, datamodule=None, ckpt_path: Optional[str] = None):
+        self._attach(model, datamodule, "fit")
+        dev = model.device
+        if ckpt_path:
+            checkpoint.load_into(model.net, ckpt_path)
+            self.ckpt_path = ckpt_path
+        cfg = model.configure_optimizers()
+        opt = cfg["optimizer"]
+        sched = cfg.get("lr_scheduler", {}).get("scheduler") if isinstance(cfg.get("lr_scheduler"), dict) else None
+        model.on_train_start()
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            model.net.train()
+            loaders = self.datamodule.train_dataloader()        # [normal loader, abnormal loader] (datamodule:144-163)
+            it = zip(*loaders) if isinstance(loaders, (list, tuple)) else iter(loaders)
+            for i, batch in enumerate(it):
+                if self.limit_train_batches is not None and i >= self.limit_train_batches:
+                    break
+                model.train_batch(_to_device(tuple(batch), dev), opt, i)
+                self.global_step += 1
+            model.on_train_epoch_end()
+            if sched is not None:
+                sched.step()
+            if (epoch + 1) % self.check_val_every_n_epoch == 0 and hasattr(self.datamodule, "val_dataloader"):
+                self._validate(model, dev)
+            if self.default_root_dir:
+                self.ckpt_path = os.path.join(self.default_root_dir, "checkpoints", "last.ckpt")
+                self.save_checkpoint(model, self.ckpt_path)
+        return self.callback_metrics
+
+    def test(self, model, datamodule=None, ckpt_path: Optional[str] = None):
+        self._attach(model, datamodule, "test")
+        dev = model.device
+        if ckpt_path:
+            checkpoint.load_into(model.net, ckpt_path)
+            self.ckpt_path = ckpt_path
+        model.net.eval()
+        model.on_test_start()
+        outputs = [model.test_step(_to_device(batch, dev), i) for i, batch in enumerate(self.datamodule.test_dataloader())]
+        m = model.test_epoch_end(outputs)
+        return [m] if m is not None else []

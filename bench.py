@@ -2,24 +2,34 @@
 """bench.py -- headline benchmark of the AnomalyCLIP hot path on MI355X.
 
 Metric (BASELINE.json): frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2.
-Workload (configs[2] of BASELINE.json / SURVEY.md 8d config 3): one STEP = one synthetic clip of
+Workload of `value` (configs[2] of BASELINE.json / SURVEY.md 8d config 3): one STEP = one synthetic clip of
 512 frames (1,512,3,224,224) f32 already resident in HBM -> `AnomalyCLIP.forward(test_mode=True,
 load_from_features=False)`: CLIP ViT-B/16 encode of the clip (one 512-frame launch by default; --vit-chunk 256
-reproduces the config's batch 256),
-text encoder (recomputed every step like the reference, anomaly_clip.py:136), selector, axial
-temporal transformer (one S=1 tile), classifier, then the eval post-processing
-softmax(similarity)*score (anomaly_clip_module.py:474-477).  Random-init weights of the UCF-Crime
-configuration (no checkpoints/network in this environment), data synthetic.
+reproduces the config's literal batch 256), text encoder (recomputed every step like the reference,
+anomaly_clip.py:136), selector, axial temporal transformer (one S=1 tile), classifier, then the eval post-processing
+softmax(similarity)*score (anomaly_clip_module.py:474-477).  Random-init weights of the UCF-Crime configuration
+(no checkpoints/network in this environment), data synthetic.
 
     python bench.py --gpus N --steps K --warmup W [--precision f32|bf16]
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Multi-GPU: clips shard across ranks (one process per GPU), no data-path collective in the eval
-path => weak scaling; value = clips of all ranks / max-over-ranks time.
+`value`: clips shard across ranks (one process per GPU); the eval path has no data-path collective (the reference's
+test_step is rank-local too) => weak scaling; value = frames of all ranks / max-over-ranks time.
 
-One JSON line on rank 0, with `roofline` (dominant kernel = the f32 MFMA GEMM; HIP-event timed
-inside the timed region by libacx's launch timer) and `cpu_baseline` (oracle on host cores,
-bounded sample, rank 0 at N=1 only).
+Extra legs, each timed like the main one (barrier + synchronize on both sides, max over ranks), reported as extra
+keys of the same JSON line:
+  * `encode_only`, `vit_chunk_256` -- ViT encode alone; the headline step with two 256-frame ViT launches (config[2]'s
+    literal batch).
+  * `head` (configs[1]) -- UCF-shaped 512-d feature sequences, B = 64 videos on one GPU: forward-only and the full
+    training step (forward, 7-term loss, backward, AdamW) in features/s, with the GEMM roofline of the training step.
+  * `dp_train` (configs[3]) -- the same training step DATA-PARALLEL over the N ranks through RCCL: gradients in
+    parallel.GradBuckets (bucketed async all-reduce, 41.7 MB), SyncBatchNorm statistics, class-parallel text
+    encoder.  `strong` = 64 videos GLOBAL (64/N per rank), `weak` = 64 videos PER RANK; step time, features/s, rank 0's
+    kernel-time breakdown of the step and the stand-alone all-reduce time of the gradient buffer.  Strong-scaling
+    efficiency = T1 / (N * TN) from the N = 1, 2, 4, 8 lines of the driver's scaling run.
+
+One JSON line on rank 0, with `roofline` (dominant kernel = the f32 MFMA GEMM; HIP-event timed inside the timed
+region by libacx's launch timer) and `cpu_baseline` (oracle on host cores, bounded sample, rank 0 at N=1 only).
 """
 import argparse
 import ctypes
@@ -40,6 +50,7 @@ GEMM_GFLOP_PER_FRAME = VIT_GFLOP_PER_FRAME - ATTN_GFLOP_PER_FRAME
 HEAD_GFLOP_PER_TILE = 10.360          # UCF head per 512-feature tile
 TEXT_GFLOP_PER_CALL = 83.43           # text encoder at 14 classes
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+HEAD_BATCH = 64                       # configs[1] / configs[3]: 64 videos x 512 features x 512-d per step
 
 
 def build_net(precision, device, vit_chunk=256):
@@ -71,7 +82,7 @@ def usable_cores():
 
 
 def cpu_baseline(sd, eot, hc):
-    """Oracle (CPU restatement of the reference path) on the host cores, bounded sample."""
+    """Oracle (CPU restatement of the reference path) on the host cores, bounded sample; both legs warmed."""
     from oracle import anomalyclip_oracle as O
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -90,17 +101,179 @@ def cpu_baseline(sd, eot, hc):
         for i in range(0, n, 32):
             O.vit_forward(sd, f[i:i + 32])
         t_vit = (time.perf_counter() - t0) / n
-        # head leg: one 512-feature tile incl. text encoder, selector, temporal, post-processing
+        # head leg: one 512-feature tile incl. text encoder, selector, temporal, post-processing (1 warm-up, median of 3)
         feats = torch.randn(1, 1, 512, 512, generator=g) * 0.3
         nc = torch.zeros(512)
-        t0 = time.perf_counter()
-        sim, sc = O.anomaly_clip_forward_test(sd, hc, feats, nc, eot, 8, 1)
-        O.eval_postprocess(sim, sc, 512)
-        t_head = (time.perf_counter() - t0) / 512
+        ts = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            sim, sc = O.anomaly_clip_forward_test(sd, hc, feats, nc, eot, 8, 1)
+            O.eval_postprocess(sim, sc, 512)
+            ts.append(time.perf_counter() - t0)
+        t_head = sorted(ts[1:])[1] / 512
     return {"value": round(1.0 / (t_vit + t_head), 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU f32 restatement): ViT-B/16 on {n} frames in batches of 32 "
                       f"({t_vit * 1e3:.1f} ms/frame) + one 512-frame head tile incl. text encoder "
-                      f"({t_head * 512 * 1e3:.0f} ms/tile)"}
+                      f"({t_head * 512 * 1e3:.0f} ms/tile, warm, median of 3)"}
+
+
+class Timer:
+    """barrier + torch.cuda.synchronize() on both sides of the timed region, MAX over ranks."""
+
+    def __init__(self, dist, dev):
+        self.dist, self.dev = dist, dev
+
+    def sync(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(self, fn, steps, warmup, on_start=None, on_stop=None):
+        for _ in range(warmup):
+            fn()
+        self.sync()
+        if on_start:
+            on_start()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.sync()
+        dt = time.perf_counter() - t0
+        if on_stop:
+            on_stop()
+        if self.dist is not None:
+            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+
+class Prof:
+    """libacx's in-library launch timer (HIP events on the launch stream around every kernel of a kind)."""
+
+    def __init__(self, local_rank):
+        from anomalyclip_amd import _lib as L
+        self.L, self.h, self.lib = L, L.ctx(local_rank), L.lib()
+
+    def start(self):
+        self.lib.acx_prof_enable(self.h, 1)
+
+    def stop(self):
+        self.lib.acx_prof_enable(self.h, 0)
+
+    def collect(self):
+        gf = ctypes.c_double(0.0)
+        self.L.check(self.lib.acx_prof_gemm_flops(self.h, ctypes.byref(gf)), self.h)
+        counts = (ctypes.c_int32 * 4)()
+        tot = (ctypes.c_double * 4)()
+        self.L.check(self.lib.acx_prof_collect(self.h, counts, tot), self.h)
+        return gf.value, list(counts), list(tot)
+
+
+def head_batch(B_global, world, rank, dev, step_seed=1):
+    """UCF-shaped synthetic batch: B videos x 512 x 512-d, first half abnormal (13 classes cycling),
+    second half normal; this rank's abnormal/normal-balanced shard as the datamodule's (nbatch, abatch) pair."""
+    from anomalyclip_amd import parallel
+    g = torch.Generator().manual_seed(step_seed)
+    feats = torch.randn(B_global, 1, 512, 512, generator=g) * 0.3
+    labels = torch.tensor([i % 13 + (1 if i % 13 >= 7 else 0) for i in range(B_global // 2)] + [7] * (B_global // 2))
+    idx = parallel.shard_videos(B_global, world, rank)
+    f_loc, l_loc = feats[idx].to(dev), labels[idx].to(dev)
+    h = len(idx) // 2
+    return ((f_loc[h:], l_loc[h:]), (f_loc[:h], l_loc[:h])), idx
+
+
+def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
+    """configs[1] (one GPU's worth of head work) and configs[3] (data-parallel training over RCCL)."""
+    from anomalyclip_amd import parallel
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    from anomalyclip_amd.components.loss import ComputeLoss
+    crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    net.load_from_features = True
+    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(dev)
+    mod.ncentroid = torch.zeros(512, device=dev)
+    opt = mod.configure_optimizers()["optimizer"]
+    prof = Prof(local_rank)
+    out = {}
+
+    def make_train(B_global, exchange=True):
+        batch, idx = head_batch(B_global, world, rank, dev)
+        step_i = [0]
+
+        def step():
+            # host mask RNG (selector_model.py:101-117): the GLOBAL batch's mask from a per-step seed, this rank's rows
+            torch.manual_seed(step_i[0])
+            step_i[0] += 1
+            m_top, m_bot = type(net.selector_model).generate_mask(net.selector_model, B_global)
+            net.selector_model.generate_mask = lambda b, mt=m_top[idx], mb=m_bot[idx]: (mt, mb)
+            mod.train_batch(batch, opt)
+        return step, batch
+
+    net.train()
+    # ---- configs[1]: one GPU, B = 64 (rank-local copy of the global batch when N > 1: not a scaling leg)
+    if world == 1:
+        step, batch = make_train(HEAD_BATCH)
+        dt = timer.run(step, steps, warmup, prof.start, prof.stop)
+        gf, counts, tot = prof.collect()
+        feats = HEAD_BATCH * 512
+        gemm_ms, n_gemm = tot[0], counts[0]
+        out["head"] = {
+            "workload": "configs[1]: 64 videos x 512 x 512-d f32, UCF head (text encoder + selector + axial temporal + "
+                        "7-term loss), one GPU",
+            "train_features_per_s": round(feats * steps / dt, 1), "train_ms_per_step": round(dt / steps * 1e3, 3),
+            "train_gemm": {"tflops": round(gf / 1e9 / gemm_ms, 2) if gemm_ms > 0 else None,
+                           "frac_of_f32_mfma_peak": round(gf / 1e9 / gemm_ms / PEAK_TFLOPS["f32"], 4) if gemm_ms > 0 else None,
+                           "launches_per_step": n_gemm // steps, "ms_per_step": round(gemm_ms / steps, 3),
+                           "executed_gflop_per_step": round(gf / 1e9 / steps, 1)},
+            "train_kernel_ms_per_step": {"gemm": round(tot[0] / steps, 3), "attention": round(tot[1] / steps, 3),
+                                         "norm_rows": round(tot[2] / steps, 3), "other": round(tot[3] / steps, 3)},
+        }
+        x = torch.cat((batch[1][0], batch[0][0]), 0).view(-1, 1, 512, 512)
+
+        def fwd():
+            with torch.no_grad():
+                net.eval()
+                net(x, None, mod.ncentroid, 1, True)
+                net.train()
+        dt = timer.run(fwd, steps, warmup)
+        out["head"]["fwd_features_per_s"] = round(feats * steps / dt, 1)
+        out["head"]["fwd_ms_per_step"] = round(dt / steps * 1e3, 3)
+
+    # ---- configs[3]: data-parallel training (N = 1 gives T1 of both curves)
+    dp = {"workload": "configs[3]: UCF-shaped 512-d feature sequences, DP training step = forward + 7-term loss + backward "
+                      "(bucketed async gradient all-reduce over RCCL, SyncBN statistics, class-parallel text encoder) + AdamW",
+          "n_gpus": world, "grad_bytes": None}
+    for mode, B_global in (("strong", HEAD_BATCH), ("weak", HEAD_BATCH * world)):
+        if (B_global // 2) % world:
+            dp[mode] = None
+            continue
+        step, _ = make_train(B_global)
+        dt = timer.run(step, steps, warmup)
+        ent = {"global_batch_videos": B_global, "videos_per_gpu": B_global // world,
+               "ms_per_step": round(dt / steps * 1e3, 3), "features_per_s": round(B_global * 512 * steps / dt, 1)}
+        # per-rank kernel-time breakdown of the same step (separate short pass: the HIP-event pairs around ~700 launches
+        # per step would otherwise sit inside the timed region above); rank 0's numbers
+        timer.run(step, 2, 0, prof.start, prof.stop)
+        _, counts, tot = prof.collect()
+        ent["rank0_kernel_ms_per_step"] = {"gemm": round(tot[0] / 2, 3), "attention": round(tot[1] / 2, 3),
+                                           "norm_rows": round(tot[2] / 2, 3), "other": round(tot[3] / 2, 3),
+                                           "launches": sum(counts) // 2}
+        dp[mode] = ent
+    if mod._buckets is not None:
+        flat = mod._buckets.flat
+        dp["grad_bytes"] = flat.numel() * 4
+        if world > 1:
+            def ar():
+                dist.all_reduce(flat)
+            dt = timer.run(ar, 20, 3)
+            dp["allreduce_grad_buffer_ms"] = round(dt / 20 * 1e3, 4)
+            dp["allreduce_bus_GBps"] = round(2 * (world - 1) / world * flat.numel() * 4 / (dt / 20) / 1e9, 1)
+            mod._buckets.zero()
+    out["dp_train"] = dp
+    net.load_from_features = False
+    net.eval()
+    return out
 
 
 def main():
@@ -110,6 +283,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (profiling runs)")
     ap.add_argument("--vit-chunk", type=int, default=512, help="frames per ViT launch (default: the whole 512-frame clip)")
     args = ap.parse_args()
 
@@ -124,50 +298,55 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from anomalyclip_amd import _lib as L
     from anomalyclip_amd import ops
 
     net, sd, eot, hc = build_net(args.precision, dev, args.vit_chunk)
     g = torch.Generator(device=dev).manual_seed(2 + rank)
     frames = torch.randn(1, FRAMES_PER_CLIP, 3, 224, 224, generator=g, device=dev)      # resident in HBM
     nc = torch.zeros(512, device=dev)
+    timer = Timer(dist, dev)
+    prof = Prof(local_rank)
 
     def step():
         with torch.no_grad():
             sim, sc = net(frames, None, nc, 1, True)
             return ops.class_probs(sim, sc), sc
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    out_holder = {}
 
-    for _ in range(args.warmup):
-        step()
-    h = L.ctx(local_rank)
-    lib = L.lib()
-    sync_all()
-    lib.acx_prof_enable(h, 1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        probs, sc = step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    lib.acx_prof_enable(h, 0)
-    gflops_exec = ctypes.c_double(0.0)
-    L.check(lib.acx_prof_gemm_flops(h, ctypes.byref(gflops_exec)), h)
-    counts = (ctypes.c_int32 * 4)()
-    tot = (ctypes.c_double * 4)()
-    L.check(lib.acx_prof_collect(h, counts, tot), h)
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def step_keep():
+        out_holder["o"] = step()
+
+    # ---- headline: EXACTLY --steps timed steps after --warmup untimed ones
+    dt = timer.run(step_keep, args.steps, args.warmup, prof.start, prof.stop)
+    gflops_exec, counts, tot = prof.collect()
+    probs, sc = out_holder["o"]
     assert torch.isfinite(sc).all() and torch.isfinite(probs).all()
+
+    extra = {}
+    if not args.no_extra_legs:
+        k = max(2, min(args.steps, 5))
+        # encode-only
+        flat_frames = frames.view(-1, 3, 224, 224)
+
+        def enc():
+            with torch.no_grad():
+                net.image_encoder(flat_frames)
+        dte = timer.run(enc, k, 1)
+        extra["encode_only"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dte, 2), "ms_per_clip": round(dte / k * 1e3, 3)}
+        if args.vit_chunk != 256:
+            net.image_encoder.chunk = 256
+            dt256 = timer.run(step_keep, k, 1)
+            net.image_encoder.chunk = args.vit_chunk
+            extra["vit_chunk_256"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt256, 2),
+                                      "ms_per_step": round(dt256 / k * 1e3, 3),
+                                      "note": "config[2]'s literal batch: two 256-frame ViT launches per clip"}
+        if args.precision == "f32":
+            extra.update(head_legs(net, dev, dist, rank, world, local_rank, max(4, min(args.steps, 10)), 2, timer))
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -183,20 +362,23 @@ def main():
         # The last ViT layer is evaluated only where its output is consumed (CLS token, clip/model.py:285), so
         # the GEMM kernel EXECUTES fewer flops than the reference's dense formulation: the roofline uses the
         # flops the launches really computed (2*M*N*K summed by libacx), the dense figure is reported beside it.
-        gemm_gflop_exec_step = gflops_exec.value / 1e9 / args.steps
+        gemm_gflop_exec_step = gflops_exec / 1e9 / args.steps
         flop_per_launch = gemm_gflop_exec_step * args.steps / max(n_gemm, 1)  # GFLOP per launch (average)
         achieved = flop_per_launch / avg_ms if avg_ms > 0 else 0.0           # GFLOP/ms == TFLOP/s
         peak = PEAK_TFLOPS[args.precision]
         # HBM traffic of the dominant kernel: PMC counters cannot be read in-process; they are collected by
         # tools/profile_bench.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
         # FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/.
-        traffic = None
-        pmc_file = os.path.join(REPO, "profiles", "r01_bench_f32_pmc.json")
-        if args.precision == "f32" and args.vit_chunk == 512 and os.path.exists(pmc_file):
-            try:
-                traffic = round(json.load(open(pmc_file))["gemm"]["hbm_bytes_per_launch"])
-            except Exception:
-                traffic = None
+        traffic, pmc_src = None, None
+        for tag in ("r02", "r01"):
+            pmc_file = os.path.join(REPO, "profiles", f"{tag}_bench_f32_pmc.json")
+            if args.precision == "f32" and args.vit_chunk == 512 and os.path.exists(pmc_file):
+                try:
+                    traffic = round(json.load(open(pmc_file))["gemm"]["hbm_bytes_per_launch"])
+                    pmc_src = f"profiles/{tag}_bench_f32_pmc.json (rocprofv3 PMC passes of this command, bytes per launch)"
+                    break
+                except Exception:
+                    traffic = None
         out = {
             "metric": "frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,7 +391,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_f32_w8_kernel / gemm_kernel, v_mfma_f32_32x32x2_f32)"
                          if args.precision == "f32" else "acx_gemm (gemm_bf16_ring_kernel / gemm_bf16_dma_kernel / gemm_kernel, v_mfma_f32_32x32x16_bf16)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": traffic, "traffic_source": "profiles/r01_bench_f32_pmc.json (rocprofv3 PMC, bytes per launch)" if traffic else None, "launches": int(n_gemm), "avg_launch_ms": round(avg_ms, 4),
+                         "traffic": traffic, "traffic_source": pmc_src, "launches": int(n_gemm), "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_gflop_per_launch": round(flop_per_launch, 3),
                          "gemm_gflop_per_step_executed": round(gemm_gflop_exec_step, 1),
                          "gemm_gflop_per_step_dense_reference": round(gemm_gflop_step, 1)},
@@ -218,6 +400,7 @@ def main():
             "end_to_end_tflops": round((VIT_GFLOP_PER_FRAME * FRAMES_PER_CLIP + TEXT_GFLOP_PER_CALL + HEAD_GFLOP_PER_TILE)
                                        * world / ms_per_step, 2),
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, eot, hc)
         print(json.dumps(out))

@@ -48,6 +48,41 @@ def _worker(rank, world, port, q):
     # --- sharding covers the batch exactly once
     idx = parallel.shard_videos(8, world, rank)
     ok &= idx == ([0, 1, 4, 5] if rank == 0 else [2, 3, 6, 7])
+    # --- class-parallel text features (functional.TextFeaturesFn): the exchange logic with the libacx row
+    # functions swapped for a torch toy of the same contract (rows independent per class).  Expected result: the
+    # data-parallel mean over ranks of the gradients of each rank's own loss, as the reference's DDP produces.
+    ok &= [parallel.shard_range(14, 8, r) for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 13), (13, 14)]
+    from types import SimpleNamespace
+    from anomalyclip_amd.components import functional as Fn
+    C, d, e = 5, 6, 4
+    gen = torch.Generator().manual_seed(7)
+    ctx0, P0 = torch.randn(C, 3, d, generator=gen), torch.randn(d, e, generator=gen)
+    wr = [torch.randn(C, e, generator=gen) for _ in range(world)]           # rank r's loss = sum(T * wr[r])
+
+    def toy_fwd(net, ctx_param, P, lo, hi):
+        return torch.tanh(ctx_param.detach()[lo:hi].sum(1)) @ P.detach(), (lo, hi)
+
+    def toy_bwd(net, P, state, d_tf):
+        lo, hi = state
+        with torch.enable_grad():
+            c = net.prompt_learner.ctx.detach()[lo:hi].clone().requires_grad_(True)
+            Pp = P.detach().clone().requires_grad_(True)
+            (torch.tanh(c.sum(1)) @ Pp).backward(d_tf)
+        return c.grad, Pp.grad
+
+    Fn._text_forward_rows, Fn._text_backward_rows = toy_fwd, toy_bwd
+    ctxp, Pp = torch.nn.Parameter(ctx0.clone()), torch.nn.Parameter(P0.clone())
+    net = SimpleNamespace(prompt_learner=SimpleNamespace(n_cls=C, ctx=ctxp))
+    gb2 = parallel.GradBuckets([ctxp, Pp])
+    gb2.zero()
+    T = Fn.TextFeaturesFn.apply(ctxp, Pp, net, True)
+    (T * wr[rank]).sum().backward()
+    gb2.finish()
+    c_ref, P_ref = ctx0.clone().requires_grad_(True), P0.clone().requires_grad_(True)
+    T_ref = torch.tanh(c_ref.sum(1)) @ P_ref
+    (sum((T_ref * w).sum() for w in wr) / world).backward()
+    ok &= torch.allclose(T.detach(), T_ref.detach(), atol=1e-6)
+    ok &= torch.allclose(ctxp.grad, c_ref.grad, atol=1e-6) and torch.allclose(Pp.grad, P_ref.grad, atol=1e-6)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -204,3 +204,136 @@ def test_lightning_checkpoint_round_trip(tmp_path, prompts_table):
             assert torch.equal(vb, va.half().float())
         else:
             assert torch.equal(va, vb), ka
+
+
+# ====================================================================================================== operator surface
+def _config_keys():
+    import json
+    return json.load(open(os.path.join(REPO, "tests", "golden", "config_keys.json")))
+
+
+def test_module_hook_signatures_match_reference():
+    """drop-in boundary, Python half: every hook pytorch_lightning.Trainer calls on the reference's AnomalyCLIPModule
+    exists here with the SAME positional argument names (fixture: names parsed from the reference with `ast`), the
+    same **kwargs constructor and the same @rank_zero_only hooks (anomaly_clip_module.py:46-53,134,203,301,339,406,
+    458,501,693)."""
+    import inspect
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP
+    from anomalyclip_amd.components.loss import ComputeLoss
+    hooks = _config_keys()["module_hooks"]
+    for name, spec in hooks.items():
+        owner = {"AnomalyCLIP.forward": AnomalyCLIP.forward, "ComputeLoss.__call__": ComputeLoss.__call__}.get(name)
+        fn = owner if owner is not None else getattr(AnomalyCLIPModule, name)
+        sig = inspect.signature(inspect.unwrap(fn))
+        params = list(sig.parameters.values())
+        pos = [p.name for p in params if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        assert pos[:len(spec["args"])] == spec["args"], (name, pos, spec["args"])
+        # anything beyond the reference's arguments must be optional (the Trainer never passes it)
+        for p in params[len(spec["args"]):]:
+            assert p.default is not p.empty or p.kind in (p.VAR_KEYWORD, p.VAR_POSITIONAL), (name, p.name)
+        if spec["kwarg"]:
+            assert any(p.kind == p.VAR_KEYWORD for p in params), name
+        if "rank_zero_only" in spec["decorators"]:
+            assert hasattr(fn, "__wrapped__"), f"{name} must be @rank_zero_only"
+
+
+@pytest.mark.parametrize("key", ["ucf", "sht", "xd"])
+def test_module_builds_from_reference_config_blocks(key, tmp_path):
+    """`net:` / `loss:` / `solver:` / `optimizer:` / `scheduler:` blocks of the reference's three model configs (fixture
+    copies of keys + scalar values, `${data.*}` resolved) instantiate the mirrors unchanged -- including the keys the
+    reference's code never reads (`dropout_prob`, `temporal_module`, ...) and `labels_file` paths that do not exist here."""
+    from functools import partial
+    from types import SimpleNamespace
+    from anomalyclip_amd import init_weights as IW
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP
+    from anomalyclip_amd.components.loss import ComputeLoss
+    from anomalyclip_amd.components.scheduler import WarmupCosineAnnealingLR
+    from anomalyclip_amd.optim import AcxAdamW
+    cfg = _config_keys()["configs"][key]
+    net_kw = {k: v for k, v in cfg["net"].items() if k != "_target_"}
+    assert cfg["net"]["_target_"] == "src.models.components.anomaly_clip.AnomalyCLIP"
+    net = AnomalyCLIP(**net_kw, clip_geometry=IW.TINY)          # tiny CLIP geometry: construction only, no 150 M-param init
+    assert len(net.classnames) == cfg["num_classes"] and net.normal_id == cfg["data"]["normal_id"]
+    hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD, "xd": IW.XD_HEAD}[key]
+    assert (net.emb_size, net.depth, net.heads, net.concat_features) == (hc.emb_size, hc.depth, hc.heads, hc.concat_features)
+    assert net.temporal_model.input_size == net.embedding_dim + (cfg["num_classes"] - 1) * int(cfg["net"]["concat_features"])
+    loss = ComputeLoss(**{k: v for k, v in cfg["loss"].items() if k != "_target_"})
+    opt_kw = {k: v for k, v in cfg["optimizer"].items() if not k.startswith("_")}
+    sch_kw = {k: v for k, v in cfg["scheduler"].items() if not k.startswith("_")}
+    mod = AnomalyCLIPModule(net=net, optimizer=partial(AcxAdamW, **opt_kw), scheduler=partial(WarmupCosineAnnealingLR, **sch_kw),
+                            loss=loss, num_classes=cfg["num_classes"], solver=cfg["solver"], save_dir=str(tmp_path))
+    assert mod.hparams.num_classes == cfg["num_classes"] and mod.hparams.solver.lr == cfg["solver"]["lr"]
+    # frozen backbone, trainable set (anomaly_clip_module.py:68-74)
+    assert not any(p.requires_grad for p in net.image_encoder.parameters())
+    assert net.text_encoder.text_projection.requires_grad and net.prompt_learner.ctx.requires_grad
+    assert not any(p.requires_grad for n, p in net.text_encoder.named_parameters() if n != "text_projection")
+    object.__setattr__(mod, "trainer", SimpleNamespace(max_epochs=50, current_epoch=0, datamodule=None, ckpt_path=None))
+    out = mod.configure_optimizers()                              # no arguments, like the Trainer calls it
+    groups = out["optimizer"].param_groups
+    assert [g["name"] for g in groups] == ["selector_model", "temporal_model", "prompt_learner", "text_projection"]
+    assert all(abs(g["initial_lr"] - cfg["solver"]["lr"]) < 1e-12 and g["weight_decay"] == 0.2 for g in groups)
+    assert out["lr_scheduler"]["interval"] == "epoch" and out["lr_scheduler"]["monitor"] == "train/loss"
+    assert isinstance(out["lr_scheduler"]["scheduler"], WarmupCosineAnnealingLR)
+
+
+def test_builtin_trainer_calls_hooks_in_lightning_order(tmp_path):
+    """anomalyclip_amd.trainer.Trainer drives a module exactly through the hooks above (stub module: no kernels)."""
+    from types import SimpleNamespace
+    from anomalyclip_amd.trainer import Trainer
+    calls = []
+
+    class Stub:
+        device = torch.device("cpu")
+        hparams = {}
+        net = SimpleNamespace(train=lambda: calls.append("net.train"), eval=lambda: calls.append("net.eval"),
+                              state_dict=lambda: {})
+
+        def configure_optimizers(self):
+            calls.append("configure_optimizers")
+            return {"optimizer": "OPT"}
+
+        def on_train_start(self):
+            calls.append("on_train_start")
+
+        def train_batch(self, batch, opt, i):
+            assert opt == "OPT" and len(batch) == 2            # (nbatch, abatch) zipped from the two loaders
+            calls.append(f"train_batch{i}")
+
+        def on_train_epoch_end(self):
+            calls.append("on_train_epoch_end")
+
+        def validation_step(self, batch, i):
+            calls.append(f"validation_step{i}")
+
+        def on_validation_epoch_end(self):
+            calls.append("on_validation_epoch_end")
+            return {"auc_roc": 0.5}
+
+        def on_test_start(self):
+            calls.append("on_test_start")
+
+        def test_step(self, batch, i):
+            calls.append(f"test_step{i}")
+            return {"i": i}
+
+        def test_epoch_end(self, outputs):
+            calls.append(f"test_epoch_end{len(outputs)}")
+            return {"ok": 1}
+
+    dm = SimpleNamespace(setup=lambda stage: calls.append("setup:" + stage),
+                         train_dataloader=lambda: [[("n0", 0), ("n1", 1)], [("a0", 0), ("a1", 1)]],
+                         val_dataloader=lambda: [1, 2], test_dataloader=lambda: [1, 2, 3])
+    tr = Trainer(max_epochs=1, accelerator="gpu", devices=4, strategy="ddp", sync_batchnorm=True, num_sanity_val_steps=0,
+                 default_root_dir=str(tmp_path))
+    m = Stub()
+    tr.fit(m, dm)
+    assert calls == ["setup:fit", "configure_optimizers", "on_train_start", "net.train", "train_batch0", "train_batch1",
+                     "on_train_epoch_end", "net.eval", "validation_step0", "validation_step1", "on_validation_epoch_end"]
+    assert m.trainer is tr and tr.datamodule is dm and os.path.isfile(tr.ckpt_path)
+    ck = torch.load(tr.ckpt_path, weights_only=False)
+    assert set(ck) >= {"state_dict", "epoch", "global_step", "hyper_parameters"} and ck["global_step"] == 2
+    calls.clear()
+    assert tr.test(m, dm) == [{"ok": 1}]
+    assert calls == ["setup:test", "net.eval", "on_test_start", "test_step0", "test_step1", "test_step2", "test_epoch_end3"]

@@ -112,7 +112,8 @@ def test_gemm_f32_w8_benchmark_shapes(M, N, K, act, res):
     scale = a.double().norm(dim=1, keepdim=True) * w.double().norm(dim=1).view(1, -1) + bias.double().abs() + 1.0
     err = ((out.double() - ref).abs() / scale).max().item()
     assert err < 2e-6, err
-    assert relerr(out, ref) < 2e-6
+    # max|err| / max|ref|: f32 accumulation round-off grows ~sqrt(K) (guide: 1e-7 .. 3.5e-7 of sum|a.b| for K = 1k .. 4k)
+    assert relerr(out, ref) < 2e-6 * max(1.0, K / 768) ** 0.5 * 1.5
 
 
 @pytest.mark.parametrize("cin,cout,act,res", [(256, 1024, 2, 0), (1024, 256, 0, 1)])

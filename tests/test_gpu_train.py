@@ -449,3 +449,67 @@ def test_train_batch_gradbuckets_rccl_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_builtin_trainer_fit_and_test_end_to_end(tmp_path, prompts_table):
+    """The module's Trainer-called hooks on the device, driven by anomalyclip_amd.trainer.Trainer with a synthetic
+    datamodule of the reference's shape: on_train_start() computes ncentroid.pt from
+    trainer.datamodule.train_dataloader_test_mode() (4-tuples), two training batches from the [normal, abnormal] loader
+    pair, validation (4-tuples) -> metrics_0.json, last.ckpt, then test (5-tuples) -> metrics.json; the numbers equal
+    a direct evaluation of the same videos."""
+    import json
+    from types import SimpleNamespace
+    from anomalyclip_amd import metrics as M
+    from anomalyclip_amd.trainer import Trainer
+    mod, net = _dp_module(prompts_table, seed=41)
+    D = IW.TINY.embed_dim
+    mod.hparams["save_dir"] = str(tmp_path / "train_run")
+    mod.hparams["logs_root"] = str(tmp_path / "logs")
+    g = torch.Generator().manual_seed(8)
+    normal_videos = [(torch.randn(1, 1, 512 * s, D, generator=g) * 0.3 + 0.05, torch.full((1, n), 7), 7, s) for s, n in ((1, 400), (2, 900))]
+
+    def tv(s, n, cls):
+        lab = torch.full((1, n), 7)
+        if cls != 7:
+            lab[0, n // 3: 2 * n // 3] = cls
+        return torch.randn(1, 1, 512 * s, D, generator=g) * 0.3, lab, cls, s
+
+    test_videos = [tv(1, 500, 1), tv(2, 1000, 7), tv(1, 512, 12), tv(1, 300, 3)]
+    feats, labels, _ = _dp_batch(4, D, 77)
+    dm = SimpleNamespace(
+        hparams=SimpleNamespace(load_from_features=True, normal_id=7, visualize=False, labels_file="ucf_labels.csv"),
+        num_classes=14,
+        train_dataloader_test_mode=lambda: normal_videos,
+        train_dataloader=lambda: [[(feats[2:], labels[2:])] * 2, [(feats[:2], labels[:2])] * 2],
+        val_dataloader=lambda: test_videos,
+        test_dataloader=lambda: [v + (f"video{i}",) for i, v in enumerate(test_videos)])
+    tr = Trainer(max_epochs=1, default_root_dir=str(tmp_path / "train_run"), strategy="ddp", sync_batchnorm=True)
+    w0 = net.temporal_model.projection.weight.clone()
+    tr.fit(mod, dm)
+    nc_file = tmp_path / "train_run" / "ncentroid.pt"
+    assert nc_file.is_file()
+    ref_nc = O.ncentroid_from_features([v[0].reshape(-1, D)[:v[1].shape[1]] for v in normal_videos])
+    assert relerr(torch.load(nc_file), ref_nc) < 1e-5
+    assert not torch.equal(w0, net.temporal_model.projection.weight)                 # two optimisation steps happened
+    assert mod.train_loss.count == 2 and torch.isfinite(mod.train_loss.compute())
+    assert set(mod.logged) >= {"train/loss", "train/dir_abn_loss", "train/sparse_loss", "test/AUC", "test/mAP"}
+    m0 = json.load(open(tmp_path / "train_run" / "metrics_0.json"))
+    assert set(m0) == {"epoch", "auc_roc", "auc_pr", "mean_mc_auroc", "mean_mc_aupr", "mc_auroc", "mc_aupr", "optimal_threshold"}
+    assert mod.labels == [] and mod.abnormal_scores == []                            # cleared (:402-404)
+    ckpt = tmp_path / "train_run" / "checkpoints" / "last.ckpt"
+    assert ckpt.is_file()
+    # eval run from the checkpoint, fresh module: on_test_start finds ncentroid under <logs>/train/runs/<ckpt parent>
+    mod2, net2 = _dp_module(prompts_table, seed=5)
+    mod2.hparams["logs_root"] = str(tmp_path / "logs")
+    run_train = tmp_path / "logs" / "train" / "runs" / "checkpoints"
+    run_train.mkdir(parents=True)
+    torch.save(torch.load(nc_file), run_train / "ncentroid.pt")
+    res = Trainer().test(mod2, dm, ckpt_path=str(ckpt))
+    m = json.load(open(tmp_path / "logs" / "eval" / "runs" / "checkpoints" / "metrics.json"))
+    assert res and set(m) == set(m0) | {"top1_accuracy", "top5_accuracy"}
+    for k in ("auc_roc", "auc_pr", "mean_mc_auroc", "optimal_threshold"):
+        assert m[k] == m0[k] or (m[k] != m[k] and m0[k] != m0[k]), k                  # same weights, same videos
+    # against a direct evaluation
+    outs = [mod2._score_video(v) for v in test_videos]
+    r = M.evaluate(torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]), 7, 14)
+    assert r["auc_roc"] == m["auc_roc"] and r["auc_pr"] == m["auc_pr"]

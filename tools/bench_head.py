@@ -1,22 +1,69 @@
 #!/usr/bin/env python
-"""Secondary benchmark: UCF-Crime-shaped synthetic 512-d feature sequences through
+"""Secondary benchmark (BASELINE.json configs[1] and [3]): UCF-Crime-shaped synthetic 512-d feature sequences through
 the head -- text encoder + selector + axial temporal transformer + loss, forward-only and full training step
-(forward, 7-term loss, backward, AdamW) -- features/s = videos * 512 * steps / time.
+(forward, 7-term loss, backward, AdamW) -- features/s = videos * 512 * steps / time.  bench.py runs the same legs
+(`head`, `dp_train`) inside the driver's command; this tool adds knobs for development:
 
     python tools/bench_head.py [--batch 64] [--steps 10] [--warmup 2]
     python -m torch.distributed.run --nproc-per-node N tools/bench_head.py --gpus N [--scaling strong|weak]
+    python tools/bench_head.py --emulate-world 8      # ONE GPU: rank 0's share of an 8-rank strong-scaling step
+                                                      # (8 videos, 2 of 14 text classes, collectives stubbed out):
+                                                      # per-rank compute + launch overhead = the efficiency ceiling
 
 Data parallel: videos shard across ranks (parallel.shard_videos), gradients through parallel.GradBuckets
-(bucketed async all-reduce over RCCL), SyncBN statistics inside the selector.  One JSON line on rank 0."""
+(bucketed async all-reduce over RCCL), SyncBN statistics inside the selector, text encoder class-parallel.
+One JSON line on rank 0."""
 import argparse
 import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def stub_collectives(world):
+    """single-process stand-in for torch.distributed inside anomalyclip_amd.parallel (timing of rank 0's share only)."""
+    from anomalyclip_amd import parallel
+
+    class _H:
+        def wait(self):
+            return None
+
+    class _Dist:
+        ReduceOp = SimpleNamespace(SUM=0, MAX=1)
+
+        @staticmethod
+        def all_reduce(t, op=None, async_op=False):
+            return _H() if async_op else None
+
+        @staticmethod
+        def all_gather(lst, t):
+            for x in lst:
+                x.copy_(t)
+
+        @staticmethod
+        def get_world_size():
+            return world
+
+        @staticmethod
+        def get_rank():
+            return 0
+
+        @staticmethod
+        def is_available():
+            return True
+
+        @staticmethod
+        def is_initialized():
+            return True
+
+    parallel.dist = _Dist
+    parallel.is_distributed = lambda: True
 
 
 def main():
@@ -26,77 +73,68 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--emulate-world", type=int, default=0)
+    ap.add_argument("--no-text-shard", action="store_true", help="replicate the text encoder on every rank (plain DP)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
+    dist = None
     if world > 1:
+        import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from anomalyclip_amd import init_weights as IW, parallel
+    import bench as B
+    from anomalyclip_amd import parallel
     from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
-    from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP, lookup_prompts
     from anomalyclip_amd.components.loss import ComputeLoss
-    from anomalyclip_amd.optim import AcxAdamW
 
-    hc = IW.UCF_HEAD
-    toks = torch.tensor(lookup_prompts(key="ucf")["tokenized_prompts"], dtype=torch.int32)
-    net = AnomalyCLIP(arch="ViT-B/16", labels_key="ucf", emb_size=256, depth=1, heads=8, dim_heads=None, num_segments=32,
-                      seg_length=16, concat_features=False, normal_id=7, stride=1, load_from_features=True,
-                      select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, ncrops=1, num_topk=3, num_bottomk=3)
-    net.load_state_dict(IW.init_anomalyclip_state_dict(IW.VIT_B16, hc, toks, seed=0), strict=True)
+    net, sd, eot, hc = B.build_net("f32", dev)
+    net.load_from_features = True
+    net.text_class_parallel = not args.no_text_shard
     crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
     mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(dev)
     mod.ncentroid = torch.zeros(512, device=dev)
     opt = mod.configure_optimizers()["optimizer"]
+    timer = B.Timer(dist, dev)
+    prof = B.Prof(local_rank)
 
-    B_global = args.batch if args.scaling == "strong" else args.batch * world
-    g = torch.Generator().manual_seed(1)
-    feats = torch.randn(B_global, 1, 512, 512, generator=g) * 0.3
-    labels = torch.tensor([i % 13 + (1 if i % 13 >= 7 else 0) for i in range(B_global // 2)] + [7] * (B_global // 2))
-    idx = parallel.shard_videos(B_global, world, rank)
-    f_loc, l_loc = feats[idx].to(dev), labels[idx].to(dev)
-    h = len(idx) // 2
-    batch = ((f_loc[h:], l_loc[h:]), (f_loc[:h], l_loc[:h]))
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def timed(fn):
-        for _ in range(args.warmup):
-            fn()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fn()
-        sync()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+    eff_world = world
+    if args.emulate_world > 1:
+        assert world == 1
+        eff_world = args.emulate_world
+    B_global = args.batch if args.scaling == "strong" else args.batch * eff_world
+    batch, idx = B.head_batch(B_global, eff_world, rank, dev)
+    if args.emulate_world > 1:
+        stub_collectives(eff_world)
 
     net.train()
     step_i = [0]
 
     def train_step():
-        torch.manual_seed(step_i[0])          # host mask RNG, identical on every rank then sharded implicitly by video
+        torch.manual_seed(step_i[0])          # host mask RNG: the global batch's mask, this rank's rows
         step_i[0] += 1
+        mt, mb = type(net.selector_model).generate_mask(net.selector_model, B_global)
+        net.selector_model.generate_mask = lambda b, mt=mt[idx], mb=mb[idx]: (mt, mb)
         mod.train_batch(batch, opt)
+
+    x = torch.cat((batch[1][0], batch[0][0]), 0).view(-1, 1, 512, 512)
 
     def fwd_step():
         with torch.no_grad():
             net.eval()
-            x = torch.cat((batch[1][0], batch[0][0]), 0)
-            net(x.view(-1, 1, 512, 512), None, mod.ncentroid, 1, True)
+            net(x, None, mod.ncentroid, 1, True)
             net.train()
 
-    dt_train = timed(train_step)
-    dt_fwd = timed(fwd_step)
+    dt_train = timer.run(train_step, args.steps, args.warmup)
+    timer.run(train_step, 2, 0, prof.start, prof.stop)
+    gf, counts, tot = prof.collect()
+    dt_fwd = timer.run(fwd_step, args.steps, args.warmup)
+    # host-side cost of issuing one step (no device wait inside): launch-bound when close to ms_per_step
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    train_step()
+    host_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
     if rank == 0:
         feats_per_step = B_global * 512
         print(json.dumps({
@@ -105,7 +143,14 @@ def main():
             "train_ms_per_step": round(dt_train / args.steps * 1e3, 3),
             "fwd_features_per_s": round(feats_per_step * args.steps / dt_fwd, 1),
             "fwd_ms_per_step": round(dt_fwd / args.steps * 1e3, 3),
-            "n_gpus": world, "global_batch_videos": B_global, "scaling": args.scaling, "dtype": "f32",
+            "host_issue_ms_per_train_step": round(host_ms, 3),
+            "kernel_ms_per_train_step": {"gemm": round(tot[0] / 2, 3), "attention": round(tot[1] / 2, 3),
+                                         "norm_rows": round(tot[2] / 2, 3), "other": round(tot[3] / 2, 3),
+                                         "launches": sum(counts) // 2},
+            "train_gemm_tflops": round(gf / 1e9 / tot[0], 2) if tot[0] > 0 else None,
+            "n_gpus": world, "emulated_world": args.emulate_world or None, "videos_this_rank": len(idx),
+            "text_class_parallel": bool(net.text_class_parallel),
+            "global_batch_videos": B_global, "scaling": args.scaling, "dtype": "f32",
             "loss": float(mod.last_losses[0]), "data": "synthetic"}))
     if world > 1:
         dist.barrier()
