@@ -214,8 +214,13 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
     # ---- configs[1]: one GPU, B = 64 (rank-local copy of the global batch when N > 1: not a scaling leg)
     if world == 1:
         step, batch = make_train(HEAD_BATCH)
-        dt = timer.run(step, steps, warmup, prof.start, prof.stop)
+        dt = timer.run(step, steps, warmup)
+        # kernel breakdown / GEMM roofline from a separate profiled pass (HIP-event pairs around ~400 launches per step
+        # cost ~3 ms per step and must not sit inside the features/s measurement)
+        psteps = 3
+        timer.run(step, psteps, 0, prof.start, prof.stop)
         gf, counts, tot = prof.collect()
+        gf, counts, tot = gf * steps / psteps, [c * steps // psteps for c in counts], [t * steps / psteps for t in tot]
         feats = HEAD_BATCH * 512
         gemm_ms, n_gemm = tot[0], counts[0]
         out["head"] = {

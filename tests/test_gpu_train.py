@@ -513,3 +513,29 @@ def test_builtin_trainer_fit_and_test_end_to_end(tmp_path, prompts_table):
     outs = [mod2._score_video(v) for v in test_videos]
     r = M.evaluate(torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]), 7, 14)
     assert r["auc_roc"] == m["auc_roc"] and r["auc_pr"] == m["auc_pr"]
+
+
+@pytest.mark.parametrize("geom", ["tiny", "ViT-B/16"])
+def test_text_features_class_blocks_equal_full(prompts_table, geom):
+    """the class-parallel text path on ONE device: evaluating the classes in the blocks an 8- (or 3-) rank job would
+    own and exchanging by hand -- rows concatenated forward, d_ctx blocks placed and d_text_projection partials summed
+    backward -- equals the unsharded function (different GEMM tilings for 2 x 77 rows: round-off only)."""
+    from anomalyclip_amd import parallel
+    from anomalyclip_amd.components import functional as Fn
+    mod, net = _dp_module(prompts_table, seed=13, geom=geom)
+    ctxp, P = net.prompt_learner.ctx, net.text_encoder.text_projection
+    C = net.prompt_learner.n_cls
+    full, st = Fn._text_forward_rows(net, ctxp, P, 0, C)
+    d_tf = torch.randn(full.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    d_ctx_full, d_P_full = Fn._text_backward_rows(net, P, st, d_tf)
+    for world in (8, 3):
+        rows, d_ctx, d_P = [], torch.zeros_like(ctxp), torch.zeros_like(P)
+        for r in range(world):
+            lo, hi = parallel.shard_range(C, world, r)
+            tf, st = Fn._text_forward_rows(net, ctxp, P, lo, hi)
+            rows.append(tf)
+            dc, dp = Fn._text_backward_rows(net, P, st, d_tf[lo:hi])
+            d_ctx[lo:hi] = dc
+            d_P += dp
+        assert relerr(torch.cat(rows), full) < 2e-6
+        assert relerr(d_ctx, d_ctx_full) < 2e-5 and relerr(d_P, d_P_full) < 2e-5
