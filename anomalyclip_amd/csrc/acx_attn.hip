@@ -198,6 +198,244 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __re
 }
 
 
+// =====================================================================================================
+// attn16_kernel -- exact-f32 attention for the ViT sequence (non-causal, 129 <= L <= 256; L = 197 for ViT-B/16).
+//
+// What limited attn_kernel<7,8> (0.43 of the f32 MFMA roof): 197 tokens padded to 7 x 32 (29 % padded MFMA work),
+// 7 query blocks on 4 SIMDs, and ONE 112 KiB workgroup per CU, so nothing overlaps a workgroup's K/V staging,
+// softmax or store phases.  This kernel
+//   * tiles with v_mfma_f32_16x16x4_f32: 197 -> 13 x 16 = 208 (11 % padding); a wave owns TWO 16-query tiles (one
+//     K / V fragment read feeds both), 7 waves per (frame, head) workgroup;
+//   * streams K and V through LDS in 32-key chunks (16 KB per stage, two stages) by LDS-DMA (global_load_lds_dwordx4,
+//     bank swizzle of K on the SOURCE address), flash-style online softmax in between -- 32 KB of LDS and <= 128 VGPRs,
+//     so TWO workgroups share a CU: one workgroup's DMA waits, barriers, softmax VALU work and output stores sit
+//     under the other's MFMAs;
+//   * keeps the transposed-score trick: S^T = K Q^T puts a lane's QUERY in the MFMA column (lane & 15), so row
+//     max / sum are per-lane scalars (+ two cross-row exchanges, v_permlane16/32_swap: no LDS), P^T registers are
+//     directly the B operand of O^T = V^T P^T, and with the output-column permutation d = 4 i + e (MFMA e of a group
+//     computes output tile e) one ds_read_b128 of V feeds four MFMAs per query tile and a lane ends up with 16
+//     CONTIGUOUS floats of its query's output row.
+// Online softmax changes the summation order and the scaling sequence only (exp(s - m) rescaled by exp(m - m')):
+// differences to the two-pass form are f32 round-off (tests: 3e-6 against fp64).
+#ifndef ACX_A16_KT
+#define ACX_A16_KT 2
+#endif
+constexpr int A16_KT = ACX_A16_KT;                  // 16-key tiles per staged chunk
+constexpr int A16_CHUNK = 16 * A16_KT;              // keys per staged chunk
+constexpr int A16_OP_B = A16_CHUNK * 256;           // one operand chunk: rows of 64 f32
+constexpr int A16_STAGE_B = 2 * A16_OP_B;           // K | V
+
+typedef __attribute__((address_space(3))) void a16_lds_t;
+
+// max / sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): v_permlane16_swap exchanges odd rows of
+// its first operand with even rows of the second, v_permlane32_swap the upper half of the first with the lower half
+// of the second; with both operands = x the two results hold x of this row pair's even and odd member.
+typedef unsigned a16_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float a16_rowmax(float x) {
+  a16_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float a16_rowsum(float x) {
+  a16_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// One wave's share of a workgroup's items.  HB: the wave owns two query tiles (ta, tb) or one (ta).
+template <bool HB, int NW>
+__device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out, int64_t ldo,
+                                        int L, int heads, int nitems, char* smem, int ta, int tb) {
+  const int W = heads * 64;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  constexpr int nw = NW;                            // waves per workgroup
+  const int qi = lane & 15, g = lane >> 4;
+  const int nkt = (L + 15) >> 4;                    // 16-key tiles ( = 16-query tiles)
+  const int nch = (nkt + A16_KT - 1) / A16_KT;      // chunks
+
+  // ---- DMA plan: a chunk is 8 KT wave-instructions of 1 KB (4 rows x 256 B): first the K rows, then the V rows;
+  // wave w issues instructions w, w + nw, ... (8 KT instructions per chunk, nw = 8 waves).  K: LDS slot p of row r holds source slot p ^ (r & 15).
+  // The DMA goes through inline asm: hipcc (ROCm 7.2) treats a global_load_lds it can see as a pending LDS write that may
+  // alias EVERY later ds_read and drains it (s_waitcnt vmcnt(0)) in front of the first fragment read of the same
+  // iteration -- the next chunk's DMA would never overlap this chunk's MFMAs.  An asm statement is opaque to that
+  // bookkeeping; its completion is counted by hand (vmcnt(0) + barrier at the end of each chunk; the loop has no
+  // other VMEM operation).  M0 (LDS destination base, wave-uniform) is written and restored inside the statement.
+  const unsigned lds0 = (unsigned)(uintptr_t)(a16_lds_t*)smem;
+#define A16_DMA(gptr, ldsaddr)                                                                                   \
+  do {                                                                                                           \
+    unsigned keep_;                                                                                              \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(gptr), "s"(ldsaddr) : "memory");                                           \
+  } while (0)
+#define A16_ISSUE1(stage, ch, i_)                                                                                \
+  do {                                                                                                           \
+    const int ii_ = (i_);                                           /* wave-uniform */                           \
+    if (ii_ < 8 * A16_KT) {                                                                                      \
+      const int r_ = 4 * (ii_ % (4 * A16_KT)) + g;                                                               \
+      const int e_ = ii_ < 4 * A16_KT ? W + 4 * (qi ^ (r_ & 15)) : 2 * W + 4 * qi;                                \
+      A16_DMA(bp_ + (int64_t)min((ch) * A16_CHUNK + r_, L - 1) * ldqkv + e_,                                     \
+              lds0 + (stage) * A16_STAGE_B + ii_ * 1024);                                                        \
+    }                                                                                                            \
+  } while (0)
+#define A16_ISSUE(bp, stage, ch)                                                                                 \
+  do { const float* bp_ = (bp);                                                                                  \
+       _Pragma("unroll") for (int j_ = 0; j_ < (8 * A16_KT + nw - 1) / nw; ++j_) A16_ISSUE1(stage, ch, wave + j_ * nw); } while (0)
+  // K fragment address: row (tile-local key = lane & 15), slot (4 c4 + g) ^ (key & 15) = ((g ^ qi) ^ 4 c4): the four
+  // slots differ by an XOR of the byte offset with 64 c4.  V: row (4 g + r), slot qi (d = 4 qi ..), linear image.
+  const int ka = qi * 256 + ((g ^ qi) * 16);
+  const int va = A16_OP_B + (4 * g) * 256 + qi * 16;
+
+  // ---- persistent over (frame, head) items; the first chunk of the NEXT item is in flight while this item's output
+  // is normalised and stored
+  int item = blockIdx.x;
+  if (item < nitems) A16_ISSUE(qkv + (int64_t)(item / heads) * L * ldqkv + (item % heads) * 64, 0, 0);
+  for (; item < nitems; item += gridDim.x) {
+    const int b = item / heads, h = item % heads;
+    const float* base = qkv + (int64_t)b * L * ldqkv + h * 64;
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (query qi, k-group g) holds d = 16 c4 + 4 g + (0..3)
+    float4 qa[4], qb[4];
+    {
+      const float* pa = base + (int64_t)min(16 * ta + qi, L - 1) * ldqkv + 4 * g;
+      const float* pb = base + (int64_t)min(16 * tb + qi, L - 1) * ldqkv + 4 * g;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        float4 v = *reinterpret_cast<const float4*>(pa + 16 * c4);
+        v.x *= 0.125f; v.y *= 0.125f; v.z *= 0.125f; v.w *= 0.125f;     // 64^-0.5, exact
+        qa[c4] = v;
+        if constexpr (HB) {
+          v = *reinterpret_cast<const float4*>(pb + 16 * c4);
+          v.x *= 0.125f; v.y *= 0.125f; v.z *= 0.125f; v.w *= 0.125f;
+          qb[c4] = v;
+        }
+      }
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 oa0 = z4, oa1 = z4, oa2 = z4, oa3 = z4;                         // O^T tiles e = 0..3 (d = 16 g + 4 reg + e)
+    f32x4 ob0 = z4, ob1 = z4, ob2 = z4, ob3 = z4;
+    float ma = -INFINITY, la = 0.f, mb = -INFINITY, lb = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int ch = 0; ch < nch; ++ch) {
+      if (ch + 1 < nch) A16_ISSUE(base, (ch + 1) & 1, ch + 1);
+      const char* sS = smem + (ch & 1) * A16_STAGE_B;
+      // ---- two 16-key tiles per chunk, each: S^T tiles of the wave's query tiles -> online softmax -> O^T += V^T P^T
+#define A16_QK(c4, off, toff)                                                                                   \
+  do {                                                                                                           \
+    const float4 k_ = *reinterpret_cast<const float4*>(sS + (ka ^ (off)) + (toff));                              \
+    sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.x, qa[c4].x, sa, 0, 0, 0);                                       \
+    if constexpr (HB) sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.x, qb[c4].x, sb, 0, 0, 0);                     \
+    sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.y, qa[c4].y, sa, 0, 0, 0);                                       \
+    if constexpr (HB) sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.y, qb[c4].y, sb, 0, 0, 0);                     \
+    sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.z, qa[c4].z, sa, 0, 0, 0);                                       \
+    if constexpr (HB) sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.z, qb[c4].z, sb, 0, 0, 0);                     \
+    sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.w, qa[c4].w, sa, 0, 0, 0);                                       \
+    if constexpr (HB) sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.w, qb[c4].w, sb, 0, 0, 0);                     \
+  } while (0)
+#define A16_SOFTMAX(S, M, LS, O0, O1, O2, O3)                                                                    \
+  do {                                                                                                           \
+    const float mx_ = a16_rowmax(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])));                                   \
+    const float mn_ = fmaxf(M, mx_);                                 /* finite: every tile holds >= 1 valid key */ \
+    const float al_ = __expf(M - mn_);                               /* first tile: exp(-inf) = 0 */             \
+    M = mn_;                                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) S[r] = __expf(S[r] - mn_);   /* exp(-inf) = 0 for masked keys */ \
+    LS = LS * al_ + ((S[0] + S[1]) + (S[2] + S[3]));                                                             \
+    if (!__all(al_ == 1.f)) {                                     /* x * 1 == x: skipping is bit-identical */     \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) { O0[r] *= al_; O1[r] *= al_; O2[r] *= al_; O3[r] *= al_; }  \
+    }                                                                                                            \
+  } while (0)
+#define A16_PV(r, toff)                                                                                         \
+  do {                                                                                                           \
+    const float4 v_ = *reinterpret_cast<const float4*>(sS + va + (toff) + (r) * 256);                            \
+    oa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.x, sa[r], oa0, 0, 0, 0);                                        \
+    if constexpr (HB) ob0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.x, sb[r], ob0, 0, 0, 0);                      \
+    oa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.y, sa[r], oa1, 0, 0, 0);                                        \
+    if constexpr (HB) ob1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.y, sb[r], ob1, 0, 0, 0);                      \
+    oa2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.z, sa[r], oa2, 0, 0, 0);                                        \
+    if constexpr (HB) ob2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.z, sb[r], ob2, 0, 0, 0);                      \
+    oa3 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.w, sa[r], oa3, 0, 0, 0);                                        \
+    if constexpr (HB) ob3 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.w, sb[r], ob3, 0, 0, 0);                      \
+  } while (0)
+#define A16_TILE(toff, kbase)                                                                                    \
+  do {                                                                                                           \
+    f32x4 sa = z4, sb = z4;                                                                                      \
+    A16_QK(0, 0, toff); A16_QK(1, 64, toff); A16_QK(2, 128, toff); A16_QK(3, 192, toff);                         \
+    if ((kbase) + 16 > L) {                                           /* only the last tile holds keys >= L */   \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
+        const bool ok_ = (kbase) + 4 * g + r < L;                                                                \
+        sa[r] = ok_ ? sa[r] : -INFINITY; sb[r] = ok_ ? sb[r] : -INFINITY;                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+    A16_SOFTMAX(sa, ma, la, oa0, oa1, oa2, oa3);                                                                 \
+    if constexpr (HB) A16_SOFTMAX(sb, mb, lb, ob0, ob1, ob2, ob3);                                               \
+    A16_PV(0, toff); A16_PV(1, toff); A16_PV(2, toff); A16_PV(3, toff);                                          \
+  } while (0)
+      A16_TILE(0, A16_CHUNK * ch);
+#pragma unroll
+      for (int j = 1; j < A16_KT; ++j)
+        if (A16_KT * ch + j < nkt) A16_TILE(j * 16 * 256, A16_CHUNK * ch + 16 * j);
+#undef A16_TILE
+#undef A16_PV
+#undef A16_SOFTMAX
+#undef A16_QK
+      // next chunk landed (this wave's DMAs) and everybody is done reading this stage
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // every wave is past its last fragment read (barrier above): stage 0 is free for the next item's first chunk
+    {
+      const int nxt = item + (int)gridDim.x;
+      if (nxt < nitems) A16_ISSUE(qkv + (int64_t)(nxt / heads) * L * ldqkv + (nxt % heads) * 64, 0, 0);
+    }
+    // ---- normalise and store: lane (query qi, g) holds O[query][16 g + 4 reg + e]
+    {
+      const float inv = 1.f / a16_rowsum(la);
+      const int q = 16 * ta + qi;
+      if (q < L) {
+        float* op = out + ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<float4*>(op + 4 * r) = make_float4(oa0[r] * inv, oa1[r] * inv, oa2[r] * inv, oa3[r] * inv);
+      }
+    }
+    if constexpr (HB) {
+      const float inv = 1.f / a16_rowsum(lb);
+      const int q = 16 * tb + qi;
+      if (q < L) {
+        float* op = out + ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<float4*>(op + 4 * r) = make_float4(ob0[r] * inv, ob1[r] * inv, ob2[r] * inv, ob3[r] * inv);
+      }
+    }
+  }   // item loop
+#undef A16_ISSUE
+#undef A16_ISSUE1
+#undef A16_DMA
+}
+
+// 8 waves per workgroup; nkt (9..16) query tiles: nd = nkt - 8 waves own two tiles, the others one (L = 197: waves 0..4
+// two tiles, 5..7 one).  Measured and rejected on top of this: 13 one-tile waves at <= 64 VGPRs (spills, 0.86 ms), chunks
+// of 16 / 64 keys (no change: the chunk barrier is not the limit), s_setprio around the MFMA groups, rotating the
+// two-tile waves between co-resident workgroups (no change).  What remains (MFMA pipe busy 0.59): the four waves of a
+// SIMD run the same QK^T -> softmax -> PV phase sequence nearly in step, so the softmax VALU phases of all of them
+// coincide, and 13 tiles load the SIMDs 4/3/3/3.
+__global__ __launch_bounds__(512, 4) void attn16_kernel(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out,
+                                                        int64_t ldo, int L, int heads, int nitems) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nkt = (L + 15) >> 4;
+  const int nd = nkt - 8;                                                 // waves with two tiles
+  const bool dbl = wave < nd;
+  const int ta = dbl ? 2 * wave : nd + wave;
+  if (dbl) a16_run<true, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta + 1);
+  else a16_run<false, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta);
+}
+
+
 // CLS-only attention for the LAST ViT layer: only token 0 of every sequence is consumed downstream
 // (clip/model.py:285 takes x[:, 0, :]), so only query row 0 needs softmax(q k^T) v.  One wavefront per
 // (sequence, head): lanes own keys for the scores, then own output dims for the weighted sum of V.
@@ -261,6 +499,16 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   const dim3 grid((unsigned)(batch * heads));
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_ATTN, (hipStream_t)stream);
+  if (!causal && L > 128 && L <= 256 && ldo % 4 == 0 && !((uintptr_t)out & 15) && ACX_DBG_SWITCH("ATTN16", true)) {
+    // ViT sequence: 16-wide tiles (one or two query tiles per wave), chunked LDS-DMA staging, two workgroups per CU
+    const int nitems = batch * heads;
+    const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+    const int slots = 2 * ncu;                                            // two workgroups per CU
+    hipLaunchKernelGGL(attn16_kernel, dim3((unsigned)(nitems < slots ? nitems : slots)), dim3(512), 2 * A16_STAGE_B, s, qkv,
+                       ldqkv, out, ldo, L, heads, nitems);
+    ACX_CHECK_LAUNCH(ctx, "acx_attention");
+    return ACX_OK;
+  }
 #define ACX_ATTN(NT, NW)                                                                           \
   do {                                                                                             \
     const size_t lds = (size_t)NT * 32 * (KROW + VROW) * 4 + NW * 32 * 4 + 16;                          \

@@ -226,7 +226,10 @@ def test_layernorm(D, mode):
     assert relerr(outb.float(), ref) < 1e-2
 
 
-@pytest.mark.parametrize("L_,heads,batch,causal", [(197, 12, 2, False), (77, 8, 3, True), (5, 2, 3, False), (224, 1, 1, False), (33, 2, 1, True)])
+@pytest.mark.parametrize("L_,heads,batch,causal", [(197, 12, 2, False), (77, 8, 3, True), (5, 2, 3, False), (224, 1, 1, False), (33, 2, 1, True),
+                                                   # attn16_kernel (non-causal, 129..208): odd / full last chunk, 1- and 2-tile tails
+                                                   (129, 2, 3, False), (144, 3, 2, False), (160, 1, 5, False), (177, 2, 2, False),
+                                                   (192, 4, 1, False), (193, 1, 2, False), (208, 2, 3, False), (197, 12, 40, False)])
 def test_attention(L_, heads, batch, causal):
     g = torch.Generator().manual_seed(L_)
     W = heads * 64
@@ -240,13 +243,16 @@ def test_attention(L_, heads, batch, causal):
     assert relerr(out, ref) < 3e-6
 
 
-def test_attention_spiked_scores():
-    """one key dominating one query row (guide rule 26: force the extreme softmax case)."""
+@pytest.mark.parametrize("spike_key", [100, 3, 196])
+def test_attention_spiked_scores(spike_key):
+    """one key dominating one query row (guide rule 26: force the extreme softmax case).  For the online-softmax kernel
+    the spike sits in a late chunk (running max jumps, everything accumulated so far is rescaled by ~exp(-100)), in
+    the first chunk (later chunks vanish) or in the very last valid key."""
     L_, heads = 197, 1
     g = torch.Generator().manual_seed(0)
     qkv = torch.randn(L_, 192, generator=g)
     qkv[7, :64] *= 30.0
-    qkv[100, 64:128] = qkv[7, :64] / 30.0 * 3
+    qkv[spike_key, 64:128] = qkv[7, :64] / 30.0 * 3
     q, k, v = qkv.view(1, L_, 3, 1, 64).permute(2, 0, 3, 1, 4).double()
     ref = (torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(L_, 64)
     out = ops.attention(qkv.to(DEV), 1, L_, heads, False)

@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from anomalyclip_amd import ops
-F, L, H = 256, 197, 12
+F, L, H = 512, 197, 12
 qkv = torch.randn(F * L, 3 * H * 64, device="cuda")
 for _ in range(3):
     ops.attention(qkv, F, L, H, False)
