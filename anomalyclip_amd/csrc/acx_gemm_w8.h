@@ -9,6 +9,9 @@
 // instead of one.  Costs 1.5x the LDS fragment reads per flop (still < 10 % of the LDS port).
 // CONV = 1: the implicit-GEMM 3x3 convolution of the axial feed-forwards (A rows are token rows shifted by the tap of
 // the current K-step, zero outside the (gn, gl) grid; cin % 32 == 0 so a K-step never straddles two taps).
+#ifndef ACX_W8_VEC_EPILOGUE
+#define ACX_W8_VEC_EPILOGUE 1
+#endif
 template <int ACT, int RES, int CONV>
 __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -16,7 +19,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int jl = bid >> 3;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + jl;
   const int tm = wg / g.tiles_n, tn = wg % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -139,7 +143,57 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
       }
     return;
   }
-  // ---- epilogue (structure of gemm_kernel's: everything computed, then stored)
+  // ---- vector epilogue.  In the 32x32 C layout a lane holds ONE column and 16 rows, so the natural store is 32 x
+  // global_store_dword per lane (64 instructions of 2 x 128 B per wave and tile, plus as many residual loads): the store
+  // tail is instruction-issue bound and costs ~1.3 K-steps per tile.  Each wave instead transposes its two 32x32
+  // accumulator tiles through a private 4.5 KB slice of the (now idle) staging LDS and goes to memory with 16-byte
+  // accesses: 8 rows x 128 B per instruction, 4 stores + 4 residual loads per accumulator tile.
+  // (every LDS read of the K loop completed before its last barrier; the slices are wave-private)
+  if (ACX_W8_VEC_EPILOGUE && d.N % 4 == 0 && d.ldc % 4 == 0 && !((uintptr_t)d.C & 15) && !((uintptr_t)d.bias & 15) &&
+      (RES == 0 || (d.ldr % 4 == 0 && !((uintptr_t)d.residual & 15)))) {
+    float* sT = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+    const int tr = lane >> 3, tc = 4 * (lane & 7);
+    const int gcol = n0 + wn * 32 + tc;
+    const bool gok = gcol < d.N;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && gok) b4 = ld4(d.bias + gcol);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sT[(4 * hh + (r & 3) + 8 * (r >> 2)) * 36 + li] = acc[mi][r];
+      const int grow0 = m0 + wm * 64 + mi * 32 + tr;
+      float4 rs[4], ov[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (RES != 0) {
+          const int row = min(grow0 + 8 * i, d.M - 1);
+          rs[i] = ld4(d.residual + (size_t)row * d.ldr + (gok ? gcol : 0));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 a4 = *reinterpret_cast<const float4*>(sT + (tr + 8 * i) * 36 + tc);
+        float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (ACT == ACX_ACT_QUICKGELU) v[e] = v[e] * (1.f / (1.f + __expf(-1.702f * v[e])));
+          if constexpr (ACT == ACX_ACT_LEAKYRELU) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        }
+        ov[i] = make_float4(rs[i].x + v[0], rs[i].y + v[1], rs[i].z + v[2], rs[i].w + v[3]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ov[i].x), "+v"(ov[i].y), "+v"(ov[i].z), "+v"(ov[i].w));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = grow0 + 8 * i;
+        if (gok && row < d.M) *reinterpret_cast<float4*>((float*)d.C + (size_t)row * d.ldc + gcol) = ov[i];
+      }
+    }
+    return;
+  }
+  // ---- scalar epilogue (structure of gemm_kernel's: everything computed, then stored)
   const int colc = cok ? col : d.N - 1;
   float bias = 0.f;
   if (d.bias) bias = d.bias[colc];
