@@ -9,6 +9,9 @@
 // instead of one.  Costs 1.5x the LDS fragment reads per flop (still < 10 % of the LDS port).
 // CONV = 1: the implicit-GEMM 3x3 convolution of the axial feed-forwards (A rows are token rows shifted by the tap of
 // the current K-step, zero outside the (gn, gl) grid; cin % 32 == 0 so a K-step never straddles two taps).
+#ifndef ACX_W8_ABL
+#define ACX_W8_ABL 0      /* ablation builds (tools/ab_gemm.sh): 1 no stores, 2 + no staging, 3 + no K-step barrier */
+#endif
 #ifndef ACX_W8_VEC_EPILOGUE
 #define ACX_W8_VEC_EPILOGUE 1
 #endif
@@ -115,15 +118,22 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
     W8_RD(y, cur, 1);
     W8_MM(x);                                    // phase 0
     W8_RD(x, cur, 2);
-    if (more) W8_STORE(nxt, 0);
+    if (more && ACX_W8_ABL < 2) W8_STORE(nxt, 0);
     W8_MM(y);                                    // phase 1
     W8_RD(y, cur, 3);
-    if (more) W8_STORE(nxt, 1);
+    if (more && ACX_W8_ABL < 2) W8_STORE(nxt, 1);
     W8_MM(x);                                    // phase 2
-    __syncthreads();                             // next tile complete in LDS; everyone holds its phase-3 fragments
-    if (kt + 2 < nk) W8_LOAD(kbeg + (kt + 2) * 32);
+    if (ACX_W8_ABL < 3) __syncthreads();         // next tile complete in LDS; everyone holds its phase-3 fragments
+    if (kt + 2 < nk && ACX_W8_ABL < 2) W8_LOAD(kbeg + (kt + 2) * 32);
     if (more) W8_RD(x, nxt, 0);
     W8_MM(y);                                    // phase 3
+  }
+  if (ACX_W8_ABL >= 1) {                         // keep the accumulators alive without the store tail
+    float s_ = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_ += acc[0][r] + acc[1][r];
+    if (s_ == 12345.678f) ((float*)d.C)[0] = s_;
+    return;
   }
 #undef W8_MM
 #undef W8_RD
