@@ -114,6 +114,7 @@ class AnomalyCLIP(nn.Module):
         input_size = self.embedding_dim + additional * int(self.concat_features)     # anomaly_clip.py:92-93
         self.temporal_model = TemporalModel(input_size, self.emb_size, 1, self.heads, self.dim_heads, self.depth,
                                             self.num_segments, self.seg_length)
+        self.temporal_model.precision = self.precision
         self.cache_text_features = bool(g("cache_text_features", False))
         # under data parallelism the (replicated) text encoder is evaluated class-parallel: every rank runs its block
         # of classes and the (C, E) features / their gradients are exchanged (functional.TextFeaturesFn)

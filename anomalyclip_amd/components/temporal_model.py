@@ -107,11 +107,15 @@ class TemporalModel(nn.Module):
         self.projection = _Linear(input_size, emb_size)
         self.axial_attn = AxialImageTransformer(emb_size, depth, heads, dim_heads, num_segments, seg_length)
         self.classifier = ClassificationHead(emb_size, output_size)
+        # "f32": exact-f32 MFMA (parity path).  "bf16" (inference only, BASELINE configs[4]): every GEMM / implicit-GEMM
+        # convolution runs on the bf16 MFMA with f32 accumulation -- bf16 weights, bf16 LayerNorm outputs and conv
+        # hidden activations; the residual streams, attention, norms and the classifier stay f32.
+        self.precision = "f32"
         self._prep = None
 
     # ---- derived weight layouts for the kernels (cached; rebuilt when a parameter changes)
     def prepared(self):
-        key = (ops.WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (ops.WEIGHT_EPOCH[0], self.precision) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._prep is not None and self._prep[0] == key:
             return self._prep[1]
         with torch.no_grad():
@@ -136,24 +140,34 @@ class TemporalModel(nn.Module):
                     P[f"c2_w{d}{fg}"] = ff[3].weight.detach().permute(0, 2, 3, 1).reshape(ff[3].weight.shape[0], -1).contiguous()
                     P[f"g{d}{fg}"] = ff[0].g.detach().reshape(-1).contiguous()
                     P[f"b{d}{fg}"] = ff[0].b.detach().reshape(-1).contiguous()
+                    if self.precision == "bf16":
+                        P[f"out_w{d}{fg}"] = ops.cast_bf16(sa.to_out.weight.detach())
+            if self.precision == "bf16":
+                for k in [k for k in P if k == "proj_w" or k.startswith(("qkv_w", "c1_w", "c2_w"))]:
+                    P[k] = ops.cast_bf16(P[k])
         self._prep = (key, P)
         return P
 
     def _attn(self, x_in, resid, d, fg, tiles, axis, P):
         N, Lg, E = self.num_segments, self.seg_length, self.emb_size
         pn = getattr(self.axial_attn.layers.blocks[2 * d], fg).net.fn
-        h = ops.layernorm(x_in, pn.norm.weight, pn.norm.bias)
-        qkv = ops.gemm(h, P[f"qkv_w{d}{fg}"])
+        bf = self.precision == "bf16"
+        prec = L.PREC_BF16 if bf else L.PREC_F32
+        h = ops.layernorm(x_in, pn.norm.weight, pn.norm.bias, out_dtype=torch.bfloat16 if bf else torch.float32)
+        qkv = ops.gemm(h, P[f"qkv_w{d}{fg}"], prec=prec)
         o = ops.axial_attention(qkv, tiles, N, Lg, self.heads, self.axial_attn.e, axis)
-        return ops.gemm(o, pn.fn.to_out.weight, bias=pn.fn.to_out.bias, residual=resid)
+        return ops.gemm(o, P[f"out_w{d}{fg}"] if bf else pn.fn.to_out.weight, bias=pn.fn.to_out.bias, residual=resid, prec=prec)
 
     def _ff(self, x_in, resid, d, fg, P):
         N, Lg, E = self.num_segments, self.seg_length, self.emb_size
         ff = getattr(self.axial_attn.layers.blocks[2 * d + 1], fg).net
-        h = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN)
-        u = ops.gemm(h, P[f"c1_w{d}{fg}"], bias=ff[1].bias, act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
+        bf = self.precision == "bf16"
+        prec, adt = (L.PREC_BF16, torch.bfloat16) if bf else (L.PREC_F32, torch.float32)
+        h = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN, out_dtype=adt)
+        u = ops.gemm(h, P[f"c1_w{d}{fg}"], bias=ff[1].bias, act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E,
+                     prec=prec, out_dtype=adt)
         return ops.gemm(u, P[f"c2_w{d}{fg}"], bias=ff[3].bias, residual=resid, amap=L.AMAP_CONV3X3, gn=N, gl=Lg,
-                        cin=4 * E)
+                        cin=4 * E, prec=prec)
 
     def forward(self, features: torch.Tensor, segment_size: int, test_mode: bool,
                 a_sub: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -166,6 +180,8 @@ class TemporalModel(nn.Module):
                 # no_grad (validation_step / test_step), so a differentiable test-mode pass is not part of the path.
                 raise RuntimeError("TemporalModel(test_mode=True) must run under torch.no_grad(): the differentiable "
                                    "path implements the training tiling only (temporal_model.py:55-60)")
+            if self.precision != "f32":
+                raise RuntimeError("the bf16 head is an inference path; training runs on the exact-f32 kernels")
             return Fn.temporal_train(self, features, a_sub)
         P = self.prepared()
         N, Lg, E = self.num_segments, self.seg_length, self.emb_size
@@ -178,7 +194,7 @@ class TemporalModel(nn.Module):
         seg = segment_size if test_mode else 0
         x0 = ops.gemm(x, P["proj_w"], bias=self.projection.bias, a_sub=a_sub,
                       amap=L.AMAP_TESTTILE if test_mode else L.AMAP_IDENTITY, gn=N, gl=Lg, seg=max(seg, 1),
-                      pos0=P["pos0"], pos1=P["pos1"])
+                      pos0=P["pos0"], pos1=P["pos1"], prec=L.PREC_BF16 if self.precision == "bf16" else L.PREC_F32)
         x1 = x2 = x0
         for d in range(self.depth):
             y1 = self._attn(x2, x1, d, "f", tiles, 0, P)      # long-term: along the N segments

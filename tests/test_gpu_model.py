@@ -321,3 +321,46 @@ def test_lightning_checkpoint_load_then_score(tmp_path, prompts_table):
     sd_half = {k[4:]: (v.float() if v.is_floating_point() else v) for k, v in lsd.items() if k.startswith("net.")}
     rsim, rsc = O.anomaly_clip_forward_test(sd_half, hc, feats, ncl, eot, IW.TINY.transformer_heads, 2)
     assert relerr(sim, rsim) < TOL and relerr(sc, rsc) < TOL
+
+
+@pytest.mark.parametrize("S", [4, 8, 16])
+def test_xd_long_segments_bf16_head(prompts_table, S):
+    """BASELINE.json configs[4]: XD-Violence head (C = 7, E = 128 -> head dim 16, 5 crops) on long test videos
+    (S = 4 / 8 / 16 tiles per crop -> 10 240 .. 40 960 rows), head GEMMs and implicit-GEMM convolutions on the bf16 MFMA
+    (bf16 weights / LayerNorm outputs / conv hidden activations, f32 accumulation, f32 residual streams).
+    NOT the parity path: compared with the f32 ORACLE on the same inputs at a stated bf16 tolerance -- anomaly scores
+    (sigmoid outputs in [0,1]) within 2e-2 absolute, similarity logits (bf16 text tower -> f32 selector) within 2e-2
+    relative -- while the f32 mode of the same configuration holds the parity tolerance."""
+    hc = IW.XD_HEAD
+    g = torch.Generator().manual_seed(S)
+    feats = torch.randn(1, hc.ncrops, 512 * S, 512, generator=g) * 0.3 + 0.02
+    nc = torch.randn(512, generator=g) * 0.05
+    out = {}
+    for precision in ("bf16", "f32"):
+        net, sd, eot = build_net("ViT-B/16", hc, "xd", 17, prompts_table, precision=precision)
+        net.eval()
+        with torch.no_grad():
+            out[precision] = net(feats.to(DEV), None, nc, S, True)
+        del net
+    rsim, rsc = O.anomaly_clip_forward_test(sd, hc, feats, nc, eot, 8, S)
+    sim, sc = out["bf16"]
+    assert sim.shape == (hc.ncrops * 512 * S, hc.num_classes - 1) and sc.shape == (hc.ncrops * 512 * S,)
+    assert relerr(out["f32"][0], rsim) < TOL and relerr(out["f32"][1], rsc) < TOL     # f32 mode: parity
+    err = (sc.double().cpu() - rsc.double()).abs().max().item()
+    print(f"bf16 head, S={S}: max |score - oracle| = {err:.3e}, similarity rel = {relerr(sim, rsim):.3e}")
+    assert err < 2e-2 and relerr(sim, rsim) < 2e-2
+
+
+def test_vit_bf16_160_frame_window(golden):
+    """configs[4], frames variant: a 5-crop x 32-frame window = 160 frames in ONE bf16 ViT launch; rows agree with the
+    2-frame launch (bf16 round-off) and identical frames give identical rows."""
+    g = golden("vit_b16")
+    vit, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="bf16")
+    vit.chunk = 160
+    base = R.vit_frames(int(g["seed"]), 2, 224)
+    idx = torch.arange(160) % 2
+    out = vit(base[idx].to(DEV))
+    small = vit(base.to(DEV))
+    assert out.shape == (160, 512) and torch.isfinite(out).all()
+    assert relerr(out[:2], small) < 3e-2 and relerr(out[158:], small) < 3e-2
+    assert relerr(out[:2], g["out"]) < 5e-2                                            # vs the REFERENCE's f32 output
