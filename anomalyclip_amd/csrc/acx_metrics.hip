@@ -43,28 +43,37 @@ __global__ __launch_bounds__(MT_THREADS) void radix_hist_kernel(const uint32_t* 
   hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];
 }
 
-// exclusive scan of `total` uint32 entries in place by ONE block (entries = 256 * nblocks, ~10^5 for 10^6 keys)
-__global__ __launch_bounds__(1024) void scan_u32_kernel(uint32_t* __restrict__ data, int total) {
-  __shared__ uint32_t part[1024];
-  const int tid = threadIdx.x;
-  const int per = (total + 1023) / 1024;
-  const int lo = min(tid * per, total), hi = min(lo + per, total);
-  uint32_t s = 0;
-  for (int i = lo; i < hi; ++i) s += data[i];
-  part[tid] = s;
+// Scatter bases, stage 1: block d turns row d of the digit-major histogram ([256][nblocks]) into its exclusive prefix
+// over the tiles (in place) and writes the digit's total to tot[d].  256 independent row scans instead of ONE block
+// walking all 256 * nblocks entries (that single-block scan was 82 % of the epilogue's kernel time); stage 2 -- the
+// exclusive scan of the 256 digit totals -- is done by every scatter block in LDS.
+__global__ __launch_bounds__(256) void scan_rows_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ tot, int nblocks) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry_s;
+  uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = tid >= off ? part[tid - off] : 0;
+  for (int base = 0; base < nblocks; base += 256) {
+    const int i = base + tid;
+    const uint32_t v = i < nblocks ? row[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    part[tid] += v;
+    uint32_t woff = 0;
+    for (int j = 0; j < w; ++j) woff += wsum[j];
+    const uint32_t carry = carry_s;
+    if (i < nblocks) row[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (tid == 255) carry_s = carry + woff + inc;
     __syncthreads();
   }
-  uint32_t run = part[tid] - s;
-  for (int i = lo; i < hi; ++i) {
-    uint32_t v = data[i];
-    data[i] = run;
-    run += v;
-  }
+  if (tid == 0) tot[blockIdx.x] = carry_s;
 }
 
 // stable scatter: wave w owns elements [w*512, (w+1)*512) of the tile and walks them in array order, ranking
@@ -73,11 +82,28 @@ __global__ __launch_bounds__(MT_THREADS) void radix_scatter_kernel(const uint32_
                                                                     const uint32_t* __restrict__ vin,
                                                                     uint32_t* __restrict__ kout,
                                                                     uint32_t* __restrict__ vout,
-                                                                    const uint32_t* __restrict__ bases, int n,
+                                                                    const uint32_t* __restrict__ bases,
+                                                                    const uint32_t* __restrict__ tot, int n,
                                                                     int nblocks, int shift, int first, int last,
                                                                     int desc) {
   __shared__ uint32_t cnt[4][256];
+  __shared__ uint32_t dbase[256];
+  __shared__ uint32_t dws[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  {   // exclusive scan of the 256 digit totals (thread = digit)
+    const uint32_t v = tot[tid];
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) dws[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int j = 0; j < wave; ++j) woff += dws[j];
+    dbase[tid] = woff + inc - v;
+  }
   for (int i = tid; i < 1024; i += MT_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const int base = blockIdx.x * MT_TILE + wave * (MT_TILE / 4);
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(MT_THREADS) void radix_scatter_kernel(const uint32_
   __syncthreads();
   {
     const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid];
-    const uint32_t gb = bases[(size_t)tid * nblocks + blockIdx.x];
+    const uint32_t gb = dbase[tid] + bases[(size_t)tid * nblocks + blockIdx.x];
     cnt[0][tid] = gb;
     cnt[1][tid] = gb + c0;
     cnt[2][tid] = gb + c0 + c1;
@@ -457,7 +483,7 @@ __global__ __launch_bounds__(256) void test_counts_kernel(const float* __restric
 extern "C" int64_t acx_sort_workspace_bytes(int64_t n) {
   if (n < 0) return -1;
   const int64_t nb = (n + MT_TILE - 1) / MT_TILE;
-  return 2 * n * 4 + 256 * (nb > 0 ? nb : 1) * 4 + 256;
+  return 2 * n * 4 + 256 * (nb > 0 ? nb : 1) * 4 + 256 * 4 + 256;
 }
 
 extern "C" int acx_sort_pairs(acx_ctx* ctx, const float* keys, const uint32_t* vals, float* keys_out,
@@ -477,6 +503,7 @@ extern "C" int acx_sort_pairs(acx_ctx* ctx, const float* keys, const uint32_t* v
   uint32_t* tk = (uint32_t*)workspace;
   uint32_t* tv = tk + n;
   uint32_t* hist = tv + n;
+  uint32_t* tot = hist + (size_t)256 * nb;
   // ping-pong: in -> tmp -> out -> tmp -> out
   const uint32_t* sk[4] = {(const uint32_t*)keys, tk, (uint32_t*)keys_out, tk};
   const uint32_t* sv[4] = {vals, tv, vals_out, tv};
@@ -485,8 +512,8 @@ extern "C" int acx_sort_pairs(acx_ctx* ctx, const float* keys, const uint32_t* v
   AcxProfScope prof(ctx, ACX_K_OTHER, st);
   for (int p = 0; p < 4; ++p) {
     radix_hist_kernel<<<nb, MT_THREADS, 0, st>>>(sk[p], hist, (int)n, nb, 8 * p, p == 0, descending);
-    scan_u32_kernel<<<1, 1024, 0, st>>>(hist, 256 * nb);
-    radix_scatter_kernel<<<nb, MT_THREADS, 0, st>>>(sk[p], sv[p], dk[p], dv[p], hist, (int)n, nb, 8 * p, p == 0,
+    scan_rows_kernel<<<256, 256, 0, st>>>(hist, tot, nb);
+    radix_scatter_kernel<<<nb, MT_THREADS, 0, st>>>(sk[p], sv[p], dk[p], dv[p], hist, tot, (int)n, nb, 8 * p, p == 0,
                                                     p == 3, descending);
   }
   hipError_t e = hipGetLastError();
