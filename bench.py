@@ -28,6 +28,11 @@ keys of the same JSON line:
     kernel-time breakdown of the step and the stand-alone all-reduce time of the gradient buffer.  Strong-scaling
     efficiency = T1 / (N * TN) from the N = 1, 2, 4, 8 lines of the driver's scaling run.
 
+  * `config4_xd_bf16` (configs[4]) -- XD-Violence-shaped long segments through the bf16 head and 160-frame windows through
+    the bf16 ViT (not the parity path; reported with the bf16 GEMM roofline fraction).
+`roofline.traffic` is measured live at N = 1: two child `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE) of
+this script's headline step; the committed profiles/ file is the fallback when rocprofv3 is unavailable.
+
 One JSON line on rank 0, with `roofline` (dominant kernel = the f32 MFMA GEMM; HIP-event timed inside the timed
 region by libacx's launch timer) and `cpu_baseline` (oracle on host cores, bounded sample, rank 0 at N=1 only).
 """
@@ -281,6 +286,99 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
     return out
 
 
+def live_pmc_traffic(vit_chunk, timeout_s=150):
+    """HBM traffic of the dominant kernel, measured NOW: two separate `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE,
+    WRITE_SIZE: they do not fit one pass) over this same script's headline step, exactly as
+    MI355X_MICROARCH.md's HBM section prescribes -- FETCH_SIZE is in KB and under-reports wide coalesced reads by 2x on
+    gfx950 (x 2), WRITE_SIZE in KB.  Returns (bytes per GEMM launch, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="acx_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs",
+                   "--no-live-pmc", "--vit-chunk", str(vit_chunk)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "p_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                name = row["Kernel_Name"]
+                if row["Counter_Name"] == ctr and "gemm_" in name and "reduce" not in name:
+                    tot += float(row["Counter_Value"])
+                    n += 1
+            if n == 0:
+                return None, "no GEMM dispatches in the counter table"
+            per[ctr] = tot / n
+        b = per["FETCH_SIZE"] * 1024 * 2 + per["WRITE_SIZE"] * 1024
+        return int(round(b)), (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                               f"(1 warm-up + 1 step each), FETCH_SIZE x 2 (gfx950 correction); read "
+                               f"{per['FETCH_SIZE'] * 2048 / 1e6:.0f} MB + write {per['WRITE_SIZE'] * 1024 / 1e6:.0f} MB per launch")
+    except Exception as e:  # noqa: BLE001
+        return None, f"live PMC failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def config4_leg(dev, timer, prof, world, steps):
+    """BASELINE.json configs[4]: XD-Violence-shaped long segments in bf16 (NOT the parity path): the XD head (C = 7, E = 128)
+    on (1, 5 crops, 512 * 16, 512) features with bf16-MFMA GEMMs / implicit-GEMM convolutions, and 5-crop x 32-frame windows
+    (160 frames per ViT launch) through the bf16 ViT.  Weak over ranks (independent videos / windows)."""
+    from anomalyclip_amd import init_weights as IW
+    from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP, lookup_prompts
+    hc = IW.XD_HEAD
+    toks = torch.tensor(lookup_prompts(key="xd")["tokenized_prompts"], dtype=torch.int32)
+    net = AnomalyCLIP(arch="ViT-B/16", labels_key="xd", emb_size=hc.emb_size, depth=hc.depth, heads=hc.heads, dim_heads=None,
+                      num_segments=32, seg_length=16, concat_features=False, normal_id=hc.normal_id, stride=1,
+                      load_from_features=True, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, ncrops=hc.ncrops,
+                      num_topk=3, num_bottomk=3, precision="bf16", vit_chunk=160)
+    net.load_state_dict(IW.init_anomalyclip_state_dict(IW.VIT_B16, hc, toks, seed=0), strict=True)
+    net = net.to(dev).eval()
+    S, windows = 16, 4
+    g = torch.Generator(device=dev).manual_seed(3)
+    feats = torch.randn(1, hc.ncrops, 512 * S, 512, generator=g, device=dev) * 0.3
+    nc = torch.zeros(512, device=dev)
+
+    def head():
+        with torch.no_grad():
+            net(feats, None, nc, S, True)
+    dt = timer.run(head, steps, 2)
+    timer.run(head, 2, 0, prof.start, prof.stop)
+    gf, counts, tot = prof.collect()
+    rows = hc.ncrops * 512 * S
+    out = {"workload": "configs[4]: XD-Violence shape (C=7, E=128, 5 crops), S=16 tiles per crop, bf16 MFMA / f32 accumulate; "
+                       "frames: 160-frame (5-crop x 32) ViT-B/16 launches in bf16 mode",
+           "head": {"rows_per_step_per_gpu": rows, "ms_per_step": round(dt / steps * 1e3, 3),
+                    "features_per_s": round(rows * steps * world / dt, 1),
+                    "gemm_tflops": round(gf / 1e9 / tot[0], 1) if tot[0] else None,
+                    "gemm_frac_of_bf16_peak": round(gf / 1e9 / tot[0] / PEAK_TFLOPS["bf16"], 4) if tot[0] else None}}
+    frames = torch.randn(160 * windows, 3, 224, 224, generator=g, device=dev)
+
+    def enc():
+        with torch.no_grad():
+            net.image_encoder(frames)
+    k = max(2, steps // 2)
+    dt = timer.run(enc, k, 1, prof.start, prof.stop)
+    gf, counts, tot = prof.collect()
+    out["frames"] = {"frames_per_s": round(160 * windows * k * world / dt, 1),
+                     "gemm_tflops": round(gf / 1e9 / tot[0], 1) if tot[0] else None,
+                     "gemm_frac_of_bf16_peak": round(gf / 1e9 / tot[0] / PEAK_TFLOPS["bf16"], 4) if tot[0] else None}
+    del net, frames, feats
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +387,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (profiling runs)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 counter passes for roofline.traffic")
     ap.add_argument("--vit-chunk", type=int, default=512, help="frames per ViT launch (default: the whole 512-frame clip)")
     args = ap.parse_args()
 
@@ -352,6 +451,7 @@ def main():
                                       "note": "config[2]'s literal batch: two 256-frame ViT launches per clip"}
         if args.precision == "f32":
             extra.update(head_legs(net, dev, dist, rank, world, local_rank, max(4, min(args.steps, 10)), 2, timer))
+            extra["config4_xd_bf16"] = config4_leg(dev, timer, prof, world, max(4, min(args.steps, 10)))
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -375,7 +475,12 @@ def main():
         # tools/profile_bench.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
         # FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/.
         traffic, pmc_src = None, None
-        for tag in ("r02", "r01"):
+        if world == 1 and args.precision == "f32" and not args.no_live_pmc and not args.no_extra_legs:
+            torch.cuda.synchronize()
+            traffic, pmc_src = live_pmc_traffic(args.vit_chunk)
+            if traffic is None:
+                pmc_src = None
+        for tag in (("r02", "r01") if traffic is None else ()):
             pmc_file = os.path.join(REPO, "profiles", f"{tag}_bench_f32_pmc.json")
             if args.precision == "f32" and args.vit_chunk == 512 and os.path.exists(pmc_file):
                 try:
