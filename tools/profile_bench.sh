@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/prof_bench
 rm -rf $OUT; mkdir -p $OUT
-CMD="python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-live-pmc"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 pmc() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -o p -- $CMD > $OUT/$1.log 2>&1; }
 pmc fetch "FETCH_SIZE"

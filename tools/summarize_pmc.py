@@ -3,7 +3,7 @@ kernel (acx_gemm's f32 MFMA kernels) with the gfx950 FETCH_SIZE correction of MI
 coalesced reads; WRITE_SIZE checked against the exactly-known output bytes)."""
 import csv, json, os, sys, collections
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_bench"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 def rows(d):
     p = os.path.join(src, d, "p_counter_collection.csv")
     return list(csv.DictReader(open(p))) if os.path.exists(p) else []
