@@ -91,7 +91,11 @@ class AnomalyCLIP(nn.Module):
                     stem = os.path.basename(str(self.labels_file)).split("_")[0].lower()
                     key = stem if stem in ("ucf", "sht", "xd") else None
                 classnames = lookup_prompts(key=key or "ucf")["classnames"]
+        ctx_init = g("ctx_init") or ""
         if tokenized is None:
+            if ctx_init:
+                raise ValueError("ctx_init is set: pass tokenized_prompts= (the reference's clip.tokenize of "
+                                 "'<ctx_init> <classname>.' per class); the shipped prompts.json holds the 'X X ... X' prompts only")
             tokenized = torch.tensor(lookup_prompts(classnames)["tokenized_prompts"], dtype=torch.int32)
         self.classnames = classnames
 
@@ -99,7 +103,7 @@ class AnomalyCLIP(nn.Module):
         self.token_embedding = _TokenEmbedding(geom.vocab_size, geom.transformer_width)
         n_ctx = g("n_ctx", 8)
         self.prompt_learner = PromptLearner(len(classnames), n_ctx, geom.transformer_width, tokenized,
-                                            self.token_embedding.weight.detach(), bool(g("shared_context", False)))
+                                            self.token_embedding.weight.detach(), bool(g("shared_context", False)), ctx_init)
         self.tokenized_prompts = self.prompt_learner.tokenized_prompts
         self.register_buffer("eot_index", tokenized.argmax(dim=-1).to(torch.int64), persistent=False)
         self.text_encoder = TextEncoder(geom.context_length, geom.transformer_width, geom.transformer_heads,

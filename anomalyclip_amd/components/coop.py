@@ -15,13 +15,21 @@ from .. import ops
 
 class PromptLearner(nn.Module):
     def __init__(self, n_cls: int, n_ctx: int, ctx_dim: int, tokenized_prompts: torch.Tensor,
-                 token_embedding: torch.Tensor = None, shared_context: bool = False):
+                 token_embedding: torch.Tensor = None, shared_context: bool = False, ctx_init: str = ""):
         super().__init__()
-        if shared_context:
-            ctx = torch.empty(n_ctx, ctx_dim)
+        if ctx_init:
+            # coop.py:19-34: context initialised from the embeddings of the given words.  The reference tokenises
+            # `ctx_init` on its own; the same ids are positions 1 .. n_ctx of every tokenised prompt
+            # ("<ctx_init> <classname>."), which the caller supplies (the BPE tokenizer is out of scope here).
+            n_ctx = len(ctx_init.replace("_", " ").split(" "))
+            if token_embedding is None:
+                raise ValueError("ctx_init needs the token embedding table")
+            with torch.no_grad():
+                vec = token_embedding[tokenized_prompts[0, 1:1 + n_ctx].long()].float().clone()
+            ctx = vec if shared_context else vec.unsqueeze(0).repeat(n_cls, 1, 1)
         else:
-            ctx = torch.empty(n_cls, n_ctx, ctx_dim)
-        nn.init.normal_(ctx, std=0.02)                                   # coop.py:35-43
+            ctx = torch.empty(n_ctx, ctx_dim) if shared_context else torch.empty(n_cls, n_ctx, ctx_dim)
+            nn.init.normal_(ctx, std=0.02)                               # coop.py:35-43
         self.ctx = nn.Parameter(ctx)
         L = tokenized_prompts.shape[1]
         if token_embedding is not None:

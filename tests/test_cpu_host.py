@@ -337,3 +337,27 @@ def test_builtin_trainer_calls_hooks_in_lightning_order(tmp_path):
     calls.clear()
     assert tr.test(m, dm) == [{"ok": 1}]
     assert calls == ["setup:test", "net.eval", "on_test_start", "test_step0", "test_step1", "test_step2", "test_epoch_end3"]
+
+
+def test_ctx_init_from_token_embeddings(prompts_table):
+    """coop.py:19-34: a non-empty `ctx_init` initialises the context from the token embeddings of its words (ids = positions
+    1..n_ctx of the tokenised prompts), class-specific (repeated) or shared; n_ctx follows the word count."""
+    from anomalyclip_amd import init_weights as IW
+    from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP
+    toks = torch.tensor(prompts_table["ucf"]["tokenized_prompts"], dtype=torch.int32).clone()
+    toks[:, 1:4] = torch.tensor([320, 1125, 539])                  # pretend "a video of" replaces the first three X tokens
+    kw = dict(arch="tiny", labels_key="ucf", emb_size=64, depth=1, heads=2, dim_heads=None, num_segments=32, seg_length=16,
+              concat_features=False, normal_id=7, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, num_topk=3,
+              num_bottomk=3, clip_geometry=IW.TINY, tokenized_prompts=toks)
+    for shared in (False, True):
+        net = AnomalyCLIP(**kw, ctx_init="a_video of", shared_context=shared)
+        pl = net.prompt_learner
+        want = net.token_embedding.weight.detach()[toks[0, 1:4].long()]
+        assert pl.n_ctx == 3 and pl.token_suffix.shape[1] == 77 - 1 - 3
+        if shared:
+            assert pl.ctx.shape == (3, IW.TINY.transformer_width) and torch.equal(pl.ctx.detach(), want)
+        else:
+            assert pl.ctx.shape == (14, 3, IW.TINY.transformer_width)
+            assert all(torch.equal(pl.ctx.detach()[c], want) for c in range(14))
+    with pytest.raises(ValueError):
+        AnomalyCLIP(**{k: v for k, v in kw.items() if k != "tokenized_prompts"}, ctx_init="a video of")

@@ -372,17 +372,21 @@ def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom):
     assert float(mods[0][1].selector_model.logit_scale) == float(np.float32(2.6592601))      # untouched by weight decay
 
 
-def _nccl_worker(rank, world, port, q):
+def _nccl_worker(rank, world, port, q, backend):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    gpu = rank if backend == "nccl" else 0              # gloo: both ranks share the only GPU (CUDA tensors over gloo)
+    torch.cuda.set_device(gpu)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import json
         from anomalyclip_amd import parallel
         global DEV
-        DEV = f"cuda:{rank}"
+        DEV = f"cuda:{gpu}"
         import test_gpu_model
         test_gpu_model.DEV = DEV
         table = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anomalyclip_amd",
@@ -430,10 +434,14 @@ def _nccl_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL); the single-GPU box covers the same code with world 1")
-def test_train_batch_gradbuckets_rccl_world2():
-    """two ranks over RCCL: the bucketed asynchronous all-reduce of libacx-produced gradients equals the hand-averaged
-    per-rank gradients, SyncBN statistics are exchanged, and every rank ends with bit-identical gradient buffers."""
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_train_batch_gradbuckets_world2(backend):
+    """two ranks: the bucketed asynchronous all-reduce of libacx-produced gradients equals the hand-averaged per-rank
+    gradients, SyncBN statistics and the class-parallel text features are exchanged, and every rank ends with
+    bit-identical gradient buffers.  "nccl" = RCCL, one GPU per rank (skips below 2 GPUs); "gloo" = the same device code
+    with both ranks on ONE GPU and the collectives carried by gloo -- the path a single-GPU box can run."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL)")
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -442,7 +450,7 @@ def test_train_batch_gradbuckets_rccl_world2():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
