@@ -147,7 +147,14 @@ int linear1(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const f
 int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
            void* C, int c_dtype, int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
            hipStream_t s, int ldr = 0, void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
-  const bool tail_split = ACX_DBG_SWITCH("TAIL_SPLIT", true);
+  bool tail_split = ACX_DBG_SWITCH("TAIL_SPLIT", true);
+  if (tail_split && !ldr) {   // the persistent strip-stream kernel balances its own tail
+    acx_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc;
+    d.a_dtype = a_dtype; d.c_dtype = c_dtype; d.prec = prec; d.act = act; d.residual = residual;
+    if (acx_gemm_takes_strip_stream(&d)) tail_split = false;
+  }
   const int tiles_n = (N + 127) / 128, tiles_m = (M + 127) / 128;
   const long tiles = (long)tiles_m * tiles_n;
   const long full = tiles / 512;

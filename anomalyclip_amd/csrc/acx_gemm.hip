@@ -414,6 +414,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 
 
 #include "acx_gemm_w8.h"     // gemm_f32_w8_kernel
+#include "acx_gemm_p256.h"   // gemm_f32_p256_kernel: persistent 256-wide strip stream
 #include "acx_gemm_bf16.h"   // gemm_bf16_dma_kernel, gemm_bf16_ring_kernel
 #include "acx_gemm_tn.h"     // gemm_tn_kernel, gemm_tn_w8_kernel, tn_reduce_kernel
 
@@ -434,6 +435,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 }  // namespace
+
+// Which problems the persistent strip-stream kernel (acx_gemm_p256.h) takes: plain row-major f32 A and C, no residual
+// (with one, the epilogue's load-then-store wait costs what the larger tile gains: 123 vs 125 TFLOP/s on out-proj),
+// >= 1024 tiles of 128x128 so every CU streams >= 8 strips.  linear() asks too: such a launch has no tail to split.
+bool acx_gemm_takes_strip_stream(const acx_gemm_desc* d) {
+  if (!ACX_DBG_SWITCH("P256", true)) return false;
+  if (d->prec != ACX_PREC_F32 || d->a_dtype == ACX_BF16 || d->c_dtype == ACX_BF16) return false;
+  if (d->amap != ACX_AMAP_IDENTITY || d->a_sub || d->pos0 || d->K % 32 || d->act == ACX_ACT_LEAKYRELU) return false;
+  if (d->residual) return false;
+  const long tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+  return tiles >= 1024 && (size_t)d->M * d->lda < ((size_t)1 << 31) && (size_t)d->N * d->ldw < ((size_t)1 << 31);
+}
 
 extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->C) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: null pointer%s");
@@ -543,6 +556,26 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   }
   // f32 FAST problems without split-K: the 8-wave variant (ACX_W8=0 keeps the 4-wave kernel)
   // (short split-K pieces of identity-map problems stay on the 4-wave kernel: no measurable difference)
+  if (g.ksplit == 1 && acx_gemm_takes_strip_stream(d)) {
+    // big f32 GEMMs without a residual: persistent strip-stream kernel, one 1024-thread block per CU (acx_gemm_p256.h)
+    const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+    const dim3 pgrid((unsigned)ncu);                       // >= 1024 tiles of 128x128 => >= 8 strips per CU
+    const size_t plds = 2 * P2_STAGE_B;
+#define ACX_P2L(ACT)                                                                                \
+  do {                                                                                              \
+    static bool attr_done = false;                                                                  \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_f32_p256_kernel<ACT, 0>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);             \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_f32_p256_kernel<ACT, 0>), pgrid, dim3(1024), plds, s, g);              \
+  } while (0)
+    if (d->act == ACX_ACT_QUICKGELU) ACX_P2L(1); else ACX_P2L(0);
+#undef ACX_P2L
+    ACX_CHECK_LAUNCH(ctx, "acx_gemm");
+    return ACX_OK;
+  }
   if (w8 && (w8_conv || (fast && g.ksplit == 1)) && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16) {
 #define ACX_W8L(ACT, RES, CV)                                                                       \
   do {                                                                                              \

@@ -86,6 +86,9 @@ static inline int acx_check_launch(acx_ctx* ctx, const char* name) {
     if (rc__ != ACX_OK) return rc__;             \
   } while (0)
 
+// acx_gemm.hip: true when acx_gemm runs `d` on the persistent strip-stream kernel (no partial last wave to split off)
+bool acx_gemm_takes_strip_stream(const acx_gemm_desc* d);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

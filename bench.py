@@ -506,7 +506,7 @@ def main():
                                    "text encoder + selector + axial temporal head + eval post-processing; "
                                    "step = one 512-frame clip per GPU, UCF-Crime head config, random-init weights",
                        "frames_per_step_per_gpu": FRAMES_PER_CLIP, "vit_chunk": args.vit_chunk, "precision": args.precision},
-            "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_f32_w8_kernel / gemm_kernel, v_mfma_f32_32x32x2_f32)"
+            "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_f32_p256_kernel / gemm_f32_w8_kernel, v_mfma_f32_32x32x2_f32)"
                          if args.precision == "f32" else "acx_gemm (gemm_bf16_ring_kernel / gemm_bf16_dma_kernel / gemm_kernel, v_mfma_f32_32x32x16_bf16)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": pmc_src, "launches": int(n_gemm), "avg_launch_ms": round(avg_ms, 4),
