@@ -220,6 +220,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_kernel(const float* __re
 #ifndef ACX_A16_KT
 #define ACX_A16_KT 2
 #endif
+#ifndef ACX_A16_ABL
+#define ACX_A16_ABL 0                               // timing ablations (wrong results), bit mask: 1 no softmax, 2 no chunk
+#endif                                              // barrier, 4 no LDS fragment reads, 8 no DMA
+constexpr int A16_ABL = ACX_A16_ABL;
 constexpr int A16_KT = ACX_A16_KT;                  // 16-key tiles per staged chunk
 constexpr int A16_CHUNK = 16 * A16_KT;              // keys per staged chunk
 constexpr int A16_OP_B = A16_CHUNK * 256;           // one operand chunk: rows of 64 f32
@@ -273,7 +277,7 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
 #define A16_ISSUE1(stage, ch, i_)                                                                                \
   do {                                                                                                           \
     const int ii_ = (i_);                                           /* wave-uniform */                           \
-    if (ii_ < 8 * A16_KT) {                                                                                      \
+    if (ii_ < 8 * A16_KT && !(A16_ABL & 8)) {                                                                      \
       const int r_ = 4 * (ii_ % (4 * A16_KT)) + g;                                                               \
       const int e_ = ii_ < 4 * A16_KT ? W + 4 * (qi ^ (r_ & 15)) : 2 * W + 4 * qi;                                \
       A16_DMA(bp_ + (int64_t)min((ch) * A16_CHUNK + r_, L - 1) * ldqkv + e_,                                     \
@@ -325,7 +329,7 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
       // ---- two 16-key tiles per chunk, each: S^T tiles of the wave's query tiles -> online softmax -> O^T += V^T P^T
 #define A16_QK(c4, off, toff)                                                                                   \
   do {                                                                                                           \
-    const float4 k_ = *reinterpret_cast<const float4*>(sS + (ka ^ (off)) + (toff));                              \
+    const float4 k_ = (A16_ABL & 4) ? qa[c4] : *reinterpret_cast<const float4*>(sS + (ka ^ (off)) + (toff));      \
     sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.x, qa[c4].x, sa, 0, 0, 0);                                       \
     if constexpr (HB) sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.x, qb[c4].x, sb, 0, 0, 0);                     \
     sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k_.y, qa[c4].y, sa, 0, 0, 0);                                       \
@@ -349,7 +353,7 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
   } while (0)
 #define A16_PV(r, toff)                                                                                         \
   do {                                                                                                           \
-    const float4 v_ = *reinterpret_cast<const float4*>(sS + va + (toff) + (r) * 256);                            \
+    const float4 v_ = (A16_ABL & 4) ? qa[r] : *reinterpret_cast<const float4*>(sS + va + (toff) + (r) * 256);      \
     oa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.x, sa[r], oa0, 0, 0, 0);                                        \
     if constexpr (HB) ob0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.x, sb[r], ob0, 0, 0, 0);                      \
     oa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v_.y, sa[r], oa1, 0, 0, 0);                                        \
@@ -369,8 +373,10 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
         sa[r] = ok_ ? sa[r] : -INFINITY; sb[r] = ok_ ? sb[r] : -INFINITY;                                        \
       }                                                                                                          \
     }                                                                                                            \
-    A16_SOFTMAX(sa, ma, la, oa0, oa1, oa2, oa3);                                                                 \
-    if constexpr (HB) A16_SOFTMAX(sb, mb, lb, ob0, ob1, ob2, ob3);                                               \
+    if constexpr (!(A16_ABL & 1)) {                                                                                \
+      A16_SOFTMAX(sa, ma, la, oa0, oa1, oa2, oa3);                                                               \
+      if constexpr (HB) A16_SOFTMAX(sb, mb, lb, ob0, ob1, ob2, ob3);                                             \
+    }                                                                                                            \
     A16_PV(0, toff); A16_PV(1, toff); A16_PV(2, toff); A16_PV(3, toff);                                          \
   } while (0)
       A16_TILE(0, A16_CHUNK * ch);
@@ -383,7 +389,7 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
 #undef A16_QK
       // next chunk landed (this wave's DMAs) and everybody is done reading this stage
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(A16_ABL & 2)) __builtin_amdgcn_s_barrier();
     }
     // every wave is past its last fragment read (barrier above): stage 0 is free for the next item's first chunk
     {
@@ -420,9 +426,14 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
 // 8 waves per workgroup; nkt (9..16) query tiles: nd = nkt - 8 waves own two tiles, the others one (L = 197: waves 0..4
 // two tiles, 5..7 one).  Measured and rejected on top of this: 13 one-tile waves at <= 64 VGPRs (spills, 0.86 ms), chunks
 // of 16 / 64 keys (no change: the chunk barrier is not the limit), s_setprio around the MFMA groups, rotating the
-// two-tile waves between co-resident workgroups (no change).  What remains (MFMA pipe busy 0.59): the four waves of a
-// SIMD run the same QK^T -> softmax -> PV phase sequence nearly in step, so the softmax VALU phases of all of them
-// coincide, and 13 tiles load the SIMDs 4/3/3/3.
+// two-tile waves between co-resident workgroups, dealing the two-tile roles by the SIMD id the waves report (s_getreg
+// HW_ID; waves w and w + 4 share a SIMD, tools/probes/wave_simd.hip) so that a CU's SIMDs carry 7/6/7/6 tiles (no
+// change), and software-pipelining the softmax inside each wave (scores of key tile j + 1 issued next to the softmax
+// of tile j, one 16-key tile per stage, ring of four: 0.785 ms, not faster; hipcc's scheduler clusters the MFMAs
+// and sched_group_barrier patterns made it 0.81).  Timing ablations (ACX_A16_ABL, profiles/r02_attn_ablation.txt):
+// no single phase is the limit -- softmax -11 %, DMA -8 %, chunk barrier -6 %, LDS fragment reads -4 %, and with ALL of
+// them removed (MFMAs, Q loads and output stores only) the kernel still takes 0.60 ms = 0.73 of the MFMA roof on its
+// padded work: 13 tiles on 8 waves, single-accumulator 16x16x4 chains, item prologue / epilogue.
 __global__ __launch_bounds__(512, 4) void attn16_kernel(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out,
                                                         int64_t ldo, int L, int heads, int nitems) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
