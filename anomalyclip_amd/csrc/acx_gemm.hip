@@ -416,6 +416,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #include "acx_gemm_w8.h"     // gemm_f32_w8_kernel
 #include "acx_gemm_p256.h"   // gemm_f32_p256_kernel: persistent 256-wide strip stream
 #include "acx_gemm_bf16.h"   // gemm_bf16_dma_kernel, gemm_bf16_ring_kernel
+#include "acx_gemm_p8.h"     // gemm_bf16_p8_kernel: the ring kernel's tile stream on a phase-interleaved schedule
 #include "acx_gemm_tn.h"     // gemm_tn_kernel, gemm_tn_w8_kernel, tn_reduce_kernel
 
 template <int C_BF16>
@@ -615,8 +616,21 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && rtiles >= ring_min && !(d->act == ACX_ACT_QUICKGELU && d->residual)) {
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     const dim3 rgrid((unsigned)(rtiles < ncu ? rtiles : ncu));
+    // even K-tile count and 32-bit operand byte offsets: the phase-interleaved kernel; else the lock-step ring kernel
+    const bool p8 = (d->K / 64) % 2 == 0 && (size_t)d->M * d->lda * 2 < ((size_t)1 << 32) &&
+                    (size_t)d->N * d->ldw * 2 < ((size_t)1 << 32) && ACX_DBG_SWITCH("P8", true);
 #define ACX_RING_L(CB, ACT, RES)                                                                    \
   do {                                                                                              \
+    if (p8) {                                                                                       \
+      static bool attr8_done = false;                                                               \
+      if (!attr8_done) {                                                                            \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<CB, ACT, RES>,                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_B);       \
+        attr8_done = true;                                                                          \
+      }                                                                                             \
+      hipLaunchKernelGGL((gemm_bf16_p8_kernel<CB, ACT, RES>), rgrid, dim3(512), (size_t)P8_LDS_B, s, g); \
+      break;                                                                                        \
+    }                                                                                               \
     static bool attr_done = false;                                                                  \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<CB, ACT, RES>,                   \
