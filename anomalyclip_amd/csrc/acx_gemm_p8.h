@@ -22,8 +22,9 @@
 //     waits precede a barrier both groups have passed; a buffer restaged in phase p was last read in phase <= p - 2;
 //   * the K-tile stream runs across output tiles (the next tile's first K-tiles land during this tile's epilogue).
 //     At a tile end the groups re-align (one extra barrier for group 0), drain the DMA queue (vmcnt(0): the epilogue's
-//     stores must not sit in front of counted waits), run the epilogue together and split again; the first K-tile of
-//     the next tile needs no DMA wait (everything it reads landed before the epilogue).
+//     stores must not sit in front of counted waits), run the epilogue together and split again; the next tile's first
+//     two K-tiles are complete in LDS before the epilogue (the halves phases 1 / 2 would issue go out at the tile end),
+//     so the first counted wait after the stores is eight phases later.
 // Measured (profiles/r02_gemm_bf16_p8.txt; M = 100864, N = 2304, f32 C): a K-tile costs 1.63 us here against 1.83 us in
 // the ring kernel, i.e. 1317 TFLOP/s = 0.53 of the 2.5 PFLOP/s roof in the limit of long K (the guide's template:
 // 1320-1340); what the in-model shapes (K = 768: 12 K-tiles per tile) see is the fixed cost per tile -- 14.7 us, of
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
     }                                                                                              \
   } while (0)
   // the tail of every phase's read section, then the MFMA section between the two barriers
-#define P8_ENTER()                                                                                 \
+#define P8_ENTER(W)                                                                                \
   do {                                                                                             \
-    if (wait_dma) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                 \
+    if (W) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
     asm volatile("" ::: "memory");                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     __builtin_amdgcn_s_barrier();                                                                  \
@@ -161,31 +162,35 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
     __builtin_amdgcn_s_barrier();                                                                  \
     asm volatile("" ::: "memory");                                                                 \
   } while (0)
-#define P8_KTILE(slot)                                                                             \
+  // I12: phases 1 / 2 issue their half-tiles (not in the first K-tile after an epilogue: issued before it);
+  // W123 / W4: the DMA wait of phases 1..3 / of phase 4
+#define P8_KTILE(slot, I12, W123, W4)                                                              \
   do {                                                                                             \
-    P8_RD_A(slot, 0); P8_RD_B(fB0, slot, 0); P8_DMA(c1, 3, (slot) ^ 1);                            \
-    P8_ENTER(); P8_MM(0, 0, fB0); P8_LEAVE();                                                      \
-    P8_RD_B(fB1, slot, 1); P8_DMA(c1, 1, (slot) ^ 1);                                              \
-    P8_ENTER(); P8_MM(0, 1, fB1); P8_LEAVE();                                                      \
+    P8_RD_A(slot, 0); P8_RD_B(fB0, slot, 0); if (I12) P8_DMA(c1, 3, (slot) ^ 1);                   \
+    P8_ENTER(W123); P8_MM(0, 0, fB0); P8_LEAVE();                                                  \
+    P8_RD_B(fB1, slot, 1); if (I12) P8_DMA(c1, 1, (slot) ^ 1);                                     \
+    P8_ENTER(W123); P8_MM(0, 1, fB1); P8_LEAVE();                                                  \
     P8_RD_A(slot, 1); P8_DMA(c2, 0, slot);                                                         \
-    P8_ENTER(); P8_MM(1, 1, fB1); P8_LEAVE();                                                      \
+    P8_ENTER(W123); P8_MM(1, 1, fB1); P8_LEAVE();                                                  \
     P8_DMA(c2, 2, slot);                                                                           \
-    P8_ENTER(); P8_MM(1, 0, fB0); P8_LEAVE();                                                      \
+    P8_ENTER(W4); P8_MM(1, 0, fB0); P8_LEAVE();                                                    \
     c1 = c2; P8_ADVANCE(c2);                                                                       \
   } while (0)
 
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // AH0(0), BH0(0) landed (this wave's share)
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier behind
-  bool wait_dma = true;
   for (int j = 0; j < my_tiles; ++j) {
     for (int kt = 0; kt < nk; kt += 2) {
-      P8_KTILE(0);
-      wait_dma = true;
-      P8_KTILE(1);
+      // the first two K-tiles after an epilogue read only what landed before it (their missing halves are issued at
+      // the tile end below): the first counted wait -- which also covers the epilogue's stores -- is 8 phases away
+      const bool fresh = j > 0 && kt == 0;
+      P8_KTILE(0, !fresh, !fresh, !fresh);
+      P8_KTILE(1, true, !fresh, true);
     }
-    // ---- tile end: re-align the groups, drain the DMA queue, epilogue, split again
+    // ---- tile end: re-align the groups, complete the K-tile after next, drain the DMA queue, epilogue, split again
     if (wm == 0) __builtin_amdgcn_s_barrier();
+    P8_DMA(c1, 3, 1); P8_DMA(c1, 1, 1);                          // BH1, AH1 of the next tile's second K-tile (slot 1 is free)
     if (!(ACX_P8_ABL & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((ACX_P8_ABL & 2) && g.ksplit != 12345) {
 #pragma unroll
@@ -266,7 +271,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (wm == 1) __builtin_amdgcn_s_barrier();
-    wait_dma = false;                            // the next tile's first K-tile reads only what landed before the epilogue
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();                    // pairs group 1's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no DMA may still be writing this workgroup's LDS at exit

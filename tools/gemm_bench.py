@@ -12,6 +12,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--shapes", default="qkv,out,fc,proj")
 ap.add_argument("--epi", type=int, default=0)   # 1: the in-model epilogues (residual on out/proj, QuickGELU on fc)
 ap.add_argument("--rounds", type=int, default=1)
+ap.add_argument("--cbf16", action="store_true")   # bf16 C (the in-model qkv / fc outputs of the bf16 mode)
 ap.add_argument("--custom", default="")   # e.g. 1536x768,4608x768  (NxK)
 args = ap.parse_args()
 M = 197 * args.frames
@@ -29,7 +30,7 @@ for name in names * args.rounds:
     if prec == L.PREC_BF16:
         w = ops.cast_bf16(w)
         a = ops.cast_bf16(a)
-    out = torch.empty(M, N, device=dev)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if args.cbf16 else torch.float32)
     kw = {}
     if args.epi and name in ("out", "proj"):
         kw["residual"] = torch.randn(M, N, device=dev)
