@@ -21,6 +21,8 @@ DEV = "cuda"
 
 
 def relerr(a, b):
+    """max |a - b| / max |b| (a NORM-wise relative error, not element-wise: near-zero elements are judged against the
+    tensor's scale); the tolerances quoted in the tests are for this quantity."""
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
