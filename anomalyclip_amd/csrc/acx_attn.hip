@@ -566,6 +566,7 @@ constexpr int BK_ROWB = 144;       // bytes per K row in LDS
 constexpr int BV_ROWB = 520;       // bytes per Vt row (224 keys * 2 B = 448, +72: stride/4 = 130 = 2 mod 64)
 
 __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) { return f2bf2(a, b); }
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict__ qkv, int64_t ldqkv, u16* __restrict__ out,
@@ -633,26 +634,37 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict
       }
       __builtin_amdgcn_sched_barrier(0);     // one key tile of fragments in flight, not all 28 (register spills)
     }
-    // ---- softmax over the keys of this lane's query: register r of tile kt is key kt*32 + (r&3) + 8(r>>2) + 4hh
+    // ---- softmax over the keys of this lane's query: register r of tile kt is key kt*32 + (r&3) + 8(r>>2) + 4hh.
+    // At the bf16 MFMA rate this VALU work weighs more than the MFMAs (SQ_ACTIVE_INST_VALU 35 % vs MFMA busy 18 %): the
+    // maximum is taken over the RAW scores (the scale is positive), only the last key tile holds keys >= L, and scale,
+    // shift and the base change are ONE (packed) fma in front of v_exp_f32: p = 2^((s - m) * 0.125 * log2 e).
+    {
+      constexpr int kt = NT - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        st[kt][r] = key < L ? st[kt][r] : -3.0e38f;
+      }
+    }
     float m = -3.0e38f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        st[kt][r] = key < L ? st[kt][r] * 0.125f : -3.0e38f;
-        m = fmaxf(m, st[kt][r]);
-      }
+      for (int r = 0; r < 16; r += 2) m = fmaxf(m, fmaxf(st[kt][r], st[kt][r + 1]));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+    const float sc_ = 0.125f * 1.4426950408889634f, nmc = -m * sc_;
+    f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __expf(st[kt][r] - m);
-        st[kt][r] = pv;
-        sum += pv;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2v s2 = {st[kt][r], st[kt][r + 1]};
+        const f32x2v a2 = __builtin_elementwise_fma(s2, (f32x2v){sc_, sc_}, (f32x2v){nmc, nmc});
+        const f32x2v p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+        st[kt][r] = p2[0]; st[kt][r + 1] = p2[1];
+        sum2 += p2;
       }
+    float sum = sum2[0] + sum2[1];
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
     // ---- O^T = V^T P^T : two 32-wide e tiles

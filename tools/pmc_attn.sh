@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/pmc_attn
 rm -rf $OUT; mkdir -p $OUT
-CMD="python /root/repo/tools/attn_bench.py"
+CMD="python /root/repo/tools/${ATTN_BENCH:-attn_bench.py}"
 pmc() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -o p -- $CMD > $OUT/$1.log 2>&1; }
 pmc sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"
 pmc sq2 "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM"
