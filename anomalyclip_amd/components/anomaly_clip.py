@@ -123,6 +123,9 @@ class AnomalyCLIP(nn.Module):
         # under data parallelism the (replicated) text encoder is evaluated class-parallel: every rank runs its block
         # of classes and the (C, E) features / their gradients are exchanged (functional.TextFeaturesFn)
         self.text_class_parallel = bool(g("text_class_parallel", True))
+        # training: replay the text tower as two HIP graphs on a side stream (functional._TextGraphs; same kernels,
+        # bit-identical results, ~230 fewer library calls per step and the tower runs beside the temporal model)
+        self.text_graph = bool(g("text_graph", False))
         self._text_cache = None
 
     # ------------------------------------------------------------------------------------------

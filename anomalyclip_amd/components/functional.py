@@ -132,7 +132,10 @@ class TextFeaturesFn(torch.autograd.Function):
 
 def _frozen_transposes(te):
     """Transposed copies of the FROZEN text-transformer weights (dX = dY @ W needs W^T as the [N,K] operand)."""
-    key = (ops.WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in te.transformer.parameters())
+    # optimizer steps through raw pointers (ops.adamw_) do not bump _version, hence WEIGHT_EPOCH -- but only for weights an
+    # optimizer can touch: the CLIP text layers are frozen (requires_grad False), their transposes survive the step
+    frozen = not any(p.requires_grad for p in te.transformer.parameters())
+    key = ((-1 if frozen else ops.WEIGHT_EPOCH[0]),) + tuple((p.data_ptr(), p._version) for p in te.transformer.parameters())
     cache = getattr(te, "_wt_cache", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -147,6 +150,130 @@ def _frozen_transposes(te):
 def text_features_train(net):
     return TextFeaturesFn.apply(net.prompt_learner.ctx, net.text_encoder.text_projection, net,
                                 getattr(net, "text_class_parallel", True))
+
+
+# ------------------------------------------------------------------------------------------------------ graph / side stream
+# `net.text_graph = True`: the text tower of a training step -- ~100 launches forward, ~130 backward, all of them small
+# (77 C rows) and the same every step -- is captured once into two HIP graphs and replayed on a SIDE stream:
+#   * the host issues 2 launches instead of ~230 library calls (the step is launch-bound from 16 videos per GPU down);
+#   * the tower runs next to the temporal model instead of in front of it: the forward graph is launched first and
+#     joined only where the selector needs the text features (configs without the logits concat run the temporal model
+#     in between); the backward graph waits for the selector's backward only and runs beside the temporal backward.
+# Same kernels in the same order on the same operands as the eager path: results are bit-identical (tests).
+class _TextGraphs:
+    def __init__(self, net, lo, hi):
+        te, pl = net.text_encoder, net.prompt_learner
+        self.key = self.make_key(net, lo, hi)
+        self.side = torch.cuda.Stream()
+        ctx_param, P = pl.ctx, te.text_projection
+        _frozen_transposes(te)                                               # cached outside the graphs
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            for _ in range(2):                                               # warm-up: lazy workspaces, function attributes
+                tf, state = _text_forward_rows(net, ctx_param, P, lo, hi)
+                _text_backward_rows(net, P, state, torch.zeros_like(tf))
+        torch.cuda.synchronize()
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd, stream=self.side):
+            self.tf, self.state = _text_forward_rows(net, ctx_param, P, lo, hi)
+        self.d_tf = torch.zeros_like(self.tf)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bwd, stream=self.side, pool=self.g_fwd.pool()):
+            self.d_ctx, self.d_P = _text_backward_rows(net, P, self.state, self.d_tf)
+        torch.cuda.synchronize()
+        self.fwd_done = torch.cuda.Event()
+
+    @staticmethod
+    def make_key(net, lo, hi):
+        te, pl = net.text_encoder, net.prompt_learner
+        ts = (pl.ctx, pl.token_prefix, pl.token_suffix, te.text_projection, te.positional_embedding, net.eot_index)
+        return (lo, hi) + tuple((t.data_ptr(), tuple(t.shape)) for t in ts) + \
+            tuple(p.data_ptr() for p in te.transformer.parameters())
+
+
+def text_graph_launch(net):
+    """Start this step's text forward on the side stream (no autograd node yet: TextGraphFn picks the result up)."""
+    par = _parallel()
+    C_all = net.prompt_learner.n_cls
+    cp = bool(getattr(net, "text_class_parallel", True)) and par.is_distributed()
+    lo, hi = par.shard_range(C_all, par.world_size(), par.rank()) if cp else (0, C_all)
+    tg = getattr(net, "_text_graphs", None)
+    if tg is None or tg.key != _TextGraphs.make_key(net, lo, hi):
+        tg = net._text_graphs = _TextGraphs(net, lo, hi)
+    tg.rows, tg.cp = (lo, hi, C_all), cp
+    tg.side.wait_stream(torch.cuda.current_stream())                         # parameters of the last optimizer step
+    with torch.cuda.stream(tg.side):
+        tg.g_fwd.replay()
+        tg.fwd_done.record()
+    return tg
+
+
+class TextGraphFn(torch.autograd.Function):
+    """Autograd node of the graph-replayed text tower; applied BEFORE the temporal model so that its backward is the
+    LAST node of the step (autograd runs later-created nodes first): by then the temporal backward is queued on the main
+    stream and the text backward, which waits only for the event recorded after the selector's backward, runs beside it."""
+
+    @staticmethod
+    def forward(ctx, ctx_param, text_projection, net):
+        ctx.net = net
+        ctx.save_for_backward(ctx_param)
+        return net._text_graphs.tf.detach()             # alias of the graph's static output; valid after text_graph_join()
+
+    @staticmethod
+    def backward(ctx, d_tf_loc):
+        net = ctx.net
+        tg = net._text_graphs
+        (ctx_param,) = ctx.saved_tensors
+        lo, hi, C_all = tg.rows
+        ev = getattr(net, "_text_grad_ready", None)
+        net._text_grad_ready = None
+        if ev is not None:
+            tg.side.wait_event(ev)                      # d_tf is final: recorded after the selector / assemble backward
+        else:
+            tg.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(tg.side):
+            tg.d_tf.copy_(d_tf_loc)
+            tg.g_bwd.replay()
+        torch.cuda.current_stream().wait_stream(tg.side)
+        d_ctx_loc, d_P = tg.d_ctx, tg.d_P
+        if tg.cp and ctx_param.dim() == 3:
+            d_ctx = torch.zeros_like(ctx_param)
+            d_ctx[lo:hi] = d_ctx_loc
+        else:
+            d_ctx = d_ctx_loc.clone()
+        return d_ctx, d_P.clone(), None
+
+
+class TextAssembleFn(torch.autograd.Function):
+    """Class-parallel exchange around the graph path (what TextFeaturesFn does inline): forward = local rows into a zero
+    (C, E) buffer + ONE all-reduce; backward = ONE all-reduce of d_features, this rank's class rows."""
+
+    @staticmethod
+    def forward(ctx, tf_loc, net):
+        tg = net._text_graphs
+        lo, hi, C_all = tg.rows
+        ctx.net = net
+        return _parallel().assemble_rows(tf_loc, lo, C_all) if tg.cp else tf_loc.clone()
+
+    @staticmethod
+    def backward(ctx, d_tf):
+        net = ctx.net
+        tg = net._text_graphs
+        lo, hi, _ = tg.rows
+        d_tf = d_tf.contiguous()
+        if tg.cp:
+            d_tf = _parallel().all_reduce_sum_(d_tf.clone())[lo:hi].contiguous()
+        ev = torch.cuda.Event()
+        ev.record()                                     # the text backward may start here
+        net._text_grad_ready = ev
+        return d_tf, None
+
+
+def text_graph_join(net, tf_loc):
+    """Main stream waits for the forward graph; returns the (C, E) text features."""
+    torch.cuda.current_stream().wait_event(net._text_graphs.fwd_done)
+    return TextAssembleFn.apply(tf_loc, net)
 
 
 # ====================================================================================================== selector
@@ -389,10 +516,26 @@ def anomaly_clip_train_forward(net, image_features, labels, ncentroid, masks=Non
     if ncrops != 1:
         raise ValueError("training expects ncrops == 1 (the reference squeezes the crop axis, anomaly_clip.py:178-181)")
     x = image_features.reshape(-1, d).contiguous().float()
-    text_features = net.get_text_features()
     sel = net.selector_model
     if masks is None:
         masks = sel.generate_mask(b)
+    trainable_text = net.prompt_learner.ctx.requires_grad or net.text_encoder.text_projection.requires_grad
+    if getattr(net, "text_graph", False) and trainable_text and x.is_cuda:
+        # text tower as two replayed graphs on a side stream (see _TextGraphs); without the logits concat the temporal
+        # model does not depend on the selector and runs between the launch and the join
+        text_graph_launch(net)
+        tf_loc = TextGraphFn.apply(net.prompt_learner.ctx, net.text_encoder.text_projection, net)
+        scores = None
+        if not net.concat_features:
+            feats, a_sub = net.get_temporal_model_input(x, None, ncentroid)
+            scores = net.temporal_model(feats, 1, False, a_sub=a_sub).view(-1)
+        text_features = text_graph_join(net, tf_loc)
+        logits, logits_topk, logits_bottomk, ia, in_, ba = selector_train(sel, x, text_features, labels, ncentroid, masks)
+        if scores is None:
+            feats, a_sub = net.get_temporal_model_input(x, logits, ncentroid)
+            scores = net.temporal_model(feats, 1, False, a_sub=a_sub).view(-1)
+        return logits, logits_topk, scores, ia, in_, ba
+    text_features = net.get_text_features()
     logits, logits_topk, logits_bottomk, ia, in_, ba = selector_train(sel, x, text_features, labels, ncentroid, masks)
     feats, a_sub = net.get_temporal_model_input(x, logits, ncentroid)
     scores = net.temporal_model(feats, 1, False, a_sub=a_sub).view(-1)

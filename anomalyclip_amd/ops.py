@@ -41,13 +41,18 @@ def _dt(t: torch.Tensor) -> int:
 
 
 _SPLITK_WS: dict = {}
+_SPLITK_RETIRED: list = []
 
 
 def _splitk_workspace(device, nbytes: int) -> torch.Tensor:
-    """one reusable split-K scratch buffer per device (stream-ordered reuse on the current stream)."""
-    key = (device.type, device.index)
+    """one reusable split-K scratch buffer per device AND stream (stream-ordered reuse; work on a side stream -- the
+    graph-replayed text tower -- must not share scratch with the main stream).  Outgrown buffers stay referenced: a
+    captured graph may still hold their address."""
+    key = (device.type, device.index, _stream() if device.type == "cuda" else 0)
     ws = _SPLITK_WS.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _SPLITK_RETIRED.append(ws)
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _SPLITK_WS[key] = ws
     return ws

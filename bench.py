@@ -216,6 +216,24 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
         return step, batch
 
     net.train()
+    # text tower as two replayed HIP graphs on a side stream (components/functional.py, bit-identical to the eager path):
+    # capture here, before any collective of a step, and agree across ranks -- a rank that cannot capture sends
+    # everybody back to the eager path
+    net.text_graph = True
+    try:
+        from anomalyclip_amd.components import functional as Fn
+        with torch.enable_grad():
+            Fn.text_graph_launch(net)
+        torch.cuda.synchronize()
+        graph_note = None
+    except Exception as e:  # noqa: BLE001
+        net.text_graph = False
+        graph_note = f"{type(e).__name__}: {e}"[:200]
+    if dist is not None:
+        flag = torch.tensor([1.0 if net.text_graph else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        net.text_graph = bool(flag.item() > 0.5)
+    out["text_graph"] = {"enabled": bool(net.text_graph), "note": graph_note}
     # ---- configs[1]: one GPU, B = 64 (rank-local copy of the global batch when N > 1: not a scaling leg)
     if world == 1:
         step, batch = make_train(HEAD_BATCH)

@@ -374,6 +374,42 @@ def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom):
     assert float(mods[0][1].selector_model.logit_scale) == float(np.float32(2.6592601))      # untouched by weight decay
 
 
+@pytest.mark.parametrize("geom", ["tiny", "ViT-B/16"])
+def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom):
+    """net.text_graph = True: the text tower replayed as two HIP graphs on a side stream (forward launched before the
+    temporal model, backward beside the temporal backward) runs the same kernels on the same operands as the eager
+    path -- three optimisation steps must leave bit-identical losses, gradients and parameters; the graphs are
+    captured once and the static buffers must survive the optimizer's in-place updates of ctx / text_projection."""
+    D = IW.TINY.embed_dim if geom == "tiny" else 512
+    B = 4
+    mods = [_dp_module(prompts_table, geom=geom) for _ in range(2)]
+    mods[0][1].text_graph = True
+    opts = [m.configure_optimizers()["optimizer"] for m, _ in mods]
+    for step in range(3):
+        feats, labels, masks = _dp_batch(B, D, 500 + step)
+        f, l = feats.to(DEV), labels.to(DEV)
+        batch = ((f[B // 2:], l[B // 2:]), (f[:B // 2], l[:B // 2]))
+        for (mod, net), opt in zip(mods, opts):
+            mod.ncentroid = torch.zeros(D, device=DEV)
+            net.selector_model.generate_mask = lambda b, m=masks: (m[0], m[1])
+            mod.train_batch(batch, opt)
+        torch.cuda.synchronize()
+        pa, pb = dict(mods[0][1].named_parameters()), dict(mods[1][1].named_parameters())
+        for a_, b_ in zip(mods[0][0].last_losses, mods[1][0].last_losses):
+            assert torch.equal(a_, b_), step
+        for n in pa:
+            if pa[n].requires_grad:
+                assert (pa[n].grad is None) == (pb[n].grad is None), (step, n)
+                if pb[n].grad is not None:
+                    assert torch.equal(pa[n].grad, pb[n].grad), (step, n)
+                assert torch.equal(pa[n], pb[n]), (step, n)
+    tg = mods[0][1]._text_graphs
+    assert tg is not None and not hasattr(mods[1][1], "_text_graphs")
+    first = tg
+    mods[0][0].train_batch(batch, opts[0])
+    assert mods[0][1]._text_graphs is first                                   # captured once
+
+
 def _nccl_worker(rank, world, port, q, backend):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -395,6 +431,7 @@ def _nccl_worker(rank, world, port, q, backend):
                                             "data", "prompts.json")))
         B, D = 8, IW.TINY.embed_dim
         (ma, na), (mb, nb) = _dp_module(table), _dp_module(table)
+        na.text_graph = True              # graph-replayed text tower + class-parallel exchange vs the eager reference module
         oa = ma.configure_optimizers()["optimizer"]
         ok = True
         for step in range(2):
