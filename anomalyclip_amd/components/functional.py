@@ -232,6 +232,7 @@ class TextGraphFn(torch.autograd.Function):
             tg.side.wait_event(ev)                      # d_tf is final: recorded after the selector / assemble backward
         else:
             tg.side.wait_stream(torch.cuda.current_stream())
+        d_tf_loc.record_stream(tg.side)                 # allocated on the main stream, read by the side stream's copy
         with torch.cuda.stream(tg.side):
             tg.d_tf.copy_(d_tf_loc)
             tg.g_bwd.replay()
