@@ -126,6 +126,8 @@ class AnomalyCLIP(nn.Module):
         # training: replay the text tower as two HIP graphs on a side stream (functional._TextGraphs; same kernels,
         # bit-identical results, ~230 fewer library calls per step and the tower runs beside the temporal model)
         self.text_graph = bool(g("text_graph", False))
+        # ... and the temporal model's forward / backward as two graphs on the main stream (functional._TemporalGraphs)
+        self.temporal_model.graph = bool(g("temporal_graph", False))
         self._text_cache = None
 
     # ------------------------------------------------------------------------------------------

@@ -464,7 +464,68 @@ class TemporalFn(torch.autograd.Function):
         return (d_feats, None, None, *out)
 
 
+class _TemporalGraphs:
+    """TemporalFn.forward / .backward -- fixed sequences of library calls for a given input shape -- captured once as two
+    HIP graphs and replayed on the caller's stream: with few videos per GPU the step is bound by how fast the host can
+    issue these ~190 small launches.  Static buffers: a copy of the input features, the upstream gradient, every
+    activation, every returned gradient.  The weight-derived tensors of TemporalModel.prepared() are recomputed INSIDE
+    the forward graph (the optimizer rewrites the weights in place between replays)."""
+
+    def __init__(self, tm, feats, a_sub, need_dfeats):
+        from types import SimpleNamespace
+        self.key = self.make_key(tm, feats, a_sub, need_dfeats)
+        params = list(tm.parameters())
+        self.x = feats.detach().clone()
+        self.a_sub = a_sub
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                                               # warm-up: lazy workspaces, function attributes
+                c = SimpleNamespace(needs_input_grad=(need_dfeats,))
+                sc = TemporalFn.forward(c, self.x, a_sub, tm, *params)
+                TemporalFn.backward(c, torch.zeros_like(sc))
+        torch.cuda.synchronize()
+        tm._prep = None                                                      # prepared() runs inside the forward graph
+        self.cx = SimpleNamespace(needs_input_grad=(need_dfeats,))
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd), torch.no_grad():
+            self.scores = TemporalFn.forward(self.cx, self.x, a_sub, tm, *params)
+        self.d_scores = torch.zeros_like(self.scores)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()), torch.no_grad():
+            self.outs = TemporalFn.backward(self.cx, self.d_scores)
+        torch.cuda.synchronize()
+        tm._prep = None                                                      # eager callers must not pick up graph-pool tensors
+
+    @staticmethod
+    def make_key(tm, feats, a_sub, need_dfeats):
+        return (tuple(feats.shape), feats.dtype, None if a_sub is None else a_sub.data_ptr(), bool(need_dfeats),
+                tm.precision) + tuple(p.data_ptr() for p in tm.parameters())
+
+
+class TemporalGraphFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, a_sub, tm, *params):
+        need = ctx.needs_input_grad[0]
+        tg = getattr(tm, "_graphs", None)
+        if tg is None or tg.key != _TemporalGraphs.make_key(tm, feats, a_sub, need):
+            tg = tm._graphs = _TemporalGraphs(tm, feats, a_sub, need)
+        tg.x.copy_(feats)
+        tg.g_fwd.replay()
+        ctx.tm = tm
+        return tg.scores.detach().clone()
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        tg = ctx.tm._graphs
+        tg.d_scores.copy_(d_scores.reshape(tg.d_scores.shape))
+        tg.g_bwd.replay()
+        return tuple(o.clone() if o is not None else None for o in tg.outs)
+
+
 def temporal_train(tm, features, a_sub):
+    if getattr(tm, "graph", False) and features.is_cuda:
+        return TemporalGraphFn.apply(features.reshape(-1, features.shape[-1]).contiguous(), a_sub, tm, *tm.parameters())
     return TemporalFn.apply(features, a_sub, tm, *tm.parameters())
 
 
@@ -520,6 +581,10 @@ def anomaly_clip_train_forward(net, image_features, labels, ncentroid, masks=Non
     sel = net.selector_model
     if masks is None:
         masks = sel.generate_mask(b)
+    if x.is_cuda:
+        # host-generated masks (selector_model.py:101-117, CPU RNG) go to the device NOW, through pinned memory: a pageable
+        # copy issued later would make the host wait for everything queued on the stream before it
+        masks = tuple(m if m.is_cuda else m.float().pin_memory().to(x.device, non_blocking=True) for m in masks)
     trainable_text = net.prompt_learner.ctx.requires_grad or net.text_encoder.text_projection.requires_grad
     if getattr(net, "text_graph", False) and trainable_text and x.is_cuda:
         # text tower as two replayed graphs on a side stream (see _TextGraphs); without the logits concat the temporal

@@ -111,6 +111,7 @@ class TemporalModel(nn.Module):
         # convolution runs on the bf16 MFMA with f32 accumulation -- bf16 weights, bf16 LayerNorm outputs and conv
         # hidden activations; the residual streams, attention, norms and the classifier stay f32.
         self.precision = "f32"
+        self.graph = False                 # training: replay forward / backward as HIP graphs (functional._TemporalGraphs)
         self._prep = None
 
     # ---- derived weight layouts for the kernels (cached; rebuilt when a parameter changes)

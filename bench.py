@@ -233,7 +233,23 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
         flag = torch.tensor([1.0 if net.text_graph else 0.0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         net.text_graph = bool(flag.item() > 0.5)
-    out["text_graph"] = {"enabled": bool(net.text_graph), "note": graph_note}
+    # ... and the temporal model's forward / backward graphs: captured inside the first training step, before any of its
+    # collectives (the selector's SyncBN exchange comes after the temporal model in the graph ordering)
+    net.temporal_model.graph = True
+    tnote = None
+    try:
+        trial, _ = make_train(HEAD_BATCH)
+        trial()
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        net.temporal_model.graph = False
+        tnote = f"{type(e).__name__}: {e}"[:200]
+    if dist is not None:
+        flag = torch.tensor([1.0 if net.temporal_model.graph else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        net.temporal_model.graph = bool(flag.item() > 0.5)
+    out["train_graphs"] = {"text": {"enabled": bool(net.text_graph), "note": graph_note},
+                           "temporal": {"enabled": bool(net.temporal_model.graph), "note": tnote}}
     # ---- configs[1]: one GPU, B = 64 (rank-local copy of the global batch when N > 1: not a scaling leg)
     if world == 1:
         step, batch = make_train(HEAD_BATCH)

@@ -384,6 +384,7 @@ def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom):
     B = 4
     mods = [_dp_module(prompts_table, geom=geom) for _ in range(2)]
     mods[0][1].text_graph = True
+    mods[0][1].temporal_model.graph = True                                    # + the temporal model's two graphs
     opts = [m.configure_optimizers()["optimizer"] for m, _ in mods]
     for step in range(3):
         feats, labels, masks = _dp_batch(B, D, 500 + step)
@@ -432,6 +433,7 @@ def _nccl_worker(rank, world, port, q, backend):
         B, D = 8, IW.TINY.embed_dim
         (ma, na), (mb, nb) = _dp_module(table), _dp_module(table)
         na.text_graph = True              # graph-replayed text tower + class-parallel exchange vs the eager reference module
+        na.temporal_model.graph = True
         oa = ma.configure_optimizers()["optimizer"]
         ok = True
         for step in range(2):

@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0)
     ap.add_argument("--no-text-shard", action="store_true", help="replicate the text encoder on every rank (plain DP)")
     ap.add_argument("--text-graph", action="store_true", help="text tower as two replayed HIP graphs on a side stream")
+    ap.add_argument("--temporal-graph", action="store_true", help="temporal model forward / backward as two replayed HIP graphs")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local_rank)
@@ -93,6 +94,7 @@ def main():
     net.load_from_features = True
     net.text_class_parallel = not args.no_text_shard
     net.text_graph = bool(args.text_graph)
+    net.temporal_model.graph = bool(args.temporal_graph)
     crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
     mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(dev)
     mod.ncentroid = torch.zeros(512, device=dev)
@@ -151,7 +153,7 @@ def main():
                                          "launches": sum(counts) // 2},
             "train_gemm_tflops": round(gf / 1e9 / tot[0], 2) if tot[0] > 0 else None,
             "n_gpus": world, "emulated_world": args.emulate_world or None, "videos_this_rank": len(idx),
-            "text_class_parallel": bool(net.text_class_parallel), "text_graph": bool(net.text_graph),
+            "text_class_parallel": bool(net.text_class_parallel), "text_graph": bool(net.text_graph), "temporal_graph": bool(net.temporal_model.graph),
             "global_batch_videos": B_global, "scaling": args.scaling, "dtype": "f32",
             "loss": float(mod.last_losses[0]), "data": "synthetic"}))
     if world > 1:
