@@ -11,5 +11,5 @@ find $OUT -name "*_kernel_trace.csv" | xargs rm -f
 ls $OUT/*
 # round 2: configs[4] (XD bf16) and rank 0's share of an 8-rank strong-scaling step (emulated on one GPU)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xd -o xd -- python /root/repo/tools/bench_xd.py --steps 4 > $OUT/xd.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dp8 -o dp8 -- python /root/repo/tools/bench_head.py --emulate-world 8 --steps 6 > $OUT/dp8.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dp8 -o dp8 -- python /root/repo/tools/bench_head.py --emulate-world 8 --text-graph --temporal-graph --steps 6 > $OUT/dp8.log 2>&1
 find $OUT -name "*_kernel_trace.csv" | xargs rm -f
