@@ -167,6 +167,13 @@ def lib() -> C.CDLL:
                     raise AcxError(f"libacx.so not found at {path} and hipcc is not available to build it; "
                                    f"there is no fallback compute path")
                 path = _build.build(verbose=False)
+            # torch first: its bundled HIP runtime must be the one libacx.so's libamdhip64 dependency resolves to.  Loaded
+            # the other way round (libacx.so, then torch) the process ends up with two HIP runtimes and the one libacx sees
+            # reports "0 devices" while torch.cuda.is_available() is true (__graft_entry__.build() followed by smoke()).
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             try:
                 L = C.CDLL(path)
             except OSError as e:
