@@ -100,18 +100,28 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
     cn0 = (r0_ - t0_ * gsz) / d.gl; cl0 = (r0_ - t0_ * gsz) - cn0 * d.gl;
     cn1 = (r1_ - t1_ * gsz) / d.gl; cl1 = (r1_ - t1_ * gsz) - cn1 * d.gl;
   }
+  // conv: the tap of a K-step (k0 / cin) changes every cin / 32 steps -- the shifted source rows, their validity and the
+  // pointers are recomputed only then; in between a load is pointer + running offset (K-steps arrive in order)
+  const float *cs0 = nullptr, *cs1 = nullptr;
+  int ctap = 0, ckin = 0;
+#define W8_TAP()                                                                                   \
+  do {                                                                                             \
+    const int dn_ = ctap / 3 - 1, dl_ = ctap - (ctap / 3) * 3 - 1;                                 \
+    const int n0_ = cn0 + dn_, l0_ = cl0 + dl_, n1_ = cn1 + dn_, l1_ = cl1 + dl_;                   \
+    ok0 = (unsigned)n0_ < (unsigned)d.gn && (unsigned)l0_ < (unsigned)d.gl;                        \
+    ok1 = (unsigned)n1_ < (unsigned)d.gn && (unsigned)l1_ < (unsigned)d.gl;                        \
+    const long s0_ = cb0 + (long)min(max(n0_, 0), d.gn - 1) * d.gl + min(max(l0_, 0), d.gl - 1);   \
+    const long s1_ = cb1 + (long)min(max(n1_, 0), d.gn - 1) * d.gl + min(max(l1_, 0), d.gl - 1);   \
+    cs0 = (const float*)d.A + (size_t)s0_ * d.lda + chunk * 4;                                     \
+    cs1 = (const float*)d.A + (size_t)s1_ * d.lda + chunk * 4;                                     \
+  } while (0)
 #define W8_LOAD(k0)                                                                                \
   do {                                                                                             \
     if constexpr (CONV != 0) {                                                                     \
-      const int tap_ = (k0) / d.cin;                    /* uniform */                             \
-      const int dn_ = tap_ / 3 - 1, dl_ = tap_ - (tap_ / 3) * 3 - 1, kc_ = (k0) - tap_ * d.cin + chunk * 4; \
-      const int n0_ = cn0 + dn_, l0_ = cl0 + dl_, n1_ = cn1 + dn_, l1_ = cl1 + dl_;                 \
-      ok0 = (unsigned)n0_ < (unsigned)d.gn && (unsigned)l0_ < (unsigned)d.gl;                      \
-      ok1 = (unsigned)n1_ < (unsigned)d.gn && (unsigned)l1_ < (unsigned)d.gl;                      \
-      const long s0_ = cb0 + (long)min(max(n0_, 0), d.gn - 1) * d.gl + min(max(l0_, 0), d.gl - 1); \
-      const long s1_ = cb1 + (long)min(max(n1_, 0), d.gn - 1) * d.gl + min(max(l1_, 0), d.gl - 1); \
-      ra0 = ld4((const float*)d.A + (size_t)s0_ * d.lda + kc_);                                    \
-      ra1 = ld4((const float*)d.A + (size_t)s1_ * d.lda + kc_);                                    \
+      if (ckin == d.cin) { ckin = 0; ++ctap; W8_TAP(); }          /* uniform */                    \
+      ra0 = ld4(cs0 + ckin);                                                                       \
+      ra1 = ld4(cs1 + ckin);                                                                       \
+      ckin += 32;                                                                                  \
     } else {                                                                                       \
       ra0 = ld4(pa0 + (k0)); ra1 = ld4(pa1 + (k0));                                                \
     }                                                                                              \
@@ -161,6 +171,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
   const int nk_total = d.K / 32;
   const int kbeg = (g.ksplit > 1 ? (int)blockIdx.y * g.kchunk : 0) * 32;
   const int nk = g.ksplit > 1 ? min(g.kchunk, nk_total - (int)blockIdx.y * g.kchunk) : nk_total;
+  if constexpr (CONV != 0) {
+    ctap = kbeg / d.cin;
+    ckin = kbeg - ctap * d.cin;
+    W8_TAP();
+  }
   W8_LOAD(kbeg);
   W8_STORE(0, 0); W8_STORE(0, 1);
   __syncthreads();
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
 #undef W8_RD
 #undef W8_STORE
 #undef W8_LOAD
+#undef W8_TAP
 
   const int col = n0 + wn * 32 + li;
   const bool cok = col < d.N;
