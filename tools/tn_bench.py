@@ -6,8 +6,8 @@ from anomalyclip_amd import ops
 
 dev = "cuda"
 M = 64 * 512
-CASES = [("conv1 dW", 1024, 256, True), ("conv2 dW", 256, 1024, True), ("qkv dW", 768, 256, False),
-         ("proj dW", 256, 512, False)]
+CASES = [("conv1 dW", 1024, 256, True), ("conv2 dW", 256, 1024, True), ("plain1 dW", 1024, 2304, False),
+         ("plain2 dW", 256, 9216, False), ("qkv dW", 768, 256, False), ("proj dW", 256, 512, False)]
 for rnd in range(2):
     for name, n1, cin, conv in CASES:
         a = torch.randn(M, n1, device=dev)
