@@ -361,3 +361,74 @@ def test_ctx_init_from_token_embeddings(prompts_table):
             assert all(torch.equal(pl.ctx.detach()[c], want) for c in range(14))
     with pytest.raises(ValueError):
         AnomalyCLIP(**{k: v for k, v in kw.items() if k != "tokenized_prompts"}, ctx_init="a video of")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Executable statements of two scheduling arguments the HIP kernels rely on (pure Python models of the index / phase
+# arithmetic in csrc/acx_gemm_p256.h and csrc/acx_gemm_p8.h; the kernels themselves are checked numerically on the GPU).
+@pytest.mark.parametrize("M,N,nb", [(100864, 2304, 256), (100864, 768, 256), (33001, 2300, 256), (20000, 3072, 304),
+                                     (65, 256, 256), (4097, 1000, 13)])
+def test_strip_stream_partition_model(M, N, nb):
+    """gemm_f32_p256_kernel: work units = 64-row x 256-column strips in column-major order; CU c (XCD-contiguous index)
+    owns [U c / n, U (c + 1) / n) and walks it in tiles of <= 4 units that never cross a column tile.  Every unit must be
+    covered exactly once, and the block -> range map must be a bijection for any grid size."""
+    TN, RU = (N + 255) // 256, (M + 63) // 64
+    U = TN * RU
+    seen = np.zeros(U, dtype=np.int32)
+    cidxs = set()
+    for bid in range(nb):
+        xcd, qb, rb = bid & 7, nb >> 3, nb & 7
+        cidx = (xcd * (qb + 1) if xcd < rb else rb * (qb + 1) + (xcd - rb) * qb) + (bid >> 3)
+        cidxs.add(cidx)
+        pos, end = U * cidx // nb, U * (cidx + 1) // nb
+        while pos < end:
+            col = pos // RU
+            ru = pos - col * RU
+            n = min(4, end - pos, RU - ru)
+            assert 1 <= n <= 4 and ru + n <= RU
+            seen[pos:pos + n] += 1
+            pos += n
+    assert cidxs == set(range(nb))
+    assert (seen == 1).all()
+
+
+def test_phase_interleaved_dma_schedule_model():
+    """gemm_bf16_p8_kernel: phase p of K-tile s issues one half-tile -- BH1(s+1), AH1(s+1), AH0(s+2), BH0(s+2) -- into the
+    slot of that K-tile and ends with vmcnt(8) (everything but the four newest half-tiles has landed); phase 1 reads AH0 and
+    BH0 of K-tile s, phase 2 BH1, phase 3 AH1.  Rules (guide): a half-tile is READ at least one phase after the wait that
+    retired it, and a buffer is RESTAGED at least two phases after its last read.  Checked over a long stream, including
+    the tile-end variant (the next tile's second K-tile completed before the epilogue, no waits for eight phases)."""
+    issues = {}            # (half, ktile) -> global phase of issue; prologue: K-tile 0 entirely, AH0 / BH0 of K-tile 1
+    order = []             # issue order (for the counted wait)
+    for h in ("AH0", "BH0", "BH1", "AH1"):
+        issues[(h, 0)] = 0; order.append((h, 0))
+    for h in ("AH0", "BH0"):
+        issues[(h, 1)] = 0; order.append((h, 1))
+    retired_at = {k: 0 for k in list(issues)[:2]}      # prologue vmcnt(8): all but the newest four
+    nkt = 40
+    plan = {1: ("BH1", 1), 2: ("AH1", 1), 3: ("AH0", 2), 4: ("BH0", 2)}
+    reads = {1: ("AH0", "BH0"), 2: ("BH1",), 3: ("AH1",), 4: ()}
+    last_read = {}
+    for s in range(nkt):
+        for ph in (1, 2, 3, 4):
+            g = 4 * s + ph
+            for h in reads[ph]:
+                key = (h, s)
+                assert key in retired_at and retired_at[key] <= g - 1, (key, g)      # read >= 1 phase after the retiring wait
+                last_read[(h, s & 1)] = g
+            h, ds = plan[ph]
+            key = (h, s + ds)
+            slot = (h, (s + ds) & 1)
+            assert slot not in last_read or last_read[slot] <= g - 2, (key, g)       # restage >= 2 phases after the last read
+            issues[key] = g; order.append(key)
+            for k in order[:-4]:                                                     # vmcnt(8): all but the newest four
+                retired_at.setdefault(k, g)
+    # tile end after K-tile s (slot 1): BH1 / AH1 of K-tile s + 2 go out early, vmcnt(0), then two K-tiles without waits
+    s = 11
+    g_end = 4 * s + 4
+    for h in ("BH1", "AH1"):                             # their slot (that of K-tile s) was last read in phases 2 / 3 of s
+        assert last_read[(h, s & 1)] <= g_end - 1
+    landed = {k for k, g in issues.items() if g <= g_end} | {("BH1", s + 2), ("AH1", s + 2)}
+    for kt in (s + 1, s + 2):
+        for h in ("AH0", "BH0", "BH1", "AH1"):
+            assert (h, kt) in landed, (h, kt)
