@@ -426,8 +426,9 @@ def test_phase_interleaved_dma_schedule_model():
     # tile end after K-tile s (slot 1): BH1 / AH1 of K-tile s + 2 go out early, vmcnt(0), then two K-tiles without waits
     s = 11
     g_end = 4 * s + 4
-    for h in ("BH1", "AH1"):                             # their slot (that of K-tile s) was last read in phases 2 / 3 of s
-        assert last_read[(h, s & 1)] <= g_end - 1
+    read_phase = {"AH0": 1, "BH0": 1, "BH1": 2, "AH1": 3}
+    for h in ("BH1", "AH1"):                             # their slot (that of K-tile s) was last read in phases 2 / 3 of s,
+        assert 4 * s + read_phase[h] <= g_end - 1        # i.e. before the tile end's re-align barrier
     landed = {k for k, g in issues.items() if g <= g_end} | {("BH1", s + 2), ("AH1", s + 2)}
     for kt in (s + 1, s + 2):
         for h in ("AH0", "BH0", "BH1", "AH1"):
