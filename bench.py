@@ -483,6 +483,10 @@ def main():
     def step_keep():
         out_holder["o"] = step()
 
+    # ---- library initialisation, outside the W + K protocol: two steps with the per-launch event pairs armed (lazy
+    # workspaces, kernel attributes, the profiler's event pool) so that the W warm-up steps warm the chip, not the host
+    timer.run(step_keep, 2, 0, prof.start, prof.stop)
+    prof.collect()
     # ---- headline: EXACTLY --steps timed steps after --warmup untimed ones
     dt = timer.run(step_keep, args.steps, args.warmup, prof.start, prof.stop)
     gflops_exec, counts, tot = prof.collect()
