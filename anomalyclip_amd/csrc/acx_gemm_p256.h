@@ -40,6 +40,8 @@ struct P2Cursor {                                // position in this CU's unit r
   __device__ __forceinline__ void next() { pos += nun; load(); }
 };
 
+// RES != 0 is kept compilable (float4 residual per accumulator tile) but NOT dispatched: acx_gemm_takes_strip_stream()
+// sends problems with a residual to gemm_f32_w8_kernel (see the comment there and DESIGN.md section 4).
 template <int ACT, int RES>
 __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
