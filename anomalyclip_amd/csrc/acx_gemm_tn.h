@@ -201,6 +201,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) {
   float4 bsub = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g.b_sub && b_cok) bsub = *reinterpret_cast<const float4*>(g.b_sub + cb);
   const int grid_sz = g.conv ? g.gn * g.gl : 1;
+  // rows r0 and r0 + 16 of every K-step: with gl | 16 on a power-of-two grid their column coordinate is a constant
+  const bool fastconv = g.conv && g.sh_gl >= 0 && g.gl <= 16 && (m_begin & 31) == 0;
+  const int ll_raw = (r0 & (g.gl - 1)) + tap_dl;
+  const bool ll_ok = ll_raw >= 0 && ll_raw < g.gl;
+  const int ll_c = min(max(ll_raw, 0), max(g.gl - 1, 0));
 
   // TN_LOAD_ROW only ISSUES the two 16-byte loads of staging row r and records their predicates; masking and
   // the b_sub recentre happen in TN_STORE_ROW, a whole K-step later, so nothing waits on memory in between.
@@ -215,6 +220,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) {
     long srow_ = mc_;                                                                              \
     bool bok_ = mok_ && b_cok;                                                                     \
     if (g.conv) {                                                                                  \
+      if (fastconv) {  /* gl | 16, power-of-two grid, m_begin % 32 == 0: the column coordinate of this thread's rows */ \
+        /* never changes over the K loop (precomputed, clamped), only the grid row moves */        \
+        int nn_ = ((mc_ >> g.sh_gl) & (g.gn - 1)) + tap_dn;                                        \
+        bok_ = bok_ && ll_ok && (unsigned)nn_ < (unsigned)g.gn;                                    \
+        nn_ = min(max(nn_, 0), g.gn - 1);                                                          \
+        srow_ = (long)(mc_ & ~(grid_sz - 1)) + nn_ * g.gl + ll_c;                                  \
+      } else {                                                                                     \
       int tile_, rem_, nn_, ll_;                                                                   \
       if (g.sh_gl >= 0) { /* power-of-two grid (every shipped config: 32 x 16): shifts, no division */ \
         tile_ = mc_ >> g.sh_grid; rem_ = mc_ & (grid_sz - 1);                                      \
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) {
       nn_ = min(max(nn_, 0), g.gn - 1);                                                            \
       ll_ = min(max(ll_, 0), g.gl - 1);                                                            \
       srow_ = (long)tile_ * grid_sz + (long)nn_ * g.gl + ll_;                                      \
+      }                                                                                            \
     }                                                                                              \
     sb##r = *reinterpret_cast<const float4*>(g.B + (size_t)srow_ * g.ldb + (b_cok ? b_col : 0));   \
     ok_a = (ok_a & ~(1u << (r))) | ((mok_ && a_cok) ? (1u << (r)) : 0u);                            \
