@@ -17,12 +17,17 @@ from __future__ import annotations
 
 from typing import Iterable, List, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # ACX_FORCE_COLLECTIVES=1 (tests): take the collective code paths in a 1-rank group too -- the only way a single-GPU box
+    # can push the step's all-reduce / all-gather calls through the real RCCL backend
+    return dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size() > 1 or os.environ.get("ACX_FORCE_COLLECTIVES") == "1")
 
 
 def world_size() -> int:

@@ -2,6 +2,8 @@
 oracle's autograd (torch CPU) and the golden vectors produced by the REFERENCE.  Index outputs are
 compared bit-exactly; floats at fp32 round-off tolerances written per test."""
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -498,6 +500,30 @@ def test_train_batch_gradbuckets_world2(backend):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_train_batch_rccl_single_rank():
+    """The same worker with ONE rank on the real RCCL backend and the collective code paths forced on
+    (ACX_FORCE_COLLECTIVES=1): bucketed async all-reduce on RCCL's stream next to the side-stream graph replays, SyncBN
+    all-gather, class-parallel text exchange.  World size 1 cannot show averaging errors -- the 2-rank gloo variant does --
+    but it is the only way a single-GPU box can run these calls through RCCL itself."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["ACX_FORCE_COLLECTIVES"] = "1"
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        p = ctx.Process(target=_nccl_worker, args=(0, 1, port, q, "nccl"))
+        p.start()
+        res = q.get(timeout=600)
+        p.join(timeout=60)
+    finally:
+        os.environ.pop("ACX_FORCE_COLLECTIVES", None)
+    assert res == (0, True), res
 
 
 def test_builtin_trainer_fit_and_test_end_to_end(tmp_path, prompts_table):
