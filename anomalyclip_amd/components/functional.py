@@ -161,6 +161,8 @@ def text_features_train(net):
 #     in between); the backward graph waits for the selector's backward only and runs beside the temporal backward.
 # Same kernels in the same order on the same operands as the eager path: results are bit-identical (tests).
 class _TextGraphs:
+    # capture_error_mode="thread_local": other threads of the process (the RCCL watchdog polling its events) must not
+    # invalidate a capture in progress
     def __init__(self, net, lo, hi):
         te, pl = net.text_encoder, net.prompt_learner
         self.key = self.make_key(net, lo, hi)
@@ -175,11 +177,11 @@ class _TextGraphs:
                 _text_backward_rows(net, P, state, torch.zeros_like(tf))
         torch.cuda.synchronize()
         self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd, stream=self.side):
+        with torch.cuda.graph(self.g_fwd, stream=self.side, capture_error_mode="thread_local"):
             self.tf, self.state = _text_forward_rows(net, ctx_param, P, lo, hi)
         self.d_tf = torch.zeros_like(self.tf)
         self.g_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bwd, stream=self.side, pool=self.g_fwd.pool()):
+        with torch.cuda.graph(self.g_bwd, stream=self.side, pool=self.g_fwd.pool(), capture_error_mode="thread_local"):
             self.d_ctx, self.d_P = _text_backward_rows(net, P, self.state, self.d_tf)
         torch.cuda.synchronize()
         self.fwd_done = torch.cuda.Event()
@@ -488,11 +490,11 @@ class _TemporalGraphs:
         tm._prep = None                                                      # prepared() runs inside the forward graph
         self.cx = SimpleNamespace(needs_input_grad=(need_dfeats,))
         self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd), torch.no_grad():
+        with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"), torch.no_grad():
             self.scores = TemporalFn.forward(self.cx, self.x, a_sub, tm, *params)
         self.d_scores = torch.zeros_like(self.scores)
         self.g_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()), torch.no_grad():
+        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), capture_error_mode="thread_local"), torch.no_grad():
             self.outs = TemporalFn.backward(self.cx, self.d_scores)
         torch.cuda.synchronize()
         tm._prep = None                                                      # eager callers must not pick up graph-pool tensors
