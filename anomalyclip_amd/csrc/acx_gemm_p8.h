@@ -39,8 +39,8 @@ constexpr int P8_HALF_B = 128 * 128;            // half-tile: 128 rows x 64 bf16
 constexpr int P8_SLOT_B = 4 * P8_HALF_B;        // K-tile slot: AH0 | AH1 | BH0 | BH1
 constexpr int P8_LDS_B = 2 * P8_SLOT_B + 8 * 4096;   // + wave-private epilogue transposers
 
-struct P8Src {                                  // DMA sources of one K-tile: byte offsets of this lane's two rows per half
-  unsigned a[2][2], w[2][2];                    // [half][instruction]
+struct P8Src {                                  // DMA source of one K-tile: wave-uniform (the per-lane part is constant)
+  int m0, n0;                                   // origin of its output tile
   int kt, j;                                    // K-tile inside the tile, tile ordinal of this workgroup
 };
 
@@ -65,19 +65,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
   const int hr0 = (2 * wave) * 8 + (lane >> 3), hr1 = hr0 + 8;            // half-tile rows of this lane's two chunks
   const int ch0 = ((lane & 7) ^ ((hr0 >> 1) & 7)) * 16, ch1 = ((lane & 7) ^ ((hr1 >> 1) & 7)) * 16;
+  // per-lane tile rows of this lane's two 16-byte pieces in each half-tile (constants), chunk byte offsets ch0 / ch1
+  const int ra00 = (hr0 >> 6) * 128 + (hr0 & 63), ra01 = (hr1 >> 6) * 128 + (hr1 & 63);              // A half 0 (+ 64: half 1)
+  const int rb00 = (hr0 >> 5) * 64 + (hr0 & 31), rb01 = (hr1 >> 5) * 64 + (hr1 & 31);                // B half 0 (+ 32: half 1)
 #define P8_SET_SRC(S, jj)                                                                          \
   do {                                                                                             \
     const int L_ = b0 + min((jj), my_tiles - 1) * G;   /* past the end: re-read the last tile (never consumed) */ \
     const int tm_ = L_ / tiles_n, tn_ = L_ - tm_ * tiles_n;                                        \
-    const int m0_ = tm_ * 256, n0_ = tn_ * 256;                                                    \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                             \
-      const int ra0_ = (hr0 >> 6) * 128 + h_ * 64 + (hr0 & 63), ra1_ = (hr1 >> 6) * 128 + h_ * 64 + (hr1 & 63); \
-      const int rb0_ = (hr0 >> 5) * 64 + h_ * 32 + (hr0 & 31), rb1_ = (hr1 >> 5) * 64 + h_ * 32 + (hr1 & 31);   \
-      S.a[h_][0] = (unsigned)min(m0_ + ra0_, d.M - 1) * (unsigned)d.lda * 2u + ch0;                \
-      S.a[h_][1] = (unsigned)min(m0_ + ra1_, d.M - 1) * (unsigned)d.lda * 2u + ch1;                \
-      S.w[h_][0] = (unsigned)min(n0_ + rb0_, d.N - 1) * (unsigned)d.ldw * 2u + ch0;                \
-      S.w[h_][1] = (unsigned)min(n0_ + rb1_, d.N - 1) * (unsigned)d.ldw * 2u + ch1;                \
-    }                                                                                              \
+    S.m0 = tm_ * 256; S.n0 = tn_ * 256;                                                            \
   } while (0)
 #define P8_ADVANCE(S)                                                                              \
   do { if (++S.kt == nk) { S.kt = 0; ++S.j; P8_SET_SRC(S, S.j); } } while (0)
@@ -90,12 +85,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
   // half-tile `half` (0: AH0, 1: AH1, 2: BH0, 3: BH1) of K-tile S into slot `slot`
 #define P8_DMA(S, half, slot)                                                                      \
   do {                                                                                             \
-    const char* base_ = (half) < 2 ? (const char*)d.A : (const char*)d.W;                          \
-    const unsigned o0_ = (half) < 2 ? S.a[(half) & 1][0] : S.w[(half) & 1][0];                     \
-    const unsigned o1_ = (half) < 2 ? S.a[(half) & 1][1] : S.w[(half) & 1][1];                     \
     const unsigned l_ = lds0 + (slot) * P8_SLOT_B + (half) * P8_HALF_B + (2 * wave) * 1024;        \
-    P8_GLDS(base_ + (size_t)o0_ + (size_t)S.kt * 128, l_);                                         \
-    P8_GLDS(base_ + (size_t)o1_ + (size_t)S.kt * 128, l_ + 1024);                                  \
+    if constexpr ((half) < 2) {                                                                    \
+      const int r0_ = min(S.m0 + ra00 + ((half) & 1) * 64, d.M - 1), r1_ = min(S.m0 + ra01 + ((half) & 1) * 64, d.M - 1); \
+      const char* b_ = (const char*)d.A + (size_t)S.kt * 128;                                      \
+      P8_GLDS(b_ + (size_t)((unsigned)r0_ * (unsigned)d.lda * 2u + (unsigned)ch0), l_);            \
+      P8_GLDS(b_ + (size_t)((unsigned)r1_ * (unsigned)d.lda * 2u + (unsigned)ch1), l_ + 1024);     \
+    } else {                                                                                       \
+      const int r0_ = min(S.n0 + rb00 + ((half) & 1) * 32, d.N - 1), r1_ = min(S.n0 + rb01 + ((half) & 1) * 32, d.N - 1); \
+      const char* b_ = (const char*)d.W + (size_t)S.kt * 128;                                      \
+      P8_GLDS(b_ + (size_t)((unsigned)r0_ * (unsigned)d.ldw * 2u + (unsigned)ch0), l_);            \
+      P8_GLDS(b_ + (size_t)((unsigned)r1_ * (unsigned)d.ldw * 2u + (unsigned)ch1), l_ + 1024);     \
+    }                                                                                              \
   } while (0)
 
   P8Src c1, c2;                                 // K-tiles s + 1 and s + 2 of the stream
