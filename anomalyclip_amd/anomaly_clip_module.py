@@ -77,9 +77,10 @@ class MeanMetric:
     """torchmetrics.MeanMetric as the module uses it (:77-84): running mean of scalars, kept on the device (no host
     sync per step); under data parallelism `compute()` averages over ranks like torchmetrics' epoch-end sync."""
 
-    def __init__(self):
+    def __init__(self, device_fn=None):
         self.total: Optional[torch.Tensor] = None
         self.count = 0
+        self._device_fn = device_fn             # where an update-less rank builds its (0, 0) contribution
 
     def __call__(self, value):
         self.update(value)
@@ -90,12 +91,15 @@ class MeanMetric:
         self.count += 1
 
     def compute(self) -> torch.Tensor:
+        # a rank that saw no update still JOINS the all-reduce (with (0, 0)): returning early would leave the others blocked
         if self.total is None:
-            return torch.tensor(float("nan"))
-        t = torch.stack([self.total, self.total.new_tensor(float(self.count))])
+            dev = self._device_fn() if self._device_fn is not None else torch.device("cpu")
+            t = torch.zeros(2, dtype=torch.float32, device=dev)
+        else:
+            t = torch.stack([self.total, self.total.new_tensor(float(self.count))])
         if parallel.is_distributed():
             parallel.all_reduce_sum_(t)
-        return t[0] / t[1]
+        return t[0] / t[1]                      # nan when nobody updated, like torchmetrics' empty MeanMetric
 
     def reset(self):
         self.total, self.count = None, 0
@@ -126,7 +130,7 @@ class AnomalyCLIPModule(_Base):
             p.requires_grad = False
         # for averaging loss across batches (:77-84)
         for n in _LOSS_NAMES:
-            object.__setattr__(self, n, MeanMetric())
+            object.__setattr__(self, n, MeanMetric(lambda: self.device))
         self.ncentroid: Optional[torch.Tensor] = None
         self.labels: List[torch.Tensor] = []
         self.abnormal_scores: List[torch.Tensor] = []
@@ -182,14 +186,24 @@ class AnomalyCLIPModule(_Base):
         if parallel.is_distributed():
             parallel.all_reduce_sum_(acc)
             parallel.all_reduce_sum_(cnt)
-        self.ncentroid = acc / cnt
+        self._set_ncentroid(acc / cnt)
         return self.ncentroid
+
+    def _set_ncentroid(self, value: torch.Tensor):
+        """ncentroid lives in ONE persistent device buffer: reloads copy into it, so its address -- part of the temporal
+        graphs' key, and the operand the captured kernels read -- never changes and no step pays a host-to-device copy."""
+        value = value.detach().to(torch.float32).reshape(-1)
+        cur = self.ncentroid
+        if torch.is_tensor(cur) and cur.device == self.device and cur.shape == value.shape and cur.dtype == torch.float32:
+            cur.copy_(value)
+        else:
+            self.ncentroid = value.to(self.device).contiguous()
 
     def _load_or_compute_ncentroid(self, save_dir: Path):
         save_dir.mkdir(parents=True, exist_ok=True)
         f = save_dir / "ncentroid.pt"
         if f.is_file():
-            self.ncentroid = torch.load(f)
+            self._set_ncentroid(torch.load(f, map_location="cpu"))
             return
         dm = self._datamodule()
         if dm is None:
@@ -220,11 +234,23 @@ class AnomalyCLIPModule(_Base):
         for name, value in zip(_LOSS_NAMES, losses):                                # :244-293
             meter = getattr(self, name)
             meter(value)
-            self.log("train/" + ("loss" if name == "train_loss" else name), meter, on_step=False, on_epoch=True, prog_bar=True)
+            # the reference logs the torchmetrics object and Lightning computes + resets it at epoch end.  Lightning's
+            # self.log only accepts numbers / tensors / torchmetrics.Metric, so under a real Trainer the step value is
+            # logged with on_epoch=True (Lightning's own epoch mean: the same number); the built-in loop keeps the meter
+            # and on_train_epoch_end turns it into the epoch mean
+            self.log("train/" + ("loss" if name == "train_loss" else name), value.detach() if _HAVE_LIGHTNING else meter,
+                     on_step=False, on_epoch=True, prog_bar=True)
         return {"loss": losses[0]}
 
     def on_train_epoch_end(self):
-        pass
+        """Per-epoch means (the reference's torchmetrics are reset by Lightning after every epoch): compute -- every rank
+        takes part in the exchange -- publish, reset."""
+        for name in _LOSS_NAMES:
+            meter = getattr(self, name)
+            mean = meter.compute()
+            if not _HAVE_LIGHTNING:
+                self.logged["train/" + ("loss" if name == "train_loss" else name)] = mean
+            meter.reset()
 
     # ------------------------------------------------------------------ evaluation (:301-337, :458-498)
     def _score_video(self, batch):
@@ -242,7 +268,13 @@ class AnomalyCLIPModule(_Base):
         save_dir = _get(self.hparams, "save_dir")
         f = Path(save_dir) / "ncentroid.pt" if save_dir else None
         if f is not None and f.is_file():
-            self.ncentroid = torch.load(f)
+            # re-read only when the file changed (the reference reloads it for every validation video, :305-311): a fresh
+            # CPU tensor per video would cost a blocking pageable H2D copy per forward and re-key the temporal graphs
+            st = f.stat()
+            stamp = (str(f), st.st_mtime_ns, st.st_size)
+            if self.ncentroid is None or getattr(self, "_ncentroid_stamp", None) != stamp:
+                self._set_ncentroid(torch.load(f, map_location="cpu"))
+                self._ncentroid_stamp = stamp
         elif self.ncentroid is None:
             raise FileNotFoundError(f"ncentroid file {f} not found")
         scores, labels, probs = self._score_video(batch)

@@ -103,7 +103,12 @@ class TextFeaturesFn(torch.autograd.Function):
         C_all = net.prompt_learner.n_cls
         cp = bool(class_parallel) and par.is_distributed()
         lo, hi = par.shard_range(C_all, par.world_size(), par.rank()) if cp else (0, C_all)
-        tf_loc, state = _text_forward_rows(net, ctx_param, text_projection, lo, hi)
+        if hi == lo:
+            # more ranks than classes (XD-Violence: 7 classes on 8 GPUs): this rank owns no class.  It contributes an empty
+            # block and zero parameter gradients but still joins BOTH exchanges -- the other ranks block in them
+            tf_loc, state = text_projection.new_zeros((0, text_projection.shape[1])), None
+        else:
+            tf_loc, state = _text_forward_rows(net, ctx_param, text_projection, lo, hi)
         if cp:
             tf = par.assemble_rows(tf_loc, lo, C_all)
         else:
@@ -120,6 +125,8 @@ class TextFeaturesFn(torch.autograd.Function):
         d_tf = d_tf.contiguous()
         if ctx.cp:
             d_tf = _parallel().all_reduce_sum_(d_tf.clone())[lo:hi]
+        if hi == lo:
+            return torch.zeros_like(ctx_param), torch.zeros_like(P), None, None
         d_ctx_loc, d_P = _text_backward_rows(net, P, ctx.state, d_tf)
         if ctx.cp and ctx_param.dim() == 3:
             d_ctx = torch.zeros_like(ctx_param)
@@ -161,6 +168,7 @@ def text_features_train(net):
 #     in between); the backward graph waits for the selector's backward only and runs beside the temporal backward.
 # Same kernels in the same order on the same operands as the eager path: results are bit-identical (tests).
 class _TextGraphs:
+    empty = False
     # capture_error_mode="thread_local": other threads of the process (the RCCL watchdog polling its events) must not
     # invalidate a capture in progress
     def __init__(self, net, lo, hi):
@@ -194,6 +202,18 @@ class _TextGraphs:
             tuple(p.data_ptr() for p in te.transformer.parameters())
 
 
+class _NoTextRows:
+    """Stand-in for _TextGraphs on a rank that owns no class (more ranks than classes): nothing to replay; an empty
+    feature block forward, zero parameter gradients backward, and the same exchanges as every other rank."""
+    empty = True
+
+    def __init__(self, net, lo, hi):
+        P = net.text_encoder.text_projection
+        self.key = _TextGraphs.make_key(net, lo, hi)
+        self.tf = P.new_zeros((0, P.shape[1]))
+        self.fwd_done = torch.cuda.Event()
+
+
 def text_graph_launch(net):
     """Start this step's text forward on the side stream (no autograd node yet: TextGraphFn picks the result up)."""
     par = _parallel()
@@ -201,6 +221,12 @@ def text_graph_launch(net):
     cp = bool(getattr(net, "text_class_parallel", True)) and par.is_distributed()
     lo, hi = par.shard_range(C_all, par.world_size(), par.rank()) if cp else (0, C_all)
     tg = getattr(net, "_text_graphs", None)
+    if hi == lo:
+        if tg is None or tg.key != _TextGraphs.make_key(net, lo, hi):
+            tg = net._text_graphs = _NoTextRows(net, lo, hi)
+        tg.rows, tg.cp = (lo, hi, C_all), cp
+        tg.fwd_done.record()
+        return tg
     if tg is None or tg.key != _TextGraphs.make_key(net, lo, hi):
         tg = net._text_graphs = _TextGraphs(net, lo, hi)
     tg.rows, tg.cp = (lo, hi, C_all), cp
@@ -230,6 +256,8 @@ class TextGraphFn(torch.autograd.Function):
         lo, hi, C_all = tg.rows
         ev = getattr(net, "_text_grad_ready", None)
         net._text_grad_ready = None
+        if getattr(tg, "empty", False):
+            return torch.zeros_like(ctx_param), torch.zeros_like(net.text_encoder.text_projection), None
         if ev is not None:
             tg.side.wait_event(ev)                      # d_tf is final: recorded after the selector / assemble backward
         else:

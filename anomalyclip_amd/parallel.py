@@ -17,13 +17,31 @@ from __future__ import annotations
 
 from typing import Iterable, List, Sequence
 
+import contextlib
 import os
 
 import torch
 import torch.distributed as dist
 
 
+_LOCAL_ONLY = [False]
+
+
+@contextlib.contextmanager
+def local_only():
+    """Inside an initialised process group, run this rank as if it were alone (no collective is issued, nothing is
+    sharded): bench.py times T1 -- the single-GPU step -- in the same N-rank run that times TN."""
+    keep = _LOCAL_ONLY[0]
+    _LOCAL_ONLY[0] = True
+    try:
+        yield
+    finally:
+        _LOCAL_ONLY[0] = keep
+
+
 def is_distributed() -> bool:
+    if _LOCAL_ONLY[0]:
+        return False
     # ACX_FORCE_COLLECTIVES=1 (tests): take the collective code paths in a 1-rank group too -- the only way a single-GPU box
     # can push the step's all-reduce / all-gather calls through the real RCCL backend
     return dist.is_available() and dist.is_initialized() and (

@@ -64,6 +64,51 @@ class Trainer:
                     "global_step": self.global_step, "hyper_parameters": dict(getattr(model, "hparams", {}) or {}),
                     "pytorch-lightning_version": "1.8.3"}, path)
 
+    # ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _shard_loader(loader, epoch: int):
+        """What Lightning's DDP strategy does to every train DataLoader (replace_sampler_ddp): a DistributedSampler over
+        the same dataset -- shuffling iff the original sampler shuffled -- re-seeded per epoch with set_epoch.  Without it
+        every rank would iterate the full set: identical batches (redundant compute) or world-times the steps per epoch,
+        and the per-epoch LR schedule would no longer line up with the reference's."""
+        from torch.utils.data import DataLoader, DistributedSampler, RandomSampler
+        if not parallel.is_distributed():
+            return loader
+        if not isinstance(loader, DataLoader):
+            raise TypeError(f"data-parallel training needs torch DataLoaders to shard (got {type(loader).__name__}); "
+                            f"alternatively hand every rank its own shard and run with world size 1 semantics")
+        if isinstance(loader.sampler, DistributedSampler):
+            loader.sampler.set_epoch(epoch)
+            return loader
+        sampler = DistributedSampler(loader.dataset, num_replicas=parallel.world_size(), rank=parallel.rank(),
+                                     shuffle=isinstance(loader.sampler, RandomSampler),
+                                     seed=int(os.environ.get("PL_GLOBAL_SEED", "0")))
+        sampler.set_epoch(epoch)
+        return DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers,
+                          collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=loader.drop_last,
+                          timeout=loader.timeout, worker_init_fn=loader.worker_init_fn,
+                          persistent_workers=loader.persistent_workers if loader.num_workers > 0 else False)
+
+    def _train_batches(self, loaders, epoch: int):
+        """Lightning 1.8's default for a LIST of train loaders, multiple_trainloader_mode='max_size_cycle': the epoch has
+        max(len) steps and a shorter loader starts over when exhausted (ShanghaiTech: 175 normal vs 63 abnormal videos --
+        `zip` would stop at the shortest and run a third of the reference's optimizer steps per epoch)."""
+        if not isinstance(loaders, (list, tuple)):
+            yield from self._shard_loader(loaders, epoch)
+            return
+        loaders = [self._shard_loader(l, epoch) for l in loaders]
+        its = [iter(l) for l in loaders]
+        for _ in range(max(len(l) for l in loaders)):
+            batch = []
+            for k in range(len(loaders)):
+                try:
+                    b = next(its[k])
+                except StopIteration:
+                    its[k] = iter(loaders[k])
+                    b = next(its[k])
+                batch.append(b)
+            yield tuple(batch)
+
     def fit(self, model, datamodule=None, ckpt_path: Optional[str] = None):
         self._attach(model, datamodule, "fit")
         dev = model.device
@@ -78,11 +123,10 @@ class Trainer:
             self.current_epoch = epoch
             model.net.train()
             loaders = self.datamodule.train_dataloader()        # [normal loader, abnormal loader] (datamodule:144-163)
-            it = zip(*loaders) if isinstance(loaders, (list, tuple)) else iter(loaders)
-            for i, batch in enumerate(it):
+            for i, batch in enumerate(self._train_batches(loaders, epoch)):
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
-                model.train_batch(_to_device(tuple(batch), dev), opt, i)
+                model.train_batch(_to_device(batch, dev), opt, i)
                 self.global_step += 1
             model.on_train_epoch_end()
             if sched is not None:

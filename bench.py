@@ -11,7 +11,8 @@ softmax(similarity)*score (anomaly_clip_module.py:474-477).  Random-init weights
 (no checkpoints/network in this environment), data synthetic.
 
     python bench.py --gpus N --steps K --warmup W [--precision f32|bf16]
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: typed like that it re-launches itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+     --master-addr 127.0.0.1`; started by that launcher -- the driver's form -- it just runs as rank RANK of WORLD_SIZE)
 
 `value`: clips shard across ranks (one process per GPU); the eval path has no data-path collective (the reference's
 test_step is rank-local too) => weak scaling; value = frames of all ranks / max-over-ranks time.
@@ -214,8 +215,8 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
         finally:
             net.text_graph, net.temporal_model.graph = keep
 
-    def make_train(B_global, exchange=True):
-        batch, idx = head_batch(B_global, world, rank, dev)
+    def make_train(B_global, w=world, r=rank):
+        batch, idx = head_batch(B_global, w, r, dev)
         step_i = [0]
 
         def step():
@@ -302,6 +303,13 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
     dp = {"workload": "configs[3]: UCF-shaped 512-d feature sequences, DP training step = forward + 7-term loss + backward "
                       "(bucketed async gradient all-reduce over RCCL, SyncBN statistics, class-parallel text encoder) + AdamW",
           "n_gpus": world, "grad_bytes": None}
+    t1 = None
+    if world > 1:
+        # T1 inside the same N-rank run: every rank steps the whole 64-video batch alone (no collective, no sharding)
+        with parallel.local_only():
+            step, _ = make_train(HEAD_BATCH, 1, 0)
+            t1 = timer.run(step, steps, warmup) / steps
+        dp["t1_ms_per_step_same_run"] = round(t1 * 1e3, 3)
     for mode, B_global in (("strong", HEAD_BATCH), ("weak", HEAD_BATCH * world)):
         if (B_global // 2) % world:
             dp[mode] = None
@@ -310,6 +318,8 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
         dt = timer.run(step, steps, warmup)
         ent = {"global_batch_videos": B_global, "videos_per_gpu": B_global // world,
                "ms_per_step": round(dt / steps * 1e3, 3), "features_per_s": round(B_global * 512 * steps / dt, 1)}
+        if t1 is not None:                            # strong: T1 / (N TN); weak: T1 / TN (same per-GPU work as T1)
+            ent["efficiency_vs_t1_same_run"] = round(t1 / ((world if mode == "strong" else 1) * dt / steps), 4)
         # per-rank kernel-time breakdown of the same step (separate short pass: the HIP-event pairs around ~700 launches
         # per step would otherwise sit inside the timed region above); rank 0's numbers
         with eager_path():
@@ -429,6 +439,22 @@ def config4_leg(dev, timer, prof, world, steps):
     return out
 
 
+def self_launch(n):
+    """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (rendezvous on
+    127.0.0.1, a free port); returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,13 +472,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: become the launcher -- one rank per GPU under torch.distributed.run on this
+        # node (the form the driver itself uses); rank 0 of the children prints the single JSON line
+        raise SystemExit(self_launch(args.gpus))
     # ACX_BENCH_BACKEND=gloo: functional smoke run of the N > 1 branch on a box with fewer GPUs than ranks (ranks share
     # GPUs, collectives over gloo; the numbers of such a run mean nothing)
     backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); one process "
+                         f"per GPU over RCCL needs --gpus <= visible GPUs (ACX_BENCH_BACKEND=gloo shares GPUs for a "
+                         f"functional smoke run only)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -561,7 +593,8 @@ def main():
                     traffic = None
         out = {
             "metric": "frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+            "world": {"size": world, "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "bf16(mfma)/f32(acc,attention)", "data": "synthetic",
             "config": {"workload": "configs[2]: synthetic 224x224 RGB frames, ViT-B/16 encode + "

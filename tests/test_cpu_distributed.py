@@ -83,6 +83,40 @@ def _worker(rank, world, port, q):
     (sum((T_ref * w).sum() for w in wr) / world).backward()
     ok &= torch.allclose(T.detach(), T_ref.detach(), atol=1e-6)
     ok &= torch.allclose(ctxp.grad, c_ref.grad, atol=1e-6) and torch.allclose(Pp.grad, P_ref.grad, atol=1e-6)
+    # --- more ranks than classes (XD-Violence: 7 classes on 8 GPUs): the rank that owns no class contributes an empty
+    # block and zero gradients but joins both exchanges (a raise or a skipped collective would hang the other rank)
+    assert parallel.shard_range(1, world, 1) == (1, 1)
+    ctx1, w1 = ctx0[:1].clone(), [w[:1] for w in wr]
+    ctxq, Pq = torch.nn.Parameter(ctx1.clone()), torch.nn.Parameter(P0.clone())
+    net1 = SimpleNamespace(prompt_learner=SimpleNamespace(n_cls=1, ctx=ctxq))
+    gb3 = parallel.GradBuckets([ctxq, Pq])
+    gb3.zero()
+    T1 = Fn.TextFeaturesFn.apply(ctxq, Pq, net1, True)
+    (T1 * w1[rank]).sum().backward()
+    gb3.finish()
+    c_ref, P_ref = ctx1.clone().requires_grad_(True), P0.clone().requires_grad_(True)
+    T_ref = torch.tanh(c_ref.sum(1)) @ P_ref
+    (sum((T_ref * w).sum() for w in w1) / world).backward()
+    ok &= T1.shape == (1, e) and torch.allclose(T1.detach(), T_ref.detach(), atol=1e-6)
+    ok &= torch.allclose(ctxq.grad, c_ref.grad, atol=1e-6) and torch.allclose(Pq.grad, P_ref.grad, atol=1e-6)
+    # --- the built-in Trainer shards torch DataLoaders like Lightning's DDP strategy (DistributedSampler + set_epoch)
+    from torch.utils.data import DataLoader, TensorDataset
+    from anomalyclip_amd.trainer import Trainer
+    dl = DataLoader(TensorDataset(torch.arange(10)), batch_size=1, shuffle=True)
+    seen = [sorted(int(b[0]) for b in Trainer._shard_loader(dl, ep)) for ep in (0, 1)]
+    allv = [torch.zeros(10), torch.zeros(10)]
+    for ep in (0, 1):
+        allv[ep][seen[ep]] = 1
+        dist.all_reduce(allv[ep])
+    ok &= len(seen[0]) == 5 and bool((allv[0] == 1).all()) and bool((allv[1] == 1).all())     # disjoint cover, every epoch
+    tb = list(Trainer()._train_batches([dl, DataLoader(TensorDataset(torch.arange(4)), batch_size=1)], 0))
+    ok &= len(tb) == 5                              # max_size_cycle over the SHARDED lengths (5 and 2)
+    # --- a meter that saw no update on this rank still joins the epoch-end exchange
+    from anomalyclip_amd.anomaly_clip_module import MeanMetric
+    mm = MeanMetric()
+    if rank == 0:
+        mm.update(torch.tensor(3.0))
+    ok &= abs(float(mm.compute()) - 3.0) < 1e-6
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -339,6 +339,15 @@ def test_builtin_trainer_calls_hooks_in_lightning_order(tmp_path):
     assert calls == ["setup:test", "net.eval", "on_test_start", "test_step0", "test_step1", "test_step2", "test_epoch_end3"]
 
 
+def test_trainer_cycles_the_shorter_train_loader():
+    """Lightning 1.8 iterates a list of train loaders in 'max_size_cycle' mode: max(len) steps per epoch, the shorter
+    loader restarted (the reference's [normal, abnormal] loaders have unequal lengths on every dataset)."""
+    from anomalyclip_amd.trainer import Trainer
+    got = list(Trainer()._train_batches([["n0", "n1", "n2", "n3", "n4"], ["a0", "a1"]], 0))
+    assert got == [("n0", "a0"), ("n1", "a1"), ("n2", "a0"), ("n3", "a1"), ("n4", "a0")]
+    assert list(Trainer()._train_batches(iter(["x", "y"]), 0)) == ["x", "y"]          # a single loader passes through
+
+
 def test_ctx_init_from_token_embeddings(prompts_table):
     """coop.py:19-34: a non-empty `ctx_init` initialises the context from the token embeddings of its words (ids = positions
     1..n_ctx of the tokenised prompts), class-specific (repeated) or shared; n_ctx follows the word count."""
