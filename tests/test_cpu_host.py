@@ -339,6 +339,49 @@ def test_builtin_trainer_calls_hooks_in_lightning_order(tmp_path):
     assert calls == ["setup:test", "net.eval", "on_test_start", "test_step0", "test_step1", "test_step2", "test_epoch_end3"]
 
 
+def test_compat_install_resolves_every_reference_target():
+    """compat.install() makes every `_target_` of the reference's model configs (fixture: config_keys.json, read from the
+    reference's YAML) importable and bound to the mirror classes -- the YAML runs unedited."""
+    import importlib
+    import inspect
+    from anomalyclip_amd import compat
+    import json
+    import sys
+    keys = json.load(open(os.path.join(REPO, "tests", "golden", "config_keys.json")))
+    targets = set()
+
+    def walk(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k == "_target_":
+                    targets.add(v)
+                walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+    walk(keys["configs"])
+    targets.add("src.models.anomaly_clip_module.AnomalyCLIPModule")               # configs/model/*.yaml:1
+    assert {t for t in targets if t.startswith("src.")} == {
+        "src.models.components.anomaly_clip.AnomalyCLIP", "src.models.components.loss.ComputeLoss",
+        "src.models.components.scheduler.WarmupCosineAnnealingLR", "src.models.anomaly_clip_module.AnomalyCLIPModule"}
+    before = {k for k in sys.modules if k == "src" or k.startswith("src.")}
+    try:
+        compat.install()
+        compat.install()                                                            # idempotent
+        for t in sorted(targets):
+            obj = compat.resolve(t)
+            assert inspect.isclass(obj), t
+            if t.startswith("src."):
+                assert obj.__module__.startswith("anomalyclip_amd."), (t, obj.__module__)
+        from src.models.components.loss import ComputeLoss                           # plain import statements work too
+        from anomalyclip_amd.components.loss import ComputeLoss as Mirror
+        assert ComputeLoss is Mirror
+        assert importlib.import_module("src.models.anomaly_clip_module").AnomalyCLIPModule.__name__ == "AnomalyCLIPModule"
+    finally:
+        compat.uninstall()
+    assert {k for k in sys.modules if k == "src" or k.startswith("src.")} == before
+
+
 def test_trainer_cycles_the_shorter_train_loader():
     """Lightning 1.8 iterates a list of train loaders in 'max_size_cycle' mode: max(len) steps per epoch, the shorter
     loader restarted (the reference's [normal, abnormal] loaders have unequal lengths on every dataset)."""
