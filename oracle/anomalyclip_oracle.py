@@ -292,8 +292,11 @@ def temporal_forward(feats, sd: SD, hc, segment_size: int, test_mode: bool,
 
 # --------------------------------------------------------------------------- assembly (a5)
 def anomaly_clip_forward_test(sd: SD, hc, image_features, ncentroid, eot_idx, text_heads,
-                              segment_size=1, frames: Optional[torch.Tensor] = None):
-    """anomaly_clip.py:117-154.  image_features (b, ncrops, t, d) (or frames (b,t,c,h,w))."""
+                              segment_size=1, frames: Optional[torch.Tensor] = None,
+                              text_feats: Optional[torch.Tensor] = None):
+    """anomaly_clip.py:117-154.  image_features (b, ncrops, t, d) (or frames (b,t,c,h,w)).  `text_feats`: the
+    (C, d) text features when the caller already evaluated them (they do not depend on the video; the reference
+    recomputes them per call, :136)."""
     if frames is not None:
         b, t, c, h, w = frames.shape
         f = vit_forward(sd, frames.view(-1, c, h, w))
@@ -302,7 +305,7 @@ def anomaly_clip_forward_test(sd: SD, hc, image_features, ncentroid, eot_idx, te
         image_features = f.view(b, hc.ncrops, -1, d)
     b, ncrops, t, d = image_features.shape
     x = image_features.reshape(-1, t, d)
-    tf = text_features(sd, eot_idx, text_heads)
+    tf = text_features(sd, eot_idx, text_heads) if text_feats is None else text_feats
     sim, _, _ = selector_logits(x, tf, ncentroid, hc.normal_id,
                                 sd["selector_model.bn_layer.running_mean"],
                                 sd["selector_model.bn_layer.running_var"], training=False)

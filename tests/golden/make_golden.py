@@ -163,6 +163,7 @@ def gen_temporal(seed=21):
         t = rearrange(idx, "(b n s l) d -> b n s l d", n=32, s=S, l=16)
         t = rearrange(t, "b n s l d -> (b s) n l d")
         arrs[f"tile_index_S{S}"] = t.reshape(-1)
+    arrs["axial_source"] = H.AXIAL_SOURCE
     save("temporal", **arrs)
 
 
@@ -258,6 +259,7 @@ def gen_e2e(table, seed=41):
     gsum = {k: float(p.grad.double().abs().sum()) for k, p in net.temporal_model.named_parameters() if p.grad is not None}
     arrs["temporal_grad_abs_sums"] = np.asarray([gsum[k] for k in sorted(gsum)])
     arrs["temporal_grad_names"] = np.asarray(sorted(gsum))
+    arrs["axial_source"] = H.AXIAL_SOURCE
     save("e2e_tiny", **arrs)
 
 
@@ -303,7 +305,61 @@ def gen_tables():
     save("tables", **arrs)
 
 
+# ---------------------------------------------------------------- 10. BASELINE configs[0], end to end through the REFERENCE
+def gen_config0(table, seed=51):
+    """ShanghaiTech-shaped evaluation from pre-extracted features (SURVEY.md 8d Config 1): eight synthetic .npy files ->
+    the reference's FeatureDataset (test mode) + DataLoader(batch_size=1) -> the reference's AnomalyCLIP (ShanghaiTech
+    head: 18 classes, depth 2, concat on; full ViT-B/16 text tower, random init) -> the two post-processing lines of
+    test_step (anomaly_clip_module.py:474-483, restated here because the module itself needs Lightning).  Stored:
+    per video the scores of every real frame, every 8th row of class_probs, the f64 sum of all of class_probs, the
+    per-frame labels and segment_size the reference's dataset produced."""
+    import importlib
+    import tempfile
+    fd = importlib.import_module("src.data.components.feature_dataset")
+    geom, hc = IW.VIT_B16, IW.SHT_HEAD
+    toks = toks_of(table, "sht")
+    sd = IW.init_anomalyclip_state_dict(geom, hc, toks, seed, with_image_encoder=False)
+    H.patch_clip_load(ns, geom.as_kwargs(), seed)
+    cfgs = dict(arch="ViT-B/16", labels_file=os.path.join(H.REF_ROOT, "data/sht_labels.csv"), emb_size=hc.emb_size,
+                depth=hc.depth, heads=hc.heads, dim_heads=None, num_segments=32, seg_length=16,
+                concat_features=True, normal_id=hc.normal_id, stride=1, load_from_features=True,
+                select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, ncrops=1, num_topk=3,
+                num_bottomk=3, n_ctx=8, shared_context=False, ctx_init="")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ns.anomaly_clip.AnomalyCLIP(**cfgs)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("image_encoder.") for k in missing), missing      # features path: the ViT is never run
+    net.eval()
+    arrs = dict(seed=seed, lengths=np.asarray(R.CONFIG0_LENGTHS), axial_source=H.AXIAL_SOURCE)
+    with tempfile.TemporaryDirectory() as d:
+        paths, arrays, labels, nc = R.config0_feature_files(d)
+        ann, tmp = R.config0_annotation_files(d, paths, labels)
+        ds = fd.VideoFrameDataset(root_path=d, annotationfile_path=ann, normal_id=hc.normal_id, num_segments=32,
+                               frames_per_segment=16, test_mode=True, ncrops=1, temporal_annotation_file=tmp,
+                               labels_file=os.path.join(H.REF_ROOT, "data/sht_labels.csv"), stride=1)
+        loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+        for i, (image_features, lab, label, segment_size, path) in enumerate(loader):
+            lab = lab.squeeze(0)
+            similarity, scores = net(image_features, lab, nc, segment_size, test_mode=True)
+            class_probs = torch.softmax(similarity, dim=1) * scores.unsqueeze(1)       # :474-477
+            n = lab.shape[0]                                                           # :480-483
+            class_probs, scores = class_probs[:n], scores[:n]
+            assert n == R.CONFIG0_LENGTHS[i] and np.array_equal(lab.numpy(), labels[i])
+            arrs[f"scores{i}"] = scores
+            arrs[f"probs8_{i}"] = class_probs[::8]
+            arrs[f"probsum{i}"] = class_probs.double().sum()
+            arrs[f"labels{i}"] = lab.numpy().astype(np.int8)
+            arrs[f"S{i}"] = int(segment_size)
+    save("config0", **arrs)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["config0"]:
+        gen_config0(json.load(open(os.path.join(REPO, "anomalyclip_amd", "data", "prompts.json"))))
+        sys.exit(0)
     table = gen_prompts()
     gen_vit("vit_tiny", IW.TINY, seed=1, nframes=3, store_tokens=True)
     gen_vit("vit_b16", IW.VIT_B16, seed=2, nframes=2, store_tokens=False)
@@ -314,3 +370,4 @@ if __name__ == "__main__":
     gen_loss()
     gen_e2e(table)
     gen_tables()
+    gen_config0(table)

@@ -19,6 +19,7 @@ import sys
 import types
 
 REF_ROOT = os.environ.get("ACX_REFERENCE_ROOT", "/root/reference")
+AXIAL_SOURCE = "not installed yet"
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -69,9 +70,27 @@ def install():
     sys.modules["src.utils"] = su
     sys.modules["src"].utils = su
 
-    from oracle import axial_attention_restated as ax
-
-    sys.modules["axial_attention"] = ax
+    # a7: the REAL `axial_attention` package when it is importable (the day the wheel is reachable the fixtures pin
+    # themselves: AXIAL_SOURCE is stamped into every fixture that runs the temporal model); the restatement otherwise
+    global AXIAL_SOURCE
+    try:
+        if getattr(sys.modules.get("axial_attention"), "__acx_restated__", False):
+            del sys.modules["axial_attention"]                   # a second install(): look for the real package again
+        real = importlib.import_module("axial_attention")
+        if getattr(real, "__acx_restated__", False):
+            raise ImportError("only the restatement is on the path")
+        ver = "unknown"
+        try:
+            from importlib import metadata
+            ver = metadata.version("axial_attention")
+        except Exception:  # noqa: BLE001
+            pass
+        AXIAL_SOURCE = f"pypi:axial_attention=={ver}"
+    except ImportError:
+        from oracle import axial_attention_restated as ax
+        ax.__acx_restated__ = True
+        sys.modules["axial_attention"] = ax
+        AXIAL_SOURCE = "restated:oracle/axial_attention_restated.py (parity unpinned)"
 
 
 def ref_modules():

@@ -25,6 +25,11 @@ def relerr(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
+def elem_ok(a, b):
+    """north_star's tolerance, element-wise: |a - b| <= 1e-3 |b| + 1e-5 max|b| for EVERY element (recipes.elem_excess)."""
+    return R.elem_excess(a, b) <= 1.0
+
+
 def make_vit(geom, seed, precision="f32"):
     vit = VisionTransformer(geom.image_resolution, geom.vision_patch_size, geom.vision_width, geom.vision_layers,
                             geom.vision_heads, geom.embed_dim, precision=precision)
@@ -165,10 +170,12 @@ def test_e2e_tiny_golden_test_mode(golden, prompts_table):
     with torch.no_grad():
         sim, sc = net(inp["test_feats"].to(DEV), torch.zeros(1000), inp["nc"], 2, True)
     assert relerr(sim, g["test_sim"]) < TOL and relerr(sc, g["test_scores"]) < TOL
+    assert elem_ok(sim, g["test_sim"]) and elem_ok(sc, g["test_scores"])
     net.load_from_features = False
     with torch.no_grad():
         sim, sc = net(inp["frames"].to(DEV), torch.zeros(500), inp["nc"], 1, True)
     assert relerr(sim, g["test_frames_sim"]) < TOL and relerr(sc, g["test_frames_scores"]) < TOL
+    assert elem_ok(sim, g["test_frames_sim"]) and elem_ok(sc, g["test_frames_scores"])
 
 
 @pytest.mark.parametrize("cfg", ["ucf", "sht", "xd"])
@@ -185,6 +192,7 @@ def test_head_vs_oracle_full_configs(prompts_table, cfg):
         sim, sc = net(feats.to(DEV), None, nc, S, True)
         rs, rc = O.anomaly_clip_forward_test(sd, hc, feats, nc, eot, 8, S)
     assert relerr(sim, rs) < TOL and relerr(sc, rc) < TOL
+    assert elem_ok(sim, rs) and elem_ok(sc, rc)
 
 
 @pytest.mark.parametrize("hw", [(240, 320), (480, 360), (224, 224), (120, 160), (720, 1280)])
@@ -229,6 +237,7 @@ def test_shared_context_and_stride_and_long_segments(prompts_table):
         rs, rc = O.anomaly_clip_forward_test(sd, hc, feats, nc, toks.argmax(-1), 8, S)
     assert sim.shape == (512 * S * 2, 6) and sc.shape == (512 * S * 2,)
     assert relerr(sim, rs) < TOL and relerr(sc, rc) < TOL
+    assert elem_ok(sim, rs) and elem_ok(sc, rc)
 
 
 def test_frames_path_with_crops_tiny(prompts_table):
@@ -244,6 +253,7 @@ def test_frames_path_with_crops_tiny(prompts_table):
         sim, sc = net(frames.to(DEV), None, nc, 2, True)
         rs, rc = O.anomaly_clip_forward_test(sd, hc, None, nc, eot, 2, 2, frames=frames)
     assert relerr(sim, rs) < TOL and relerr(sc, rc) < TOL
+    assert elem_ok(sim, rs) and elem_ok(sc, rc)
 
 
 def test_ncentroid_and_module_test_step(prompts_table):
@@ -264,6 +274,7 @@ def test_ncentroid_and_module_test_step(prompts_table):
     cp, sc = O.eval_postprocess(rs, rc, 1000)
     assert out["class_probs"].shape == (1000, 13) and out["abnormal_scores"].shape == (1000,)
     assert relerr(out["class_probs"], cp) < TOL and relerr(out["abnormal_scores"], sc) < TOL
+    assert elem_ok(out["class_probs"], cp) and elem_ok(out["abnormal_scores"], sc)
 
 
 def test_feature_stream_matches_reference_loop(tmp_path, prompts_table):
@@ -291,6 +302,48 @@ def test_feature_stream_matches_reference_loop(tmp_path, prompts_table):
             sim, sc = net(feats, None, nc, S, True)
             rs, rc = O.anomaly_clip_forward_test(sd, hc, torch.from_numpy(ref).view(1, 1, -1, 128), nc, eot, 2, S)
         assert relerr(sc[:T_], rc[:T_]) < TOL
+
+
+def test_config0_shanghaitech_eval_from_feature_files(golden, prompts_table, tmp_path):
+    """BASELINE.json configs[0] on the HIP path, end to end: eight `.npy` feature files (T = 300 ... 5000, up to S = 10
+    tiles) -> FeatureStream (one gather into pinned memory, async copy) -> AnomalyCLIPModule.test_step (ShanghaiTech head:
+    18 classes, depth 2, concat on; text tower, selector, tiled axial transformer, classifier, class_probs, truncation to
+    the real frames) -> test_epoch_end, against the outputs the REFERENCE produced for the same files (config0.npz) --
+    element-wise within north_star's 1e-3 -- and the metrics epilogue against the metrics oracle on the reference's
+    numbers."""
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    from anomalyclip_amd.feature_stream import FeatureStream
+    g = golden("config0")
+    paths, arrays, labels, nc = R.config0_feature_files(tmp_path)
+    hc = IW.SHT_HEAD
+    toks = torch.tensor(prompts_table["sht"]["tokenized_prompts"], dtype=torch.int32)
+    net = AnomalyCLIP(arch="ViT-B/16", labels_key="sht", emb_size=hc.emb_size, depth=hc.depth, heads=hc.heads,
+                      dim_heads=None, num_segments=32, seg_length=16, concat_features=True, normal_id=hc.normal_id,
+                      stride=1, load_from_features=True, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7,
+                      ncrops=1, num_topk=3, num_bottomk=3, n_ctx=8, shared_context=False, ctx_init="")
+    sd = IW.init_anomalyclip_state_dict(IW.VIT_B16, hc, toks, int(g["seed"]), with_image_encoder=False)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("image_encoder.") for k in missing)
+    net = net.to(DEV).eval()
+    mod = AnomalyCLIPModule(net, None, None, None, num_classes=18, solver={"lr": 1e-5}, logs_root=str(tmp_path / "logs"))
+    mod.ncentroid = nc.to(DEV)
+    outs = []
+    for i, (feats, T_, S, path) in enumerate(FeatureStream(paths, device=torch.device(DEV))):
+        assert T_ == R.CONFIG0_LENGTHS[i] and S == int(g[f"S{i}"]) and feats.shape == (1, 1, 512 * S, 512)
+        out = mod.test_step((feats, torch.from_numpy(labels[i]).unsqueeze(0), int(labels[i].min()), S, path), i)
+        assert out["abnormal_scores"].shape == (T_,) and out["class_probs"].shape == (T_, 17)      # padded frames stripped
+        assert relerr(out["abnormal_scores"], g[f"scores{i}"]) < TOL and elem_ok(out["abnormal_scores"], g[f"scores{i}"])
+        assert elem_ok(out["class_probs"][::8], g[f"probs8_{i}"])
+        ps = float(out["class_probs"].double().sum())
+        assert abs(ps - float(g[f"probsum{i}"])) < 1e-5 * abs(float(g[f"probsum{i}"]))
+        outs.append(out)
+    m = mod.test_epoch_end(outs)
+    from oracle import metrics_oracle as MO
+    ref_scores = np.concatenate([g[f"scores{i}"] for i in range(8)])
+    ref_bin = (np.concatenate(labels) != hc.normal_id).astype(np.int64)
+    # scores agree to ~1e-6, so a few near-tied pairs may swap rank between the two sets: AUROC within 1e-3
+    assert abs(m["auc_roc"] - MO.binary_auroc(ref_scores, ref_bin)) < 1e-3
+    assert (tmp_path / "logs" / "eval" / "runs" / "ckpt" / "metrics.json").is_file()
 
 
 def test_lightning_checkpoint_load_then_score(tmp_path, prompts_table):

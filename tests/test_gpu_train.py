@@ -251,6 +251,75 @@ def test_e2e_train_forward_golden(golden, prompts_table):
     assert torch.equal(ia.cpu(), torch.from_numpy(g["idx_topk_abn"])) and torch.equal(in_.cpu(), torch.from_numpy(g["idx_topk_nor"]))
     assert torch.equal(ba.cpu(), torch.from_numpy(g["idx_bottomk_abn"]))
     assert relerr(lg, g["train_logits"]) < 1e-4 and relerr(lt, g["train_logits_topk"]) < 1e-4 and relerr(sc, g["train_scores"]) < 1e-4
+    # north_star's 1e-3, element-wise (|a - b| <= 1e-3 |b| + 1e-5 max|b| for every logit / score)
+    assert R.elem_excess(lg, g["train_logits"]) <= 1 and R.elem_excess(lt, g["train_logits_topk"]) <= 1
+    assert R.elem_excess(sc, g["train_scores"]) <= 1
+
+
+def test_train_from_frames_tiny_vs_oracle(prompts_table):
+    """Training with load_from_features=False (anomaly_clip.py:156-169: frames -> frozen ViT -> "(b ncrops n l) d" view ->
+    the same head): B = 4 videos x 512 tiny frames, forward outputs, MIL indices (bit-exact), the 8 loss terms and the
+    trainable gradients against the oracle's frames branch (fp64 autograd as gradient ground truth)."""
+    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1)
+    net, sd, eot = build_net("tiny", hc, "ucf", 31, prompts_table)
+    net.load_from_features = False
+    g = torch.Generator().manual_seed(8)
+    B = 4
+    frames = torch.randn(B, 512, 3, 32, 32, generator=g)
+    labels = torch.tensor([2, 11, 7, 7])
+    nc = torch.randn(IW.TINY.embed_dim, generator=g) * 0.1
+    mask = torch.bernoulli(torch.ones(B, 32) * 0.3, generator=g)
+    mask[:, :3] = 1
+    crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(DEV)     # freezes the towers
+    mod.ncentroid = nc.to(DEV)
+    net.train()
+    net.selector_model.generate_mask = lambda b: (mask, mask)
+    fr, lb = frames.to(DEV), labels.to(DEV)
+    with torch.enable_grad():
+        out = mod.training_step(((fr[2:], lb[2:]), (fr[:2], lb[:2])))
+        out["loss"].backward()
+        lg, lt, sc, ia, in_, ba = net(fr, lb, mod.ncentroid)
+    th = IW.TINY.transformer_heads
+    o = O.anomaly_clip_forward_train(sd, hc, None, labels, nc, eot, th, mask, mask, frames=frames)
+    ol = O.compute_loss(o[0], o[1], labels, o[2], o[3], o[4], o[5], normal_id=7, num_topk=3, num_segments=32,
+                        frames_per_segment=16)
+    assert torch.equal(ia.cpu(), o[3]) and torch.equal(in_.cpu(), o[4]) and torch.equal(ba.cpu(), o[5])
+    assert relerr(lg, o[0]) < 1e-4 and relerr(lt, o[1]) < 1e-4 and relerr(sc, o[2]) < 1e-4
+    assert R.elem_excess(lg, o[0]) <= 1 and R.elem_excess(sc, o[2]) <= 1
+    assert relerr(torch.stack(mod.last_losses), torch.stack(ol)) < 1e-4
+    names = [n for n, p in net.named_parameters() if p.requires_grad and n != "selector_model.logit_scale"]
+    assert not any(n.startswith("image_encoder.") for n in names)                     # the ViT stays frozen
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        for n in names:
+            sd64[n] = sd64[n].clone().requires_grad_(True)
+        o64 = O.anomaly_clip_forward_train(sd64, hc, None, labels, nc.double(), eot, th, mask.double(), mask.double(),
+                                           frames=frames.double())
+        O.compute_loss(o64[0], o64[1], labels, o64[2], o[3], o[4], o[5], normal_id=7, num_topk=3, num_segments=32,
+                       frames_per_segment=16)[0].backward()
+    params = dict(net.named_parameters())
+    for n in names:
+        tol = 2.5e-2 if (".net.1.weight" in n or ".net.1.bias" in n) else 2e-3           # LeakyReLU kink, see above
+        assert relerr(params[n].grad, sd64[n].grad) < tol, n
+
+
+def test_ncentroid_from_frames_tiny(prompts_table):
+    """a10 with load_from_features=False (anomaly_clip_module.py:160-167): the normal videos' FRAMES go through the image
+    encoder, the first len(labels) embeddings of each are averaged."""
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1)
+    net, sd, eot = build_net("tiny", hc, "ucf", 33, prompts_table)
+    net.load_from_features = False
+    mod = AnomalyCLIPModule(net, None, None, None, num_classes=14, solver={"lr": 1e-5}).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    vids = [torch.randn(1, 512 * s, 3, 32, 32, generator=g) for s in (1, 2)]
+    lens = [300, 700]
+    loader = [(v, torch.zeros(1, n), 7, s) for v, n, s in zip(vids, lens, (1, 2))]
+    nc = mod.compute_ncentroid(loader, load_from_features=False)
+    ref = O.ncentroid_from_features([O.vit_forward(sd, v[0][:n]) for v, n in zip(vids, lens)])
+    assert nc.shape == (IW.TINY.embed_dim,) and relerr(nc, ref) < 1e-5 and R.elem_excess(nc, ref) <= 1
 
 
 @pytest.mark.parametrize("cfg,B", [("ucf", 4), ("sht", 4), ("ucf", 64), ("sht", 16)])

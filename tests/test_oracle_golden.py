@@ -156,3 +156,31 @@ def test_tables(golden):
             assert np.array_equal(si, g[f"start_T{T_}_s{stride}"].astype(np.int64)) and S == len(si) // 32
     lrs = [O.warmup_cosine_lr(1e-5, ep, 5, 50) for ep in range(55)]
     assert np.allclose(lrs, g["lr_table"], rtol=1e-12, atol=0)
+
+
+def test_config0_shanghaitech_eval_from_feature_files(golden, prompts_table, tmp_path):
+    """BASELINE.json configs[0], end to end on the CPU path: eight synthetic `.npy` feature files (T = 300 ... 5000) ->
+    this package's loader index logic (feature_index, one vectorised gather) -> ShanghaiTech head (18 classes, depth 2,
+    concat on) -> scores / class probabilities -> padded frames stripped, against what the REFERENCE produced for the same
+    files through its own FeatureDataset + DataLoader + AnomalyCLIP (fixture config0.npz, tests/golden/make_golden.py)."""
+    from anomalyclip_amd import feature_index as FI
+    g = golden("config0")
+    assert tuple(g["lengths"]) == R.CONFIG0_LENGTHS
+    paths, arrays, labels, nc = R.config0_feature_files(tmp_path)
+    hc = IW.SHT_HEAD
+    toks = torch.tensor(prompts_table["sht"]["tokenized_prompts"], dtype=torch.int32)
+    sd = IW.init_anomalyclip_state_dict(IW.VIT_B16, hc, toks, int(g["seed"]), with_image_encoder=False)
+    eot = toks.argmax(-1)
+    tf = O.text_features(sd, eot, IW.VIT_B16.transformer_heads)          # independent of the video: evaluated once
+    for i, (path, T_) in enumerate(zip(paths, R.CONFIG0_LENGTHS)):
+        feats, S = FI.gather_test_features(np.load(path), 32, 16, 1, 1)    # [1, 512*S, 512]
+        assert S == int(g[f"S{i}"]) == -(-T_ // 512) and feats.shape == (1, 512 * S, 512)
+        sim, sc = O.anomaly_clip_forward_test(sd, hc, torch.from_numpy(feats).unsqueeze(0), nc, eot,
+                                              IW.VIT_B16.transformer_heads, S, text_feats=tf)
+        assert sim.shape == (512 * S, 17) and sc.shape == (512 * S,)
+        probs, sc = O.eval_postprocess(sim, sc, T_)                        # truncation to the real frames
+        assert probs.shape == (T_, 17) and sc.shape == (T_,)
+        assert np.array_equal(g[f"labels{i}"].astype(np.int64), labels[i])
+        close(sc, g[f"scores{i}"])
+        close(probs[::8], g[f"probs8_{i}"])
+        assert abs(float(probs.double().sum()) - float(g[f"probsum{i}"])) < 1e-4 * abs(float(g[f"probsum{i}"]))
