@@ -83,7 +83,10 @@ _SIGS = {
     "acx_text_directions": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "acx_selector_project": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                        c_void_p]),
-    "acx_bn_stats": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acx_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "acx_bn_stats": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "acx_selector_project_stats": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "acx_selector_bn": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                   c_float, c_void_p]),
     "acx_axial_attention": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -109,7 +112,7 @@ _SIGS = {
     "acx_conv_weight_dx": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "acx_seq_attention_bwd": (C.c_int, [c_void_p] * 4 + [c_int32] * 7 + [c_void_p, c_void_p]),
     "acx_pos_grad": (C.c_int, [c_void_p] * 5 + [c_int32] * 4 + [c_void_p]),
-    "acx_bn_bwd_stats": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
+    "acx_bn_bwd_stats": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p, c_size_t, c_void_p]),
     "acx_bn_bwd_apply": (C.c_int, [c_void_p] * 6 + [c_int32, c_int64, c_int64, c_int32, c_float, c_void_p]),
     "acx_axpby": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
     "acx_colsum_partials": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
@@ -119,6 +122,8 @@ _SIGS = {
     "acx_scatter_segments": (C.c_int, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "acx_mil_loss": (C.c_int, [c_void_p] * 13 + [c_size_t] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p]),
     "acx_adamw": (C.c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int32, c_void_p]),
+    "acx_adamw_multi": (C.c_int, [c_void_p, c_int32] + [C.POINTER(c_void_p)] * 4 + [C.POINTER(c_int64), C.POINTER(c_float),
+                                  C.POINTER(c_float), c_float, c_float, c_float, c_int32, c_void_p]),
     "acx_ctx_grad": (C.c_int, [c_void_p] * 3 + [c_int32] * 5 + [c_void_p]),
     "acx_scatter_rows": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
     "acx_preprocess_frames": (C.c_int, [c_void_p] * 6 + [c_int32, c_void_p, c_void_p, c_int32] + [c_int32] * 5 +

@@ -315,8 +315,7 @@ class SelectorTrainFn(torch.autograd.Function):
         x = x.contiguous()
         tf = text_features.detach().contiguous()
         dirs = ops.text_directions(tf, ncentroid, sel.normal_id)
-        raw = ops.selector_project(x, ncentroid, dirs)
-        mean, var_b, var_u = ops.bn_stats(raw)
+        raw, mean, var_b, var_u = ops.selector_project_stats(x, ncentroid, dirs)     # statistics in the projection's epilogue
         par = _parallel()
         rows = raw.shape[0]
         total_rows = rows

@@ -85,39 +85,162 @@ __global__ __launch_bounds__(256) void selector_project_kernel(const float* __re
   }
 }
 
-// ------------------------------------------------------------------ batch-norm statistics
-// deterministic (fixed-order) per-column mean / biased var / unbiased var of raw[rows, C1]
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ raw, int64_t rows, int C1,
-                                                       float* __restrict__ mean, float* __restrict__ var_b,
-                                                       float* __restrict__ var_u) {
-  __shared__ double red[256];
-  const int c = blockIdx.x;
-  double s = 0.0;
-  for (int64_t r = threadIdx.x; r < rows; r += 256) s += (double)raw[r * C1 + c];
-  red[threadIdx.x] = s;
+// ------------------------------------------------------------------ selector projection on the f32 MFMA
+// raw[r, c] = (x[r,:] - nc) . dirs[c,:] is a skinny GEMM (K = D, N = C-1 <= 64): the wave-per-row kernel above reads all
+// C-1 directions from LDS for every row (26 KB of LDS reads + 78 cross-lane adds per 2 KB of HBM at C-1 = 13), which
+// bounds it at ~1.5 TB/s.  Here a wave owns 16 rows and NT <= 4 column tiles of 16 directions and runs
+// v_mfma_f32_16x16x4_f32: lane (i = lane & 15, q = lane >> 4) loads 32 contiguous bytes of row i per 32-wide K-step
+// straight from HBM into registers (every wave-level load covers 16 full 128-B lines), the SAME k-permutation is applied
+// to the direction fragments it reads from LDS (rows padded by 16 B: conflict-free ds_read_b128), and the centroid is
+// subtracted in registers like the reference does before its matmul (selector_model.py:54,62).  All K-steps' loads of a
+// 16-row group are issued before the first MFMA (32 KB in flight per wave).
+// STATS: per-column (sum, sum of squares) of the rows this block produced, accumulated in f64 in a fixed order and
+// written to part[block][2][16*NT]; bn_finalize_kernel adds the blocks in order -> training BatchNorm1d statistics
+// without re-reading raw.
+template <int D, int NT, bool STATS>
+__global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const float* __restrict__ x, const float* __restrict__ nc,
+                                                                       const float* __restrict__ dirs, float* __restrict__ raw,
+                                                                       int64_t rows, int C1, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LD = D + 4;                      // floats per direction row in LDS (16-B pad)
+  constexpr int KS = D / 32;                     // K-steps
+  constexpr int CH = KS >= 8 ? 4 : KS / 2;       // K-steps per staged chunk
+  constexpr int NCH = KS / CH;                   // even for every supported D
+  static_assert(NCH % 2 == 0 && NCH * CH == KS, "chunking");
+  float* sd = reinterpret_cast<float*>(smem);    // [16*NT][LD], rows >= C1 are zero
+  float* sc = sd + 16 * NT * LD;                 // [D] centroid
+  for (int i = threadIdx.x; i < 16 * NT * (D / 4); i += 256) {
+    const int r = i / (D / 4), k4 = i - r * (D / 4);
+    const float4 v = r < C1 ? reinterpret_cast<const float4*>(dirs + (size_t)r * D)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(sd + r * LD + 4 * k4) = v;
+  }
+  for (int i = threadIdx.x; i < D / 4; i += 256) reinterpret_cast<float4*>(sc)[i] = reinterpret_cast<const float4*>(nc)[i];
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, q = lane >> 4;
+  const int64_t ngroups = (rows + 15) >> 4;
+  double s_[NT], q_[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { s_[t] = 0.0; q_[t] = 0.0; }
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    int64_t row = grp * 16 + li;
+    if (row >= rows) row = rows - 1;                                   // clamped; masked at the store
+    const float* xr = x + row * D + 8 * q;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K in chunks of CH steps, two register sets in ping-pong: chunk c+1 is in flight while chunk c feeds the MFMAs
+    // (all-K-up-front costs 128 VGPRs of staging at D = 512 and spills)
+    float4 a0[CH][2], a1[CH][2];
+#define SELM_LOAD(A, c)                                                        \
+  _Pragma("unroll") for (int j = 0; j < CH; ++j) {                             \
+    A[j][0] = *reinterpret_cast<const float4*>(xr + 32 * ((c) * CH + j));      \
+    A[j][1] = *reinterpret_cast<const float4*>(xr + 32 * ((c) * CH + j) + 4);  \
+  }
+#define SELM_MMA(A, c)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < CH; ++j) {                                                       \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
+      const int k0 = 32 * ((c) * CH + j) + 8 * q + 4 * h;                                                \
+      const float4 c4 = *reinterpret_cast<const float4*>(sc + k0);                                       \
+      const float4 xa = make_float4(A[j][h].x - c4.x, A[j][h].y - c4.y, A[j][h].z - c4.z, A[j][h].w - c4.w); \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                   \
+        const float4 b4 = *reinterpret_cast<const float4*>(sd + (16 * t + li) * LD + k0);                \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, b4.x, acc[t], 0, 0, 0);                      \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, b4.y, acc[t], 0, 0, 0);                      \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, b4.z, acc[t], 0, 0, 0);                      \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, b4.w, acc[t], 0, 0, 0);                      \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+    SELM_LOAD(a0, 0)
+#pragma unroll 1
+    for (int c = 0; c < NCH; c += 2) {
+      SELM_LOAD(a1, c + 1)
+      SELM_MMA(a0, c)
+      if (c + 2 < NCH) { SELM_LOAD(a0, c + 2) }
+      SELM_MMA(a1, c + 1)
+    }
+#undef SELM_LOAD
+#undef SELM_MMA
+    // lane holds column 16 t + li of rows grp*16 + 4 q + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t rr = grp * 16 + 4 * q + r;
+      if (rr < rows) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = 16 * t + li;
+          if (c < C1) raw[rr * C1 + c] = acc[t][r];
+          if constexpr (STATS) { s_[t] += (double)acc[t][r]; q_[t] += (double)acc[t][r] * (double)acc[t][r]; }
+        }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    __syncthreads();                                                   // directions no longer needed: reuse LDS
+    double* red = reinterpret_cast<double*>(smem);                     // [4 waves][2][16*NT]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double s = s_[t], qq = q_[t];
+      s += __shfl_xor(s, 16, 64);  qq += __shfl_xor(qq, 16, 64);      // the four row quarters (fixed order)
+      s += __shfl_xor(s, 32, 64);  qq += __shfl_xor(qq, 32, 64);
+      if (q == 0) { red[(wave * 2 + 0) * 16 * NT + 16 * t + li] = s; red[(wave * 2 + 1) * 16 * NT + 16 * t + li] = qq; }
+    }
     __syncthreads();
+    if (threadIdx.x < 2 * 16 * NT) {
+      const int k = threadIdx.x / (16 * NT), c = threadIdx.x - k * 16 * NT;
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += red[(w * 2 + k) * 16 * NT + c];
+      part[(size_t)blockIdx.x * 2 * 16 * NT + threadIdx.x] = v;
+    }
   }
-  const double m = red[0] / (double)rows;
+}
+
+// ------------------------------------------------------------------ batch-norm statistics (two stages, fixed order)
+// stage 1: block b owns a contiguous slab of rows; thread (c = t % C1, rl = t / C1) walks rows rl, rl + RL, ... of the slab
+// (consecutive threads read consecutive addresses), f64 sums of x and x^2 (K2 = 0) or of dl and dl * xhat (K2 = 1);
+// part[b][2][CP].  stage 2 (bn_finalize_kernel / bn_sums_finalize_kernel): one thread per (kind, column) adds the
+// blocks' partials in block order.  Replaces one-workgroup-per-column kernels (13 workgroups on a 256-CU chip).
+template <int K2>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t rows, int C1,
+                                                         int CP, int64_t rows_per_block, double* __restrict__ part) {
+  __shared__ double red[2][256];
+  const int RL = 256 / C1;
+  const int c = threadIdx.x % C1, rl = threadIdx.x / C1;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  double s = 0.0, qq = 0.0;
+  if (rl < RL) {
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      const double v = (double)a[r * C1 + c];
+      if constexpr (K2 == 0) { s += v; qq += v * v; }
+      else { const double g = (double)b[r * C1 + c]; s += g; qq += g * v; }
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = qq;
   __syncthreads();
-  double q = 0.0;
-  for (int64_t r = threadIdx.x; r < rows; r += 256) {
-    const double dlt = (double)raw[r * C1 + c] - m;
-    q += dlt * dlt;
+  if (threadIdx.x < 2 * C1) {
+    const int k = threadIdx.x / C1, cc = threadIdx.x - k * C1;
+    double v = 0.0;
+    for (int l = 0; l < RL; ++l) v += red[k][l * C1 + cc];
+    part[((size_t)blockIdx.x * 2 + k) * CP + cc] = v;
   }
-  red[threadIdx.x] = q;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    mean[c] = (float)m;
-    var_b[c] = (float)(red[0] / (double)rows);
-    var_u[c] = rows > 1 ? (float)(red[0] / (double)(rows - 1)) : 0.f;
-  }
+}
+// mean / biased / unbiased variance from the (sum, sum of squares) partials: var = E[x^2] - mean^2 in f64 (the column
+// values are O(1): 53 bits leave ~1e-13 after the cancellation)
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ part, int nblocks, int CP, int C1, int64_t rows,
+                                                         float* __restrict__ mean, float* __restrict__ var_b, float* __restrict__ var_u) {
+  const int c = threadIdx.x;
+  if (c >= C1) return;
+  double s = 0.0, qq = 0.0;
+  for (int b = 0; b < nblocks; ++b) { s += part[((size_t)b * 2 + 0) * CP + c]; qq += part[((size_t)b * 2 + 1) * CP + c]; }
+  const double n = (double)rows, m = s / n;
+  double m2 = qq - s * m;                                              // sum (x - m)^2
+  if (m2 < 0.0) m2 = 0.0;
+  mean[c] = (float)m;
+  var_b[c] = (float)(m2 / n);
+  var_u[c] = rows > 1 ? (float)(m2 / (n - 1.0)) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void selector_bn_kernel(const float* __restrict__ raw, const float* __restrict__ mean,
@@ -352,6 +475,61 @@ extern "C" int acx_text_directions(acx_ctx* ctx, const float* text, const float*
   return ACX_OK;
 }
 
+static inline int bn_blocks(int64_t rows) {
+  int64_t nb = (rows + 255) / 256;
+  return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
+}
+extern "C" size_t acx_bn_workspace_bytes(int64_t rows, int32_t C1) {
+  (void)rows;
+  return (size_t)1024 * 2 * 64 * sizeof(double) * (C1 > 0 ? 1 : 1);     // [<= 1024 blocks][2][<= 64 columns] f64
+}
+
+// shared launcher: projection (+ optional fused batch statistics); returns false when the shape does not fit the MFMA kernel
+static bool launch_selector_mfma(const float* x, const float* nc, const float* dirs, float* raw, int64_t rows, int D, int C1,
+                                 double* part, int* nblocks, int ncu, hipStream_t s) {
+  const int NT = (C1 + 15) / 16;
+  const size_t lds = ((size_t)16 * NT * (D + 4) + D) * 4;
+  if ((D != 64 && D != 128 && D != 256 && D != 512 && D != 768 && D != 1024) || lds > 160 * 1024) return false;
+  const int64_t ngroups = (rows + 15) / 16;
+  int64_t nb = (ngroups + 3) / 4;
+  const int64_t cap = 2 * (int64_t)ncu;                                 // two resident blocks per CU
+  if (nb > cap) nb = cap;
+  *nblocks = (int)nb;
+  const dim3 grid((unsigned)nb), block(256);
+#define ACX_SELM(DD, N_)                                                                                                  \
+  do {                                                                                                                    \
+    if (part) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)selector_project_mfma_kernel<DD, N_, true>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+      hipLaunchKernelGGL((selector_project_mfma_kernel<DD, N_, true>), grid, block, lds, s, x, nc, dirs, raw, rows, C1, part); \
+    } else {                                                                                                              \
+      (void)hipFuncSetAttribute((const void*)selector_project_mfma_kernel<DD, N_, false>,                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+      hipLaunchKernelGGL((selector_project_mfma_kernel<DD, N_, false>), grid, block, lds, s, x, nc, dirs, raw, rows, C1, part); \
+    }                                                                                                                     \
+  } while (0)
+#define ACX_SELD(DD)                                                         \
+  do {                                                                       \
+    switch (NT) {                                                            \
+      case 1: ACX_SELM(DD, 1); break;                                        \
+      case 2: ACX_SELM(DD, 2); break;                                        \
+      case 3: ACX_SELM(DD, 3); break;                                        \
+      default: ACX_SELM(DD, 4); break;                                       \
+    }                                                                        \
+  } while (0)
+  switch (D) {
+    case 64: ACX_SELD(64); break;
+    case 128: ACX_SELD(128); break;
+    case 256: ACX_SELD(256); break;
+    case 512: ACX_SELD(512); break;
+    case 768: ACX_SELD(768); break;
+    default: ACX_SELD(1024); break;
+  }
+#undef ACX_SELD
+#undef ACX_SELM
+  return true;
+}
+
 extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
                                     int64_t rows, int32_t D, int32_t C1, void* stream) {
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
@@ -360,11 +538,20 @@ extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* n
   if (C1 <= 0 || C1 > 64) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_project: need 1 <= C-1 <= 64%s");
   if (D % 64 || D > 1024 || (D / 64 != 1 && D / 64 != 2 && (D / 64) % 4))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_project: D must be 64/128/256/512/768/1024%s");
+  if ((((uintptr_t)x | (uintptr_t)ncentroid | (uintptr_t)dirs) & 15))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project: x / ncentroid / dirs must be 16-byte aligned%s");
+  hipStream_t s = (hipStream_t)stream;
+  int nb_unused = 0;
+  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  if (launch_selector_mfma(x, ncentroid, dirs, raw, rows, D, C1, nullptr, &nb_unused, ncu, s)) {
+    ACX_CHECK_LAUNCH(ctx, "acx_selector_project");
+    return ACX_OK;
+  }
+  // (C-1) * D too large for the MFMA kernel's LDS layout: wave-per-row kernel
   const size_t lds = (size_t)C1 * D * 4;
   int64_t nb = (rows + 3) / 4;
   if (nb > 2048) nb = 2048;
   const dim3 grid((unsigned)nb), block(256);
-  hipStream_t s = (hipStream_t)stream;
 #define ACX_SEL(V)                                                                                         \
   do {                                                                                                     \
     (void)hipFuncSetAttribute((const void*)selector_project_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -384,12 +571,76 @@ extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* n
 }
 
 extern "C" int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_t C1, float* mean, float* var_biased,
-                            float* var_unbiased, void* stream) {
+                            float* var_unbiased, void* workspace, size_t workspace_bytes, void* stream) {
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
-  if (!raw || !mean || !var_biased || !var_unbiased) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: null pointer%s");
-  if (rows <= 0 || C1 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: empty%s");
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(C1), dim3(256), 0, (hipStream_t)stream, raw, rows, C1, mean, var_biased, var_unbiased);
+  if (!raw || !mean || !var_biased || !var_unbiased || !workspace) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: null pointer%s");
+  if (rows <= 0 || C1 <= 0 || C1 > 64) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: need rows > 0 and 1 <= C1 <= 64%s");
+  if (workspace_bytes < acx_bn_workspace_bytes(rows, C1) || ((uintptr_t)workspace & 7))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_bn_stats: workspace too small (acx_bn_workspace_bytes) or misaligned%s");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = bn_blocks(rows);
+  const int64_t rpb = (rows + nb - 1) / nb;
+  hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(nb), dim3(256), 0, s, raw, (const float*)nullptr, rows, C1, 64, rpb, (double*)workspace);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nb, 64, C1, rows, mean, var_biased,
+                     var_unbiased);
   ACX_CHECK_LAUNCH(ctx, "acx_bn_stats");
+  return ACX_OK;
+}
+
+// sums[0:C1] = sum dl, sums[C1:2C1] = sum dl * xhat  (BatchNorm1d training backward, part A)
+__global__ __launch_bounds__(128) void bn_sums_finalize_kernel(const double* __restrict__ part, int nblocks, int CP, int C1,
+                                                               float* __restrict__ sums) {
+  if ((int)threadIdx.x >= 2 * C1) return;
+  const int k = threadIdx.x / C1, c = threadIdx.x - k * C1;
+  double v = 0.0;
+  for (int b = 0; b < nblocks; ++b) v += part[((size_t)b * 2 + k) * CP + c];
+  sums[k * C1 + c] = (float)v;
+}
+extern "C" int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* dlogits, float* sums /* [2*C1] */,
+                                int64_t rows, int32_t C1, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!logits || !dlogits || !sums || !workspace) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_stats: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  if (C1 <= 0 || C1 > 64) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_stats: need 1 <= C1 <= 64%s");
+  if (workspace_bytes < acx_bn_workspace_bytes(rows, C1) || ((uintptr_t)workspace & 7))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_stats: workspace too small (acx_bn_workspace_bytes) or misaligned%s");
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+  const int nb = bn_blocks(rows);
+  const int64_t rpb = (rows + nb - 1) / nb;
+  hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(nb), dim3(256), 0, s, logits, dlogits, rows, C1, 64, rpb, (double*)workspace);
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(1), dim3(128), 0, s, (const double*)workspace, nb, 64, C1, sums);
+  ACX_CHECK_LAUNCH(ctx, "acx_bn_bwd_stats");
+  return ACX_OK;
+}
+
+extern "C" int acx_selector_project_stats(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
+                                          int64_t rows, int32_t D, int32_t C1, float* mean, float* var_biased,
+                                          float* var_unbiased, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!mean || !var_biased || !var_unbiased || !workspace)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project_stats: null pointer%s");
+  if (rows <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project_stats: empty%s");
+  if (C1 <= 0 || C1 > 64) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_project_stats: need 1 <= C-1 <= 64%s");
+  if (workspace_bytes < acx_bn_workspace_bytes(rows, C1) || ((uintptr_t)workspace & 7))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project_stats: workspace too small or misaligned%s");
+  if (!x || !ncentroid || !dirs || !raw || (((uintptr_t)x | (uintptr_t)ncentroid | (uintptr_t)dirs) & 15))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project_stats: null or misaligned pointer%s");
+  hipStream_t s = (hipStream_t)stream;
+  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  int nb = 0;
+  {
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    if (!launch_selector_mfma(x, ncentroid, dirs, raw, rows, D, C1, (double*)workspace, &nb, ncu, s)) {
+      // shape outside the MFMA kernel: projection, then the stand-alone statistics
+      int rc = acx_selector_project(ctx, x, ncentroid, dirs, raw, rows, D, C1, stream);
+      if (rc != ACX_OK) return rc;
+      return acx_bn_stats(ctx, raw, rows, C1, mean, var_biased, var_unbiased, workspace, workspace_bytes, stream);
+    }
+  }
+  AcxProfScope prof2__(ctx, ACX_K_OTHER, s);
+  const int CP = 16 * ((C1 + 15) / 16);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nb, CP, C1, rows, mean, var_biased,
+                     var_unbiased);
+  ACX_CHECK_LAUNCH(ctx, "acx_selector_project_stats");
   return ACX_OK;
 }
 

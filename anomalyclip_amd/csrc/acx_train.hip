@@ -672,27 +672,7 @@ __global__ __launch_bounds__(256) void pos_grad_part_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ BatchNorm (training) backward
-// logits = (raw - mean) * rstd ;  part A: per column sums  sdl[c] = sum dl, sdx[c] = sum dl*xhat (fixed order)
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ logits, const float* __restrict__ dl,
-                                                           int64_t rows, int C1, float* __restrict__ sdl, float* __restrict__ sdx) {
-  __shared__ double red[256];
-  const int c = blockIdx.x;
-  double a = 0.0, b = 0.0;
-  for (int64_t r = threadIdx.x; r < rows; r += 256) {
-    const double g = dl[r * C1 + c];
-    a += g;
-    b += g * (double)logits[r * C1 + c];
-  }
-  red[threadIdx.x] = a;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  const double ta = red[0];
-  __syncthreads();
-  red[threadIdx.x] = b;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) { sdl[c] = (float)ta; sdx[c] = (float)red[0]; }
-}
+// logits = (raw - mean) * rstd ;  part A (per column sums sdl[c] = sum dl, sdx[c] = sum dl*xhat): acx_head.hip, bn_partial_kernel<1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ logits, const float* __restrict__ dl,
                                                            const float* __restrict__ var_b, const float* __restrict__ sdl,
                                                            const float* __restrict__ sdx, float* __restrict__ draw, int ldo,
@@ -1004,6 +984,58 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// Multi-tensor AdamW: ONE launch updates up to ADAMW_MAX_SEG parameter tensors (the reference's four param groups differ in
+// lr only, anomaly_clip_module.py:693-746).  The segment table travels in the kernel arguments (no device-side table, no
+// extra copy, replayable inside a HIP graph as long as lr / step do not change); block b finds its segment by a binary
+// search over the prefix of 1024-element chunks and updates 4 x 256 elements with coalesced dword accesses (the flat
+// gradient buffer hands out 4-byte-aligned views, so 16-byte accesses are not available for g).
+constexpr int ADAMW_MAX_SEG = 48;
+struct AdamwSegs {
+  float* p[ADAMW_MAX_SEG];
+  const float* g[ADAMW_MAX_SEG];
+  float* m[ADAMW_MAX_SEG];
+  float* v[ADAMW_MAX_SEG];
+  long long n[ADAMW_MAX_SEG];
+  float lr[ADAMW_MAX_SEG];
+  float wd[ADAMW_MAX_SEG];
+  int chunk0[ADAMW_MAX_SEG + 1];      // first 1024-element chunk of every segment
+  int nseg;
+};
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSegs t, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.nseg - 1;
+  while (lo < hi) {                                                    // last segment with chunk0 <= b (uniform per block)
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.chunk0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int sgi = lo;
+  float* __restrict__ p = t.p[sgi];
+  const float* __restrict__ g = t.g[sgi];
+  float* __restrict__ m = t.m[sgi];
+  float* __restrict__ v = t.v[sgi];
+  const long long n = t.n[sgi];
+  const float lr = t.lr[sgi], decay = 1.f - lr * t.wd[sgi], step_size = lr / bc1;
+  const long long base = (long long)(b - t.chunk0[sgi]) * 1024 + threadIdx.x;
+  float pi[4], gi[4], mi[4], vi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) { pi[k] = p[i]; gi[k] = g[i]; mi[k] = m[i]; vi[k] = v[i]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) {
+      const float pw = pi[k] * decay;
+      const float mn = b1 * mi[k] + (1.f - b1) * gi[k];
+      const float vn = b2 * vi[k] + (1.f - b2) * gi[k] * gi[k];
+      m[i] = mn;
+      v[i] = vn;
+      p[i] = pw - step_size * (mn / (sqrtf(vn) / bc2_sqrt + eps));
+    }
+  }
+}
+
 // d_ctx[c][t][:] = dx[c][1+t][:]  (or summed over classes when the context is shared)  (coop.py:74-90)
 __global__ __launch_bounds__(256) void ctx_grad_kernel(const float* __restrict__ dx, float* __restrict__ dctx, int C, int n_ctx,
                                                        int Lc, int W, int shared_ctx) {
@@ -1194,17 +1226,6 @@ extern "C" int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1,
   return ACX_OK;
 }
 
-extern "C" int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* dlogits, float* sums /* [2*C1] */,
-                                int64_t rows, int32_t C1, void* stream) {
-  if (!logits || !dlogits || !sums) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_stats: null pointer%s");
-  if (rows <= 0) return ACX_OK;
-  hipStream_t s = (hipStream_t)stream;
-  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C1), dim3(256), 0, s, logits, dlogits, rows, C1, sums, sums + C1);
-  ACX_CHECK_LAUNCH(ctx, "acx_bn_bwd_stats");
-  return ACX_OK;
-}
-
 extern "C" int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* dlogits, const float* var_biased,
                                 const float* sums, float* draw, int32_t ldo, int64_t rows, int64_t total_rows, int32_t C1,
                                 float eps, void* stream) {
@@ -1326,6 +1347,41 @@ extern "C" int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float
   hipLaunchKernelGGL(adamw_kernel, GRID1(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                      bc1, bc2s);
   ACX_CHECK_LAUNCH(ctx, "acx_adamw");
+  return ACX_OK;
+}
+
+extern "C" int acx_adamw_multi(acx_ctx* ctx, int32_t nseg, void* const* p, const void* const* g, void* const* m, void* const* v,
+                               const int64_t* n, const float* lr, const float* weight_decay, float beta1, float beta2, float eps,
+                               int32_t step, void* stream) {
+  if (nseg <= 0) return ACX_OK;
+  if (!p || !g || !m || !v || !n || !lr || !weight_decay) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi: null pointer%s");
+  if (step <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi: step starts at 1%s");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < nseg) {
+    AdamwSegs t;
+    memset(&t, 0, sizeof(t));
+    long long chunks = 0;
+    int k = 0;
+    for (; i < nseg && k < ADAMW_MAX_SEG; ++i) {
+      if (n[i] <= 0) continue;
+      if (!p[i] || !g[i] || !m[i] || !v[i]) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi: null tensor pointer%s");
+      t.p[k] = (float*)p[i]; t.g[k] = (const float*)g[i]; t.m[k] = (float*)m[i]; t.v[k] = (float*)v[i];
+      t.n[k] = n[i]; t.lr[k] = lr[i]; t.wd[k] = weight_decay[i];
+      t.chunk0[k] = (int)chunks;
+      chunks += (n[i] + 1023) / 1024;
+      ++k;
+    }
+    if (k == 0) continue;
+    if (chunks > 0x7fffffffLL) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_adamw_multi: too many elements for one launch%s");
+    t.chunk0[k] = (int)chunks;
+    t.nseg = k;
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, beta1, beta2, eps, bc1, bc2);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_adamw_multi");
   return ACX_OK;
 }
 

@@ -153,13 +153,34 @@ def selector_project(x: torch.Tensor, ncentroid: torch.Tensor, dirs: torch.Tenso
     return raw
 
 
+def _bn_workspace(t: torch.Tensor, rows: int, C1: int) -> torch.Tensor:
+    return torch.empty(int(L.lib().acx_bn_workspace_bytes(rows, C1)) // 8, dtype=torch.float64, device=t.device)
+
+
 def bn_stats(raw: torch.Tensor):
     rows, C1 = raw.shape
     st = torch.empty(3, C1, dtype=torch.float32, device=raw.device)
     h = _h(raw)
+    ws = _bn_workspace(raw, rows, C1)
     L.check(L.lib().acx_bn_stats(h, raw.data_ptr(), rows, C1, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
-                                 _stream()), h)
+                                 ws.data_ptr(), ws.numel() * 8, _stream()), h)
     return st[0], st[1], st[2]
+
+
+def selector_project_stats(x: torch.Tensor, ncentroid: torch.Tensor, dirs: torch.Tensor):
+    """projection + batch statistics of its output in the projection's epilogue -> (raw, mean, var_biased, var_unbiased)."""
+    x = x.reshape(-1, x.shape[-1])
+    assert x.is_contiguous()
+    rows, D = x.shape
+    C1 = dirs.shape[0]
+    raw = torch.empty(rows, C1, dtype=torch.float32, device=x.device)
+    st = torch.empty(3, C1, dtype=torch.float32, device=x.device)
+    ws = _bn_workspace(x, rows, C1)
+    h = _h(x)
+    L.check(L.lib().acx_selector_project_stats(h, x.data_ptr(), ncentroid.data_ptr(), dirs.data_ptr(), raw.data_ptr(), rows, D,
+                                               C1, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), ws.data_ptr(),
+                                               ws.numel() * 8, _stream()), h)
+    return raw, st[0], st[1], st[2]
 
 
 def selector_bn(raw: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps=1e-5,
@@ -353,7 +374,9 @@ def bn_bwd_stats(logits, dlogits) -> torch.Tensor:
     rows, C1 = logits.shape
     sums = torch.empty(2 * C1, dtype=torch.float32, device=logits.device)
     h = _h(logits)
-    L.check(L.lib().acx_bn_bwd_stats(h, logits.data_ptr(), dlogits.data_ptr(), sums.data_ptr(), rows, C1, _stream()), h)
+    ws = _bn_workspace(logits, rows, C1)
+    L.check(L.lib().acx_bn_bwd_stats(h, logits.data_ptr(), dlogits.data_ptr(), sums.data_ptr(), rows, C1, ws.data_ptr(),
+                                     ws.numel() * 8, _stream()), h)
     return sums
 
 
@@ -448,6 +471,18 @@ def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step) -> None:
     h = _h(p)
     L.check(L.lib().acx_adamw(h, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                               weight_decay, step, _stream()), h)
+
+
+def adamw_multi_(ps, gs, ms, vs, lrs, wds, beta1, beta2, eps, step) -> None:
+    """one launch for all the tensors (lists of equal length; per-tensor lr / weight decay)."""
+    n = len(ps)
+    if n == 0:
+        return
+    h = _h(ps[0])
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])           # noqa: E731
+    L.check(L.lib().acx_adamw_multi(h, n, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * n)(*[p.numel() for p in ps]),
+                                    (C.c_float * n)(*[float(x) for x in lrs]), (C.c_float * n)(*[float(x) for x in wds]),
+                                    beta1, beta2, eps, step, _stream()), h)
 
 
 def ctx_grad(dx, C, n_ctx, Lc, W, shared) -> torch.Tensor:

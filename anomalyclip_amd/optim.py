@@ -20,6 +20,9 @@ class AcxAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        # every tensor that shares (betas, eps, step) -- in practice all of them -- goes into ONE acx_adamw_multi launch
+        # (per-tensor lr / weight decay carry the reference's four param groups); 34 launches -> 1 at the UCF config
+        batches: dict = {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -28,11 +31,17 @@ class AcxAdamW(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                if not p.is_contiguous():
+                    raise ops.L.AcxError("AcxAdamW updates parameters in place through raw pointers: contiguous parameters only")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                ops.adamw_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
-                           group["weight_decay"], st["step"])
+                key = (p.device, float(b1), float(b2), float(group["eps"]), int(st["step"]))
+                b = batches.setdefault(key, ([], [], [], [], [], []))
+                for lst, val in zip(b, (p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), float(group["weight_decay"]))):
+                    lst.append(val)
+        for (_, b1, b2, eps, step), (ps, gs, ms, vs, lrs, wds) in batches.items():
+            ops.adamw_multi_(ps, gs, ms, vs, lrs, wds, b1, b2, eps, step)
         ops.WEIGHT_EPOCH[0] += 1
         return loss

@@ -178,10 +178,21 @@ int acx_text_directions(acx_ctx* ctx, const float* text, const float* ncentroid,
  * x [rows, D] (D in {64,128,256,512,768,1024}), raw [rows, C1], C1 <= 64. */
 int acx_selector_project(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs,
                          float* raw, int64_t rows, int32_t D, int32_t C1, void* stream);
-/* acx_bn_stats: deterministic per-column batch statistics of raw[rows, C1] (training BatchNorm1d:
- * biased variance normalises, unbiased variance feeds running_var). */
+/* acx_bn_stats: deterministic per-column batch statistics of raw[rows, C1] (training BatchNorm1d,
+ * selector_model.py:30,65: biased variance normalises, unbiased variance feeds running_var).  Two
+ * stages (row slabs -> f64 partials in `workspace` -> fixed-order sum); C1 <= 64;
+ * workspace >= acx_bn_workspace_bytes(rows, C1), 8-byte aligned. */
+size_t acx_bn_workspace_bytes(int64_t rows, int32_t C1);
 int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_t C1, float* mean,
-                 float* var_biased, float* var_unbiased, void* stream);
+                 float* var_biased, float* var_unbiased, void* workspace, size_t workspace_bytes,
+                 void* stream);
+/* acx_selector_project_stats: acx_selector_project with the batch statistics of its output
+ * accumulated in the projection's epilogue (raw is not read again): the training-mode pair
+ * selector_model.py:62 + :65's statistics in two launches.  Same workspace rule as acx_bn_stats. */
+int acx_selector_project_stats(acx_ctx* ctx, const float* x, const float* ncentroid,
+                               const float* dirs, float* raw, int64_t rows, int32_t D, int32_t C1,
+                               float* mean, float* var_biased, float* var_unbiased,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* acx_selector_bn: logits = (raw - mean) / sqrt(var + eps)  (BatchNorm1d(C-1, affine=False),
  * selector_model.py:30,65).  mean/var [C1] (running stats in eval, batch stats in train). */
 int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean, const float* var,
@@ -281,7 +292,7 @@ int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1, float* par
  * sums in between): stats -> sums[2*C1] = (sum dl, sum dl*xhat) per column over this rank's rows; apply ->
  * draw[r*ldo + c] with total_rows = rows of ALL ranks. */
 int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* dlogits, float* sums, int64_t rows,
-                     int32_t C1, void* stream);
+                     int32_t C1, void* workspace /* acx_bn_workspace_bytes */, size_t workspace_bytes, void* stream);
 int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* dlogits, const float* var_biased,
                      const float* sums, float* draw, int32_t ldo, int64_t rows, int64_t total_rows, int32_t C1,
                      float eps, void* stream);
@@ -314,6 +325,12 @@ int acx_mil_loss(acx_ctx* ctx, const float* sim, const float* sim_topk, const in
 /* acx_adamw: one torch.optim.AdamW step (decoupled weight decay, bias correction; step counts from 1). */
 int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* acx_adamw_multi: the same update for nseg parameter tensors in ONE launch (per-tensor lr / weight decay: the
+ * reference's four param groups, anomaly_clip_module.py:693-746; common betas / eps / step).  The pointer and size
+ * arrays are HOST arrays of length nseg; entries with n[i] <= 0 are skipped. */
+int acx_adamw_multi(acx_ctx* ctx, int32_t nseg, void* const* p, const void* const* g, void* const* m, void* const* v,
+                    const int64_t* n, const float* lr, const float* weight_decay, float beta1, float beta2, float eps,
+                    int32_t step, void* stream);
 int acx_ctx_grad(acx_ctx* ctx, const float* dx, float* dctx, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
                  int32_t shared_ctx, void* stream);
 int acx_scatter_rows(acx_ctx* ctx, const float* src, const int64_t* idx, float* out, int64_t n, int32_t W,

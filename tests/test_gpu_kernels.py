@@ -301,6 +301,37 @@ def test_selector_kernels():
         assert relerr(vu, ref_raw.var(0, unbiased=True)) < 1e-5
 
 
+@pytest.mark.parametrize("rows,D,C1", [(32768, 512, 13), (16 * 511 + 5, 512, 17), (1000, 512, 6), (40960, 512, 6), (777, 128, 13),
+                                      (100, 64, 33), (3, 256, 64), (513, 1024, 13), (600, 768, 13), (64, 1024, 64)])
+def test_selector_project_mfma_and_fused_stats(rows, D, C1):
+    """selector_model.py:54,62,65: the projection as a skinny f32-MFMA GEMM (16-row groups, 1..4 column tiles of 16
+    directions, ragged last group, every supported width; (1024, 64) overflows the LDS layout and takes the wave-per-row
+    kernel) with BatchNorm's batch statistics accumulated in its epilogue, against fp64; the stand-alone two-stage
+    statistics and the backward column sums against fp64 as well.  Element-wise: |err| <= 2e-6 * sum_k |x - c||d|."""
+    g = torch.Generator().manual_seed(rows + D + C1)
+    x = torch.randn(rows, D, generator=g) * 0.3 + 0.1
+    nc = torch.randn(D, generator=g) * 0.1
+    dirs = torch.nn.functional.normalize(torch.randn(C1, D, generator=g), dim=1)
+    ref = (x - nc).double() @ dirs.double().t()
+    bound = 2e-6 * ((x - nc).abs().double() @ dirs.abs().double().t()) + 1e-30
+    xd, ncd, dd = x.to(DEV), nc.to(DEV), dirs.to(DEV)
+    raw = ops.selector_project(xd, ncd, dd)
+    assert raw.shape == (rows, C1) and bool(((raw.cpu().double() - ref).abs() <= bound).all())
+    raw2, m, vb, vu = ops.selector_project_stats(xd, ncd, dd)
+    assert torch.equal(raw2, raw)                                                  # same kernel, same order
+    r64 = raw.cpu().double()
+    assert relerr(m, r64.mean(0)) < 1e-6 and relerr(vb, r64.var(0, unbiased=False)) < 1e-6
+    if rows > 1:
+        assert relerr(vu, r64.var(0, unbiased=True)) < 1e-6
+    m2, vb2, vu2 = ops.bn_stats(raw)
+    assert relerr(m2, r64.mean(0)) < 1e-6 and relerr(vb2, r64.var(0, unbiased=False)) < 1e-6 and relerr(vu2, vu) < 1e-6
+    dl = torch.randn(rows, C1, generator=g)
+    sums = ops.bn_bwd_stats(raw, dl.to(DEV))
+    assert relerr(sums[:C1], dl.double().sum(0)) < 1e-6 and relerr(sums[C1:], (dl.double() * r64).sum(0)) < 1e-6
+    # run-to-run identical (fixed-order reductions)
+    assert torch.equal(ops.bn_bwd_stats(raw, dl.to(DEV)), sums) and torch.equal(ops.selector_project_stats(xd, ncd, dd)[1], m)
+
+
 def test_cls_head_class_probs_misc():
     g = torch.Generator().manual_seed(4)
     E, N, Lg, S = 256, 32, 16, 2

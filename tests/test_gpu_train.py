@@ -208,6 +208,46 @@ def test_adamw_matches_torch():
     assert relerr(pa, pb) < 1e-6
 
 
+def test_adamw_multi_tensor_groups_match_torch():
+    """One acx_adamw_multi launch over many tensors with the reference's param-group structure (per-group lr,
+    anomaly_clip_module.py:693-746): ragged sizes (1 ... 3 M elements, not multiples of the 1024-element chunks), more
+    tensors than one launch's segment table (48), gradients that are 4-byte-aligned VIEWS of a flat buffer
+    (parallel.GradBuckets), a parameter without gradient (skipped like torch does) -- against torch.optim.AdamW, 4 steps
+    with an lr change in between (the per-epoch schedule)."""
+    g = torch.Generator().manual_seed(7)
+    sizes = [1, 3, 1023, 1024, 1025, 4096, 70000, 3 * 1024 * 1024 + 5] + [17 + 31 * i for i in range(50)]
+    ps = [torch.randn(n, generator=g) for n in sizes]
+    pa = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    pb = [torch.nn.Parameter(p.clone()) for p in ps]
+    lrs = [1e-3, 5e-4, 2e-3, 1e-4]
+
+    def groups(params):
+        return [{"params": params[i::4], "lr": lrs[i]} for i in range(4)]
+    oa = AcxAdamW(groups(pa), weight_decay=0.2)
+    ob = torch.optim.AdamW(groups(pb), weight_decay=0.2)
+    flat = torch.zeros(sum(sizes) + 1, device=DEV)
+    for step in range(4):
+        off = 1                                                    # odd offset: views are only 4-byte aligned
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.randn(sizes[i], generator=g)
+            if i == 5 and step < 2:
+                a.grad, b.grad = None, None                        # unused parameter: no update, no state
+            else:
+                flat[off:off + sizes[i]] = gr.to(DEV)
+                a.grad, b.grad = flat[off:off + sizes[i]], gr.clone()
+            off += sizes[i]
+        if step == 2:
+            for o in (oa, ob):
+                for grp in o.param_groups:
+                    grp["lr"] *= 0.5
+        oa.step()
+        ob.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert relerr(a, b) < 1e-6, (i, sizes[i])
+        if i != 5:
+            assert relerr(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-6
+
+
 def _train_step_tiny(golden, prompts_table):
     g = golden("e2e_tiny")
     seed = int(g["seed"])

@@ -26,9 +26,26 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
-def stub_collectives(world):
-    """single-process stand-in for torch.distributed inside anomalyclip_amd.parallel (timing of rank 0's share only)."""
+def stub_collectives(world, net=None):
+    """single-process stand-in for torch.distributed inside anomalyclip_amd.parallel (timing of rank 0's share only).
+    The class-parallel text exchange (parallel.assemble_rows) is emulated with REAL data: the text features of all
+    classes are evaluated once here, untimed, and the stubbed exchange fills the other ranks' class rows from that copy --
+    a no-op all-reduce would leave them zero, (T - c)/|T - c| = 0/0 with the zero ncentroid of the benchmark, and every
+    kernel downstream would be timed on NaNs."""
     from anomalyclip_amd import parallel
+    if net is not None:
+        import torch as _t
+        from anomalyclip_amd.components import functional as Fn
+        with _t.no_grad():
+            full, _ = Fn._text_forward_rows(net, net.prompt_learner.ctx, net.text_encoder.text_projection, 0,
+                                            net.prompt_learner.n_cls)
+        full = full.detach().clone()
+
+        def assemble_rows(local, lo, n):
+            out = full.clone()
+            out[lo:lo + local.shape[0]] = local
+            return out
+        parallel.assemble_rows = assemble_rows
 
     class _H:
         def wait(self):
@@ -109,7 +126,7 @@ def main():
     B_global = args.batch if args.scaling == "strong" else args.batch * eff_world
     batch, idx = B.head_batch(B_global, eff_world, rank, dev)
     if args.emulate_world > 1:
-        stub_collectives(eff_world)
+        stub_collectives(eff_world, net)
 
     net.train()
     step_i = [0]
