@@ -1,0 +1,80 @@
+// Measured denominators for the roofline report ("the builder must measure a GEMM peak and a
+// stream-copy peak on the box and report both nominal and measured denominators").  Two micro-kernels, no product path
+// uses them:
+//   acx_probe_mfma  -- register-only MFMA loop (v_mfma_f32_32x32x2_f32 or v_mfma_f32_32x32x16_bf16), four independent
+//                      accumulator chains per wave, `waves_per_simd` waves on every SIMD of the chip: the issue-rate
+//                      ceiling of the matrix pipe at the clock the chip sustains under that load;
+//   acx_probe_copy  -- 16-byte-per-lane grid-stride copy (global_load_dwordx4 / global_store_dwordx4): the HBM stream
+//                      ceiling (read + write) the row kernels are measured against.
+#include "acx_internal.h"
+
+namespace {
+
+template <int BF16>
+__global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, float* __restrict__ sink) {
+  f32x16 a0, a1, a2, a3;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; a2[e] = 0.f; a3[e] = 0.f; }
+  const float x = 1.0f + (float)(threadIdx.x & 7) * 0.125f, y = 0.5f;
+  if constexpr (BF16) {
+    bf16x8 xa, xb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xa[e] = (__bf16)x; xb[e] = (__bf16)y; }
+    for (int i = 0; i < iters; ++i) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, a3, 0, 0, 0);
+    }
+  } else {
+    for (int i = 0; i < iters; ++i) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += a0[e] + a1[e] + a2[e] + a3[e];
+  if (s == 12345.678f) sink[0] = s;              // keeps the chains alive; never true
+}
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += stride) {
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + 256 * k < n16) v[k] = src[i + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + 256 * k < n16) dst[i + 256 * k] = v[k];
+  }
+}
+
+}  // namespace
+
+extern "C" int acx_probe_mfma(acx_ctx* ctx, int32_t bf16, int32_t iters, int32_t waves_per_simd, float* sink, double* flops_out,
+                              void* stream) {
+  if (!sink || iters <= 0 || waves_per_simd <= 0 || waves_per_simd > 8)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_probe_mfma: bad argument%s");
+  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  const dim3 grid((unsigned)(ncu * waves_per_simd)), block(256);           // 4 waves per block = one per SIMD
+  hipStream_t s = (hipStream_t)stream;
+  if (bf16) hipLaunchKernelGGL((probe_mfma_kernel<1>), grid, block, 0, s, iters, sink);
+  else hipLaunchKernelGGL((probe_mfma_kernel<0>), grid, block, 0, s, iters, sink);
+  if (flops_out) *flops_out = (double)grid.x * 4.0 * (double)iters * 4.0 * (bf16 ? 32768.0 : 4096.0);
+  ACX_CHECK_LAUNCH(ctx, "acx_probe_mfma");
+  return ACX_OK;
+}
+
+extern "C" int acx_probe_copy(acx_ctx* ctx, const void* src, void* dst, int64_t bytes, void* stream) {
+  if (!src || !dst || bytes <= 0 || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_probe_copy: need 16-byte aligned buffers and size%s");
+  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)(ncu * 8)), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+                     (float4*)dst, bytes / 16);
+  ACX_CHECK_LAUNCH(ctx, "acx_probe_copy");
+  return ACX_OK;
+}

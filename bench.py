@@ -56,6 +56,7 @@ GEMM_GFLOP_PER_FRAME = VIT_GFLOP_PER_FRAME - ATTN_GFLOP_PER_FRAME
 HEAD_GFLOP_PER_TILE = 10.360          # UCF head per 512-feature tile
 TEXT_GFLOP_PER_CALL = 83.43           # text encoder at 14 classes
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+HBM_PEAK_TBPS = 8.0                   # HBM3E nominal (MI355X_MICROARCH.md; ~6.3 achievable with a float4 copy)
 HEAD_BATCH = 64                       # configs[1] / configs[3]: 64 videos x 512 features x 512-d per step
 
 
@@ -346,6 +347,130 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
     return out
 
 
+def _event_time(fn, iters, warm=3):
+    """average seconds per call of `fn`, HIP events on the current stream (where libacx launches)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def peaks_measured(dev, local_rank):
+    """measured denominators next to the nominal ones -- a register-only MFMA loop on every SIMD (f32 and
+    bf16) and a 16-byte-per-lane stream copy over 1 GiB (4x the 256 MiB Infinity Cache), both timed with HIP events."""
+    from anomalyclip_amd import _lib as L
+    lib, h = L.lib(), L.ctx(local_rank)
+    st = torch.cuda.current_stream().cuda_stream
+    sink = torch.zeros(4, device=dev)
+    out = {}
+    for name, bf16, nominal in (("mfma_f32_tflops", 0, PEAK_TFLOPS["f32"]), ("mfma_bf16_tflops", 1, PEAK_TFLOPS["bf16"])):
+        best = 0.0
+        for wps in (1, 2, 4):
+            fl = ctypes.c_double(0.0)
+            iters = 20000 if bf16 else 4000                        # ~1-2 ms per launch
+
+            def run(wps=wps, iters=iters, fl=fl, bf16=bf16):
+                L.check(lib.acx_probe_mfma(h, bf16, iters, wps, sink.data_ptr(), ctypes.byref(fl), st), h)
+            dt = _event_time(run, 5, 2)
+            best = max(best, fl.value / dt / 1e12)
+        out[name] = {"measured": round(best, 1), "nominal": nominal, "ratio": round(best / nominal, 4)}
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+
+    def cp():
+        L.check(lib.acx_probe_copy(h, src.data_ptr(), dst.data_ptr(), n, st), h)
+    dt = _event_time(cp, 10, 2)
+    out["hbm_copy_TBps"] = {"measured": round(2 * n / dt / 1e12, 3), "nominal": HBM_PEAK_TBPS,
+                            "ratio": round(2 * n / dt / 1e12 / HBM_PEAK_TBPS, 4),
+                            "note": "read + write bytes of a 1 GiB float4 grid-stride copy"}
+    del src, dst
+    torch.cuda.empty_cache()
+    return out
+
+
+def hbm_kernel_legs(dev, copy_TBps):
+    """The HBM-bound kernels of the path at their benchmark shapes (UCF, B = 64; ViT LayerNorm at 512 frames): algorithmic
+    bytes / HIP-event time, as a fraction of the nominal 8 TB/s and of the copy rate measured on this box.  Inputs
+    smaller than the 256 MiB Infinity Cache are ROTATED over >= 512 MB of distinct buffers so that a repeat does not read
+    them from that cache."""
+    from anomalyclip_amd import _lib as L
+    from anomalyclip_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    rows, D, C1, E = HEAD_BATCH * 512, 512, 13, 256
+    out = {}
+
+    def entry(name, nbytes, dt, note=None):
+        tb = nbytes / dt / 1e12
+        e = {"bytes": int(nbytes), "us": round(dt * 1e6, 2), "GBps": round(tb * 1e3, 1), "frac_of_8TBps": round(tb / HBM_PEAK_TBPS, 4),
+             "frac_of_measured_copy": round(tb / copy_TBps, 4) if copy_TBps else None}
+        if note:
+            e["note"] = note
+        out[name] = e
+
+    def ring(n, *shape):
+        return [torch.randn(*shape, generator=g, device=dev) * 0.3 for _ in range(n)]
+    nc = torch.zeros(D, device=dev)
+    dirs = torch.nn.functional.normalize(torch.randn(C1, D, generator=g, device=dev), dim=1)
+    xs = ring(8, rows, D)                                                    # 8 x 67 MB
+    it = [0]
+
+    def nxt(lst):
+        it[0] += 1
+        return lst[it[0] % len(lst)]
+    entry("selector_project", rows * D * 4 + rows * C1 * 4, _event_time(lambda: ops.selector_project(nxt(xs), nc, dirs), 24),
+          "x (32768, 512) -> raw (32768, 13): f32-MFMA skinny GEMM")
+    entry("selector_project_stats", rows * D * 4 + rows * C1 * 4,
+          _event_time(lambda: ops.selector_project_stats(nxt(xs), nc, dirs), 24), "the same + BatchNorm batch statistics (2 launches)")
+    acc = torch.zeros(D, device=dev)
+    entry("colsum_ncentroid", rows * D * 4, _event_time(lambda: ops.colsum_(acc, nxt(xs)), 24))
+    del xs
+    lw, lb = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+    xv = torch.randn(512 * 197, 768, generator=g, device=dev)
+    entry("layernorm_vit", 2 * xv.numel() * 4, _event_time(lambda: ops.layernorm(xv, lw, lb), 10), "(100864, 768) in + out")
+    del xv
+    x1s, x2s = ring(8, rows, E), ring(8, rows, E)
+    cw, cb = torch.randn(1, E, generator=g, device=dev) * 0.1, torch.zeros(1, device=dev)
+    l2w, l2b = torch.ones(E, device=dev), torch.zeros(E, device=dev)
+    entry("cls_head", 2 * rows * E * 4 + rows * 4, _event_time(lambda: ops.cls_head(nxt(x1s), nxt(x2s), l2w, l2b, cw, cb, 32, 16, 0), 24))
+    del x1s, x2s
+    raws = ring(64, rows, C1)
+    mean, var = torch.zeros(C1, device=dev), torch.ones(C1, device=dev)
+    entry("selector_bn", 2 * rows * C1 * 4, _event_time(lambda: ops.selector_bn(nxt(raws), mean, var), 24),
+          "1.7 MB in + out: launch-latency bound")
+    dls = ring(8, rows, C1)
+    entry("bn_bwd_stats", 2 * rows * C1 * 4, _event_time(lambda: ops.bn_bwd_stats(nxt(raws), nxt(dls)), 24), "2 launches, 3.4 MB")
+    # loss: (B*512, 13) logits + top-k gather + scores: one fused forward+backward pass
+    B = HEAD_BATCH
+    sim, simk = raws[0], torch.randn(B * 3 * 16, C1, generator=g, device=dev)
+    sc = torch.rand(rows, generator=g, device=dev)
+    labels = torch.tensor([i % 13 + (1 if i % 13 >= 7 else 0) for i in range(B // 2)] + [7] * (B // 2), device=dev)
+    idx = torch.stack([torch.randperm(32, generator=g, device=dev)[:3] for _ in range(B // 2)])
+    lam = (1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3)
+    entry("mil_loss", (2 * rows * C1 + 2 * simk.numel() + 2 * rows) * 4,
+          _event_time(lambda: ops.mil_loss(sim, simk, labels, sc, idx, idx, idx, 32, 16, 3, 7, lam), 24),
+          "reads logits/top-k/scores, writes their gradients; 3 small launches")
+    del raws, dls
+    # AdamW over the UCF head's trainable set: one multi-tensor launch, 16 B read + 12 B written per value
+    n_par = 10_430_466
+    sizes = [n_par // 34] * 33 + [n_par - 33 * (n_par // 34)]
+    sets = [[torch.randn(n, generator=g, device=dev) * 0.02 for n in sizes] for _ in range(4)]      # p, g, m, v
+    sets[3] = [t.abs() for t in sets[3]]
+    st = [1]
+
+    def adam():
+        st[0] += 1
+        ops.adamw_multi_(sets[0], sets[1], sets[2], sets[3], [1e-5] * len(sizes), [0.2] * len(sizes), 0.9, 0.999, 1e-8, st[0])
+    entry("adamw_multi", n_par * 28, _event_time(adam, 10), "10.43 M parameters in 34 tensors, ONE launch; 292 MB ~ the Infinity Cache size")
+    return out
+
+
 def live_pmc_traffic(vit_chunk, timeout_s=150):
     """HBM traffic of the dominant kernel, measured NOW: two separate `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE,
     WRITE_SIZE: they do not fit one pass) over this same script's headline step, exactly as
@@ -550,6 +675,13 @@ def main():
                 extra.update(head_legs(net, dev, dist, rank, world, local_rank, max(4, min(args.steps, 10)), 2, timer))
             except Exception as e:  # noqa: BLE001
                 extra["head_legs_error"] = f"{type(e).__name__}: {e}"[:300]
+            if world == 1:
+                try:
+                    pk = peaks_measured(dev, local_rank)
+                    extra["peaks_measured"] = pk
+                    extra["hbm_kernels"] = hbm_kernel_legs(dev, pk["hbm_copy_TBps"]["measured"])
+                except Exception as e:  # noqa: BLE001
+                    extra["peaks_measured_error"] = f"{type(e).__name__}: {e}"[:300]
             try:
                 extra["config4_xd_bf16"] = config4_leg(dev, timer, prof, world, max(4, min(args.steps, 10)))
             except Exception as e:  # noqa: BLE001
@@ -604,6 +736,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_f32_p256_kernel / gemm_f32_w8_kernel, v_mfma_f32_32x32x2_f32)"
                          if args.precision == "f32" else "acx_gemm (gemm_bf16_p8_kernel / gemm_bf16_dma_kernel / gemm_kernel, v_mfma_f32_32x32x16_bf16)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "frac_of_measured_mfma_peak": (round(achieved / extra["peaks_measured"][
+                             "mfma_f32_tflops" if args.precision == "f32" else "mfma_bf16_tflops"]["measured"], 4)
+                             if "peaks_measured" in extra else None),
                          "traffic": traffic, "traffic_source": pmc_src, "launches": int(n_gemm), "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_gflop_per_launch": round(flop_per_launch, 3),
                          "gemm_gflop_per_step_executed": round(gemm_gflop_exec_step, 1),

@@ -382,6 +382,15 @@ int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms);
 /* executed GEMM flops (2*M*N*K of every acx_gemm / acx_gemm_tn launch) since acx_prof_enable(ctx, 1) */
 int acx_prof_gemm_flops(acx_ctx* ctx, double* flops);
 
+/* ------------------------------------------------------------------------------------------
+ * Measured roofline denominators (bench.py `peaks_measured`).  Not on the product path.
+ * acx_probe_mfma: register-only MFMA loop on every SIMD (bf16 = 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16),
+ *   `iters` x 4 MFMAs per wave, waves_per_simd waves per SIMD; *flops_out (host) = flops the launch executes.
+ * acx_probe_copy: dst = src, 16 bytes per lane, grid-stride: the HBM stream (read + write) ceiling. */
+int acx_probe_mfma(acx_ctx* ctx, int32_t bf16, int32_t iters, int32_t waves_per_simd, float* sink, double* flops_out,
+                   void* stream);
+int acx_probe_copy(acx_ctx* ctx, const void* src, void* dst, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
