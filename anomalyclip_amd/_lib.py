@@ -15,7 +15,7 @@ PREC_F32, PREC_BF16 = 0, 1
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE = 0, 1, 2
 NORM_LAYER, NORM_CHAN = 0, 1
-OPT_RING_MIN_TILES = 1
+OPT_RING_MIN_TILES, OPT_SK_MAX_M = 1, 2
 
 
 class GemmDesc(C.Structure):
@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("amap", c_int32), ("gn", c_int32), ("gl", c_int32), ("cin", c_int32), ("seg", c_int32),
         ("pos0", c_void_p), ("pos1", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("a_act", c_int32), ("gelu_grad_of", c_void_p), ("ldg", c_int32),
     ]
 
 
@@ -106,7 +107,7 @@ _SIGS = {
     "acx_gemm_tn": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                               c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "acx_reduce_rows": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "acx_layernorm_bwd": (C.c_int, [c_void_p] * 6 + [c_int64, c_int32, c_float, c_int32, c_float, c_void_p]),
+    "acx_layernorm_bwd": (C.c_int, [c_void_p] * 6 + [c_int64, c_int32, c_float, c_int32, c_float, c_void_p, c_void_p]),
     "acx_cls_head_bwd": (C.c_int, [c_void_p] * 10 + [c_int64, c_int32, c_void_p]),
     "acx_act": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_add": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

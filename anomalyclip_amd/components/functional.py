@@ -38,6 +38,9 @@ def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int):
     C = x0.shape[0]
     x = x0.view(C * Lc, W)
     saved = []
+    # few rows (a data-parallel rank's block of classes: 77 rows per class): acx_gemm runs the few-row kernel and the
+    # activation / its derivative ride in its prologue / epilogue instead of separate launches
+    few = C * Lc <= ops.SK_MAX_ROWS and (4 * W) % 256 == 0 and W % 256 == 0
     for blk in tr.resblocks:
         h1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
         qkv = ops.gemm(h1, blk.attn.in_proj_weight.detach(), bias=blk.attn.in_proj_bias.detach())
@@ -45,8 +48,12 @@ def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int):
         x_mid = ops.gemm(att, blk.attn.out_proj.weight.detach(), bias=blk.attn.out_proj.bias.detach(), residual=x)
         h2 = ops.layernorm(x_mid, blk.ln_2.weight, blk.ln_2.bias)
         pre = ops.gemm(h2, blk.mlp.c_fc.weight.detach(), bias=blk.mlp.c_fc.bias.detach())
-        act = ops.act(pre, None, 2)
-        x_next = ops.gemm(act, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid)
+        if few:                                       # QuickGELU applied as the few-row GEMM reads its A operand
+            x_next = ops.gemm(pre, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid,
+                              a_act=L.ACT_QUICKGELU)
+        else:
+            act = ops.act(pre, None, 2)
+            x_next = ops.gemm(act, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid)
         saved.append((x, qkv, x_mid, pre))
         x = x_next
     rows_idx = torch.arange(C, device=x.device, dtype=torch.int64) * Lc + net.eot_index[lo:hi]
@@ -67,20 +74,22 @@ def _text_backward_rows(net, text_projection, state, d_tf):
     d_eot, _, _ = ops.layernorm_bwd(eot, te.ln_final.weight, d_eln, need_params=False)
     d_x = ops.scatter_rows(d_eot, rows_idx, C * Lc)
     wt = _frozen_transposes(te)
+    few = C * Lc <= ops.SK_MAX_ROWS and (4 * W) % 256 == 0 and W % 256 == 0
     for li in range(len(saved) - 1, -1, -1):
         blk = te.transformer.resblocks[li]
         x, qkv, x_mid, pre = saved[li]
         t_in, t_out, t_fc, t_proj = wt[li]
-        d_act = ops.gemm(d_x, t_proj)                                        # [rows,4W] = d_x @ proj_w
-        d_pre = ops.act(pre, d_act, 1)
+        if few:
+            d_pre = ops.gemm(d_x, t_proj, gelu_grad_of=pre)                  # (d_x @ proj_w) * gelu'(pre) in the epilogue
+        else:
+            d_act = ops.gemm(d_x, t_proj)                                    # [rows,4W] = d_x @ proj_w
+            d_pre = ops.act(pre, d_act, 1)
         d_h2 = ops.gemm(d_pre, t_fc)                                         # [rows,W]
-        d_ln, _, _ = ops.layernorm_bwd(x_mid, blk.ln_2.weight, d_h2, need_params=False)
-        d_x_mid = ops.add(d_x, d_ln)
+        d_x_mid, _, _ = ops.layernorm_bwd(x_mid, blk.ln_2.weight, d_h2, need_params=False, add=d_x)   # d_x + LN2'
         d_att = ops.gemm(d_x_mid, t_out)
         d_qkv = ops.seq_attention_bwd(qkv, d_att, C, 1, Lc, heads, 64, 1, causal=True)
         d_h1 = ops.gemm(d_qkv, t_in)
-        d_ln, _, _ = ops.layernorm_bwd(x, blk.ln_1.weight, d_h1, need_params=False)
-        d_x = ops.add(d_x_mid, d_ln)
+        d_x, _, _ = ops.layernorm_bwd(x, blk.ln_1.weight, d_h1, need_params=False, add=d_x_mid)      # d_x_mid + LN1'
     d_ctx = ops.ctx_grad(d_x, C, pl.n_ctx, Lc, W, shared)
     return d_ctx, d_P
 

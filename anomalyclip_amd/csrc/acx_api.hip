@@ -37,6 +37,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->device = device;
   c->multiprocessors = prop.multiProcessorCount;
   c->opt_ring_min_tiles = 512;
+  c->opt_sk_max_m = 320;
   c->err[0] = 0;
   c->prof_on = false;
   c->prof_n = c->prof_created = 0;
@@ -92,6 +93,10 @@ extern "C" int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value) {
     case ACX_OPT_RING_MIN_TILES:
       if (value < 1) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: ring_min_tiles must be >= 1%s");
       ctx->opt_ring_min_tiles = (int)value;
+      return ACX_OK;
+    case ACX_OPT_SK_MAX_M:
+      if (value < 0) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: sk_max_m must be >= 0%s");
+      ctx->opt_sk_max_m = (int)value;
       return ACX_OK;
     default:
       return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_set_option: unknown option %s%ld", "", (long)option);

@@ -54,6 +54,7 @@ constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 144;                // LDS row stride in bytes (128 data + 16 pad)
 constexpr int TILE_B = BM * ROWB;        // 18432
 constexpr int NTHREADS = 256;
+constexpr int ACX_SK_MAX_M = 320;        // acx_gemm sends f32 problems with at most this many rows to the few-row kernel
 
 struct Args {
   acx_gemm_desc d;
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 
 #include "acx_gemm_w8.h"     // gemm_f32_w8_kernel
 #include "acx_gemm_p256.h"   // gemm_f32_p256_kernel: persistent 256-wide strip stream
+#include "acx_gemm_sk.h"     // gemm_f32_sk_kernel: few-row problems (text tower of a data-parallel rank), no K-loop barrier
 #include "acx_gemm_bf16.h"   // gemm_bf16_dma_kernel, gemm_bf16_ring_kernel
 #include "acx_gemm_p8.h"     // gemm_bf16_p8_kernel: the ring kernel's tile stream on a phase-interleaved schedule
 #include "acx_gemm_tn.h"     // gemm_tn_kernel, gemm_tn_w8_kernel, tn_reduce_kernel
@@ -516,6 +518,50 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       if (d->residual) ACX_LAUNCH(P, AB, CB, 1, 0, 1); else ACX_LAUNCH(P, AB, CB, 1, 0, 0); \
     }                                                                                 \
   } while (0)
+  // few-row f32 problems (and every problem that asks for the few-row fusions): 32x32 tiles, K split over the waves
+  {
+    const bool sk_fusion = d->a_act != ACX_ACT_NONE || d->gelu_grad_of != nullptr;
+    const bool sk_ok = fast && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16 && d->K % SK_CH == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 &&
+                       !((uintptr_t)d->C & 15) && (!d->residual || (d->ldr % 4 == 0 && !((uintptr_t)d->residual & 15))) &&
+                       (!d->gelu_grad_of || (d->ldg % 4 == 0 && !((uintptr_t)d->gelu_grad_of & 15) && !d->residual &&
+                                             d->act == ACX_ACT_NONE)) &&
+                       !(d->act == ACX_ACT_QUICKGELU && d->residual) && (d->a_act == ACX_ACT_NONE || d->a_act == ACX_ACT_QUICKGELU) &&
+                       (size_t)d->M * d->lda < ((size_t)1 << 31) && (size_t)d->N * d->ldw < ((size_t)1 << 31);
+    if (sk_fusion && !sk_ok)
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_act / gelu_grad_of need the few-row f32 kernel (see acx_gemm_desc)%s");
+    if (sk_ok && (sk_fusion || d->M <= (ctx ? ctx->opt_sk_max_m : ACX_SK_MAX_M))) {
+      const dim3 kgrid((unsigned)(((d->M + 31) / 32) * ((d->N + 31) / 32)));
+#define ACX_SKL(E, AG)                                                                              \
+  do {                                                                                              \
+    static bool attr_done = false;                                                                  \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_f32_sk_kernel<E, AG>,                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_B);         \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_f32_sk_kernel<E, AG>), kgrid, dim3(256), (size_t)SK_LDS_B, s, g);      \
+  } while (0)
+      const int epi = d->gelu_grad_of ? SK_EPI_GELUGRAD : d->residual ? SK_EPI_RES : d->act == ACX_ACT_QUICKGELU ? SK_EPI_QUICKGELU : SK_EPI_PLAIN;
+      if (d->a_act == ACX_ACT_QUICKGELU) {
+        switch (epi) {
+          case SK_EPI_PLAIN: ACX_SKL(SK_EPI_PLAIN, 1); break;
+          case SK_EPI_QUICKGELU: ACX_SKL(SK_EPI_QUICKGELU, 1); break;
+          case SK_EPI_RES: ACX_SKL(SK_EPI_RES, 1); break;
+          default: ACX_SKL(SK_EPI_GELUGRAD, 1); break;
+        }
+      } else {
+        switch (epi) {
+          case SK_EPI_PLAIN: ACX_SKL(SK_EPI_PLAIN, 0); break;
+          case SK_EPI_QUICKGELU: ACX_SKL(SK_EPI_QUICKGELU, 0); break;
+          case SK_EPI_RES: ACX_SKL(SK_EPI_RES, 0); break;
+          default: ACX_SKL(SK_EPI_GELUGRAD, 0); break;
+        }
+      }
+#undef ACX_SKL
+      ACX_CHECK_LAUNCH(ctx, "acx_gemm");
+      return ACX_OK;
+    }
+  }
   const bool w8_conv = d->amap == ACX_AMAP_CONV3X3 && !d->a_sub && !d->pos0 && d->K % 32 == 0 && d->cin % 32 == 0 &&
                        prec == ACX_PREC_F32 && !c_bf16 && !a_bf16;
   // small branch-free f32 problems (text tower): 64x64 tiles, four blocks per CU, no split-K

@@ -109,6 +109,23 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
   static_assert(NCH % 2 == 0 && NCH * CH == KS, "chunking");
   float* sd = reinterpret_cast<float*>(smem);    // [16*NT][LD], rows >= C1 are zero
   float* sc = sd + 16 * NT * LD;                 // [D] centroid
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, q = lane >> 4;
+  const int64_t ngroups = (rows + 15) >> 4;
+  // the first group's first chunk of x is requested BEFORE the directions are staged: the HBM latency of the row stream
+  // runs under the LDS fill (a wave processes one or two groups per launch at the benchmark shapes)
+  float4 a0[CH][2], a1[CH][2];
+  const int64_t grp0 = (int64_t)blockIdx.x * 4 + wave;
+  {
+    int64_t row = grp0 * 16 + li;
+    if (row >= rows) row = rows - 1;
+    const float* xr = x + row * D + 8 * q;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      a0[j][0] = *reinterpret_cast<const float4*>(xr + 32 * j);
+      a0[j][1] = *reinterpret_cast<const float4*>(xr + 32 * j + 4);
+    }
+  }
   for (int i = threadIdx.x; i < 16 * NT * (D / 4); i += 256) {
     const int r = i / (D / 4), k4 = i - r * (D / 4);
     const float4 v = r < C1 ? reinterpret_cast<const float4*>(dirs + (size_t)r * D)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -116,13 +133,10 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
   }
   for (int i = threadIdx.x; i < D / 4; i += 256) reinterpret_cast<float4*>(sc)[i] = reinterpret_cast<const float4*>(nc)[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, q = lane >> 4;
-  const int64_t ngroups = (rows + 15) >> 4;
   double s_[NT], q_[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { s_[t] = 0.0; q_[t] = 0.0; }
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+  for (int64_t grp = grp0; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
     int64_t row = grp * 16 + li;
     if (row >= rows) row = rows - 1;                                   // clamped; masked at the store
     const float* xr = x + row * D + 8 * q;
@@ -131,7 +145,6 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // K in chunks of CH steps, two register sets in ping-pong: chunk c+1 is in flight while chunk c feeds the MFMAs
     // (all-K-up-front costs 128 VGPRs of staging at D = 512 and spills)
-    float4 a0[CH][2], a1[CH][2];
 #define SELM_LOAD(A, c)                                                        \
   _Pragma("unroll") for (int j = 0; j < CH; ++j) {                             \
     A[j][0] = *reinterpret_cast<const float4*>(xr + 32 * ((c) * CH + j));      \
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
       }                                                                                                  \
     }                                                                                                    \
   }
-    SELM_LOAD(a0, 0)
+    if (grp != grp0) { SELM_LOAD(a0, 0) }
 #pragma unroll 1
     for (int c = 0; c < NCH; c += 2) {
       SELM_LOAD(a1, c + 1)
@@ -227,14 +240,36 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     part[((size_t)blockIdx.x * 2 + k) * CP + cc] = v;
   }
 }
+// stage 2: 256 threads; pair p = (kind, column) < 2*C1 is summed by G = 256 / (2*C1) threads, thread g of a pair taking blocks
+// g, g + G, ... in order; the G partial sums meet in LDS and are added in g order -- a pure function of (nblocks, C1), so
+// results are run-to-run identical.  (One thread per pair walking 512 blocks took 120 us: a chain of dependent L2 misses.)
+__device__ __forceinline__ double bn_pair_total(const double* __restrict__ part, int nblocks, int CP, int C1, double* red) {
+  const int P = 2 * C1, G = 256 / P;
+  const int p = threadIdx.x % P, g = threadIdx.x / P;
+  double v = 0.0;
+  if (g < G) {
+    const int k = p / C1, c = p - k * C1;
+    for (int b = g; b < nblocks; b += G) v += part[((size_t)b * 2 + k) * CP + c];
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  double tot = 0.0;
+  if ((int)threadIdx.x < P)
+    for (int gg = 0; gg < G; ++gg) tot += red[gg * P + threadIdx.x];
+  return tot;                                                          // valid for threadIdx.x < 2*C1: pair (k = t / C1, c = t % C1)
+}
 // mean / biased / unbiased variance from the (sum, sum of squares) partials: var = E[x^2] - mean^2 in f64 (the column
 // values are O(1): 53 bits leave ~1e-13 after the cancellation)
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ part, int nblocks, int CP, int C1, int64_t rows,
-                                                         float* __restrict__ mean, float* __restrict__ var_b, float* __restrict__ var_u) {
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblocks, int CP, int C1, int64_t rows,
+                                                          float* __restrict__ mean, float* __restrict__ var_b, float* __restrict__ var_u) {
+  __shared__ double red[256];
+  __shared__ double tot[128];
+  const double v = bn_pair_total(part, nblocks, CP, C1, red);
+  if ((int)threadIdx.x < 2 * C1) tot[threadIdx.x] = v;
+  __syncthreads();
   const int c = threadIdx.x;
   if (c >= C1) return;
-  double s = 0.0, qq = 0.0;
-  for (int b = 0; b < nblocks; ++b) { s += part[((size_t)b * 2 + 0) * CP + c]; qq += part[((size_t)b * 2 + 1) * CP + c]; }
+  const double s = tot[c], qq = tot[C1 + c];
   const double n = (double)rows, m = s / n;
   double m2 = qq - s * m;                                              // sum (x - m)^2
   if (m2 < 0.0) m2 = 0.0;
@@ -549,6 +584,7 @@ extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* n
   }
   // (C-1) * D too large for the MFMA kernel's LDS layout: wave-per-row kernel
   const size_t lds = (size_t)C1 * D * 4;
+  if (lds > 160 * 1024) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_project: (C-1) * D * 4 bytes exceed the 160 KB of LDS%s");
   int64_t nb = (rows + 3) / 4;
   if (nb > 2048) nb = 2048;
   const dim3 grid((unsigned)nb), block(256);
@@ -581,20 +617,18 @@ extern "C" int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_
   const int nb = bn_blocks(rows);
   const int64_t rpb = (rows + nb - 1) / nb;
   hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(nb), dim3(256), 0, s, raw, (const float*)nullptr, rows, C1, 64, rpb, (double*)workspace);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nb, 64, C1, rows, mean, var_biased,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, 64, C1, rows, mean, var_biased,
                      var_unbiased);
   ACX_CHECK_LAUNCH(ctx, "acx_bn_stats");
   return ACX_OK;
 }
 
 // sums[0:C1] = sum dl, sums[C1:2C1] = sum dl * xhat  (BatchNorm1d training backward, part A)
-__global__ __launch_bounds__(128) void bn_sums_finalize_kernel(const double* __restrict__ part, int nblocks, int CP, int C1,
+__global__ __launch_bounds__(256) void bn_sums_finalize_kernel(const double* __restrict__ part, int nblocks, int CP, int C1,
                                                                float* __restrict__ sums) {
-  if ((int)threadIdx.x >= 2 * C1) return;
-  const int k = threadIdx.x / C1, c = threadIdx.x - k * C1;
-  double v = 0.0;
-  for (int b = 0; b < nblocks; ++b) v += part[((size_t)b * 2 + k) * CP + c];
-  sums[k * C1 + c] = (float)v;
+  __shared__ double red[256];
+  const double v = bn_pair_total(part, nblocks, CP, C1, red);
+  if ((int)threadIdx.x < 2 * C1) sums[threadIdx.x] = (float)v;         // pair index == k * C1 + c
 }
 extern "C" int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* dlogits, float* sums /* [2*C1] */,
                                 int64_t rows, int32_t C1, void* workspace, size_t workspace_bytes, void* stream) {
@@ -608,7 +642,7 @@ extern "C" int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* 
   const int nb = bn_blocks(rows);
   const int64_t rpb = (rows + nb - 1) / nb;
   hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(nb), dim3(256), 0, s, logits, dlogits, rows, C1, 64, rpb, (double*)workspace);
-  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(1), dim3(128), 0, s, (const double*)workspace, nb, 64, C1, sums);
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, 64, C1, sums);
   ACX_CHECK_LAUNCH(ctx, "acx_bn_bwd_stats");
   return ACX_OK;
 }
@@ -638,7 +672,7 @@ extern "C" int acx_selector_project_stats(acx_ctx* ctx, const float* x, const fl
   }
   AcxProfScope prof2__(ctx, ACX_K_OTHER, s);
   const int CP = 16 * ((C1 + 15) / 16);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nb, CP, C1, rows, mean, var_biased,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, CP, C1, rows, mean, var_biased,
                      var_unbiased);
   ACX_CHECK_LAUNCH(ctx, "acx_selector_project_stats");
   return ACX_OK;

@@ -40,16 +40,16 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, float* __res
   if (s == 12345.678f) sink[0] = s;              // keeps the chains alive; never true
 }
 
-__global__ __launch_bounds__(256) void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n16) {
-  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += stride) {
-    float4 v[4];
+__global__ __launch_bounds__(256) void probe_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  for (int64_t i = (int64_t)blockIdx.x * 2048 + threadIdx.x; i < n16; i += stride) {
+    f32x4 v[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (i + 256 * k < n16) v[k] = src[i + 256 * k];
+    for (int k = 0; k < 8; ++k)
+      if (i + 256 * k < n16) v[k] = __builtin_nontemporal_load(src + i + 256 * k);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (i + 256 * k < n16) dst[i + 256 * k] = v[k];
+    for (int k = 0; k < 8; ++k)
+      if (i + 256 * k < n16) __builtin_nontemporal_store(v[k], dst + i + 256 * k);
   }
 }
 
@@ -73,8 +73,8 @@ extern "C" int acx_probe_copy(acx_ctx* ctx, const void* src, void* dst, int64_t 
   if (!src || !dst || bytes <= 0 || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15))
     return acx_fail(ctx, ACX_E_BADARG, "acx_probe_copy: need 16-byte aligned buffers and size%s");
   const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
-  hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)(ncu * 8)), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
-                     (float4*)dst, bytes / 16);
+  hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)(ncu * 16)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src,
+                     (f32x4*)dst, bytes / 16);
   ACX_CHECK_LAUNCH(ctx, "acx_probe_copy");
   return ACX_OK;
 }

@@ -42,7 +42,10 @@ template <int VPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, float* __restrict__ dx,
                                                             float* __restrict__ part, int64_t rows, float eps, int mode,
-                                                            float dx_scale) {
+                                                            float dx_scale, const float* __restrict__ add, int rpw) {
+  // rpw rows per wave: 16 when the per-block parameter-gradient partials are wanted (64 rows per block), 1 otherwise (the
+  // frozen text layers: dX only -- 154 rows then fill 39 workgroups instead of walking 16 rows per wave on 3);
+  // add (may be NULL): dx = add + dx_scale * dL/dx, the residual branch of a pre-norm block folded into the same pass
   constexpr int D = 64 * VPL;
   constexpr float invD = 1.f / D;
   __shared__ float sred[4][2 * D];
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   load_row<VPL>(w, lane, ww);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) dwa[i] = dba[i] = 0.f;
-  const int64_t rbase = (int64_t)blockIdx.x * 64 + wave * 16;
-  for (int rr = 0; rr < 16; ++rr) {
+  const int64_t rbase = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+  for (int rr = 0; rr < rpw; ++rr) {
     const int64_t row = rbase + rr;
     if (row >= rows) break;
     float v[VPL], g[VPL];
@@ -85,6 +88,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       float o[VPL];
 #pragma unroll
       for (int i = 0; i < VPL; ++i) o[i] = (sc * (g[i] - sg) - c2 * v[i]) * dx_scale;
+      if (add) {
+        float ad[VPL];
+        load_row<VPL>(add + row * D, lane, ad);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) o[i] += ad[i];
+      }
       if constexpr (VPL % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < VPL / 4; ++i)
@@ -637,6 +646,152 @@ __global__ __launch_bounds__(512) void seq_attn_bwd_block_kernel(const float* __
   }
 }
 
+// Text-tower attention backward on the f32 MFMA (T <= 80 tokens, head dim 64; CLIP's context length is 77).
+// seq_attn_bwd_block_kernel above spends 85 us per launch on 16 workgroups at two classes per GPU -- one FMA per lane per
+// (query, key, channel) on the VALU -- 12 times per step.  The five products of the backward are small GEMMs:
+//   S = Q K^T, dP = dO V^T (T x T x 64),   dV = P^T dO, dQ = dS K, dK = dS^T Q (T x 64 x T)
+// One workgroup per (sequence, head), four waves, v_mfma_f32_16x16x4_f32 (77 -> 5 x 16 = 80: 4 % padding):
+//   A  Q, K, V, dO staged once in LDS (rows padded to 68 floats: conflict-free ds_read_b128 across 16 rows);
+//   B  the (i, j) score tiles -- lower triangle only when causal -- dealt round-robin to the waves: S and dP of a tile from
+//      float4 fragment reads (both operands are k-contiguous), written to two T x T LDS matrices;
+//   C  softmax rows (wave per row, lane per key): P, D_i = sum_j P_ij dP_ij, dS = P (dP - D_i) scale, in place;
+//   D  the 3 x 5 x 4 output tiles, round-robin: dQ reads dS rows as float4 and K columns as dwords, dK / dV read dS / P
+//      columns (consecutive lanes -> consecutive addresses); the k range is cut to the non-zero band when causal.
+// Exact f32 products and fixed summation orders: results differ from the VALU kernels by f32 round-off only.
+constexpr int AB_TP = 80, AB_LDP = 84, AB_ROWF = 68;
+constexpr int AB_LDS_B = (4 * AB_TP * AB_ROWF + 2 * AB_TP * AB_LDP) * 4;        // 87,040 + 53,760 B
+__global__ __launch_bounds__(256) void seq_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                float* __restrict__ dqkv, int T, int heads, int causal,
+                                                                float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_ab[];
+  float* sQ = reinterpret_cast<float*>(smem_ab);
+  float* sK = sQ + AB_TP * AB_ROWF;
+  float* sV = sK + AB_TP * AB_ROWF;
+  float* sO = sV + AB_TP * AB_ROWF;
+  float* sP = sO + AB_TP * AB_ROWF;               // [TP][LDP]  S -> P
+  float* sD = sP + AB_TP * AB_LDP;                // [TP][LDP]  dP -> dS
+  const int h = blockIdx.x % heads;
+  const int64_t seq = blockIdx.x / heads;
+  const int He = heads * 64, ld = 3 * He;
+  const float* base = qkv + seq * T * ld + h * 64;
+  const float* dob = dout + seq * T * He + h * 64;
+  float* dqb = dqkv + seq * T * ld + h * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int TT = (T + 15) >> 4;
+  // ---- A: stage (rows >= T zero)
+  for (int i = t; i < AB_TP * 16; i += 256) {
+    const int row = i >> 4, c4 = i & 15;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, o4 = q4;
+    if (row < T) {
+      const float* p = base + (int64_t)row * ld + 4 * c4;
+      q4 = *reinterpret_cast<const float4*>(p);
+      k4 = *reinterpret_cast<const float4*>(p + He);
+      v4 = *reinterpret_cast<const float4*>(p + 2 * He);
+      o4 = *reinterpret_cast<const float4*>(dob + (int64_t)row * He + 4 * c4);
+    }
+    *reinterpret_cast<float4*>(sQ + row * AB_ROWF + 4 * c4) = q4;
+    *reinterpret_cast<float4*>(sK + row * AB_ROWF + 4 * c4) = k4;
+    *reinterpret_cast<float4*>(sV + row * AB_ROWF + 4 * c4) = v4;
+    *reinterpret_cast<float4*>(sO + row * AB_ROWF + 4 * c4) = o4;
+  }
+  __syncthreads();
+  // ---- B: score tiles.  tile (ib, jb): lane holds column j = 16 jb + li, rows i = 16 ib + 4 kq + r
+  {
+    int n = 0;
+    for (int ib = 0; ib < TT; ++ib) {
+      const int jend = causal ? ib + 1 : TT;
+      for (int jb = 0; jb < jend; ++jb, ++n) {
+        if ((n & 3) != wave) continue;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;
+        const float* qa = sQ + (16 * ib + li) * AB_ROWF + 4 * kq;
+        const float* oa = sO + (16 * ib + li) * AB_ROWF + 4 * kq;
+        const float* kb = sK + (16 * jb + li) * AB_ROWF + 4 * kq;
+        const float* vb = sV + (16 * jb + li) * AB_ROWF + 4 * kq;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qa + 16 * s4), k4 = *reinterpret_cast<const float4*>(kb + 16 * s4);
+          const float4 o4 = *reinterpret_cast<const float4*>(oa + 16 * s4), v4 = *reinterpret_cast<const float4*>(vb + 16 * s4);
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x, k4.x, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.x, v4.x, da, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y, k4.y, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.y, v4.y, da, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z, k4.z, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.z, v4.z, da, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w, k4.w, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.w, v4.w, da, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sP[(16 * ib + 4 * kq + r) * AB_LDP + 16 * jb + li] = sa[r] * scale;
+          sD[(16 * ib + 4 * kq + r) * AB_LDP + 16 * jb + li] = da[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- C: softmax rows and dS.  Columns of the computed band: j < jw (a multiple of 16); valid keys: j < jmax
+  for (int i = wave; i < 16 * TT; i += 4) {
+    const int jmax = i < T ? (causal ? i + 1 : T) : 0;
+    const int jw = causal ? 16 * ((i >> 4) + 1) : 16 * TT;
+    float* pr = sP + i * AB_LDP;
+    float* dr = sD + i * AB_LDP;
+    const int j0 = lane, j1 = lane + 64;
+    const float s0 = j0 < jmax ? pr[j0] : -INFINITY, s1 = j1 < jmax ? pr[j1] : -INFINITY;
+    const float mx = wave_max(fmaxf(s0, s1));
+    const float e0 = j0 < jmax ? __expf(s0 - mx) : 0.f, e1 = j1 < jmax ? __expf(s1 - mx) : 0.f;
+    const float sum = wave_sum(e0 + e1);
+    const float inv = jmax > 0 ? 1.f / sum : 0.f;
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    const float d0 = j0 < jmax ? dr[j0] : 0.f, d1 = j1 < jmax ? dr[j1] : 0.f;
+    const float Di = wave_sum(p0 * d0 + p1 * d1);
+    if (j0 < jw) { pr[j0] = p0; dr[j0] = p0 * (d0 - Di) * scale; }
+    if (j1 < jw) { pr[j1] = p1; dr[j1] = p1 * (d1 - Di) * scale; }
+  }
+  __syncthreads();
+  // ---- D: output tiles.  which 0: dQ (rows = queries), 1: dK, 2: dV (rows = keys); tile (rb, eb): lane holds channel
+  // e = 16 eb + li of rows 16 rb + 4 kq + r
+  {
+    int n = 0;
+    for (int which = 0; which < 3; ++which) {
+      for (int rb = 0; rb < TT; ++rb) {
+        const int k_lo = (which != 0 && causal) ? 16 * rb : 0;            // keys see queries i >= j only
+        const int k_hi = (which == 0 && causal) ? 16 * (rb + 1) : 16 * TT; // queries see keys j <= i only
+        for (int eb = 0; eb < 4; ++eb, ++n) {
+          if ((n & 3) != wave) continue;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          if (which == 0) {
+            // dQ[i][e] = sum_j dS[i][j] K[j][e]: a = dS row i (float4 along j), b = K[j][e] (one dword per MFMA)
+            const float* ar = sD + (16 * rb + li) * AB_LDP + 4 * kq;
+            const float* bc = sK + 16 * eb + li;
+            for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+              const float4 a4 = *reinterpret_cast<const float4*>(ar + k0);
+              const int j = k0 + 4 * kq;
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bc[(j + 0) * AB_ROWF], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bc[(j + 1) * AB_ROWF], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bc[(j + 2) * AB_ROWF], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bc[(j + 3) * AB_ROWF], acc, 0, 0, 0);
+            }
+          } else {
+            // dK[j][e] = sum_i dS[i][j] Q[i][e];  dV[j][e] = sum_i P[i][j] dO[i][e]: both operands walk rows i
+            const float* ac = (which == 1 ? sD : sP) + 16 * rb + li;
+            const float* bc = (which == 1 ? sQ : sO) + 16 * eb + li;
+            for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
+              const int i = k0 + kq;
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[i * AB_LDP], bc[i * AB_ROWF], acc, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rb + 4 * kq + r;
+            if (row < T) dqb[(int64_t)row * ld + which * He + 16 * eb + li] = acc[r];
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ positional-embedding gradients
 // d_pos0[n][e] = sum_{tile,l} dx[(tile,n,l)][e];  d_pos1[l][e] = sum_{tile,n} dx[(tile,n,l)][e]
 // stage 1: block (tile, group of 4 segment rows n): p0[tile][n][e] = sum_l dx, p1[tile*ng + g][l][e] = sum_{n in group} dx;
@@ -1086,13 +1241,16 @@ extern "C" int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int3
 }
 
 extern "C" int acx_layernorm_bwd(acx_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* part,
-                                 int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, void* stream) {
+                                 int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, const float* add,
+                                 void* stream) {
   if (!x || !w || !dy) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm_bwd: null pointer%s");
+  if (add && !dx) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm_bwd: add without dx%s");
   if (rows <= 0) return ACX_OK;
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
-  const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
-  DISPATCH_VPL(D, layernorm_bwd_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x, w, dy, dx, part, rows, eps, mode, dx_scale));
+  const int rpw = part ? 16 : 1;
+  const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), block(256);
+  DISPATCH_VPL(D, layernorm_bwd_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x, w, dy, dx, part, rows, eps, mode, dx_scale, add, rpw));
   ACX_CHECK_LAUNCH(ctx, "acx_layernorm_bwd");
   return ACX_OK;
 }
@@ -1154,6 +1312,16 @@ extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float
   if (tiles <= 0) return ACX_OK;
   const int T = axis == 0 ? gn : gl;
   const bool sab_rows = ACX_DBG_SWITCH("SAB_ROWS", false);    // keep the two-launch rows kernel (A/B, debug builds)
+  if (e == 64 && gn == 1 && axis == 1 && T <= AB_TP && !sab_rows && ACX_DBG_SWITCH("SAB_MFMA", true)) {
+    // text-tower shape up to 80 tokens: the five products on the f32 MFMA, one workgroup per (sequence, head)
+    hipStream_t s4 = (hipStream_t)stream;
+    AcxProfScope prof4__(ctx, ACX_K_ATTN, s4);
+    (void)hipFuncSetAttribute((const void*)seq_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS_B);
+    hipLaunchKernelGGL(seq_attn_bwd_mfma_kernel, dim3((unsigned)(tiles * heads)), dim3(256), (size_t)AB_LDS_B, s4, qkv, dout, dqkv, T,
+                       heads, causal, 0.125f);
+    ACX_CHECK_LAUNCH(ctx, "acx_seq_attention_bwd(mfma)");
+    return ACX_OK;
+  }
   if (e == 64 && gn == 1 && axis == 1 && T <= 128 && !sab_rows) {
     // text-tower shape: one workgroup per (sequence, head), operands staged once in LDS, both passes in one launch
     hipStream_t s3 = (hipStream_t)stream;

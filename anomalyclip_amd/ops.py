@@ -40,6 +40,17 @@ def _dt(t: torch.Tensor) -> int:
     raise L.AcxError(f"unsupported dtype {t.dtype}")
 
 
+SK_MAX_ROWS = 320        # == the library's ACX_OPT_SK_MAX_M default: f32 GEMMs with at most this many rows run the few-row kernel
+
+
+def set_few_row_limit(device_index: int, rows: int) -> None:
+    """ACX_OPT_SK_MAX_M on this device's context and the wrapper's mirror of it (ops.gemm hands such problems no split-K
+    workspace, the text-tower glue picks the fused few-row launches below it)."""
+    global SK_MAX_ROWS
+    h = L.ctx(device_index)
+    L.check(L.lib().acx_set_option(h, L.OPT_SK_MAX_M, int(rows)), h)
+    SK_MAX_ROWS = int(rows)
+
 _SPLITK_WS: dict = {}
 _SPLITK_RETIRED: list = []
 
@@ -68,7 +79,8 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None, M: Optional[int] = None,
          bias=None, act=L.ACT_NONE, residual=None, a_sub=None, prec=L.PREC_F32, out_dtype=torch.float32,
-         amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, seg=0, pos0=None, pos1=None) -> torch.Tensor:
+         amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, seg=0, pos0=None, pos1=None, a_act=L.ACT_NONE,
+         gelu_grad_of=None) -> torch.Tensor:
     """out[M,N] = epilogue(amap(a)[M,K] @ w[N,K]^T); see include/acx.h acx_gemm_desc."""
     assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
     N, K = w.shape
@@ -90,9 +102,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     d.a_sub = _ptr(a_sub)
     d.amap, d.gn, d.gl, d.cin, d.seg = amap, gn, gl, cin, seg
     d.pos0, d.pos1 = _ptr(pos0), _ptr(pos1)
+    d.a_act = a_act
+    d.gelu_grad_of, d.ldg = _ptr(gelu_grad_of), (gelu_grad_of.stride(0) if gelu_grad_of is not None else 0)
     ws = None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles <= 128 and K >= 256 and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and a_sub is None and pos0 is None:
+    few_rows = (M <= SK_MAX_ROWS and K % 256 == 0 and prec == L.PREC_F32 and amap == L.AMAP_IDENTITY and a_sub is None
+                and pos0 is None and act != L.ACT_LEAKYRELU)                  # acx_gemm takes the few-row kernel: no split-K
+    if (tiles <= 128 and K >= 256 and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and a_sub is None and pos0 is None
+            and not few_rows):
         ws = _splitk_workspace(a.device, min(16, 512 // tiles) * M * N * 4)     # skinny problem: let the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a)
@@ -289,8 +306,8 @@ def reduce_rows(part: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def layernorm_bwd(x, w, dy, *, eps=1e-5, mode=L.NORM_LAYER, need_dx=True, need_params=True, dx_scale=1.0):
-    """returns (dx or None, dw or None, db or None)."""
+def layernorm_bwd(x, w, dy, *, eps=1e-5, mode=L.NORM_LAYER, need_dx=True, need_params=True, dx_scale=1.0, add=None):
+    """returns (dx or None, dw or None, db or None); `add` [rows, D]: dx = add + dx_scale * dL/dx in the same pass."""
     D = w.numel()
     x = x.reshape(-1, D)
     dy = dy.reshape(-1, D)
@@ -299,8 +316,11 @@ def layernorm_bwd(x, w, dy, *, eps=1e-5, mode=L.NORM_LAYER, need_dx=True, need_p
     dx = torch.empty_like(x) if need_dx else None
     part = torch.empty((rows + 63) // 64, 2 * D, dtype=torch.float32, device=x.device) if need_params else None
     h = _h(x)
+    if add is not None:
+        add = add.reshape(-1, D)
+        assert need_dx and add.is_contiguous() and add.shape == x.shape
     L.check(L.lib().acx_layernorm_bwd(h, x.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(part), rows, D, eps, mode,
-                                      dx_scale, _stream()), h)
+                                      dx_scale, _ptr(add), _stream()), h)
     if need_params:
         s = reduce_rows(part)
         return dx, s[:D], s[D:]

@@ -51,7 +51,10 @@ const char* acx_last_error(acx_ctx* ctx);
 /* Per-context tuning options (dispatch thresholds; results never depend on them beyond summation order).
  *   ACX_OPT_RING_MIN_TILES  bf16 GEMMs with at least this many 256x256 output tiles take the persistent
  *                           256x256 LDS-DMA kernel instead of the 128x128 one (default 512). */
-enum { ACX_OPT_RING_MIN_TILES = 1 };
+/*   ACX_OPT_SK_MAX_M        f32 acx_gemm problems with at most this many rows take the few-row kernel (32x32 tiles,
+ *                           K split over the waves, no split-K reduction launch; default 320; 0 disables it except
+ *                           for the a_act / gelu_grad_of fusions, which always need it). */
+enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2 };
 int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value);
 
 /* ------------------------------------------------------------------------------------------
@@ -86,6 +89,12 @@ typedef struct acx_gemm_desc {
   const float* pos1;      /* [gl, N] axial positional embedding param_1 (or NULL) */
   void* workspace;        /* optional: enables split-K for skinny problems (few output tiles, long K); */
   size_t workspace_bytes; /* needs up to 16*M*N*4 bytes, less is fine (fewer splits or none)           */
+  /* Few-row fusions of the text tower (clip/model.py:183-185,188-230 and its dX chain).  Both need the few-row f32
+   * kernel: f32 operands, identity row map, K % 256 == 0, N % 4 == 0, 16-byte aligned C / residual / gelu_grad_of;
+   * ACX_E_UNSUPPORTED otherwise. */
+  int32_t a_act;          /* ACX_ACT_QUICKGELU: the activation is applied to A as it is read (x_next = gelu(pre) @ W^T) */
+  const float* gelu_grad_of; /* [M, ldg] saved pre-activation p: C = (A W^T + bias) * d gelu(p)/dp  (no act / residual) */
+  int32_t ldg;
 } acx_gemm_desc;
 int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
 
@@ -263,10 +272,11 @@ int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32
                 int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
                 int32_t cin, void* workspace, size_t workspace_bytes, void* stream);
 int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int32_t nparts, int32_t width, void* stream);
-/* LayerNorm / ChanLayerNorm backward.  dx (may be NULL) = dx_scale * dL/dx; part (may be NULL) receives
- * ceil(rows/64) rows of [dw(D) | db(D)] partials. */
+/* LayerNorm / ChanLayerNorm backward.  dx (may be NULL) = [add +] dx_scale * dL/dx (add [rows, D] may be NULL: the
+ * residual branch of a pre-norm block, clip/model.py:214-216, folded into the same pass); part (may be NULL)
+ * receives ceil(rows/64) rows of [dw(D) | db(D)] partials. */
 int acx_layernorm_bwd(acx_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* part,
-                      int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, void* stream);
+                      int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, const float* add, void* stream);
 /* backward of acx_cls_head (seg == 0): dx = dL/dx1 = dL/dx2; part: ceil(rows/64) rows of
  * [d ln_w (E) | d ln_b (E) | d lin_w (E) | d lin_b (1) | pad 3]. */
 int acx_cls_head_bwd(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w, const float* ln_b,

@@ -34,6 +34,58 @@ def test_gemm_f32_plain(M, N, K):
     assert relerr(out, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M", [1, 31, 77, 154, 320])
+@pytest.mark.parametrize("K,N", [(512, 1536), (512, 512), (512, 2048), (2048, 512), (1536, 512), (256, 36), (768, 100)])
+def test_gemm_few_rows_kernel(M, K, N):
+    """gemm_f32_sk_kernel (acx_gemm with <= 320 rows, K % 256 == 0): the text-tower shapes of a data-parallel rank
+    (77 rows per class; qkv / out / fc / proj forward and the transposed dX chain) plus ragged N, every epilogue --
+    bias, QuickGELU, residual (also in place), the QuickGELU derivative of a saved pre-activation -- and the QuickGELU
+    prologue on A, element-wise against fp64: |err| <= 2e-6 * (sum_k |a||w| + |bias| + |residual|)."""
+    g = torch.Generator().manual_seed(M * 7 + K + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).view(-1, 1) * 1e-4       # asymmetric (guide rule 16)
+    bias, res, pre = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    ad, wd, bd, rd, pd = (t.to(DEV) for t in (a, w, bias, res, pre))
+    a64, w64 = a.double(), w.double()
+    lin = a64 @ w64.t() + bias.double()
+    bound = 2e-6 * (a64.abs() @ w64.abs().t() + bias.abs().double() + res.abs().double()) + 1e-30
+
+    def ok(out, ref, scale=1.0):
+        return bool(((out.cpu().double() - ref).abs() <= bound * scale).all())
+    assert ok(ops.gemm(ad, wd, bias=bd), lin)
+    assert ok(ops.gemm(ad, wd), lin - bias.double())
+    assert ok(ops.gemm(ad, wd, bias=bd, act=L.ACT_QUICKGELU), O.quick_gelu(lin), 1.5)
+    assert ok(ops.gemm(ad, wd, bias=bd, residual=rd), lin + res.double())
+    x = rd.clone()
+    ops.gemm(ad, wd, bias=bd, residual=x, out=x)                                          # C aliases the residual
+    assert ok(x, lin + res.double())
+    with torch.enable_grad():
+        p64 = pre.double().requires_grad_(True)
+        O.quick_gelu(p64).backward(torch.ones_like(p64))
+    assert ok(ops.gemm(ad, wd, gelu_grad_of=pd), (lin - bias.double()) * p64.grad, 2.0)
+    ga = O.quick_gelu(a64)
+    bound_g = 2e-6 * (ga.abs() @ w64.abs().t() + bias.abs().double() + res.abs().double()) + 1e-30
+    out = ops.gemm(ad, wd, bias=bd, residual=rd, a_act=L.ACT_QUICKGELU)
+    assert bool(((out.cpu().double() - (ga @ w64.t() + bias.double() + res.double())).abs() <= 2 * bound_g).all())
+
+
+def test_gemm_few_row_fusions_are_refused_elsewhere():
+    """a_act / gelu_grad_of exist in the few-row kernel only: a shape it cannot take fails loudly, and the row limit is an
+    option of the context (above it the tile kernels run and give the same result)."""
+    g = torch.Generator().manual_seed(3)
+    a, w = torch.randn(64, 96, generator=g).to(DEV), torch.randn(32, 96, generator=g).to(DEV)      # K % 256 != 0
+    with pytest.raises(L.AcxError, match="few-row"):
+        ops.gemm(a, w, a_act=L.ACT_QUICKGELU)
+    a, w = torch.randn(154, 512, generator=g).to(DEV), torch.randn(512, 512, generator=g).to(DEV)
+    few = ops.gemm(a, w)
+    ops.set_few_row_limit(torch.cuda.current_device(), 0)
+    try:
+        tiles = ops.gemm(a, w)
+    finally:
+        ops.set_few_row_limit(torch.cuda.current_device(), 320)
+    assert relerr(few, tiles) < 2e-6 and relerr(few, a.double().cpu() @ w.double().cpu().t()) < 2e-6
+
+
 def test_gemm_epilogues_and_asub():
     g = torch.Generator().manual_seed(5)
     M, N, K = 300, 200, 96
@@ -302,11 +354,11 @@ def test_selector_kernels():
 
 
 @pytest.mark.parametrize("rows,D,C1", [(32768, 512, 13), (16 * 511 + 5, 512, 17), (1000, 512, 6), (40960, 512, 6), (777, 128, 13),
-                                      (100, 64, 33), (3, 256, 64), (513, 1024, 13), (600, 768, 13), (64, 1024, 64)])
+                                      (100, 64, 33), (3, 256, 64), (513, 1024, 13), (600, 768, 13), (64, 512, 64), (200, 1024, 33)])
 def test_selector_project_mfma_and_fused_stats(rows, D, C1):
     """selector_model.py:54,62,65: the projection as a skinny f32-MFMA GEMM (16-row groups, 1..4 column tiles of 16
-    directions, ragged last group, every supported width; (1024, 64) overflows the LDS layout and takes the wave-per-row
-    kernel) with BatchNorm's batch statistics accumulated in its epilogue, against fp64; the stand-alone two-stage
+    directions, ragged last group, every supported width; (1024, 33) overflows the MFMA kernel's LDS layout and takes the
+    wave-per-row kernel) with BatchNorm's batch statistics accumulated in its epilogue, against fp64; the stand-alone two-stage
     statistics and the backward column sums against fp64 as well.  Element-wise: |err| <= 2e-6 * sum_k |x - c||d|."""
     g = torch.Generator().manual_seed(rows + D + C1)
     x = torch.randn(rows, D, generator=g) * 0.3 + 0.1

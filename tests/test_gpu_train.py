@@ -69,6 +69,12 @@ def test_layernorm_bwd(D, mode):
         y.backward(dy)
     dx, dw, db = ops.layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), mode=mode)
     assert relerr(dx, xr.grad) < 1e-5 and relerr(dw, wr.grad) < 1e-5 and relerr(db, br.grad) < 1e-5
+    # dX only (frozen layers): one row per wave, the residual branch's gradient added in the same pass
+    add = torch.randn(777, D, generator=g)
+    dx2, dw2, db2 = ops.layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), mode=mode, need_params=False, add=add.to(DEV))
+    assert dw2 is None and db2 is None and relerr(dx2, xr.grad + add) < 1e-5
+    dx3, _, _ = ops.layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), mode=mode, need_params=False)
+    assert torch.equal(dx3, dx)                                   # same arithmetic per row in both row-to-wave mappings
 
 
 @pytest.mark.parametrize("axis,e,heads", [(0, 32, 8), (1, 32, 8), (0, 16, 8), (1, 32, 2)])
@@ -90,6 +96,30 @@ def test_axial_attention_bwd(axis, e, heads):
         o.reshape(-1, He).backward(dout.double())
     dq = ops.seq_attention_bwd(qkv.to(DEV), dout.to(DEV), tiles, N, Lg, heads, e, axis)
     assert relerr(dq, t.grad) < 1e-5
+
+
+@pytest.mark.parametrize("Lc,causal", [(77, True), (77, False), (80, True), (64, True), (33, False), (17, True), (5, True),
+                                       (100, True)])
+def test_mha_attention_bwd_mfma(Lc, causal):
+    """The text-tower attention backward: up to 80 tokens the five products run on the f32 MFMA (seq_attn_bwd_mfma_kernel:
+    ragged last 16-token tile, causal band limits, padded rows), beyond that the LDS/VALU kernel -- dq, dk, dv of every
+    (sequence, head) element-wise against fp64 autograd."""
+    g = torch.Generator().manual_seed(Lc)
+    Bc, heads = 3, 8
+    W = heads * 64
+    qkv = torch.randn(Bc * Lc, 3 * W, generator=g)
+    qkv[:, :W] *= 3.0                                             # peaked softmax rows
+    dout = torch.randn(Bc * Lc, W, generator=g)
+    with torch.enable_grad():
+        t = qkv.clone().double().requires_grad_(True)
+        q, k, v = t.view(Bc, Lc, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        s = (q * 0.125) @ k.transpose(-1, -2)
+        if causal:
+            s = s + torch.full((Lc, Lc), float("-inf"), dtype=torch.float64).triu_(1)
+        (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(Bc * Lc, W).backward(dout.double())
+    dq = ops.seq_attention_bwd(qkv.to(DEV), dout.to(DEV), Bc, 1, Lc, heads, 64, 1, causal=causal)
+    assert relerr(dq, t.grad) < 1e-5
+    assert R.elem_excess(dq, t.grad, rtol=1e-4, afrac=1e-5) <= 1
 
 
 def test_mha_attention_bwd_causal():
