@@ -496,9 +496,12 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM, (hipStream_t)stream);
   if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * d->M * (double)d->N * d->K;
+  // hipFuncSetAttribute is a per-DEVICE setting: the "already done" flags of the launch macros below are indexed by the
+  // context's device, so one process may drive several GPUs
+  const int dev_slot = (ctx ? ctx->device : 0) & 63;
 #define ACX_LAUNCH(P, AB, CB, F, ACT, RES)                                                          \
   do {                                                                                              \
-    static bool attr_done = false;                                                                  \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_kernel<P, AB, CB, F, ACT, RES>,                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
@@ -533,7 +536,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       const dim3 kgrid((unsigned)(((d->M + 31) / 32) * ((d->N + 31) / 32)));
 #define ACX_SKL(E, AG)                                                                              \
   do {                                                                                              \
-    static bool attr_done = false;                                                                  \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_f32_sk_kernel<E, AG>,                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_B);         \
@@ -572,7 +575,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     const dim3 sgrid((unsigned)(st_m * st_n));
 #define ACX_S64L(ACT, RES)                                                                          \
   do {                                                                                              \
-    static bool attr_done = false;                                                                  \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_f32_s64_kernel<ACT, RES>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);            \
@@ -610,7 +613,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     const size_t plds = 2 * P2_STAGE_B;
 #define ACX_P2L(ACT)                                                                                \
   do {                                                                                              \
-    static bool attr_done = false;                                                                  \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_f32_p256_kernel<ACT, 0>,                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);             \
@@ -626,7 +629,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   if (w8 && (w8_conv || (fast && g.ksplit == 1)) && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16) {
 #define ACX_W8L(ACT, RES, CV)                                                                       \
   do {                                                                                              \
-    static bool attr_done = false;                                                                  \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_f32_w8_kernel<ACT, RES, CV>,                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
@@ -668,7 +671,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
 #define ACX_RING_L(CB, ACT, RES)                                                                    \
   do {                                                                                              \
     if (p8) {                                                                                       \
-      static bool attr8_done = false;                                                               \
+      static bool attr8_dev_[64] = {}; bool& attr8_done = attr8_dev_[dev_slot];                                                               \
       if (!attr8_done) {                                                                            \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<CB, ACT, RES>,                   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_B);       \
@@ -677,7 +680,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       hipLaunchKernelGGL((gemm_bf16_p8_kernel<CB, ACT, RES>), rgrid, dim3(512), (size_t)P8_LDS_B, s, g); \
       break;                                                                                        \
     }                                                                                               \
-    static bool attr_done = false;                                                                  \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<CB, ACT, RES>,                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * RG_STAGE_B + 8 * 4096)); \
@@ -699,7 +702,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     const size_t dlds = 2 * DMA_STAGE_B;
 #define ACX_DMA(CB, ACT, RES)                                                                       \
   do {                                                                                              \
-    static bool attr_done = false;                                                                  \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<CB, ACT, RES>,                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);             \
@@ -803,14 +806,15 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM, s);
   if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2;
-  static bool attr_done = false;
+  const int dev_slot = (ctx ? ctx->device : 0) & 63;            // kernel attributes are per device
+  static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const bool tn_w8 = ACX_DBG_SWITCH("TN_W8", true);
   if (tn_w8) {
-    static bool attr8_done = false;
+    static bool attr8_dev_[64] = {}; bool& attr8_done = attr8_dev_[dev_slot];
     if (!attr8_done) {
       (void)hipFuncSetAttribute((const void*)gemm_tn_w8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr8_done = true;

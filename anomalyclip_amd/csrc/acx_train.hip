@@ -1151,12 +1151,13 @@ struct AdamwSegs {
   float* m[ADAMW_MAX_SEG];
   float* v[ADAMW_MAX_SEG];
   long long n[ADAMW_MAX_SEG];
-  float lr[ADAMW_MAX_SEG];
-  float wd[ADAMW_MAX_SEG];
+  float decay[ADAMW_MAX_SEG];         // 1 - lr * weight_decay
+  float step_size[ADAMW_MAX_SEG];     // lr / (1 - beta1^step)
   int chunk0[ADAMW_MAX_SEG + 1];      // first 1024-element chunk of every segment
   int nseg;
 };
-__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSegs t, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSegs t, float b1, float b2, float omb1, float omb2, float eps,
+                                                          float bc2_sqrt) {
   const int b = blockIdx.x;
   int lo = 0, hi = t.nseg - 1;
   while (lo < hi) {                                                    // last segment with chunk0 <= b (uniform per block)
@@ -1169,7 +1170,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSegs t, flo
   float* __restrict__ m = t.m[sgi];
   float* __restrict__ v = t.v[sgi];
   const long long n = t.n[sgi];
-  const float lr = t.lr[sgi], decay = 1.f - lr * t.wd[sgi], step_size = lr / bc1;
+  const float decay = t.decay[sgi], step_size = t.step_size[sgi];
   const long long base = (long long)(b - t.chunk0[sgi]) * 1024 + threadIdx.x;
   float pi[4], gi[4], mi[4], vi[4];
 #pragma unroll
@@ -1182,8 +1183,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSegs t, flo
     const long long i = base + 256 * k;
     if (i < n) {
       const float pw = pi[k] * decay;
-      const float mn = b1 * mi[k] + (1.f - b1) * gi[k];
-      const float vn = b2 * vi[k] + (1.f - b2) * gi[k] * gi[k];
+      const float mn = b1 * mi[k] + omb1 * gi[k];
+      const float vn = b2 * vi[k] + omb2 * gi[k] * gi[k];
       m[i] = mn;
       v[i] = vn;
       p[i] = pw - step_size * (mn / (sqrtf(vn) / bc2_sqrt + eps));
@@ -1519,13 +1520,15 @@ extern "C" int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float
 }
 
 extern "C" int acx_adamw_multi(acx_ctx* ctx, int32_t nseg, void* const* p, const void* const* g, void* const* m, void* const* v,
-                               const int64_t* n, const float* lr, const float* weight_decay, float beta1, float beta2, float eps,
+                               const int64_t* n, const double* lr, const double* weight_decay, double beta1, double beta2, double eps,
                                int32_t step, void* stream) {
   if (nseg <= 0) return ACX_OK;
   if (!p || !g || !m || !v || !n || !lr || !weight_decay) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi: null pointer%s");
   if (step <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi: step starts at 1%s");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  // scalar terms in f64 on the host and rounded ONCE, exactly as torch.optim.AdamW forms them from its Python floats
+  // (1 - beta2 = 0.001 there; 1.f - 0.999f = 0.00100005 would put exp_avg_sq 5e-5 off)
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const float bc2 = (float)sqrt(1.0 - pow(beta2, (double)step));
   hipStream_t s = (hipStream_t)stream;
   int i = 0;
   while (i < nseg) {
@@ -1537,7 +1540,7 @@ extern "C" int acx_adamw_multi(acx_ctx* ctx, int32_t nseg, void* const* p, const
       if (n[i] <= 0) continue;
       if (!p[i] || !g[i] || !m[i] || !v[i]) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi: null tensor pointer%s");
       t.p[k] = (float*)p[i]; t.g[k] = (const float*)g[i]; t.m[k] = (float*)m[i]; t.v[k] = (float*)v[i];
-      t.n[k] = n[i]; t.lr[k] = lr[i]; t.wd[k] = weight_decay[i];
+      t.n[k] = n[i]; t.decay[k] = (float)(1.0 - lr[i] * weight_decay[i]); t.step_size[k] = (float)(lr[i] / bc1);
       t.chunk0[k] = (int)chunks;
       chunks += (n[i] + 1023) / 1024;
       ++k;
@@ -1547,7 +1550,8 @@ extern "C" int acx_adamw_multi(acx_ctx* ctx, int32_t nseg, void* const* p, const
     t.chunk0[k] = (int)chunks;
     t.nseg = k;
     AcxProfScope prof__(ctx, ACX_K_OTHER, s);
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, beta1, beta2, eps, bc1, bc2);
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, bc2);
   }
   ACX_CHECK_LAUNCH(ctx, "acx_adamw_multi");
   return ACX_OK;

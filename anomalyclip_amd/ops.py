@@ -501,7 +501,7 @@ def adamw_multi_(ps, gs, ms, vs, lrs, wds, beta1, beta2, eps, step) -> None:
     h = _h(ps[0])
     arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])           # noqa: E731
     L.check(L.lib().acx_adamw_multi(h, n, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * n)(*[p.numel() for p in ps]),
-                                    (C.c_float * n)(*[float(x) for x in lrs]), (C.c_float * n)(*[float(x) for x in wds]),
+                                    (C.c_double * n)(*[float(x) for x in lrs]), (C.c_double * n)(*[float(x) for x in wds]),
                                     beta1, beta2, eps, step, _stream()), h)
 
 

@@ -337,9 +337,10 @@ int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float* v, int64_
               float beta2, float eps, float weight_decay, int32_t step, void* stream);
 /* acx_adamw_multi: the same update for nseg parameter tensors in ONE launch (per-tensor lr / weight decay: the
  * reference's four param groups, anomaly_clip_module.py:693-746; common betas / eps / step).  The pointer and size
- * arrays are HOST arrays of length nseg; entries with n[i] <= 0 are skipped. */
+ * arrays are HOST arrays of length nseg; entries with n[i] <= 0 are skipped.  Hyper-parameters are doubles: the scalar
+ * terms (1 - beta, bias corrections, lr / bc1, 1 - lr * wd) are formed in f64 and rounded once, like torch does. */
 int acx_adamw_multi(acx_ctx* ctx, int32_t nseg, void* const* p, const void* const* g, void* const* m, void* const* v,
-                    const int64_t* n, const float* lr, const float* weight_decay, float beta1, float beta2, float eps,
+                    const int64_t* n, const double* lr, const double* weight_decay, double beta1, double beta2, double eps,
                     int32_t step, void* stream);
 int acx_ctx_grad(acx_ctx* ctx, const float* dx, float* dctx, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
                  int32_t shared_ctx, void* stream);
