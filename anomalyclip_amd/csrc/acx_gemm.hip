@@ -542,7 +542,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_B);         \
       attr_done = true;                                                                             \
     }                                                                                               \
-    hipLaunchKernelGGL((gemm_f32_sk_kernel<E, AG>), kgrid, dim3(256), (size_t)SK_LDS_B, s, g);      \
+    hipLaunchKernelGGL((gemm_f32_sk_kernel<E, AG>), kgrid, dim3(512), (size_t)SK_LDS_B, s, g);      \
   } while (0)
       const int epi = d->gelu_grad_of ? SK_EPI_GELUGRAD : d->residual ? SK_EPI_RES : d->act == ACX_ACT_QUICKGELU ? SK_EPI_QUICKGELU : SK_EPI_PLAIN;
       if (d->a_act == ACX_ACT_QUICKGELU) {

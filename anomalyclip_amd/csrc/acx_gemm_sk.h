@@ -5,41 +5,43 @@
 // At M = 154 the tile kernels are bound by LATENCY, not by flops or bytes: a 128x128 tile walks 16-64 K-steps of
 // {global load -> LDS -> barrier -> MFMA} on 8-24 CUs, then a second launch reduces its split-K partials
 // (profiles/r02_dp8_rank_share_kernel_stats.csv: 15 + 5.5 us per GEMM, ~100 GEMMs per step).  Here
-//   * a workgroup owns a 32x32 output tile -- 5 x N/32 = 80 ... 320 workgroups at M = 154, one per CU -- and its four
-//     waves split K: wave w owns k-blocks {2w, 2w+1} of every 256-wide K chunk, ISSUES THE LDS-DMA FOR EXACTLY THAT
-//     DATA ITSELF (global_load_lds_dwordx4, 16 KB per wave per chunk, bank swizzle on the source address) and waits on its
+//   * a workgroup owns a 32x32 output tile -- 5 x N/32 = 80 ... 320 workgroups at M = 154, one per CU -- and its EIGHT
+//     waves split K: wave w owns k-block w (32 floats) of every 256-wide K chunk, ISSUES THE LDS-DMA FOR EXACTLY THAT
+//     DATA ITSELF (global_load_lds_dwordx4, 8 KB per wave per chunk, bank swizzle on the source address) and waits on its
 //     own vmcnt only: no workgroup barrier anywhere in the K loop;
 //   * two 64 KB stages: K = 512 is resident in ONE burst (every load of the tile in flight at once, ~one HBM latency),
 //     longer K streams chunk c+2 into the stage chunk c just left;
-//   * the four partial 32x32 accumulators meet once, in LDS, in wave order (fixed summation order), and 256 threads
-//     finish with one 16-byte store each: bias, QuickGELU, residual, or the QuickGELU derivative of a saved
+//   * the eight partial 32x32 accumulators meet once, in LDS, in wave order (fixed summation order), and 512 threads
+//     finish with one 8-byte store each: bias, QuickGELU, residual, or the QuickGELU derivative of a saved
 //     pre-activation (dX chain: d_pre = (d_x @ W) * gelu'(pre), clip/model.py:183-185 backward);
 //   * optional A prologue: QuickGELU applied to the A fragments as they leave LDS (x_next = gelu(pre) @ W^T: the
 //     activation is never materialised).
-constexpr int SK_CH = 256;                         // K chunk (floats): 8 k-blocks of 32
+constexpr int SK_CH = 256;                         // K chunk (floats): 8 k-blocks of 32, one per wave
 constexpr int SK_OP_B = 32 * SK_CH * 4;            // one operand image of a chunk: [8 k-blocks][32 rows][128 B] = 32 KB
 constexpr int SK_STAGE_B = 2 * SK_OP_B;            // A | W
-constexpr int SK_RED_F = 32 * 36;                  // per-wave accumulator image: 32 rows x (32 + 4 pad) floats
-constexpr int SK_LDS_B = 2 * SK_STAGE_B + 4 * SK_RED_F * 4;
+constexpr int SK_LDS_B = 2 * SK_STAGE_B;           // 128 KB: two stages; the K-partials reuse them after the loop
 
 enum { SK_EPI_PLAIN = 0, SK_EPI_QUICKGELU = 1, SK_EPI_RES = 2, SK_EPI_GELUGRAD = 3 };
 
-__device__ __forceinline__ float sk_quickgelu(float v) { return v * (1.f / (1.f + __expf(-1.702f * v))); }
+// QuickGELU x * sigmoid(1.702 x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the prologue variant runs
+// it on every A fragment of every column tile
+__device__ __forceinline__ float sk_sigmoid1702(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v)); }
+__device__ __forceinline__ float sk_quickgelu(float v) { return v * sk_sigmoid1702(v); }
 
 template <int EPI, int A_GELU>
-__global__ __launch_bounds__(256) void gemm_f32_sk_kernel(const Args g) {
+__global__ __launch_bounds__(512) void gemm_f32_sk_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
   const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);                   // 0..7: owns k-block `wave` of every chunk
   const int li = lane & 31, hh = lane >> 5;
   const int tiles_n = (d.N + 31) / 32;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;     // n fastest: neighbours share the A rows in L2
   const int m0 = tm * 32, n0 = tn * 32;
   const int nch = d.K / SK_CH;
 
-  // ---- DMA: this wave's 16 KB of a chunk = k-blocks 2w, 2w+1 of A and of W, 4 row groups of 8 rows each.
-  // wave-instruction (kb, rg): lane l -> row 8 rg + l/8, LDS position l%8 holds source chunk (l%8) ^ ((row >> 1) & 7)
+  // ---- DMA: this wave's 8 KB of a chunk = k-block `wave` of A and of W, 4 row groups of 8 rows each.
+  // wave-instruction rg: lane l -> row 8 rg + l/8, LDS position l%8 holds source chunk (l%8) ^ ((row >> 1) & 7)
   const unsigned lds0 = (unsigned)(uintptr_t)(p2_lds_t*)smem;
   const int drow = lane >> 3;
   unsigned aoff[4], woff[4];                                                 // element offsets of the lane's 4 row groups
@@ -47,8 +49,8 @@ __global__ __launch_bounds__(256) void gemm_f32_sk_kernel(const Args g) {
   for (int rg = 0; rg < 4; ++rg) {
     const int row = 8 * rg + drow;
     const int sc = ((lane & 7) ^ ((row >> 1) & 7)) * 4;
-    aoff[rg] = (unsigned)min(m0 + row, d.M - 1) * (unsigned)d.lda + sc;
-    woff[rg] = (unsigned)min(n0 + row, d.N - 1) * (unsigned)d.ldw + sc;
+    aoff[rg] = (unsigned)min(m0 + row, d.M - 1) * (unsigned)d.lda + sc + 32 * wave;
+    woff[rg] = (unsigned)min(n0 + row, d.N - 1) * (unsigned)d.ldw + sc + 32 * wave;
   }
 #define SK_DMA1(gptr, ldsaddr)                                                                     \
   do {                                                                                             \
@@ -58,13 +60,11 @@ __global__ __launch_bounds__(256) void gemm_f32_sk_kernel(const Args g) {
   } while (0)
 #define SK_ISSUE(c)                                                                                \
   do {                                                                                             \
-    const unsigned s_ = lds0 + ((c) & 1) * SK_STAGE_B + (2 * wave) * 4096;                         \
-    const int k0_ = (c) * SK_CH + 64 * wave;                                                       \
-    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                             \
-      _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                           \
-        SK_DMA1((const float*)d.A + (size_t)(aoff[rg] + k0_ + 32 * kb), s_ + kb * 4096 + rg * 1024);            \
-        SK_DMA1((const float*)d.W + (size_t)(woff[rg] + k0_ + 32 * kb), s_ + SK_OP_B + kb * 4096 + rg * 1024);  \
-      }                                                                                            \
+    const unsigned s_ = lds0 + ((c) & 1) * SK_STAGE_B + wave * 4096;                               \
+    const int k0_ = (c) * SK_CH;                                                                   \
+    _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                             \
+      SK_DMA1((const float*)d.A + (size_t)(aoff[rg] + k0_), s_ + rg * 1024);                       \
+      SK_DMA1((const float*)d.W + (size_t)(woff[rg] + k0_), s_ + SK_OP_B + rg * 1024);             \
     }                                                                                              \
   } while (0)
 
@@ -74,71 +74,70 @@ __global__ __launch_bounds__(256) void gemm_f32_sk_kernel(const Args g) {
   SK_ISSUE(0);
   if (nch > 1) SK_ISSUE(1);
   const int sw = (li >> 1) & 7;
-  const int fr = (2 * wave) * 4096 + li * 128;                               // this lane's row in the wave's first k-block
+  const int fr = wave * 4096 + li * 128;                                     // this lane's row in the wave's k-block
   for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // chunk c landed; chunk c+1 may be in flight
+    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // chunk c landed; chunk c+1 may be in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const char* sA = smem + (c & 1) * SK_STAGE_B + fr;
     const char* sW = sA + SK_OP_B;
+    float4 xa[4], xb[4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int o = kb * 4096 + (((2 * cc + hh) ^ sw) * 16);
-        float4 xa = *reinterpret_cast<const float4*>(sA + o);
-        const float4 xb = *reinterpret_cast<const float4*>(sW + o);
-        if constexpr (A_GELU != 0) { xa.x = sk_quickgelu(xa.x); xa.y = sk_quickgelu(xa.y); xa.z = sk_quickgelu(xa.z); xa.w = sk_quickgelu(xa.w); }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc, 0, 0, 0);
-      }
+    for (int cc = 0; cc < 4; ++cc) {
+      const int o = ((2 * cc + hh) ^ sw) * 16;
+      xa[cc] = *reinterpret_cast<const float4*>(sA + o);
+      xb[cc] = *reinterpret_cast<const float4*>(sW + o);
     }
     if (c + 2 < nch) {
-      // this wave's fragment reads of stage c&1 have all returned (their values fed the MFMAs above)
+      // every fragment of stage c&1 is in registers: the stage can be refilled while the MFMAs below run
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       SK_ISSUE(c + 2);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      if constexpr (A_GELU != 0) {
+        xa[cc].x = sk_quickgelu(xa[cc].x); xa[cc].y = sk_quickgelu(xa[cc].y);
+        xa[cc].z = sk_quickgelu(xa[cc].z); xa[cc].w = sk_quickgelu(xa[cc].w);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cc].x, xb[cc].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cc].y, xb[cc].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cc].z, xb[cc].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cc].w, xb[cc].w, acc, 0, 0, 0);
     }
   }
 #undef SK_ISSUE
 #undef SK_DMA1
-  // ---- the four K-partials meet in LDS (own region: nothing else lives there), summed in wave order
-  float* red = reinterpret_cast<float*>(smem + 2 * SK_STAGE_B);
+  // ---- the eight K-partials meet in LDS, each wave writing into ITS OWN stage-0 region (nobody else ever touches it, and
+  // its last DMA has landed), then summed in wave order
+  float* red = reinterpret_cast<float*>(smem + wave * 4096);                  // [32 rows][32 cols]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave * SK_RED_F + (4 * hh + (r & 3) + 8 * (r >> 2)) * 36 + li] = acc[r];
+  for (int r = 0; r < 16; ++r) red[(4 * hh + (r & 3) + 8 * (r >> 2)) * 32 + li] = acc[r];
   __syncthreads();
-  const int row = t >> 3, c4 = (t & 7) * 4;
-  float4 v = *reinterpret_cast<const float4*>(red + row * 36 + c4);
+  const int row = t >> 4, c2 = (t & 15) * 2;
+  const float* r0 = reinterpret_cast<const float*>(smem) + row * 32 + c2;
+  float2 v = *reinterpret_cast<const float2*>(r0);
 #pragma unroll
-  for (int w = 1; w < 4; ++w) {
-    const float4 p = *reinterpret_cast<const float4*>(red + w * SK_RED_F + row * 36 + c4);
-    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  for (int w = 1; w < 8; ++w) {
+    const float2 p = *reinterpret_cast<const float2*>(r0 + w * 1024);
+    v.x += p.x; v.y += p.y;
   }
-  const int gm = m0 + row, gn = n0 + c4;
-  if (gm >= d.M || gn >= d.N) return;
-  float o[4] = {v.x, v.y, v.z, v.w};
-  const bool full = gn + 3 < d.N;                                            // N % 4 == 0 is required, so always true; kept for safety
-  if (d.bias) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (full || gn + j < d.N) o[j] += d.bias[gn + j];
-  }
-  if constexpr (EPI == SK_EPI_QUICKGELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = sk_quickgelu(o[j]);
-  }
+  const int gm = m0 + row, gn = n0 + c2;
+  if (gm >= d.M || gn >= d.N) return;                                        // N % 4 == 0: a pair is in range or not
+  float o[2] = {v.x, v.y};
+  if (d.bias) { o[0] += d.bias[gn]; o[1] += d.bias[gn + 1]; }
+  if constexpr (EPI == SK_EPI_QUICKGELU) { o[0] = sk_quickgelu(o[0]); o[1] = sk_quickgelu(o[1]); }
   if constexpr (EPI == SK_EPI_RES) {
-    const float4 r4 = *reinterpret_cast<const float4*>(d.residual + (size_t)gm * d.ldr + gn);
-    o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
+    const float2 r2 = *reinterpret_cast<const float2*>(d.residual + (size_t)gm * d.ldr + gn);
+    o[0] += r2.x; o[1] += r2.y;
   }
   if constexpr (EPI == SK_EPI_GELUGRAD) {
     // y = p * sigmoid(1.702 p):  dy/dp = s * (1 + 1.702 p (1 - s))
-    const float4 p4 = *reinterpret_cast<const float4*>(d.gelu_grad_of + (size_t)gm * d.ldg + gn);
-    const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+    const float2 p2 = *reinterpret_cast<const float2*>(d.gelu_grad_of + (size_t)gm * d.ldg + gn);
+    const float pp[2] = {p2.x, p2.y};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float s = 1.f / (1.f + __expf(-1.702f * pp[j]));
-      o[j] *= s * (1.f + 1.702f * pp[j] * (1.f - s));
+    for (int j = 0; j < 2; ++j) {
+      const float sg = sk_sigmoid1702(pp[j]);
+      o[j] *= sg * (1.f + 1.702f * pp[j] * (1.f - sg));
     }
   }
-  *reinterpret_cast<float4*>((float*)d.C + (size_t)gm * d.ldc + gn) = make_float4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<float2*>((float*)d.C + (size_t)gm * d.ldc + gn) = make_float2(o[0], o[1]);
 }

@@ -650,7 +650,7 @@ __global__ __launch_bounds__(512) void seq_attn_bwd_block_kernel(const float* __
 // seq_attn_bwd_block_kernel above spends 85 us per launch on 16 workgroups at two classes per GPU -- one FMA per lane per
 // (query, key, channel) on the VALU -- 12 times per step.  The five products of the backward are small GEMMs:
 //   S = Q K^T, dP = dO V^T (T x T x 64),   dV = P^T dO, dQ = dS K, dK = dS^T Q (T x 64 x T)
-// One workgroup per (sequence, head), four waves, v_mfma_f32_16x16x4_f32 (77 -> 5 x 16 = 80: 4 % padding):
+// One workgroup per (sequence, head), eight waves, v_mfma_f32_16x16x4_f32 (77 -> 5 x 16 = 80: 4 % padding):
 //   A  Q, K, V, dO staged once in LDS (rows padded to 68 floats: conflict-free ds_read_b128 across 16 rows);
 //   B  the (i, j) score tiles -- lower triangle only when causal -- dealt round-robin to the waves: S and dP of a tile from
 //      float4 fragment reads (both operands are k-contiguous), written to two T x T LDS matrices;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) void seq_attn_bwd_block_kernel(const float* __
 // Exact f32 products and fixed summation orders: results differ from the VALU kernels by f32 round-off only.
 constexpr int AB_TP = 80, AB_LDP = 84, AB_ROWF = 68;
 constexpr int AB_LDS_B = (4 * AB_TP * AB_ROWF + 2 * AB_TP * AB_LDP) * 4;        // 87,040 + 53,760 B
-__global__ __launch_bounds__(256) void seq_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(512) void seq_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 float* __restrict__ dqkv, int T, int heads, int causal,
                                                                 float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_ab[];
@@ -676,11 +676,11 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_mfma_kernel(const float* __r
   const float* base = qkv + seq * T * ld + h * 64;
   const float* dob = dout + seq * T * He + h * 64;
   float* dqb = dqkv + seq * T * ld + h * 64;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;        // 8 waves: two per SIMD
   const int li = lane & 15, kq = lane >> 4;
   const int TT = (T + 15) >> 4;
   // ---- A: stage (rows >= T zero)
-  for (int i = t; i < AB_TP * 16; i += 256) {
+  for (int i = t; i < AB_TP * 16; i += 512) {
     const int row = i >> 4, c4 = i & 15;
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, o4 = q4;
     if (row < T) {
@@ -702,24 +702,28 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_mfma_kernel(const float* __r
     for (int ib = 0; ib < TT; ++ib) {
       const int jend = causal ? ib + 1 : TT;
       for (int jb = 0; jb < jend; ++jb, ++n) {
-        if ((n & 3) != wave) continue;
+        if ((n & 7) != wave) continue;
         f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;
         const float* qa = sQ + (16 * ib + li) * AB_ROWF + 4 * kq;
         const float* oa = sO + (16 * ib + li) * AB_ROWF + 4 * kq;
         const float* kb = sK + (16 * jb + li) * AB_ROWF + 4 * kq;
         const float* vb = sV + (16 * jb + li) * AB_ROWF + 4 * kq;
+        float4 q4[4], k4[4], o4[4], v4[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const float4 q4 = *reinterpret_cast<const float4*>(qa + 16 * s4), k4 = *reinterpret_cast<const float4*>(kb + 16 * s4);
-          const float4 o4 = *reinterpret_cast<const float4*>(oa + 16 * s4), v4 = *reinterpret_cast<const float4*>(vb + 16 * s4);
-          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x, k4.x, sa, 0, 0, 0);
-          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.x, v4.x, da, 0, 0, 0);
-          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y, k4.y, sa, 0, 0, 0);
-          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.y, v4.y, da, 0, 0, 0);
-          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z, k4.z, sa, 0, 0, 0);
-          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.z, v4.z, da, 0, 0, 0);
-          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w, k4.w, sa, 0, 0, 0);
-          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.w, v4.w, da, 0, 0, 0);
+          q4[s4] = *reinterpret_cast<const float4*>(qa + 16 * s4); k4[s4] = *reinterpret_cast<const float4*>(kb + 16 * s4);
+          o4[s4] = *reinterpret_cast<const float4*>(oa + 16 * s4); v4[s4] = *reinterpret_cast<const float4*>(vb + 16 * s4);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[s4].x, k4[s4].x, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4[s4].x, v4[s4].x, da, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[s4].y, k4[s4].y, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4[s4].y, v4[s4].y, da, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[s4].z, k4[s4].z, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4[s4].z, v4[s4].z, da, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[s4].w, k4[s4].w, sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(o4[s4].w, v4[s4].w, da, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -730,55 +734,84 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_mfma_kernel(const float* __r
     }
   }
   __syncthreads();
-  // ---- C: softmax rows and dS.  Columns of the computed band: j < jw (a multiple of 16); valid keys: j < jmax
-  for (int i = wave; i < 16 * TT; i += 4) {
+  // ---- C: softmax rows and dS, four rows per wave at a time: 16 lanes per row, lane li holds columns li, li + 16, ...
+  // (<= 5 per lane), reductions over the 16-lane group only.  Columns of the computed band: j < jw; valid keys: j < jmax
+  for (int i = 4 * wave + kq; i < 16 * TT; i += 32) {
     const int jmax = i < T ? (causal ? i + 1 : T) : 0;
     const int jw = causal ? 16 * ((i >> 4) + 1) : 16 * TT;
     float* pr = sP + i * AB_LDP;
     float* dr = sD + i * AB_LDP;
-    const int j0 = lane, j1 = lane + 64;
-    const float s0 = j0 < jmax ? pr[j0] : -INFINITY, s1 = j1 < jmax ? pr[j1] : -INFINITY;
-    const float mx = wave_max(fmaxf(s0, s1));
-    const float e0 = j0 < jmax ? __expf(s0 - mx) : 0.f, e1 = j1 < jmax ? __expf(s1 - mx) : 0.f;
-    const float sum = wave_sum(e0 + e1);
+    float sv[5], dv[5];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int j = li + 16 * u;
+      sv[u] = j < jmax ? pr[j] : -INFINITY;
+      dv[u] = j < jmax ? dr[j] : 0.f;
+      mx = fmaxf(mx, sv[u]);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { sv[u] = li + 16 * u < jmax ? __expf(sv[u] - mx) : 0.f; sum += sv[u]; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = jmax > 0 ? 1.f / sum : 0.f;
-    const float p0 = e0 * inv, p1 = e1 * inv;
-    const float d0 = j0 < jmax ? dr[j0] : 0.f, d1 = j1 < jmax ? dr[j1] : 0.f;
-    const float Di = wave_sum(p0 * d0 + p1 * d1);
-    if (j0 < jw) { pr[j0] = p0; dr[j0] = p0 * (d0 - Di) * scale; }
-    if (j1 < jw) { pr[j1] = p1; dr[j1] = p1 * (d1 - Di) * scale; }
+    float Di = 0.f;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { sv[u] *= inv; Di += sv[u] * dv[u]; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) Di += __shfl_xor(Di, o, 64);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int j = li + 16 * u;
+      if (j < jw) { pr[j] = sv[u]; dr[j] = sv[u] * (dv[u] - Di) * scale; }
+    }
   }
   __syncthreads();
   // ---- D: output tiles.  which 0: dQ (rows = queries), 1: dK, 2: dV (rows = keys); tile (rb, eb): lane holds channel
-  // e = 16 eb + li of rows 16 rb + 4 kq + r
+  // e = 16 eb + li of rows 16 rb + 4 kq + r.  The reduction walks 16-wide k blocks kb (uniform bounds: the non-zero band
+  // when causal); every block's operands are requested before its four MFMAs
   {
     int n = 0;
     for (int which = 0; which < 3; ++which) {
       for (int rb = 0; rb < TT; ++rb) {
-        const int k_lo = (which != 0 && causal) ? 16 * rb : 0;            // keys see queries i >= j only
-        const int k_hi = (which == 0 && causal) ? 16 * (rb + 1) : 16 * TT; // queries see keys j <= i only
+        const int kb_lo = (which != 0 && causal) ? rb : 0;                 // keys see queries i >= j only
+        const int kb_hi = (which == 0 && causal) ? rb + 1 : TT;            // queries see keys j <= i only
         for (int eb = 0; eb < 4; ++eb, ++n) {
-          if ((n & 3) != wave) continue;
+          if ((n & 7) != wave) continue;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           if (which == 0) {
             // dQ[i][e] = sum_j dS[i][j] K[j][e]: a = dS row i (float4 along j), b = K[j][e] (one dword per MFMA)
             const float* ar = sD + (16 * rb + li) * AB_LDP + 4 * kq;
-            const float* bc = sK + 16 * eb + li;
-            for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-              const float4 a4 = *reinterpret_cast<const float4*>(ar + k0);
-              const int j = k0 + 4 * kq;
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bc[(j + 0) * AB_ROWF], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bc[(j + 1) * AB_ROWF], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bc[(j + 2) * AB_ROWF], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bc[(j + 3) * AB_ROWF], acc, 0, 0, 0);
+            const float* bc = sK + 16 * eb + li + 4 * kq * AB_ROWF;
+#pragma unroll
+            for (int kb = 0; kb < AB_TP / 16; ++kb) {
+              if (kb < kb_lo || kb >= kb_hi) continue;
+              const float4 a4 = *reinterpret_cast<const float4*>(ar + 16 * kb);
+              const float* bb = bc + 16 * kb * AB_ROWF;
+              const float b0 = bb[0], b1 = bb[AB_ROWF], b2 = bb[2 * AB_ROWF], b3 = bb[3 * AB_ROWF];
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b2, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b3, acc, 0, 0, 0);
             }
           } else {
-            // dK[j][e] = sum_i dS[i][j] Q[i][e];  dV[j][e] = sum_i P[i][j] dO[i][e]: both operands walk rows i
-            const float* ac = (which == 1 ? sD : sP) + 16 * rb + li;
-            const float* bc = (which == 1 ? sQ : sO) + 16 * eb + li;
-            for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
-              const int i = k0 + kq;
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[i * AB_LDP], bc[i * AB_ROWF], acc, 0, 0, 0);
+            // dK[j][e] = sum_i dS[i][j] Q[i][e];  dV[j][e] = sum_i P[i][j] dO[i][e]: both operands walk rows i = 16 kb + 4 u + kq
+            const float* ac = (which == 1 ? sD : sP) + 16 * rb + li + kq * AB_LDP;
+            const float* bc = (which == 1 ? sQ : sO) + 16 * eb + li + kq * AB_ROWF;
+#pragma unroll
+            for (int kb = 0; kb < AB_TP / 16; ++kb) {
+              if (kb < kb_lo || kb >= kb_hi) continue;
+              const float* aa = ac + 16 * kb * AB_LDP;
+              const float* bb = bc + 16 * kb * AB_ROWF;
+              const float a0 = aa[0], a1 = aa[4 * AB_LDP], a2 = aa[8 * AB_LDP], a3 = aa[12 * AB_LDP];
+              const float b0 = bb[0], b1 = bb[4 * AB_ROWF], b2 = bb[8 * AB_ROWF], b3 = bb[12 * AB_ROWF];
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
             }
           }
 #pragma unroll
@@ -1318,7 +1351,7 @@ extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float
     hipStream_t s4 = (hipStream_t)stream;
     AcxProfScope prof4__(ctx, ACX_K_ATTN, s4);
     (void)hipFuncSetAttribute((const void*)seq_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS_B);
-    hipLaunchKernelGGL(seq_attn_bwd_mfma_kernel, dim3((unsigned)(tiles * heads)), dim3(256), (size_t)AB_LDS_B, s4, qkv, dout, dqkv, T,
+    hipLaunchKernelGGL(seq_attn_bwd_mfma_kernel, dim3((unsigned)(tiles * heads)), dim3(512), (size_t)AB_LDS_B, s4, qkv, dout, dqkv, T,
                        heads, causal, 0.125f);
     ACX_CHECK_LAUNCH(ctx, "acx_seq_attention_bwd(mfma)");
     return ACX_OK;
