@@ -116,7 +116,7 @@ _SIGS = {
     "acx_seq_attention_bwd": (C.c_int, [c_void_p] * 4 + [c_int32] * 7 + [c_void_p, c_void_p]),
     "acx_pos_grad": (C.c_int, [c_void_p] * 5 + [c_int32] * 4 + [c_void_p]),
     "acx_bn_bwd_stats": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p, c_size_t, c_void_p]),
-    "acx_bn_bwd_apply": (C.c_int, [c_void_p] * 6 + [c_int32, c_int64, c_int64, c_int32, c_float, c_void_p]),
+    "acx_bn_bwd_apply": (C.c_int, [c_void_p] * 6 + [c_int32, c_int64, c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "acx_axpby": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
     "acx_colsum_partials": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "acx_text_directions_bwd": (C.c_int, [c_void_p] * 5 + [c_int32] * 3 + [c_void_p]),

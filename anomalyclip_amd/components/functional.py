@@ -207,8 +207,12 @@ class _TextGraphs:
     def make_key(net, lo, hi):
         te, pl = net.text_encoder, net.prompt_learner
         ts = (pl.ctx, pl.token_prefix, pl.token_suffix, te.text_projection, te.positional_embedding, net.eot_index)
-        return (lo, hi) + tuple((t.data_ptr(), tuple(t.shape)) for t in ts) + \
-            tuple(p.data_ptr() for p in te.transformer.parameters())
+        # the frozen layers' parameter OBJECTS are listed once (Module.parameters() walks the module tree: 0.4 ms per step
+        # for 144 tensors); their addresses are still read every step
+        plist = te.__dict__.get("_acx_plist")
+        if plist is None:
+            plist = te.__dict__["_acx_plist"] = list(te.transformer.parameters())
+        return (lo, hi) + tuple((t.data_ptr(), tuple(t.shape)) for t in ts) + tuple(p.data_ptr() for p in plist)
 
 
 class _NoTextRows:
@@ -375,7 +379,11 @@ def selector_train(sel, x, text_features, labels, ncentroid, masks):
 
 # ====================================================================================================== temporal
 def _temporal_param_list(tm) -> List[torch.nn.Parameter]:
-    return list(tm.parameters())
+    """tm.parameters() in registration order, listed once per module (the tree walk costs ~0.2 ms per call)."""
+    plist = tm.__dict__.get("_acx_plist")
+    if plist is None:
+        plist = tm.__dict__["_acx_plist"] = list(tm.parameters())
+    return plist
 
 
 class TemporalFn(torch.autograd.Function):
@@ -497,7 +505,7 @@ class TemporalFn(torch.autograd.Function):
         if need_dfeats:
             d_feats = ops.gemm(d_x0, ops.transpose(tm.prepared()["proj_w"]))           # [rows, Kp]
         ctx.saved_acts = None
-        out = [grads.get(p) for p in tm.parameters()]
+        out = [grads.get(p) for p in _temporal_param_list(tm)]
         out = [g.contiguous() if g is not None else None for g in out]
         return (d_feats, None, None, *out)
 
@@ -512,7 +520,7 @@ class _TemporalGraphs:
     def __init__(self, tm, feats, a_sub, need_dfeats):
         from types import SimpleNamespace
         self.key = self.make_key(tm, feats, a_sub, need_dfeats)
-        params = list(tm.parameters())
+        params = _temporal_param_list(tm)
         self.x = feats.detach().clone()
         self.a_sub = a_sub
         side = torch.cuda.Stream()
@@ -537,8 +545,9 @@ class _TemporalGraphs:
 
     @staticmethod
     def make_key(tm, feats, a_sub, need_dfeats):
+        plist = _temporal_param_list(tm)
         return (tuple(feats.shape), feats.dtype, None if a_sub is None else a_sub.data_ptr(), bool(need_dfeats),
-                tm.precision) + tuple(p.data_ptr() for p in tm.parameters())
+                tm.precision) + tuple(p.data_ptr() for p in plist)
 
 
 class TemporalGraphFn(torch.autograd.Function):
@@ -563,8 +572,8 @@ class TemporalGraphFn(torch.autograd.Function):
 
 def temporal_train(tm, features, a_sub):
     if getattr(tm, "graph", False) and features.is_cuda:
-        return TemporalGraphFn.apply(features.reshape(-1, features.shape[-1]).contiguous(), a_sub, tm, *tm.parameters())
-    return TemporalFn.apply(features, a_sub, tm, *tm.parameters())
+        return TemporalGraphFn.apply(features.reshape(-1, features.shape[-1]).contiguous(), a_sub, tm, *_temporal_param_list(tm))
+    return TemporalFn.apply(features, a_sub, tm, *_temporal_param_list(tm))
 
 
 class ConcatFeaturesFn(torch.autograd.Function):

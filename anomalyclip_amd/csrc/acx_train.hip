@@ -864,9 +864,11 @@ __global__ __launch_bounds__(256) void pos_grad_part_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ logits, const float* __restrict__ dl,
                                                            const float* __restrict__ var_b, const float* __restrict__ sdl,
                                                            const float* __restrict__ sdx, float* __restrict__ draw, int ldo,
-                                                           int64_t total, int C1, float eps, float inv_rows) {
+                                                           int64_t total, int C1, float eps, float inv_rows_host,
+                                                           const float* __restrict__ total_rows_dev) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  const float inv_rows = total_rows_dev ? 1.f / total_rows_dev[0] : inv_rows_host;
   const int c = (int)(i % C1);
   const int64_t r = i / C1;
   const float rstd = 1.f / sqrtf(var_b[c] + eps);
@@ -1430,14 +1432,15 @@ extern "C" int acx_pos_grad(acx_ctx* ctx, const float* dx, float* d0, float* d1,
 
 extern "C" int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* dlogits, const float* var_biased,
                                 const float* sums, float* draw, int32_t ldo, int64_t rows, int64_t total_rows, int32_t C1,
-                                float eps, void* stream) {
+                                float eps, const float* total_rows_dev, void* stream) {
   if (!logits || !dlogits || !var_biased || !sums || !draw) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_apply: null pointer%s");
   if (rows <= 0) return ACX_OK;
+  if (!total_rows_dev && total_rows <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_apply: total_rows must be positive%s");
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_OTHER, s);
   const int64_t total = rows * C1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, GRID1(total), dim3(256), 0, s, logits, dlogits, var_biased, sums, sums + C1, draw, ldo,
-                     total, C1, eps, 1.f / (float)total_rows);
+                     total, C1, eps, total_rows > 0 ? 1.f / (float)total_rows : 0.f, total_rows_dev);
   ACX_CHECK_LAUNCH(ctx, "acx_bn_bwd_apply");
   return ACX_OK;
 }

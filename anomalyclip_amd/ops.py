@@ -401,13 +401,18 @@ def bn_bwd_stats(logits, dlogits) -> torch.Tensor:
 
 
 def bn_bwd_apply(logits, dlogits, var_biased, sums, total_rows, eps=1e-5, pad_to: int = 4) -> torch.Tensor:
-    """returns draw padded to a multiple of `pad_to` columns (zero pad) so it can feed acx_gemm_tn."""
+    """returns draw padded to a multiple of `pad_to` columns (zero pad) so it can feed acx_gemm_tn.  `total_rows`: a host
+    int, or a device f32 scalar tensor (SyncBN: the all-gathered row count never visits the host)."""
     rows, C1 = logits.shape
     C1p = (C1 + pad_to - 1) // pad_to * pad_to
     draw = torch.zeros(rows, C1p, dtype=torch.float32, device=logits.device)
     h = _h(logits)
+    dev_n = total_rows if torch.is_tensor(total_rows) else None
+    if dev_n is not None:
+        assert dev_n.is_cuda and dev_n.dtype == torch.float32 and dev_n.numel() == 1
     L.check(L.lib().acx_bn_bwd_apply(h, logits.data_ptr(), dlogits.data_ptr(), var_biased.data_ptr(), sums.data_ptr(),
-                                     draw.data_ptr(), C1p, rows, total_rows, C1, eps, _stream()), h)
+                                     draw.data_ptr(), C1p, rows, 0 if dev_n is not None else int(total_rows), C1, eps,
+                                     _ptr(dev_n), _stream()), h)
     return draw
 
 

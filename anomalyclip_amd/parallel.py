@@ -88,14 +88,18 @@ def combine_bn_stats(means: torch.Tensor, m2s: torch.Tensor, counts: torch.Tenso
 
 
 def sync_bn_stats(mean: torch.Tensor, var_b: torch.Tensor, rows: int):
-    """Local (mean, biased var, rows) -> global (mean, var_biased, var_unbiased, total_rows)."""
+    """Local (mean, biased var, rows) -> global (mean, var_biased, var_unbiased, total_rows).  Nothing here synchronises the
+    host with the device: the row count is written by a fill kernel (`new_tensor([..])` is a blocking pageable copy that
+    waits for everything queued on the stream -- 2 ms in the middle of every forward) and the TOTAL stays a device scalar
+    (ops.bn_bwd_apply reads it there) unless the tensors live on the CPU."""
     C1 = mean.numel()
-    local = torch.cat([mean, var_b * rows, mean.new_tensor([float(rows)])])
+    local = torch.cat([mean, var_b * rows, torch.full((1,), float(rows), dtype=mean.dtype, device=mean.device)])
     gathered = [torch.empty_like(local) for _ in range(world_size())]
     dist.all_gather(gathered, local)
     g = torch.stack(gathered)
     m, vb, vu, n = combine_bn_stats(g[:, :C1], g[:, C1:2 * C1], g[:, 2 * C1])
-    return m.contiguous(), vb.contiguous(), vu.contiguous(), int(round(float(n)))
+    total = n.reshape(1).contiguous() if n.is_cuda else int(round(float(n)))
+    return m.contiguous(), vb.contiguous(), vu.contiguous(), total
 
 
 def shard_videos(batch: int, world: int, r: int) -> List[int]:

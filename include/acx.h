@@ -305,7 +305,8 @@ int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* dlogits, fl
                      int32_t C1, void* workspace /* acx_bn_workspace_bytes */, size_t workspace_bytes, void* stream);
 int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* dlogits, const float* var_biased,
                      const float* sums, float* draw, int32_t ldo, int64_t rows, int64_t total_rows, int32_t C1,
-                     float eps, void* stream);
+                     float eps, const float* total_rows_dev /* device scalar overriding total_rows, or NULL: SyncBN keeps
+                     the all-gathered row count on the device instead of synchronising the host for it */, void* stream);
 /* y = a*x + b*y (BatchNorm running-statistics update, selector_model.py:30 momentum 0.1) */
 int acx_axpby(acx_ctx* ctx, const float* x, float* y, int32_t n, float a, float b, void* stream);
 /* deterministic column sums: part[blk][D] partials over rows_per_block rows each (then acx_reduce_rows) */

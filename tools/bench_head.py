@@ -146,6 +146,19 @@ def main():
             net(x, None, mod.ncentroid, 1, True)
             net.train()
 
+    if os.environ.get("ACX_CPROFILE"):
+        # where the HOST spends a step (development aid): cumulative-time table of 20 steps to stderr
+        import cProfile
+        import pstats
+        timer.run(train_step, 3, 0)
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(20):
+            train_step()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
     dt_train = timer.run(train_step, args.steps, args.warmup)
     timer.run(train_step, 2, 0, prof.start, prof.stop)
     gf, counts, tot = prof.collect()
