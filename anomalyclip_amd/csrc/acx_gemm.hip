@@ -773,9 +773,29 @@ static int tn_choose_splits(int64_t M, int64_t N1, int64_t N2) {
   return best;
 }
 
+// Large weight gradients take the 256 x 256 LDS-DMA kernel: at least 36 full-ish tiles' worth of output and enough rows
+// that a split still streams >= 1024 of them; its splits fill the CUs once (one workgroup per CU).
+static bool tn_takes_p256(int64_t M, int64_t N1, int64_t N2, bool b_sub) {
+  return !b_sub && N1 >= 192 && N2 >= 256 && M >= 8192 && ((N1 + 255) / 256) * ((N2 + 255) / 256) >= 8;
+}
+static int tn_p256_splits(int64_t M, int64_t N1, int64_t N2, int ncu) {
+  const int tiles = (int)(((N1 + 255) / 256) * ((N2 + 255) / 256));
+  int s = ncu / tiles;
+  if (s < 1) s = 1;
+  while (s > 1 && M / s < 1024) --s;
+  return s;
+}
+constexpr size_t TN_ZERO_B = 1024;               // zero page at the end of the workspace (the DMA kernel's padding source)
+
 extern "C" size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2) {
   const int splits = tn_choose_splits(M, N1, N2);
-  return splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;
+  size_t need = splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;
+  if (tn_takes_p256(M, N1, N2, false)) {        // sized for a 256-CU device; fewer CUs mean fewer splits
+    const int sp = tn_p256_splits(M, N1, N2, 256);
+    const size_t need2 = (sp > 1 ? (size_t)sp * N1 * N2 * sizeof(float) : 0) + TN_ZERO_B;
+    if (need2 > need) need = need2;
+  }
+  return need;
 }
 
 extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
@@ -788,6 +808,46 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
   if (conv && (cin <= 0 || N2 != 9 * cin || cin % 4 || gn <= 0 || gl <= 0 || M % (gn * gl)))
     return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: bad conv geometry%s");
   if (b_sub && ((uintptr_t)b_sub & 15)) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: b_sub alignment%s");
+  if (tn_takes_p256(M, N1, N2, b_sub != nullptr) && workspace && (size_t)M * lda < ((size_t)1 << 40)) {
+    const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+    int splits = tn_p256_splits(M, N1, N2, ncu > 256 ? 256 : ncu);
+    const size_t part = (size_t)N1 * N2 * sizeof(float);
+    while (splits > 1 && (size_t)splits * part + TN_ZERO_B > workspace_bytes) --splits;
+    const size_t zoff = splits > 1 ? (size_t)splits * part : 0;
+    if (zoff + TN_ZERO_B <= workspace_bytes && !(zoff & 15)) {
+      hipStream_t s = (hipStream_t)stream;
+      AcxProfScope prof__(ctx, ACX_K_GEMM, s);
+      if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2;
+      float* zeros = (float*)((char*)workspace + zoff);
+      if (hipMemsetAsync(zeros, 0, TN_ZERO_B, s) != hipSuccess) return acx_fail(ctx, ACX_E_HIP, "acx_gemm_tn: memset failed%s");
+      TnArgs g;
+      g.A = A; g.B = B; g.C = splits > 1 ? (float*)workspace : C;
+      g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+      g.b_sub = nullptr; g.conv = conv; g.gn = gn; g.gl = gl; g.cin = cin;
+      g.m_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
+      g.sh_gl = g.sh_grid = -1;
+      if (conv && !(gl & (gl - 1)) && !((gn * gl) & (gn * gl - 1))) {
+        g.sh_gl = __builtin_ctz((unsigned)gl);
+        g.sh_grid = __builtin_ctz((unsigned)(gn * gl));
+      }
+      const int dev_slot = (ctx ? ctx->device : 0) & 63;
+      static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_p256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TP_LDS_B);
+        attr_done = true;
+      }
+      const int tiles = ((N1 + 255) / 256) * ((N2 + 255) / 256);
+      hipLaunchKernelGGL(gemm_tn_p256_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(1024), (size_t)TP_LDS_B, s, g,
+                         (const float*)zeros);
+      if (splits > 1) {
+        const int64_t n4 = (int64_t)N1 * N2 / 4;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, n4,
+                           splits);
+      }
+      ACX_CHECK_LAUNCH(ctx, "acx_gemm_tn");
+      return ACX_OK;
+    }
+  }
   const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
   const int splits = tn_choose_splits(M, N1, N2);
   const size_t need = splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;

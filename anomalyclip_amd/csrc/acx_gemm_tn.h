@@ -333,6 +333,129 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) {
 #undef TN_STORE_ROW
 }
 
+// ---- 256 x 256 tiles, one 16-wave workgroup per CU, operands by LDS-DMA ("strip" geometry of gemm_f32_p256_kernel)
+// The 128 x 128 kernels above re-read A once per N2 tile and B once per N1 tile: at the conv weight gradient of the UCF
+// head (M = 32768, N1 = 1024, N2 = 2304) that is 4.8 GB through L2 per launch = 3.3 TB/s at the measured 1.48 ms, and
+// the kernel sits at 0.66 of the f32 MFMA roof next to a forward convolution of the same flops at 0.80.  A 256 x 256 tile
+// halves the bytes per flop in both directions:
+//   * 16 waves (4 x 4, 64 x 64 of C each = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32), four per SIMD, <= 128 VGPRs;
+//   * a K-step is 32 rows of m; a wave instruction of global_load_lds_dwordx4 moves ONE m-row of 256 columns (1 KB,
+//     fully coalesced), wave w stages rows 2w and 2w+1 of A and of B; LDS rows are 1152 B apart (256 floats + 128 B) so
+//     that the two half-waves of a ds_read_b32 fragment read (rows 2s and 2s+1) fall into different bank halves;
+//   * rows past the end of the split read A from a ZERO buffer (the product vanishes), taps outside the (gn, gl) grid read
+//     B from it -- the conv gather is a per-lane source address, there is no im2col and no predicate on the LDS side;
+//   * two stages (144 KB); per K-step: issue the DMA of step kt+1, wait for this wave's step kt, barrier, 16 x (4 fragment
+//     reads + 4 MFMA), barrier.
+constexpr int TP_ROWB = 1152;
+constexpr int TP_OP_B = 32 * TP_ROWB;            // 36,864
+constexpr int TP_STAGE_B = 2 * TP_OP_B;          // A | B
+constexpr int TP_LDS_B = 2 * TP_STAGE_B;         // 147,456
+
+__global__ __launch_bounds__(1024) void gemm_tn_p256_kernel(const TnArgs g, const float* __restrict__ zeros) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tiles_n2 = (g.N2 + 255) / 256;
+  const int tm = blockIdx.x / tiles_n2, tn = blockIdx.x - tm * tiles_n2;
+  const int n1_0 = tm * 256, n2_0 = tn * 256;
+  const int split = blockIdx.y;
+  const int m_begin = split * g.m_per_split;
+  const int m_end = min(g.M, m_begin + g.m_per_split);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, hh = lane >> 5;
+
+  // ---- DMA sources: lane -> columns 4 lane .. 4 lane + 3 of the tile (clamped into the matrix: masked at the store)
+  const int ca = min(n1_0 + 4 * lane, g.N1 - 4), cb = min(n2_0 + 4 * lane, g.N2 - 4);
+  int tap_dn = 0, tap_dl = 0, b_col = cb;
+  if (g.conv) {
+    const int tap = cb / g.cin;
+    tap_dn = tap / 3 - 1;
+    tap_dl = tap - (tap / 3) * 3 - 1;
+    b_col = cb - tap * g.cin;
+  }
+  const int grid_sz = g.conv ? g.gn * g.gl : 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(p2_lds_t*)smem;
+#define TP_DMA1(gptr, ldsaddr)                                                                     \
+  do {                                                                                             \
+    unsigned keep_;                                                                                \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(gptr), "s"(ldsaddr) : "memory");                             \
+  } while (0)
+#define TP_ISSUE(stage, kt_)                                                                       \
+  do {                                                                                             \
+    _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                             \
+      const int m_ = m_begin + (kt_) * 32 + 2 * wave + rr;                                         \
+      const bool mok_ = m_ < m_end;                                                                \
+      const int mc_ = mok_ ? m_ : m_end - 1;                                                       \
+      const float* pa_ = mok_ ? g.A + (size_t)mc_ * g.lda + ca : zeros;                            \
+      const float* pb_;                                                                            \
+      if (g.conv) {                                                                                \
+        int tile_, rem_, n0_;                                                                      \
+        if (g.sh_gl >= 0) { tile_ = mc_ >> g.sh_grid; rem_ = mc_ & (grid_sz - 1); n0_ = rem_ >> g.sh_gl; }   \
+        else { tile_ = mc_ / grid_sz; rem_ = mc_ - tile_ * grid_sz; n0_ = rem_ / g.gl; }           \
+        const int nn_ = n0_ + tap_dn, ll_ = rem_ - n0_ * g.gl + tap_dl;                            \
+        const bool ok_ = (unsigned)nn_ < (unsigned)g.gn && (unsigned)ll_ < (unsigned)g.gl;         \
+        pb_ = ok_ ? g.B + ((size_t)tile_ * grid_sz + (size_t)nn_ * g.gl + ll_) * g.ldb + b_col : zeros; \
+      } else {                                                                                     \
+        pb_ = g.B + (size_t)mc_ * g.ldb + cb;                                                      \
+      }                                                                                            \
+      const unsigned s_ = lds0 + (stage) * TP_STAGE_B + (2 * wave + rr) * TP_ROWB;                 \
+      TP_DMA1(pa_, s_);                                                                            \
+      TP_DMA1(pb_, s_ + TP_OP_B);                                                                  \
+    }                                                                                              \
+  } while (0)
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+  const int nk = (m_end - m_begin + 31) / 32;
+  const int fa = hh * TP_ROWB + (wm * 64 + li) * 4;
+  const int fb = TP_OP_B + hh * TP_ROWB + (wn * 64 + li) * 4;
+  if (nk > 0) TP_ISSUE(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      TP_ISSUE(cur ^ 1, kt + 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this wave's 4 rows of step kt have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                            // ... and everybody else's
+    const char* sS = smem + cur * TP_STAGE_B;
+    float a0 = *reinterpret_cast<const float*>(sS + fa), a1 = *reinterpret_cast<const float*>(sS + fa + 128);
+    float b0 = *reinterpret_cast<const float*>(sS + fb), b1 = *reinterpret_cast<const float*>(sS + fb + 128);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (s2 + 1 < 16) {
+        const int o = 2 * (s2 + 1) * TP_ROWB;
+        na0 = *reinterpret_cast<const float*>(sS + fa + o); na1 = *reinterpret_cast<const float*>(sS + fa + o + 128);
+        nb0 = *reinterpret_cast<const float*>(sS + fb + o); nb1 = *reinterpret_cast<const float*>(sS + fb + o + 128);
+      }
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // stage `cur` is free for the DMA of step kt + 2
+  }
+#undef TP_ISSUE
+#undef TP_DMA1
+  float* Cs = g.C + (size_t)split * g.N1 * g.ldc;
+#define TP_ST(ACC, mi, ni)                                                                         \
+  do {                                                                                             \
+    const int col = n2_0 + wn * 64 + (ni) * 32 + li;                                               \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+      const int row = n1_0 + wm * 64 + (mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;                \
+      if (row < g.N1 && col < g.N2) Cs[(size_t)row * g.ldc + col] = ACC[r];                        \
+    }                                                                                              \
+  } while (0)
+  TP_ST(acc00, 0, 0); TP_ST(acc01, 0, 1); TP_ST(acc10, 1, 0); TP_ST(acc11, 1, 1);
+#undef TP_ST
+}
+
 // out[i] = sum_s part[s][i]   (fixed order)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                         int64_t n4, int splits) {

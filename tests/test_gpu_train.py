@@ -38,6 +38,38 @@ def test_gemm_tn_plain(M, N1, N2):
     assert relerr(ops.gemm_tn(a.to(DEV), b.to(DEV), b_sub=sub.to(DEV)), a.double().t() @ (b - sub).double()) < 3e-6
 
 
+@pytest.mark.parametrize("M,N1,N2", [(8192, 1024, 2304), (16384 + 77, 512, 1028), (32768, 256, 2304)])
+def test_gemm_tn_256_tiles_plain(M, N1, N2):
+    """gemm_tn_p256_kernel (weight gradients with >= 8 tiles of 256 x 256 and >= 8192 rows): ragged M (zero-page rows past
+    the split end), ragged N2, several splits + fixed-order reduce -- element-wise against fp64 with the bound
+    2e-6 * sum_m |a||b|, and run-to-run identical."""
+    g = torch.Generator().manual_seed(M + N1)
+    a, b = torch.randn(M, N1, generator=g), torch.randn(M, N2, generator=g) + torch.arange(N2) * 1e-3
+    out = ops.gemm_tn(a.to(DEV), b.to(DEV))
+    ref = a.double().t() @ b.double()
+    bound = 2e-6 * (a.double().abs().t() @ b.double().abs())
+    assert bool(((out.cpu().double() - ref).abs() <= bound).all())
+    assert torch.equal(out, ops.gemm_tn(a.to(DEV), b.to(DEV)))
+
+
+@pytest.mark.parametrize("cin,cout,tiles", [(256, 1024, 16), (1024, 256, 16), (128, 512, 40)])
+def test_conv_grads_256_tiles(cin, cout, tiles):
+    """The conv weight gradient of the head at benchmark size through the 256 x 256 LDS-DMA kernel (taps outside the
+    (32, 16) grid read the zero page; cin = 128 puts two taps into one tile) against torch's conv2d weight gradient in fp64."""
+    g = torch.Generator().manual_seed(cin + tiles)
+    N, Lg = 32, 16
+    x = torch.randn(tiles, N, Lg, cin, generator=g) * 0.5
+    dy = torch.randn(tiles * N * Lg, cout, generator=g) * 0.5
+    with torch.enable_grad():
+        wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x.double().permute(0, 3, 1, 2), wt, None, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+        y.backward(dy.double())
+    gw = ops.gemm_tn(dy.to(DEV), x.reshape(-1, cin).to(DEV), conv=True, gn=N, gl=Lg, cin=cin)      # [cout, 9*cin] ([tap][cin])
+    got = gw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    assert relerr(got, wt.grad) < 2e-6
+    assert R.elem_excess(got, wt.grad, rtol=1e-4, afrac=2e-6) <= 1
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 256), (256, 64)])
 def test_conv_grads(cin, cout):
     """dW (TN implicit GEMM) and dX (NT implicit GEMM with flipped weights) of the 3x3 conv vs autograd."""
