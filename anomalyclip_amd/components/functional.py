@@ -443,7 +443,9 @@ class TemporalFn(torch.autograd.Function):
         grads[c.linear.weight], grads[c.linear.bias] = g_w.view(1, -1), g_b
         d1, d2 = dz, dz                                   # d(x1), d(x2) of the last block pair
 
-        def attn_bwd(rec, d_out):
+        # every branch ends in a LayerNorm backward: the gradient of the residual path it joins (`add`) is summed in that
+        # same pass instead of a separate elementwise launch
+        def attn_bwd(rec, d_out, add):
             _, d, fg, axis, x_in, h, qkv, o = rec
             pn = getattr(blks[2 * d], fg).net.fn
             sa = pn.fn
@@ -457,11 +459,11 @@ class TemporalFn(torch.autograd.Function):
             grads[sa.to_kv.weight] = g_qkv[He:]
             qkv_w = tm.prepared()[f"qkv_w{d}{fg}"]
             d_h = ops.gemm(d_qkv, ops.transpose(qkv_w))                                # [rows, E]
-            d_in, gw, gb = ops.layernorm_bwd(x_in, pn.norm.weight, d_h)
+            d_in, gw, gb = ops.layernorm_bwd(x_in, pn.norm.weight, d_h, add=add)
             grads[pn.norm.weight], grads[pn.norm.bias] = gw, gb
             return d_in
 
-        def ff_bwd(rec, d_out):
+        def ff_bwd(rec, d_out, add):
             _, d, fg, _, x_in, h, u, _ = rec
             f = getattr(blks[2 * d + 1], fg).net
             P = tm.prepared()
@@ -474,7 +476,7 @@ class TemporalFn(torch.autograd.Function):
             gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E)                 # [4E, 9E]
             grads[f[1].weight] = gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2)
             d_h = ops.gemm(d_pre, ops.conv_weight_dx(f[1].weight.detach()), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
-            d_in, gg, gb = ops.layernorm_bwd(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN)
+            d_in, gg, gb = ops.layernorm_bwd(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN, add=add)
             grads[f[0].g], grads[f[0].b] = gg.view(1, -1, 1, 1), gb.view(1, -1, 1, 1)
             return d_in
 
@@ -483,14 +485,14 @@ class TemporalFn(torch.autograd.Function):
             r_af, r_ag, r_ff, r_fg = recs[4 * d: 4 * d + 4]
             # x2' = y2 + ffG(x1')  ;  x1' = y1 + ffF(y2)
             d_y2 = d2
-            d1 = ops.add(d1, ff_bwd(r_fg, d2))
+            d1 = ff_bwd(r_fg, d2, d1)                      # d1 + dffG/dx1'
             d_y1 = d1
-            d_y2 = ops.add(d_y2, ff_bwd(r_ff, d1))
+            d_y2 = ff_bwd(r_ff, d1, d_y2)                  # d_y2 + dffF/dy2
             # y2 = x2 + attnG(y1) ; y1 = x1 + attnF(x2)
             d_x2 = d_y2
-            d_y1 = ops.add(d_y1, attn_bwd(r_ag, d_y2))
+            d_y1 = attn_bwd(r_ag, d_y2, d_y1)              # d_y1 + dattnG/dy1
             d_x1 = d_y1
-            d_x2 = ops.add(d_x2, attn_bwd(r_af, d_y1))
+            d_x2 = attn_bwd(r_af, d_y1, d_x2)              # d_x2 + dattnF/dx2
             d1, d2 = d_x1, d_x2
         d_x0 = ops.add(d1, d2)
         pe = tm.axial_attn.pos_emb

@@ -3,7 +3,8 @@ kernel (acx_gemm's f32 MFMA kernels) with the gfx950 FETCH_SIZE correction of MI
 coalesced reads; WRITE_SIZE checked against the exactly-known output bytes)."""
 import csv, json, os, sys, collections
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_bench"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
 def rows(d):
     p = os.path.join(src, d, "p_counter_collection.csv")
     return list(csv.DictReader(open(p))) if os.path.exists(p) else []
@@ -12,7 +13,8 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for d in ("fetch", "write", "sq", "grbm", "l2"):
     for r in rows(d):
         name = r["Kernel_Name"]
-        kind = "gemm" if ("gemm_" in name and "reduce" not in name) else ("attn" if ("attn_kernel" in name or "attn16_kernel" in name) else None)
+        kind = "gemm" if ("gemm_" in name and "reduce" not in name) else (
+            "attn" if ("attn_kernel" in name or "attn16_kernel" in name or "attn_bf16_kernel" in name) else None)
         if kind is None:
             continue
         agg[kind][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -36,12 +38,12 @@ for kind in agg:
         o["l2_hit_rate"] = o["TCC_HIT_sum_per_launch"] / (o["TCC_HIT_sum_per_launch"] + o["TCC_MISS_sum_per_launch"])
     out[kind] = o
 os.makedirs("profiles", exist_ok=True)
-json.dump(out, open(f"profiles/{tag}_bench_f32_pmc.json", "w"), indent=1)
+json.dump(out, open(f"profiles/{tag}_bench_{prec}_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 st = os.path.join(src, "stats", "bench_kernel_stats.csv")
 if os.path.exists(st):
     import shutil
-    shutil.copy(st, f"profiles/{tag}_bench_f32_kernel_stats.csv")
+    shutil.copy(st, f"profiles/{tag}_bench_{prec}_kernel_stats.csv")
     for line in open(os.path.join(src, "stats.log")):
         if line.startswith('{"metric"'):
-            open(f"profiles/{tag}_bench_f32_under_rocprof.json", "w").write(line)
+            open(f"profiles/{tag}_bench_{prec}_under_rocprof.json", "w").write(line)
