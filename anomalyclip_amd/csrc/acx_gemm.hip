@@ -773,16 +773,16 @@ static int tn_choose_splits(int64_t M, int64_t N1, int64_t N2) {
   return best;
 }
 
-// Large weight gradients take the 256 x 256 LDS-DMA kernel: at least 36 full-ish tiles' worth of output and enough rows
-// that a split still streams >= 1024 of them; its splits fill the CUs once (one workgroup per CU).
+// Large weight gradients take the 256 x 256 LDS-DMA kernel: at least 8 tiles of output and enough rows that a split still
+// streams >= 512 of them; its splits fill the CUs once (one workgroup per CU).
 static bool tn_takes_p256(int64_t M, int64_t N1, int64_t N2, bool b_sub) {
-  return !b_sub && N1 >= 192 && N2 >= 256 && M >= 8192 && ((N1 + 255) / 256) * ((N2 + 255) / 256) >= 8;
+  return !b_sub && N1 >= 192 && N2 >= 256 && M >= 4096 && ((N1 + 255) / 256) * ((N2 + 255) / 256) >= 8;
 }
 static int tn_p256_splits(int64_t M, int64_t N1, int64_t N2, int ncu) {
   const int tiles = (int)(((N1 + 255) / 256) * ((N2 + 255) / 256));
   int s = ncu / tiles;
   if (s < 1) s = 1;
-  while (s > 1 && M / s < 1024) --s;
+  while (s > 1 && M / s < 512) --s;
   return s;
 }
 constexpr size_t TN_ZERO_B = 1024;               // zero page at the end of the workspace (the DMA kernel's padding source)
