@@ -15,7 +15,7 @@ PREC_F32, PREC_BF16 = 0, 1
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE = 0, 1, 2
 NORM_LAYER, NORM_CHAN = 0, 1
-OPT_RING_MIN_TILES, OPT_SK_MAX_M = 1, 2
+OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS = 1, 2, 3
 
 
 class GemmDesc(C.Structure):

@@ -38,6 +38,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->multiprocessors = prop.multiProcessorCount;
   c->opt_ring_min_tiles = 512;
   c->opt_sk_max_m = 320;
+  c->opt_tn_p256_min_rows = 4096;
   c->err[0] = 0;
   c->prof_on = false;
   c->prof_n = c->prof_created = 0;
@@ -93,6 +94,10 @@ extern "C" int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value) {
     case ACX_OPT_RING_MIN_TILES:
       if (value < 1) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: ring_min_tiles must be >= 1%s");
       ctx->opt_ring_min_tiles = (int)value;
+      return ACX_OK;
+    case ACX_OPT_TN_P256_MIN_ROWS:
+      if (value < 1) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: tn_p256_min_rows must be >= 1%s");
+      ctx->opt_tn_p256_min_rows = (int)(value > 0x7fffffff ? 0x7fffffff : value);
       return ACX_OK;
     case ACX_OPT_SK_MAX_M:
       if (value < 0) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: sk_max_m must be >= 0%s");

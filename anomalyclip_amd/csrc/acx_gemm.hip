@@ -808,7 +808,7 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
   if (conv && (cin <= 0 || N2 != 9 * cin || cin % 4 || gn <= 0 || gl <= 0 || M % (gn * gl)))
     return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: bad conv geometry%s");
   if (b_sub && ((uintptr_t)b_sub & 15)) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: b_sub alignment%s");
-  if (tn_takes_p256(M, N1, N2, b_sub != nullptr) && workspace && (size_t)M * lda < ((size_t)1 << 40)) {
+  if (tn_takes_p256(M, N1, N2, b_sub != nullptr) && workspace && M >= (ctx ? ctx->opt_tn_p256_min_rows : 4096)) {
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     int splits = tn_p256_splits(M, N1, N2, ncu > 256 ? 256 : ncu);
     const size_t part = (size_t)N1 * N2 * sizeof(float);
@@ -819,7 +819,9 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
       AcxProfScope prof__(ctx, ACX_K_GEMM, s);
       if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2;
       float* zeros = (float*)((char*)workspace + zoff);
-      if (hipMemsetAsync(zeros, 0, TN_ZERO_B, s) != hipSuccess) return acx_fail(ctx, ACX_E_HIP, "acx_gemm_tn: memset failed%s");
+      // a KERNEL clears the page: as a hipMemsetAsync node inside a captured graph the clear was observed to run unordered
+      // with the consumer (stale workspace bytes read as padding, run-to-run different gradients under graph replay)
+      hipLaunchKernelGGL(tn_zero_page_kernel, dim3(1), dim3(TN_ZERO_B / 16), 0, s, reinterpret_cast<float4*>(zeros));
       TnArgs g;
       g.A = A; g.B = B; g.C = splits > 1 ? (float*)workspace : C;
       g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -456,6 +456,8 @@ __global__ __launch_bounds__(1024) void gemm_tn_p256_kernel(const TnArgs g, cons
 #undef TP_ST
 }
 
+__global__ void tn_zero_page_kernel(float4* __restrict__ page) { page[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
 // out[i] = sum_s part[s][i]   (fixed order)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                         int64_t n4, int splits) {

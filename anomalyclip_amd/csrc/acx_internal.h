@@ -36,6 +36,7 @@ struct acx_ctx {
   int multiprocessors;      // CUs of the device (persistent-kernel grid size)
   int opt_ring_min_tiles;   // ACX_OPT_RING_MIN_TILES
   int opt_sk_max_m;         // ACX_OPT_SK_MAX_M
+  int opt_tn_p256_min_rows; // ACX_OPT_TN_P256_MIN_ROWS
   char err[512];
   bool prof_on;
   int prof_n;          // recorded pairs

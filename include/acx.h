@@ -54,7 +54,9 @@ const char* acx_last_error(acx_ctx* ctx);
 /*   ACX_OPT_SK_MAX_M        f32 acx_gemm problems with at most this many rows take the few-row kernel (32x32 tiles,
  *                           K split over the waves, no split-K reduction launch; default 320; 0 disables it except
  *                           for the a_act / gelu_grad_of fusions, which always need it). */
-enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2 };
+/*   ACX_OPT_TN_P256_MIN_ROWS acx_gemm_tn problems with at least this many rows (and >= 8 output tiles of 256 x 256, no
+ *                           b_sub) take the 256 x 256 LDS-DMA kernel (default 4096). */
+enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2, ACX_OPT_TN_P256_MIN_ROWS = 3 };
 int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value);
 
 /* ------------------------------------------------------------------------------------------

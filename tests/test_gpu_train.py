@@ -547,14 +547,16 @@ def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom):
     assert float(mods[0][1].selector_model.logit_scale) == float(np.float32(2.6592601))      # untouched by weight decay
 
 
-@pytest.mark.parametrize("geom", ["tiny", "ViT-B/16"])
-def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom):
+@pytest.mark.parametrize("geom,B", [("tiny", 4), ("ViT-B/16", 4), ("ViT-B/16", 8)])
+def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom, B):
     """net.text_graph = True: the text tower replayed as two HIP graphs on a side stream (forward launched before the
     temporal model, backward beside the temporal backward) runs the same kernels on the same operands as the eager
     path -- three optimisation steps must leave bit-identical losses, gradients and parameters; the graphs are
-    captured once and the static buffers must survive the optimizer's in-place updates of ctx / text_projection."""
+    captured once and the static buffers must survive the optimizer's in-place updates of ctx / text_projection.
+    B = 8 at the UCF geometry (4096 rows, a data-parallel rank's share) puts the 256 x 256 weight-gradient kernel -- its
+    zero-page clear, split workspace and fixed-order reduce -- inside the captured graphs (a hipMemsetAsync node there once
+    ran unordered with its consumer)."""
     D = IW.TINY.embed_dim if geom == "tiny" else 512
-    B = 4
     mods = [_dp_module(prompts_table, geom=geom) for _ in range(2)]
     mods[0][1].text_graph = True
     mods[0][1].temporal_model.graph = True                                    # + the temporal model's two graphs

@@ -130,6 +130,11 @@ def main():
 
     net.train()
     step_i = [0]
+    if os.environ.get("ACX_TN_P256_MIN_ROWS"):           # development A/B: 2147483647 keeps the 128 x 128 weight-gradient kernels
+        from anomalyclip_amd import _lib as L_
+        L_.check(L_.lib().acx_set_option(L_.ctx(local_rank), L_.OPT_TN_P256_MIN_ROWS, int(os.environ["ACX_TN_P256_MIN_ROWS"])),
+                 L_.ctx(local_rank))
+    loss_trace = []
 
     def train_step():
         torch.manual_seed(step_i[0])          # host mask RNG: the global batch's mask, this rank's rows
@@ -137,6 +142,8 @@ def main():
         mt, mb = type(net.selector_model).generate_mask(net.selector_model, B_global)
         net.selector_model.generate_mask = lambda b, mt=mt[idx], mb=mb[idx]: (mt, mb)
         mod.train_batch(batch, opt)
+        if len(loss_trace) < 4:
+            loss_trace.append(mod.last_losses[0].detach())
 
     x = torch.cat((batch[1][0], batch[0][0]), 0).view(-1, 1, 512, 512)
 
@@ -185,7 +192,7 @@ def main():
             "n_gpus": world, "emulated_world": args.emulate_world or None, "videos_this_rank": len(idx),
             "text_class_parallel": bool(net.text_class_parallel), "text_graph": bool(net.text_graph), "temporal_graph": bool(net.temporal_model.graph),
             "global_batch_videos": B_global, "scaling": args.scaling, "dtype": "f32",
-            "loss": float(mod.last_losses[0]), "data": "synthetic"}))
+            "loss": float(mod.last_losses[0]), "first_losses": [round(float(v), 6) for v in loss_trace], "data": "synthetic"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
