@@ -19,10 +19,6 @@ from .. import _lib as L
 from .. import ops
 
 
-import os as _os
-_DBG_NO_FUSED_ADD = _os.environ.get("ACX_NO_FUSED_ADD") == "1"
-
-
 # ------------------------------------------------------------------------------------------------------
 def _parallel():
     from .. import parallel
@@ -463,11 +459,7 @@ class TemporalFn(torch.autograd.Function):
             grads[sa.to_kv.weight] = g_qkv[He:]
             qkv_w = tm.prepared()[f"qkv_w{d}{fg}"]
             d_h = ops.gemm(d_qkv, ops.transpose(qkv_w))                                # [rows, E]
-            if _DBG_NO_FUSED_ADD:
-                d_in, gw, gb = ops.layernorm_bwd(x_in, pn.norm.weight, d_h)
-                d_in = ops.add(add, d_in)
-            else:
-                d_in, gw, gb = ops.layernorm_bwd(x_in, pn.norm.weight, d_h, add=add)
+            d_in, gw, gb = ops.layernorm_bwd(x_in, pn.norm.weight, d_h, add=add)
             grads[pn.norm.weight], grads[pn.norm.bias] = gw, gb
             return d_in
 
@@ -484,11 +476,7 @@ class TemporalFn(torch.autograd.Function):
             gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E)                 # [4E, 9E]
             grads[f[1].weight] = gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2)
             d_h = ops.gemm(d_pre, ops.conv_weight_dx(f[1].weight.detach()), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
-            if _DBG_NO_FUSED_ADD:
-                d_in, gg, gb = ops.layernorm_bwd(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN)
-                d_in = ops.add(add, d_in)
-            else:
-                d_in, gg, gb = ops.layernorm_bwd(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN, add=add)
+            d_in, gg, gb = ops.layernorm_bwd(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN, add=add)
             grads[f[0].g], grads[f[0].b] = gg.view(1, -1, 1, 1), gb.view(1, -1, 1, 1)
             return d_in
 

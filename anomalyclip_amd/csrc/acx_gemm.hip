@@ -532,7 +532,11 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
                        (size_t)d->M * d->lda < ((size_t)1 << 31) && (size_t)d->N * d->ldw < ((size_t)1 << 31);
     if (sk_fusion && !sk_ok)
       return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_act / gelu_grad_of need the few-row f32 kernel (see acx_gemm_desc)%s");
-    if (sk_ok && (sk_fusion || d->M <= (ctx ? ctx->opt_sk_max_m : ACX_SK_MAX_M))) {
+    // narrow outputs (N <= 512: out-proj, proj and the dX chain of the text tower) stay ahead of the 64x64-tile kernel up to
+    // ~1300 rows -- 17-34 row tiles x 16 column tiles fill the chip where 64x64 tiles leave half of it idle
+    // (profiles/r03_text_gemm.txt); wide outputs only up to the row limit
+    const int sk_max_m = ctx ? ctx->opt_sk_max_m : ACX_SK_MAX_M;
+    if (sk_ok && (sk_fusion || d->M <= sk_max_m || (sk_max_m > 0 && d->N <= 512 && d->M <= 4 * sk_max_m))) {
       const dim3 kgrid((unsigned)(((d->M + 31) / 32) * ((d->N + 31) / 32)));
 #define ACX_SKL(E, AG)                                                                              \
   do {                                                                                              \
