@@ -249,7 +249,17 @@ __device__ __forceinline__ double bn_pair_total(const double* __restrict__ part,
   double v = 0.0;
   if (g < G) {
     const int k = p / C1, c = p - k * C1;
-    for (int b = g; b < nblocks; b += G) v += part[((size_t)b * 2 + k) * CP + c];
+    const double* src = part + (size_t)k * CP + c;
+    const size_t bs = (size_t)2 * CP;
+    int b = g;
+    for (; b + 7 * G < nblocks; b += 8 * G) {                         // eight independent loads in flight, added in block order
+      double t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t8[u] = src[(size_t)(b + u * G) * bs];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t8[u];
+    }
+    for (; b < nblocks; b += G) v += src[(size_t)b * bs];
   }
   red[threadIdx.x] = v;
   __syncthreads();
