@@ -1,5 +1,5 @@
 #!/bin/bash
-# One pass over everything profiles/r02_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
+# One pass over everything profiles/r03_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
 set -x
 R=/root/repo
 OUT=$R/gpurun_out/refresh
@@ -12,11 +12,10 @@ python tools/bench_head.py --steps 10 > $OUT/bench_head_eager.json 2>/dev/null
 for n in 2 4 8; do python tools/bench_head.py --steps 10 --emulate-world $n --text-graph --temporal-graph > $OUT/bench_head_emulated_world$n.json 2>/dev/null; done
 python tools/bench_head.py --steps 10 --emulate-world 8 > $OUT/bench_head_emulated_world8_eager.json 2>/dev/null
 python tools/bench_xd.py --steps 6 > $OUT/bench_xd_bf16.json 2>/dev/null
-python tools/bench_metrics.py > $OUT/bench_metrics.txt 2>&1
-python tools/gemm_bench.py --frames 512 --epi 1 > $OUT/gemm_f32.txt 2>&1
-python tools/gemm_bench.py --frames 512 --epi 1 --prec bf16 > $OUT/gemm_bf16.txt 2>&1
-python tools/attn_bench.py > $OUT/attn.txt 2>&1
-python tools/attn_bf16_bench.py >> $OUT/attn.txt 2>&1
-bash tools/profile_bench.sh > $OUT/profile_bench.log 2>&1
+python tools/text_gemm_bench.py > $OUT/text_gemm.txt 2>&1
+python tools/tn_bench.py > $OUT/tn_bench.txt 2>&1
+ACX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_gloo2_smoke.json 2> $OUT/bench_gloo2_smoke.err
+bash tools/profile_bench.sh f32 > $OUT/profile_bench.log 2>&1
+bash tools/profile_bench.sh bf16 > $OUT/profile_bench_bf16.log 2>&1
 bash tools/profile_extra.sh > $OUT/profile_extra.log 2>&1
 ls -la $OUT
