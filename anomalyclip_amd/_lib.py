@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
         ("amap", c_int32), ("gn", c_int32), ("gl", c_int32), ("cin", c_int32), ("seg", c_int32),
         ("pos0", c_void_p), ("pos1", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
-        ("a_act", c_int32), ("gelu_grad_of", c_void_p), ("ldg", c_int32),
+        ("zero_page", c_void_p), ("a_act", c_int32), ("gelu_grad_of", c_void_p), ("ldg", c_int32),
     ]
 
 

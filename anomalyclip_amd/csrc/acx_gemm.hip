@@ -62,6 +62,7 @@ struct Args {
   long long* trace;        // debug timeline buffer (ACX_TRACE builds only)
   int ksplit, kchunk;      // split-K (FAST path, skinny problems): gridDim.y splits of kchunk K-steps each
   float* partial;          // [ksplit][M][N] raw partial sums (epilogue applied by splitk_reduce_kernel)
+  const float* zeros;      // acx_gemm_desc.zero_page (conv taps outside the grid on the LDS-DMA kernels)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -445,8 +446,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 bool acx_gemm_takes_strip_stream(const acx_gemm_desc* d) {
   if (!ACX_DBG_SWITCH("P256", true)) return false;
   if (d->prec != ACX_PREC_F32 || d->a_dtype == ACX_BF16 || d->c_dtype == ACX_BF16) return false;
-  if (d->amap != ACX_AMAP_IDENTITY || d->a_sub || d->pos0 || d->K % 32 || d->act == ACX_ACT_LEAKYRELU) return false;
-  if (d->residual) return false;
+  if (d->a_sub || d->pos0 || d->K % 32 || d->residual) return false;
+  if (d->amap == ACX_AMAP_CONV3X3) {
+    // implicit-GEMM convolutions: wide outputs only (N = 256 leaves half of the 256-column strip kernel's waves idle),
+    // power-of-two token grid, a caller-provided zero page for the taps outside the grid
+    if (!d->zero_page || ((uintptr_t)d->zero_page & 15) || d->N < 512 || d->cin % 32 || d->act == ACX_ACT_QUICKGELU) return false;
+    if ((d->gl & (d->gl - 1)) || ((d->gn * d->gl) & (d->gn * d->gl - 1)) || d->M % 64) return false;
+  } else if (d->amap != ACX_AMAP_IDENTITY || d->act == ACX_ACT_LEAKYRELU) {
+    return false;
+  }
   const long tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
   return tiles >= 1024 && (size_t)d->M * d->lda < ((size_t)1 << 31) && (size_t)d->N * d->ldw < ((size_t)1 << 31);
 }
@@ -492,6 +500,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
 #endif
   dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
   g.ksplit = 1; g.kchunk = 0; g.partial = nullptr;
+  g.zeros = (const float*)d->zero_page;
   const size_t lds = 4 * TILE_B;
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM, (hipStream_t)stream);
@@ -615,17 +624,18 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     const dim3 pgrid((unsigned)ncu);                       // >= 1024 tiles of 128x128 => >= 8 strips per CU
     const size_t plds = 2 * P2_STAGE_B;
-#define ACX_P2L(ACT)                                                                                \
+#define ACX_P2L(ACT, CV)                                                                            \
   do {                                                                                              \
-    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                          \
     if (!attr_done) {                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_f32_p256_kernel<ACT, 0>,                          \
+      (void)hipFuncSetAttribute((const void*)gemm_f32_p256_kernel<ACT, 0, CV>,                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);             \
       attr_done = true;                                                                             \
     }                                                                                               \
-    hipLaunchKernelGGL((gemm_f32_p256_kernel<ACT, 0>), pgrid, dim3(1024), plds, s, g);              \
+    hipLaunchKernelGGL((gemm_f32_p256_kernel<ACT, 0, CV>), pgrid, dim3(1024), plds, s, g);          \
   } while (0)
-    if (d->act == ACX_ACT_QUICKGELU) ACX_P2L(1); else ACX_P2L(0);
+    if (d->amap == ACX_AMAP_CONV3X3) { if (d->act == ACX_ACT_LEAKYRELU) ACX_P2L(2, 1); else ACX_P2L(0, 1); }
+    else if (d->act == ACX_ACT_QUICKGELU) ACX_P2L(1, 0); else ACX_P2L(0, 0);
 #undef ACX_P2L
     ACX_CHECK_LAUNCH(ctx, "acx_gemm");
     return ACX_OK;

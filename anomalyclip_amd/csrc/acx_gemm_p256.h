@@ -42,7 +42,10 @@ struct P2Cursor {                                // position in this CU's unit r
 
 // RES != 0 is kept compilable (float4 residual per accumulator tile) but NOT dispatched: acx_gemm_takes_strip_stream()
 // sends problems with a residual to gemm_f32_w8_kernel (see the comment there and DESIGN.md section 4).
-template <int ACT, int RES>
+// CV != 0: A is the implicit-GEMM operand of a 3x3 convolution over the (gn, gl) token grid (power-of-two grid, cin % 32
+// == 0): K-step kt reads channels [32 (kt % (cin/32)), +32) of the row shifted by tap kt / (cin/32); taps outside the grid
+// read the caller's zero page (g.zeros) -- a per-lane DMA source address, nothing else changes.
+template <int ACT, int RES, int CV = 0>
 __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -71,12 +74,19 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
   const int dchunk1 = ((lane & 7) ^ (((drow + 8) >> 1) & 7)) * 4;
   int da0 = 0, da1 = 0, dw0 = 0, dw1 = 0, dma_kt = 0;
   bool dma_a = true;                                                      // this wave's A rows exist in the DMA cursor's tile
+  // conv: grid coordinates of this lane's two A rows (tile base row, n, l)
+  int cvr0 = 0, cvr1 = 0;                                                 // the two A rows themselves; decomposed per issue
+  const int cv_kpt = CV ? d.cin / 32 : 1;                                 // K-steps per tap
+  const int cv_shl = CV ? __builtin_ctz((unsigned)d.gl) : 0;
 #define P2_DMA_SRC()                                                                               \
   do {                                                                                             \
     const int m0_ = dc.ru * 64, n0_ = dc.col * P2_BN;                                              \
     dma_a = 16 * wave < dc.nun * 64;                                                               \
     da0 = min(m0_ + drow, d.M - 1) * d.lda + dchunk0;                                              \
     da1 = min(m0_ + drow + 8, d.M - 1) * d.lda + dchunk1;                                          \
+    if constexpr (CV != 0) {                                                                       \
+      cvr0 = min(m0_ + drow, d.M - 1); cvr1 = min(m0_ + drow + 8, d.M - 1);                        \
+    }                                                                                              \
     dw0 = min(n0_ + drow, d.N - 1) * d.ldw + dchunk0;                                              \
     dw1 = min(n0_ + drow + 8, d.N - 1) * d.ldw + dchunk1;                                          \
   } while (0)
@@ -93,8 +103,25 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
       const unsigned s_ = lds0 + (stage) * P2_STAGE_B + wave * 2048;                               \
       const int ko_ = dma_kt * 32;                                                                 \
       if (dma_a) {                                                                                 \
-        P2_DMA1((const float*)d.A + (size_t)(unsigned)(da0 + ko_), s_);                            \
-        P2_DMA1((const float*)d.A + (size_t)(unsigned)(da1 + ko_), s_ + 1024);                     \
+        if constexpr (CV != 0) {                                                                   \
+          const int tap_ = dma_kt / cv_kpt, ci_ = (dma_kt - tap_ * cv_kpt) * 32;                   \
+          const int t3_ = tap_ / 3, dn_ = t3_ - 1, dl_ = tap_ - 3 * t3_ - 1;                       \
+          const int gm_ = d.gn * d.gl - 1;                                                         \
+          const int cvb0 = cvr0 & ~gm_, cvb1 = cvr1 & ~gm_;                                        \
+          const int nA_ = ((cvr0 & gm_) >> cv_shl) + dn_, lA_ = (cvr0 & (d.gl - 1)) + dl_;         \
+          const int nB_ = ((cvr1 & gm_) >> cv_shl) + dn_, lB_ = (cvr1 & (d.gl - 1)) + dl_;         \
+          const bool okA_ = (unsigned)nA_ < (unsigned)d.gn && (unsigned)lA_ < (unsigned)d.gl;      \
+          const bool okB_ = (unsigned)nB_ < (unsigned)d.gn && (unsigned)lB_ < (unsigned)d.gl;      \
+          const float* pA_ = okA_ ? (const float*)d.A + (size_t)(cvb0 + (nA_ << cv_shl) + lA_) * d.lda + ci_ + dchunk0 \
+                                  : g.zeros + dchunk0;                                             \
+          const float* pB_ = okB_ ? (const float*)d.A + (size_t)(cvb1 + (nB_ << cv_shl) + lB_) * d.lda + ci_ + dchunk1 \
+                                  : g.zeros + dchunk1;                                             \
+          P2_DMA1(pA_, s_);                                                                        \
+          P2_DMA1(pB_, s_ + 1024);                                                                 \
+        } else {                                                                                   \
+          P2_DMA1((const float*)d.A + (size_t)(unsigned)(da0 + ko_), s_);                          \
+          P2_DMA1((const float*)d.A + (size_t)(unsigned)(da1 + ko_), s_ + 1024);                   \
+        }                                                                                          \
       }                                                                                            \
       P2_DMA1((const float*)d.W + (size_t)(unsigned)(dw0 + ko_), s_ + P2_OP_B);                    \
       P2_DMA1((const float*)d.W + (size_t)(unsigned)(dw1 + ko_), s_ + P2_OP_B + 1024);             \
@@ -207,6 +234,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
         float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};                         \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
           if constexpr (ACT == ACX_ACT_QUICKGELU) v[e] = v[e] * (1.f / (1.f + __expf(-1.702f * v[e]))); \
+          if constexpr (ACT == ACX_ACT_LEAKYRELU) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];          \
         }                                                                                          \
         float4 ov = make_float4(v[0], v[1], v[2], v[3]);                                           \
         if constexpr (RES != 0) ov = make_float4(rs[i].x + v[0], rs[i].y + v[1], rs[i].z + v[2], rs[i].w + v[3]); \
@@ -222,6 +250,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
         const int row = m0 + wm * 64 + (mi) * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);                \
         float v = ACC[r] + bias;                                                                   \
         if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));       \
+        if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;                       \
         if constexpr (RES != 0) v += d.residual[(size_t)min(row, d.M - 1) * d.ldr + colc];         \
         if (cok && row < d.M) ((float*)d.C)[(size_t)row * d.ldc + col] = v;                        \
         ACC[r] = 0.f;                                                                              \

@@ -69,6 +69,18 @@ def _splitk_workspace(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+_ZERO_PAGES: dict = {}
+
+
+def _zero_page(device) -> torch.Tensor:
+    """256 bytes of zeros per device, allocated once and never written: the padding source of the conv kernels' LDS-DMA."""
+    key = (device.type, device.index)
+    z = _ZERO_PAGES.get(key)
+    if z is None:
+        z = _ZERO_PAGES[key] = torch.zeros(64, dtype=torch.float32, device=device)
+    return z
+
+
 def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     src = src.contiguous()
     dst = torch.empty(src.shape, dtype=_BF16, device=src.device)
@@ -103,6 +115,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     d.amap, d.gn, d.gl, d.cin, d.seg = amap, gn, gl, cin, seg
     d.pos0, d.pos1 = _ptr(pos0), _ptr(pos1)
     d.a_act = a_act
+    if amap == L.AMAP_CONV3X3:
+        d.zero_page = _zero_page(a.device).data_ptr()
     d.gelu_grad_of, d.ldg = _ptr(gelu_grad_of), (gelu_grad_of.stride(0) if gelu_grad_of is not None else 0)
     ws = None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)

@@ -94,6 +94,9 @@ typedef struct acx_gemm_desc {
   /* Few-row fusions of the text tower (clip/model.py:183-185,188-230 and its dX chain).  Both need the few-row f32
    * kernel: f32 operands, identity row map, K % 256 == 0, N % 4 == 0, 16-byte aligned C / residual / gelu_grad_of;
    * ACX_E_UNSUPPORTED otherwise. */
+  const void* zero_page;  /* optional: >= 256 bytes of zeros, 16-byte aligned, caller-owned.  With it, large CONV3X3 problems
+                             (N >= 512, power-of-two grid, no residual) run on the LDS-DMA strip kernel: a tap outside the
+                             token grid is a DMA from this page */
   int32_t a_act;          /* ACX_ACT_QUICKGELU: the activation is applied to A as it is read (x_next = gelu(pre) @ W^T) */
   const float* gelu_grad_of; /* [M, ldg] saved pre-activation p: C = (A W^T + bias) * d gelu(p)/dp  (no act / residual) */
   int32_t ldg;

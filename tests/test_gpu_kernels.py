@@ -170,13 +170,16 @@ def test_gemm_f32_w8_benchmark_shapes(M, N, K, act, res):
     assert relerr(out, ref) < 2e-6 * max(1.0, K / 768) ** 0.5 * 1.5
 
 
-@pytest.mark.parametrize("cin,cout,act,res", [(256, 1024, 2, 0), (1024, 256, 0, 1)])
+@pytest.mark.parametrize("cin,cout,act,res", [(256, 1024, 2, 0), (256, 1024, 0, 0), (128, 512, 2, 0), (1024, 256, 0, 1),
+                                              (256, 1024, 0, 1)])
 def test_gemm_conv3x3_benchmark_rows(cin, cout, act, res):
     """The implicit-GEMM 3x3 convolutions of the UCF head at benchmark row counts: 33 tiles of 512 tokens = 16 896 rows
-    -> 264 / 1056 output tiles, so NO split-K: gemm_f32_w8_kernel<2,0,1> (conv1 + LeakyReLU) and <0,1,1> (conv2 +
-    residual), the kernels behind the features/s numbers (the B = 4 training test runs its convs through split-K).
-    Reference: nine shifted fp64 matmuls on the CPU."""
-    tiles, N, Lg = 33, 32, 16
+    -> 264 ... 1056 output tiles, so NO split-K.  Wide outputs without a residual (>= 1024 tiles of 128 x 128, N >= 512)
+    run on the LDS-DMA strip kernel in conv mode -- gemm_f32_p256_kernel<ACT,0,1>: taps outside the grid are DMAs from the
+    zero page, two K-steps per tap at cin = 64 ... eight at cin = 256 -- the rest on gemm_f32_w8_kernel<.,.,1> (conv2 +
+    residual, N = 256); these are the kernels behind the features/s numbers (the B = 4 training test runs its convs
+    through split-K).  Reference: nine shifted fp64 matmuls on the CPU; element-wise bound 3e-6 * sum |x||w|."""
+    tiles, N, Lg = (66 if cout == 512 else 33), 32, 16
     M = tiles * N * Lg
     assert ((M + 127) // 128) * ((cout + 127) // 128) > 256
     g = torch.Generator().manual_seed(cin + act)
@@ -186,9 +189,11 @@ def test_gemm_conv3x3_benchmark_rows(cin, cout, act, res):
     r = torch.randn(M, cout, generator=g) if res else None
     xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1))            # zero halo on the (N, L) grid
     ref = b.double().expand(M, cout).clone()
+    mag = b.double().abs().expand(M, cout).clone()
     for kh in range(3):
         for kw in range(3):
             ref += xp[:, kh:kh + N, kw:kw + Lg, :].reshape(M, cin) @ w[:, :, kh, kw].double().t()
+            mag += xp[:, kh:kh + N, kw:kw + Lg, :].reshape(M, cin).abs() @ w[:, :, kh, kw].double().abs().t()
     if act == 2:
         ref = torch.nn.functional.leaky_relu(ref, 0.01)
     if res:
@@ -197,6 +202,7 @@ def test_gemm_conv3x3_benchmark_rows(cin, cout, act, res):
     out = ops.gemm(x.reshape(-1, cin).to(DEV), wk.to(DEV), bias=b.to(DEV), act=act, residual=r.to(DEV) if res else None,
                    amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=cin)
     assert relerr(out, ref) < 3e-6
+    assert bool(((out.cpu().double() - ref).abs() <= 3e-6 * (mag + (r.double().abs() if res else 0))).all())
 
 
 @pytest.mark.parametrize("M,N,K,act,res,obf", [(20011, 320, 768, 0, 0, 0), (33000, 256, 128, 1, 1, 0),
