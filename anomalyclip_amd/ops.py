@@ -123,8 +123,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     few_rows = ((M <= SK_MAX_ROWS or (N <= 512 and M <= 4 * SK_MAX_ROWS)) and K % 256 == 0 and prec == L.PREC_F32
                 and amap == L.AMAP_IDENTITY and a_sub is None and pos0 is None
                 and act != L.ACT_LEAKYRELU)                                   # acx_gemm takes the few-row kernel: no split-K
-    if (tiles <= 128 and K >= 256 and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and a_sub is None and pos0 is None
-            and not few_rows):
+    # split-K candidates: <= 128 output tiles, or up to 256 with a long K (the convolutions of a data-parallel rank's 4096
+    # rows: 256 tiles = ONE 8-wave block per CU; two K halves put two blocks on every CU for the price of a 12 us reduce)
+    if ((tiles <= 128 and K >= 256 or tiles <= 256 and K >= 1024) and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3)
+            and a_sub is None and pos0 is None and not few_rows):
         ws = _splitk_workspace(a.device, min(16, 512 // tiles) * M * N * 4)     # skinny problem: let the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a)
