@@ -13,3 +13,6 @@ ls $OUT/*
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xd -o xd -- python /root/repo/tools/bench_xd.py --steps 4 > $OUT/xd.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dp8 -o dp8 -- python /root/repo/tools/bench_head.py --emulate-world 8 --text-graph --temporal-graph --steps 6 > $OUT/dp8.log 2>&1
 find $OUT -name "*_kernel_trace.csv" | xargs rm -f
+# round 3: rank 0's share of a 2-rank step as well
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dp2 -o dp2 -- python /root/repo/tools/bench_head.py --emulate-world 2 --text-graph --temporal-graph --steps 6 > $OUT/dp2.log 2>&1
+find $OUT -name "*_kernel_trace.csv" | xargs rm -f

@@ -12,6 +12,13 @@ python tools/bench_head.py --steps 10 > $OUT/bench_head_eager.json 2>/dev/null
 for n in 2 4 8; do python tools/bench_head.py --steps 10 --emulate-world $n --text-graph --temporal-graph > $OUT/bench_head_emulated_world$n.json 2>/dev/null; done
 python tools/bench_head.py --steps 10 --emulate-world 8 > $OUT/bench_head_emulated_world8_eager.json 2>/dev/null
 python tools/bench_xd.py --steps 6 > $OUT/bench_xd_bf16.json 2>/dev/null
+python tools/bench_metrics.py > $OUT/bench_metrics.txt 2>&1
+python tools/gemm_bench.py --frames 512 --epi 1 > $OUT/gemm_f32.txt 2>&1
+python tools/gemm_bench.py --frames 512 --epi 1 --prec bf16 > $OUT/gemm_bf16.txt 2>&1
+python tools/conv_bench.py > $OUT/conv_bench.txt 2>&1
+python tools/attn_bench.py > $OUT/attn.txt 2>&1
+python tools/attn_bf16_bench.py >> $OUT/attn.txt 2>&1
+python tools/probes/selector_bench.py > $OUT/selector_bench.txt 2>&1
 python tools/text_gemm_bench.py > $OUT/text_gemm.txt 2>&1
 python tools/tn_bench.py > $OUT/tn_bench.txt 2>&1
 ACX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_gloo2_smoke.json 2> $OUT/bench_gloo2_smoke.err
