@@ -212,6 +212,148 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
   }
 }
 
+// LDS-DMA variant of the kernel above (D % 64 == 0, up to two column tiles): the A fragment of the 16x16x4 MFMA gives a
+// row only FOUR lanes, so a direct global_load_dwordx4 covers 64 B of each of 16 rows -- every 128-B line is touched by two
+// instructions and the kernel sits at 6.2 B/clk/CU of half-line accesses against the ~10 B/clk a CU's vector-memory path
+// sustains (3.9 TB/s).  Here a wave streams its 16-row groups through a private LDS ring instead: a K chunk is 64 floats
+// (256 B per row), one global_load_lds_dwordx4 moves 4 rows x 256 B (sixteen lanes per row: full lines), the 16-B slot of
+// row r holding source chunk (slot ^ r) so that the fragment reads (ds_read_b128, 16 rows x one slot) are conflict-free;
+// two 4 KB stages per wave, the chunks of consecutive groups form one stream (the next group's first chunks are in flight
+// during the stores), one workgroup of eight waves per CU.
+typedef __attribute__((address_space(3))) void selm_lds_t;
+template <int D, int NT, bool STATS>
+__global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* __restrict__ x, const float* __restrict__ nc,
+                                                                   const float* __restrict__ dirs, float* __restrict__ raw,
+                                                                   int64_t rows, int C1, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int LD = D + 4;
+  constexpr int NCK = D / 64;                    // 64-float chunks per row
+  char* ring = smem;                             // [8 waves][2 stages][16 rows][256 B]
+  float* sd = reinterpret_cast<float*>(smem + 8 * 2 * 4096);   // [16*NT][LD]
+  float* sc = sd + 16 * NT * LD;                 // [D]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, q = lane >> 4;
+  const int64_t ngroups = (rows + 15) >> 4;
+  const int64_t gstride = (int64_t)gridDim.x * 8;
+  const int64_t grp0 = (int64_t)blockIdx.x * 8 + wave;
+  const int64_t mygroups = grp0 < ngroups ? (ngroups - grp0 + gstride - 1) / gstride : 0;
+  const int64_t S = mygroups * NCK;              // this wave's chunk stream
+  const unsigned ring0 = (unsigned)(uintptr_t)(selm_lds_t*)ring + wave * 8192;
+  const int drow = lane >> 4, dpos = lane & 15;  // DMA: instruction i moves rows 4 i .. 4 i + 3; lane -> (row, 16-B slot)
+#define SELD_DMA1(gptr, ldsaddr)                                                                   \
+  do {                                                                                             \
+    unsigned keep_;                                                                                \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(gptr), "s"(ldsaddr) : "memory");                             \
+  } while (0)
+#define SELD_ISSUE(s_)                                                                             \
+  do {                                                                                             \
+    const int64_t g_ = grp0 + ((s_) / NCK) * gstride;                                              \
+    const int ck_ = (int)((s_) % NCK);                                                             \
+    const unsigned st_ = ring0 + (unsigned)((s_) & 1) * 4096;                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+      const int r_ = 4 * i + drow;                                                                 \
+      int64_t row_ = g_ * 16 + r_;                                                                 \
+      if (row_ >= rows) row_ = rows - 1;                                                           \
+      SELD_DMA1(x + row_ * D + 64 * ck_ + 4 * (dpos ^ r_), st_ + i * 1024);                        \
+    }                                                                                              \
+  } while (0)
+  if (S > 0) SELD_ISSUE((int64_t)0);
+  if (S > 1) SELD_ISSUE((int64_t)1);
+  // directions / centroid staged while the first chunks are in flight
+  for (int i = threadIdx.x; i < 16 * NT * (D / 4); i += 512) {
+    const int r = i / (D / 4), k4 = i - r * (D / 4);
+    const float4 v = r < C1 ? reinterpret_cast<const float4*>(dirs + (size_t)r * D)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(sd + r * LD + 4 * k4) = v;
+  }
+  for (int i = threadIdx.x; i < D / 4; i += 512) reinterpret_cast<float4*>(sc)[i] = reinterpret_cast<const float4*>(nc)[i];
+  __syncthreads();
+  double s_[NT], q_[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { s_[t] = 0.0; q_[t] = 0.0; }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* myring = ring + wave * 8192 + li * 256;
+  for (int64_t s = 0; s < S; ++s) {
+    if (s + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // chunk s landed; chunk s + 1 may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ck = (int)(s % NCK);
+    const char* st = myring + (s & 1) * 4096;
+    float4 xa[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) xa[j][h] = *reinterpret_cast<const float4*>(st + (((8 * j + 2 * q + h) ^ li) * 16));
+    // the stage is in registers: refill it -- at a group end AFTER the group's stores (gfx9 stores count in vmcnt: issued
+    // behind the next DMA they would make the next counted wait cover that DMA too)
+    const bool last = ck == NCK - 1;
+    if (!last && s + 2 < S) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SELD_ISSUE(s + 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k0 = 64 * ck + 32 * j + 8 * q + 4 * h;
+        const float4 c4 = *reinterpret_cast<const float4*>(sc + k0);
+        const float4 a4 = make_float4(xa[j][h].x - c4.x, xa[j][h].y - c4.y, xa[j][h].z - c4.z, xa[j][h].w - c4.w);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 b4 = *reinterpret_cast<const float4*>(sd + (16 * t + li) * LD + k0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (last) {                                                        // group complete: store, restart the accumulators
+      const int64_t grp = grp0 + (s / NCK) * gstride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t rr = grp * 16 + 4 * q + r;
+        if (rr < rows) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int c = 16 * t + li;
+            if (c < C1) raw[rr * C1 + c] = acc[t][r];
+            if constexpr (STATS) { s_[t] += (double)acc[t][r]; q_[t] += (double)acc[t][r] * (double)acc[t][r]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (s + 2 < S) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SELD_ISSUE(s + 2);
+      }
+    }
+  }
+#undef SELD_ISSUE
+#undef SELD_DMA1
+  if constexpr (STATS) {
+    __syncthreads();                                                   // ring / directions no longer needed: reuse LDS
+    double* red = reinterpret_cast<double*>(smem);                     // [8 waves][2][16*NT]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double sv = s_[t], qq = q_[t];
+      sv += __shfl_xor(sv, 16, 64);  qq += __shfl_xor(qq, 16, 64);
+      sv += __shfl_xor(sv, 32, 64);  qq += __shfl_xor(qq, 32, 64);
+      if (q == 0) { red[(wave * 2 + 0) * 16 * NT + 16 * t + li] = sv; red[(wave * 2 + 1) * 16 * NT + 16 * t + li] = qq; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * 16 * NT) {
+      const int k = threadIdx.x / (16 * NT), c = threadIdx.x - k * 16 * NT;
+      double v = 0.0;
+      for (int w = 0; w < 8; ++w) v += red[(w * 2 + k) * 16 * NT + c];
+      part[(size_t)blockIdx.x * 2 * 16 * NT + threadIdx.x] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ batch-norm statistics (two stages, fixed order)
 // stage 1: block b owns a contiguous slab of rows; thread (c = t % C1, rl = t / C1) walks rows rl, rl + RL, ... of the slab
 // (consecutive threads read consecutive addresses), f64 sums of x and x^2 (K2 = 0) or of dl and dl * xhat (K2 = 1);
@@ -538,6 +680,38 @@ static bool launch_selector_mfma(const float* x, const float* nc, const float* d
   const int NT = (C1 + 15) / 16;
   const size_t lds = ((size_t)16 * NT * (D + 4) + D) * 4;
   if ((D != 64 && D != 128 && D != 256 && D != 512 && D != 768 && D != 1024) || lds > 160 * 1024) return false;
+  // LDS-DMA variant: one 8-wave workgroup per CU streaming full 128-B lines (64 KB of per-wave rings + the directions)
+  const size_t lds_dma = 8 * 2 * 4096 + lds;
+  if (NT <= 2 && (D == 512 || D == 256 || D == 128 || D == 1024 || D == 768) && lds_dma <= 160 * 1024 && rows >= 256) {
+    const int64_t ng = (rows + 15) / 16;
+    int64_t nbd = (ng + 7) / 8;
+    if (nbd > ncu) nbd = ncu;
+    *nblocks = (int)nbd;
+    const dim3 dgrid((unsigned)nbd), dblock(512);
+#define ACX_SELDMA(DD, N_)                                                                                                \
+  do {                                                                                                                    \
+    if (part) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)selector_project_dma_kernel<DD, N_, true>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);                                \
+      hipLaunchKernelGGL((selector_project_dma_kernel<DD, N_, true>), dgrid, dblock, lds_dma, s, x, nc, dirs, raw, rows, C1, part); \
+    } else {                                                                                                              \
+      (void)hipFuncSetAttribute((const void*)selector_project_dma_kernel<DD, N_, false>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);                                \
+      hipLaunchKernelGGL((selector_project_dma_kernel<DD, N_, false>), dgrid, dblock, lds_dma, s, x, nc, dirs, raw, rows, C1, part); \
+    }                                                                                                                     \
+  } while (0)
+#define ACX_SELDMA_D(DD) do { if (NT == 1) ACX_SELDMA(DD, 1); else ACX_SELDMA(DD, 2); } while (0)
+    switch (D) {
+      case 128: ACX_SELDMA_D(128); break;
+      case 256: ACX_SELDMA_D(256); break;
+      case 512: ACX_SELDMA_D(512); break;
+      case 768: ACX_SELDMA_D(768); break;
+      default: ACX_SELDMA_D(1024); break;
+    }
+#undef ACX_SELDMA_D
+#undef ACX_SELDMA
+    return true;
+  }
   const int64_t ngroups = (rows + 15) / 16;
   int64_t nb = (ngroups + 3) / 4;
   const int64_t cap = 2 * (int64_t)ncu;                                 // two resident blocks per CU
