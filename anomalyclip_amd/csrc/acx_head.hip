@@ -218,9 +218,10 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
 // sustains (3.9 TB/s).  Here a wave streams its 16-row groups through a private LDS ring instead: a K chunk is 64 floats
 // (256 B per row), one global_load_lds_dwordx4 moves 4 rows x 256 B (sixteen lanes per row: full lines), the 16-B slot of
 // row r holding source chunk (slot ^ r) so that the fragment reads (ds_read_b128, 16 rows x one slot) are conflict-free;
-// two 4 KB stages per wave, the chunks of consecutive groups form one stream (the next group's first chunks are in flight
+// three 4 KB stages per wave, the chunks of consecutive groups form one stream (the next group's first chunks are in flight
 // during the stores), one workgroup of eight waves per CU.
 typedef __attribute__((address_space(3))) void selm_lds_t;
+constexpr int SELD_ST = 3;                      // ring stages per wave (12 KB: two chunks in flight behind the one being consumed)
 template <int D, int NT, bool STATS>
 __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* __restrict__ x, const float* __restrict__ nc,
                                                                    const float* __restrict__ dirs, float* __restrict__ raw,
@@ -228,8 +229,8 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int LD = D + 4;
   constexpr int NCK = D / 64;                    // 64-float chunks per row
-  char* ring = smem;                             // [8 waves][2 stages][16 rows][256 B]
-  float* sd = reinterpret_cast<float*>(smem + 8 * 2 * 4096);   // [16*NT][LD]
+  char* ring = smem;                             // [8 waves][SELD_ST stages][16 rows][256 B]
+  float* sd = reinterpret_cast<float*>(smem + 8 * SELD_ST * 4096);   // [16*NT][LD]
   float* sc = sd + 16 * NT * LD;                 // [D]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
   const int64_t grp0 = (int64_t)blockIdx.x * 8 + wave;
   const int64_t mygroups = grp0 < ngroups ? (ngroups - grp0 + gstride - 1) / gstride : 0;
   const int64_t S = mygroups * NCK;              // this wave's chunk stream
-  const unsigned ring0 = (unsigned)(uintptr_t)(selm_lds_t*)ring + wave * 8192;
+  const unsigned ring0 = (unsigned)(uintptr_t)(selm_lds_t*)ring + wave * (SELD_ST * 4096);
   const int drow = lane >> 4, dpos = lane & 15;  // DMA: instruction i moves rows 4 i .. 4 i + 3; lane -> (row, 16-B slot)
 #define SELD_DMA1(gptr, ldsaddr)                                                                   \
   do {                                                                                             \
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
   do {                                                                                             \
     const int64_t g_ = grp0 + ((s_) / NCK) * gstride;                                              \
     const int ck_ = (int)((s_) % NCK);                                                             \
-    const unsigned st_ = ring0 + (unsigned)((s_) & 1) * 4096;                                      \
+    const unsigned st_ = ring0 + (unsigned)((s_) % SELD_ST) * 4096;                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
       const int r_ = 4 * i + drow;                                                                 \
       int64_t row_ = g_ * 16 + r_;                                                                 \
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
   } while (0)
   if (S > 0) SELD_ISSUE((int64_t)0);
   if (S > 1) SELD_ISSUE((int64_t)1);
+  if (S > 2) SELD_ISSUE((int64_t)2);
   // directions / centroid staged while the first chunks are in flight
   for (int i = threadIdx.x; i < 16 * NT * (D / 4); i += 512) {
     const int r = i / (D / 4), k4 = i - r * (D / 4);
@@ -275,12 +277,13 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const char* myring = ring + wave * 8192 + li * 256;
+  const char* myring = ring + wave * (SELD_ST * 4096) + li * 256;
   for (int64_t s = 0; s < S; ++s) {
-    if (s + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // chunk s landed; chunk s + 1 may be in flight
+    if (s + 2 < S) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // chunk s landed; chunks s + 1, s + 2 may be in flight
+    else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ck = (int)(s % NCK);
-    const char* st = myring + (s & 1) * 4096;
+    const char* st = myring + (s % SELD_ST) * 4096;
     float4 xa[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -289,9 +292,9 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
     // the stage is in registers: refill it -- at a group end AFTER the group's stores (gfx9 stores count in vmcnt: issued
     // behind the next DMA they would make the next counted wait cover that DMA too)
     const bool last = ck == NCK - 1;
-    if (!last && s + 2 < S) {
+    if (!last && s + SELD_ST < S) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      SELD_ISSUE(s + 2);
+      SELD_ISSUE(s + SELD_ST);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -326,9 +329,9 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (s + 2 < S) {
+      if (s + SELD_ST < S) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SELD_ISSUE(s + 2);
+        SELD_ISSUE(s + SELD_ST);
       }
     }
   }
@@ -680,8 +683,8 @@ static bool launch_selector_mfma(const float* x, const float* nc, const float* d
   const int NT = (C1 + 15) / 16;
   const size_t lds = ((size_t)16 * NT * (D + 4) + D) * 4;
   if ((D != 64 && D != 128 && D != 256 && D != 512 && D != 768 && D != 1024) || lds > 160 * 1024) return false;
-  // LDS-DMA variant: one 8-wave workgroup per CU streaming full 128-B lines (64 KB of per-wave rings + the directions)
-  const size_t lds_dma = 8 * 2 * 4096 + lds;
+  // LDS-DMA variant: one 8-wave workgroup per CU streaming full 128-B lines (96 KB of per-wave rings + the directions)
+  const size_t lds_dma = 8 * SELD_ST * 4096 + lds;
   if (NT <= 2 && (D == 512 || D == 256 || D == 128 || D == 1024 || D == 768) && lds_dma <= 160 * 1024 && rows >= 256) {
     const int64_t ng = (rows + 15) / 16;
     int64_t nbd = (ng + 7) / 8;
