@@ -713,7 +713,7 @@ def main():
             traffic, pmc_src = live_pmc_traffic(args.vit_chunk)
             if traffic is None:
                 pmc_src = None
-        for tag in (("r02", "r01") if traffic is None else ()):
+        for tag in (("r03", "r02", "r01") if traffic is None else ()):
             pmc_file = os.path.join(REPO, "profiles", f"{tag}_bench_f32_pmc.json")
             if args.precision == "f32" and args.vit_chunk == 512 and os.path.exists(pmc_file):
                 try:

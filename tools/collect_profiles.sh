@@ -1,0 +1,33 @@
+#!/bin/bash
+# Copies what tools/refresh_profiles.sh left under gpurun_out/ into profiles/<tag>_* (run in the development container after
+# the gpurun call merged its outputs back).  usage: tools/collect_profiles.sh [tag]   (default r03)
+set -e
+TAG=${1:-r03}
+R=$(cd "$(dirname "$0")/.." && pwd)
+G=$R/gpurun_out
+P=$R/profiles
+cd $R
+cp $G/refresh/bench_f32.json $P/${TAG}_bench_f32.json
+cp $G/refresh/bench_bf16.json $P/${TAG}_bench_bf16.json
+cp $G/refresh/bench_head.json $P/${TAG}_bench_head.json
+cp $G/refresh/bench_head_eager.json $P/${TAG}_bench_head_eager.json
+for n in 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_bench_head_emulated_world$n.json; done
+cp $G/refresh/bench_head_emulated_world8_eager.json $P/${TAG}_bench_head_emulated_world8_eager.json
+cp $G/refresh/bench_xd_bf16.json $P/${TAG}_bench_xd_bf16.json
+cp $G/refresh/bench_gloo2_smoke.json $P/${TAG}_bench_gloo2_smoke.json
+cp $G/refresh/bench_metrics.txt $P/${TAG}_bench_metrics.txt
+{ echo "# tools/gemm_bench.py --frames 512 --epi 1 (f32)"; grep -v amdgpu.ids $G/refresh/gemm_f32.txt;
+  echo "# tools/gemm_bench.py --frames 512 --epi 1 --prec bf16"; grep -v amdgpu.ids $G/refresh/gemm_bf16.txt;
+  echo "# tools/conv_bench.py"; grep -v amdgpu.ids $G/refresh/conv_bench.txt;
+  echo "# tools/tn_bench.py"; grep -v amdgpu.ids $G/refresh/tn_bench.txt;
+  echo "# tools/attn_bench.py, tools/attn_bf16_bench.py"; grep -v amdgpu.ids $G/refresh/attn.txt;
+  echo "# tools/probes/selector_bench.py"; grep -v amdgpu.ids $G/refresh/selector_bench.txt; } > $P/${TAG}_kernel_microbench.txt
+grep -v amdgpu.ids $G/refresh/text_gemm.txt > $P/${TAG}_text_gemm.txt
+python tools/summarize_pmc.py gpurun_out/prof_bench $TAG f32 > /dev/null
+python tools/summarize_pmc.py gpurun_out/prof_bench_bf16 $TAG bf16 > /dev/null
+cp $G/prof_extra/train/t_kernel_stats.csv $P/${TAG}_train_step_kernel_stats.csv
+cp $G/prof_extra/dp8/dp8_kernel_stats.csv $P/${TAG}_dp8_rank_share_kernel_stats.csv
+cp $G/prof_extra/dp2/dp2_kernel_stats.csv $P/${TAG}_dp2_rank_share_kernel_stats.csv
+cp $G/prof_extra/xd/xd_kernel_stats.csv $P/${TAG}_xd_bf16_kernel_stats.csv
+cp $G/prof_extra/metrics/m_kernel_stats.csv $P/${TAG}_metrics_epilogue_kernel_stats.csv
+ls -la $P/${TAG}_*
