@@ -4,6 +4,7 @@ no-fallback rule.  No kernel is launched here."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -380,6 +381,31 @@ def test_compat_install_resolves_every_reference_target():
     finally:
         compat.uninstall()
     assert {k for k in sys.modules if k == "src" or k.startswith("src.")} == before
+
+
+def test_bench_gpus_n_self_launches_under_torchrun(monkeypatch):
+    """`python bench.py --gpus N` typed as such (no WORLD_SIZE in the environment) becomes the launcher: the same argv under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_trainer_cycles_the_shorter_train_loader():
