@@ -646,6 +646,173 @@ __global__ __launch_bounds__(512) void seq_attn_bwd_block_kernel(const float* __
   }
 }
 
+// Axial attention backward on the f32 MFMA (temporal model: sequences of T = 32 segments or T = 16 frames, head dim 32 or 16,
+// thousands of independent (line, head) groups per launch; seq_attn_bwd_kernel above spends 145 us per launch on the VALU).
+// One WAVE per group, four groups per workgroup, grid-stride; q, k, v, dO of the group in a wave-private LDS slice (rows
+// padded by 4 floats).  Two passes, so that every register tile is consumed in the layout the MFMA leaves it in:
+//   pass 1  S^T = K Q^T and dP^T = V dO^T (lane = query column): softmax statistics are in-lane sums + two cross-quarter
+//           shuffles; dS^T tiles are the A operand of dQ = dS K as they stand (A[i][j] = dS^T[j][i]: lane & 15 = i,
+//           MFMA step r <-> key j = 4 kq + r);
+//   pass 2  S = Q K^T and dP = dO V^T (lane = key column) with the row statistics read back from LDS: the P and dS tiles are
+//           the A operand of dV = P^T dO and dK = dS^T Q as they stand.
+// 224 MFMAs of 16x16x4 per (T = 32, E = 32) group; exact f32 products, fixed summation order.
+template <int T, int E>
+__global__ __launch_bounds__(256) void axial_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                  float* __restrict__ dqkv, int gn, int gl, int heads, int axis,
+                                                                  float scale, int64_t ngroups) {
+  constexpr int ES = E + 4;                      // LDS row stride (floats)
+  constexpr int TT = T / 16, ET = E / 16, KS = E / 16;
+  constexpr int WF = 4 * T * ES + 4 * T;          // floats per wave: Q, K, V, dO, stats (m, inv, D, pad)
+  extern __shared__ __attribute__((aligned(16))) char smem_ax[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  float* sQ = reinterpret_cast<float*>(smem_ax) + wave * WF;
+  float* sK = sQ + T * ES;
+  float* sV = sK + T * ES;
+  float* sO = sV + T * ES;
+  float* sS = sO + T * ES;                        // [3][T]
+  const int He = heads * E, ld = 3 * He;
+  const int other = axis == 0 ? gl : gn;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t line = grp / heads;
+    const int h = (int)(grp - line * heads);
+    const int64_t tile = line / other;
+    const int o = (int)(line - tile * other);
+    // row of sequence element t: axis 0 walks n (stride gl rows), axis 1 walks l (stride 1)
+    const int64_t row0 = axis == 0 ? tile * gn * gl + o : (tile * gn + o) * gl;
+    const int64_t rstep = axis == 0 ? gl : 1;
+    // ---- stage the group (float4 per lane, E/4 lanes per row)
+#pragma unroll
+    for (int idx = lane; idx < T * (E / 4); idx += 64) {
+      const int t = idx / (E / 4), c4 = idx - t * (E / 4);
+      const int64_t r = row0 + t * rstep;
+      const float* p = qkv + r * ld + h * E + 4 * c4;
+      *reinterpret_cast<float4*>(sQ + t * ES + 4 * c4) = *reinterpret_cast<const float4*>(p);
+      *reinterpret_cast<float4*>(sK + t * ES + 4 * c4) = *reinterpret_cast<const float4*>(p + He);
+      *reinterpret_cast<float4*>(sV + t * ES + 4 * c4) = *reinterpret_cast<const float4*>(p + 2 * He);
+      *reinterpret_cast<float4*>(sO + t * ES + 4 * c4) = *reinterpret_cast<const float4*>(dout + r * He + h * E + 4 * c4);
+    }
+    // (wave-private LDS: the wave's own ds_write -> ds_read order is enough, no workgroup barrier)
+    // ---- pass 1: transposed scores, lane column = query i
+    f32x4 st[TT][TT], dt[TT][TT];                 // [jt][it]
+#pragma unroll
+    for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+      for (int it = 0; it < TT; ++it) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 k4 = *reinterpret_cast<const float4*>(sK + (16 * jt + li) * ES + 16 * ks + 4 * kq);
+          const float4 q4 = *reinterpret_cast<const float4*>(sQ + (16 * it + li) * ES + 16 * ks + 4 * kq);
+          const float4 v4 = *reinterpret_cast<const float4*>(sV + (16 * jt + li) * ES + 16 * ks + 4 * kq);
+          const float4 o4 = *reinterpret_cast<const float4*>(sO + (16 * it + li) * ES + 16 * ks + 4 * kq);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.x, q4.x, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.x, o4.x, b, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.y, q4.y, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.y, o4.y, b, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.z, q4.z, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.z, o4.z, b, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.w, q4.w, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.w, o4.w, b, 0, 0, 0);
+        }
+        st[jt][it] = a; dt[jt][it] = b;
+      }
+#pragma unroll
+    for (int it = 0; it < TT; ++it) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[jt][it][r] *= scale; mx = fmaxf(mx, st[jt][it][r]); }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[jt][it][r] = __expf(st[jt][it][r] - mx); sum += st[jt][it][r]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      float Di = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[jt][it][r] *= inv; Di += st[jt][it][r] * dt[jt][it][r]; }
+      Di += __shfl_xor(Di, 16, 64);
+      Di += __shfl_xor(Di, 32, 64);
+#pragma unroll
+      for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dt[jt][it][r] = st[jt][it][r] * (dt[jt][it][r] - Di) * scale;     // dS^T
+      if (kq == 0) { sS[16 * it + li] = mx; sS[T + 16 * it + li] = inv; sS[2 * T + 16 * it + li] = Di; }
+      // dQ rows of this query tile: A = dS^T tiles as they stand, B = K[j][e]
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dt[jt][it][r], sK[(16 * jt + 4 * kq + r) * ES + 16 * et + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dqkv[(row0 + (16 * it + 4 * kq + r) * rstep) * ld + h * E + 16 * et + li] = acc[r];
+      }
+    }
+    // ---- pass 2: scores with lane column = key j; row statistics from LDS
+#pragma unroll
+    for (int jt = 0; jt < TT; ++jt) {
+      f32x4 pt[TT], gt[TT];                        // [it]: P and dS tiles (rows i, column j)
+#pragma unroll
+      for (int it = 0; it < TT; ++it) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 q4 = *reinterpret_cast<const float4*>(sQ + (16 * it + li) * ES + 16 * ks + 4 * kq);
+          const float4 k4 = *reinterpret_cast<const float4*>(sK + (16 * jt + li) * ES + 16 * ks + 4 * kq);
+          const float4 o4 = *reinterpret_cast<const float4*>(sO + (16 * it + li) * ES + 16 * ks + 4 * kq);
+          const float4 v4 = *reinterpret_cast<const float4*>(sV + (16 * jt + li) * ES + 16 * ks + 4 * kq);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x, k4.x, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.x, v4.x, b, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y, k4.y, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.y, v4.y, b, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z, k4.z, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.z, v4.z, b, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w, k4.w, a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.w, v4.w, b, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * it + 4 * kq + r;
+          const float p = __expf(a[r] * scale - sS[i]) * sS[T + i];
+          a[r] = p;
+          b[r] = p * (b[r] - sS[2 * T + i]) * scale;
+        }
+        pt[it] = a; gt[it] = b;
+      }
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = dk;
+#pragma unroll
+        for (int it = 0; it < TT; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * kq + r;
+            dk = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[it][r], sQ[i * ES + 16 * et + li], dk, 0, 0, 0);
+            dv = __builtin_amdgcn_mfma_f32_16x16x4f32(pt[it][r], sO[i * ES + 16 * et + li], dv, 0, 0, 0);
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* dst = dqkv + (row0 + (16 * jt + 4 * kq + r) * rstep) * ld + h * E + 16 * et + li;
+          dst[He] = dk[r];
+          dst[2 * He] = dv[r];
+        }
+      }
+    }
+  }
+}
+
 // Text-tower attention backward on the f32 MFMA (T <= 80 tokens, head dim 64; CLIP's context length is 77).
 // seq_attn_bwd_block_kernel above spends 85 us per launch on 16 workgroups at two classes per GPU -- one FMA per lane per
 // (query, key, channel) on the VALU -- 12 times per step.  The five products of the backward are small GEMMs:
@@ -1387,6 +1554,28 @@ extern "C" int acx_seq_attention_bwd(acx_ctx* ctx, const float* qkv, const float
       else hipLaunchKernelGGL((seq_attn_bwd_rows_kernel<64, 4>), grid2, block2, 0, s2, qkv, dout, dqkv, stats_ws, T, heads, causal, scale2, pass, nrows);
     }
     ACX_CHECK_LAUNCH(ctx, "acx_seq_attention_bwd(rows)");
+    return ACX_OK;
+  }
+  if (!causal && (T == 16 || T == 32) && (e == 16 || e == 32) && ACX_DBG_SWITCH("AXB_MFMA", true)) {
+    // axial attention of the temporal model: one wave per (line, head) group on the f32 MFMA
+    const int64_t ngroups_m = (int64_t)tiles * (axis == 0 ? gl : gn) * heads;
+    hipStream_t sm = (hipStream_t)stream;
+    AcxProfScope profm__(ctx, ACX_K_ATTN, sm);
+    const float scale_m = 1.f / sqrtf((float)e);
+    const size_t lds_m = (size_t)4 * (4 * T * (e + 4) + 4 * T) * sizeof(float);
+    int64_t nbm = (ngroups_m + 3) / 4;
+    const int64_t capm = 2 * (int64_t)(ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256);
+    if (nbm > capm) nbm = capm;
+#define ACX_AXB(TT_, EE_)                                                                                    \
+  do {                                                                                                       \
+    (void)hipFuncSetAttribute((const void*)axial_attn_bwd_mfma_kernel<TT_, EE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m); \
+    hipLaunchKernelGGL((axial_attn_bwd_mfma_kernel<TT_, EE_>), dim3((unsigned)nbm), dim3(256), lds_m, sm, qkv, dout, dqkv, gn, gl, heads, \
+                       axis, scale_m, ngroups_m);                                                            \
+  } while (0)
+    if (T == 32) { if (e == 32) ACX_AXB(32, 32); else ACX_AXB(32, 16); }
+    else { if (e == 32) ACX_AXB(16, 32); else ACX_AXB(16, 16); }
+#undef ACX_AXB
+    ACX_CHECK_LAUNCH(ctx, "acx_seq_attention_bwd(axial mfma)");
     return ACX_OK;
   }
   if (T <= 0 || T > 256 || (e != 16 && e != 32 && e != 64))
