@@ -881,12 +881,115 @@ extern "C" int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean
   return ACX_OK;
 }
 
+// Axial attention forward on the f32 MFMA: one wave per (line, head) group, q / k / v in a wave-private LDS slice.
+// S^T = K Q^T puts a lane's QUERY in the MFMA column, so the softmax is in-lane sums + two cross-quarter shuffles and
+// the P^T tiles are the B operand of O^T = V^T P^T as they stand (B[k = j][n = i]: lane & 15 = i, MFMA step r <-> key
+// j = 4 kq + r); a lane ends with four contiguous output channels of one query (one 16-byte store).  The thread-per-query
+// kernel above (51 / 41 us per launch at 64 videos) keeps the shapes this one does not cover.
+template <int T, int E>
+__global__ __launch_bounds__(256) void axial_attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int gn,
+                                                                  int gl, int heads, int axis, float scale, int64_t ngroups) {
+  constexpr int ES = E + 4;
+  constexpr int TT = T / 16, ET = E / 16, KS = E / 16;
+  constexpr int WF = 3 * T * ES;
+  extern __shared__ __attribute__((aligned(16))) char smem_af[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  float* sQ = reinterpret_cast<float*>(smem_af) + wave * WF;
+  float* sK = sQ + T * ES;
+  float* sV = sK + T * ES;
+  const int He = heads * E, ld = 3 * He;
+  const int other = axis == 0 ? gl : gn;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t line = grp / heads;
+    const int h = (int)(grp - line * heads);
+    const int64_t tile = line / other;
+    const int o = (int)(line - tile * other);
+    const int64_t row0 = axis == 0 ? tile * gn * gl + o : (tile * gn + o) * gl;
+    const int64_t rstep = axis == 0 ? gl : 1;
+#pragma unroll
+    for (int idx = lane; idx < T * (E / 4); idx += 64) {
+      const int t = idx / (E / 4), c4 = idx - t * (E / 4);
+      const float* p = qkv + (row0 + t * rstep) * ld + h * E + 4 * c4;
+      *reinterpret_cast<float4*>(sQ + t * ES + 4 * c4) = *reinterpret_cast<const float4*>(p);
+      *reinterpret_cast<float4*>(sK + t * ES + 4 * c4) = *reinterpret_cast<const float4*>(p + He);
+      *reinterpret_cast<float4*>(sV + t * ES + 4 * c4) = *reinterpret_cast<const float4*>(p + 2 * He);
+    }
+#pragma unroll
+    for (int it = 0; it < TT; ++it) {
+      f32x4 st[TT];                                // [jt]: S^T tiles of query tile it (rows j, column i)
+#pragma unroll
+      for (int jt = 0; jt < TT; ++jt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 k4 = *reinterpret_cast<const float4*>(sK + (16 * jt + li) * ES + 16 * ks + 4 * kq);
+          const float4 q4 = *reinterpret_cast<const float4*>(sQ + (16 * it + li) * ES + 16 * ks + 4 * kq);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.x, q4.x, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.y, q4.y, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.z, q4.z, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.w, q4.w, a, 0, 0, 0);
+        }
+        st[jt] = a;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[jt][r] *= scale; mx = fmaxf(mx, st[jt][r]); }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[jt][r] = __expf(st[jt][r] - mx); sum += st[jt][r]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      // O^T[e][i] = sum_j V[j][e] P^T[j][i]: A = V^T (lane & 15 = e, step r <-> j = 4 kq + r), B = the P^T tiles
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < TT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sV[(16 * jt + 4 * kq + r) * ES + 16 * et + li], st[jt][r], acc, 0, 0, 0);
+        // lane: query i = 16 it + li, channels e = 16 et + 4 kq + (0..3)
+        *reinterpret_cast<float4*>(out + (row0 + (16 * it + li) * rstep) * He + h * E + 16 * et + 4 * kq) =
+            make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+      }
+    }
+  }
+}
+
 extern "C" int acx_axial_attention(acx_ctx* ctx, const float* qkv, float* out, int32_t tiles, int32_t gn, int32_t gl,
                                    int32_t heads, int32_t e, int32_t axis, void* stream) {
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!qkv || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_axial_attention: null pointer%s");
   if (tiles <= 0) return ACX_OK;
   const int T = axis == 0 ? gn : gl;
+  if ((T == 16 || T == 32) && (e == 16 || e == 32) && heads > 0 && !(((uintptr_t)qkv | (uintptr_t)out) & 15)) {
+    const int64_t ngroups = (int64_t)tiles * (axis == 0 ? gl : gn) * heads;
+    const size_t ldsm = (size_t)4 * 3 * T * (e + 4) * sizeof(float);
+    int64_t nbm = (ngroups + 3) / 4;
+    const int64_t capm = 2 * (int64_t)(ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256);
+    if (nbm > capm) nbm = capm;
+    const float scale = 1.f / sqrtf((float)e);
+    hipStream_t sm = (hipStream_t)stream;
+#define ACX_AXF(TT_, EE_)                                                                                  \
+  do {                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)axial_attn_fwd_mfma_kernel<TT_, EE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
+    hipLaunchKernelGGL((axial_attn_fwd_mfma_kernel<TT_, EE_>), dim3((unsigned)nbm), dim3(256), ldsm, sm, qkv, out, gn, gl, heads, axis, \
+                       scale, ngroups);                                                                    \
+  } while (0)
+    if (T == 32) { if (e == 32) ACX_AXF(32, 32); else ACX_AXF(32, 16); }
+    else { if (e == 32) ACX_AXF(16, 32); else ACX_AXF(16, 16); }
+#undef ACX_AXF
+    ACX_CHECK_LAUNCH(ctx, "acx_axial_attention(mfma)");
+    return ACX_OK;
+  }
   if ((T != 16 && T != 32) || (e != 16 && e != 32) || heads <= 0 || 256 % (T * heads))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_axial_attention: need axis length in {16,32}, e in {16,32}, T*heads | 256%s");
   const int lpb = 256 / (T * heads);
