@@ -73,10 +73,16 @@ _ZERO_PAGES: dict = {}
 
 
 def _zero_page(device) -> torch.Tensor:
-    """256 bytes of zeros per device, allocated once and never written: the padding source of the conv kernels' LDS-DMA."""
+    """256 bytes of zeros per device, allocated once and never written: the padding source of the conv kernels' LDS-DMA.
+    Must not be born inside a stream capture (it would live in that graph's private pool and be re-filled by the captured
+    fill kernel only when that graph replays): every capture in this package is preceded by eager warm-up calls, which
+    create it; a first use under capture is refused."""
     key = (device.type, device.index)
     z = _ZERO_PAGES.get(key)
     if z is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.AcxError("the conv zero page must be created by an eager call before a HIP graph is captured "
+                             "(run the op once outside the capture)")
         z = _ZERO_PAGES[key] = torch.zeros(64, dtype=torch.float32, device=device)
     return z
 
