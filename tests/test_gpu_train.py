@@ -789,3 +789,32 @@ def test_text_features_class_blocks_equal_full(prompts_table, geom):
             d_P += dp
         assert relerr(torch.cat(rows), full) < 2e-6
         assert relerr(d_ctx, d_ctx_full) < 2e-5 and relerr(d_P, d_P_full) < 2e-5
+
+
+@pytest.mark.parametrize("c_local", [1, 2, 14])
+def test_text_tower_rows_vs_oracle(prompts_table, c_local):
+    """The text tower of a data-parallel rank against the ORACLE directly (coop.py:74-90, text_encoder.py:14-25,
+    clip/model.py:188-230): features of the first c_local classes and the gradients of ctx / text_projection for a random
+    upstream gradient, against the oracle's fp64 autograd on the same weights.  c_local = 1, 2: the few-row kernels
+    (gemm_f32_sk_kernel with the fused QuickGELU prologue / derivative epilogue, MFMA attention backward, LayerNorm backward
+    with the residual folded in); c_local = 14: the tile kernels with the separate activation launches."""
+    from anomalyclip_amd.components import functional as Fn
+    mod, net = _dp_module(prompts_table, seed=17, geom="ViT-B/16")
+    ctxp, P = net.prompt_learner.ctx, net.text_encoder.text_projection
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    eot = net.eot_index.cpu()
+    tf, st = Fn._text_forward_rows(net, ctxp, P, 0, c_local)
+    g = torch.Generator().manual_seed(c_local)
+    d_tf = torch.randn(tf.shape, generator=g)
+    d_ctx, d_P = Fn._text_backward_rows(net, P, st, d_tf.to(DEV))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for k in ("prompt_learner.ctx", "prompt_learner.token_prefix", "prompt_learner.token_suffix"):
+        sd64[k] = sd64[k][:c_local].clone()
+    with torch.enable_grad():
+        sd64["prompt_learner.ctx"].requires_grad_(True)
+        sd64["text_encoder.text_projection"] = sd64["text_encoder.text_projection"].clone().requires_grad_(True)
+        ref = O.text_features(sd64, eot[:c_local], IW.VIT_B16.transformer_heads)
+        ref.backward(d_tf.double())
+    assert tf.shape == (c_local, 512) and relerr(tf, ref.detach()) < 2e-5 and R.elem_excess(tf, ref.detach()) <= 1
+    assert relerr(d_ctx, sd64["prompt_learner.ctx"].grad) < 1e-4
+    assert relerr(d_P, sd64["text_encoder.text_projection"].grad) < 1e-4
