@@ -447,3 +447,52 @@ def test_conv_gemm_split_k(M, cin, cout, act, res):
     out = ops.gemm(x.to(DEV), wk.to(DEV), bias=b.to(DEV), act=act, residual=r.to(DEV) if res else None,
                    amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=cin)
     assert relerr(out, ref) < 1e-5
+
+
+def test_round3_gemm_kernels_random_shapes():
+    """Seeded random shapes through the three GEMM kernels added in round 3, element-wise against fp64 (bound
+    2e-6 ... 3e-6 * sum |a||w|): the few-row kernel (M <= 1280 with N <= 512, or M <= 320; K a multiple of 256; ragged N),
+    the 256 x 256 weight-gradient kernel (ragged M / N1 / N2) and the strip kernel's conv mode (ragged tile counts)."""
+    rng = np.random.default_rng(2026)
+    g = torch.Generator().manual_seed(2026)
+    for _ in range(10):                                             # few-row
+        wide = bool(rng.integers(0, 2))
+        M = int(rng.integers(1, 321)) if wide else int(rng.integers(1, 1281))
+        N = 4 * int(rng.integers(1, 600)) if wide else 4 * int(rng.integers(1, 129))
+        K = 256 * int(rng.integers(1, 9))
+        a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g)
+        out = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), residual=res.to(DEV))
+        ref = a.double() @ w.double().t() + b.double() + res.double()
+        bound = 2e-6 * (a.double().abs() @ w.double().abs().t() + b.abs().double() + res.abs().double())
+        assert bool(((out.cpu().double() - ref).abs() <= bound).all()), ("few-row", M, N, K)
+    for _ in range(4):                                              # weight gradient, 256 x 256 tiles
+        M = int(rng.integers(4096, 20000))
+        N1, N2 = 4 * int(rng.integers(48, 280)), 4 * int(rng.integers(256, 640))
+        if ((N1 + 255) // 256) * ((N2 + 255) // 256) < 8:
+            N2 = 4 * 640
+        a, bm = torch.randn(M, N1, generator=g), torch.randn(M, N2, generator=g)
+        out = ops.gemm_tn(a.to(DEV), bm.to(DEV))
+        ref = a.double().t() @ bm.double()
+        assert bool(((out.cpu().double() - ref).abs() <= 2e-6 * (a.double().abs().t() @ bm.double().abs())).all()), ("tn", M, N1, N2)
+    for _ in range(3):                                              # strip kernel, conv mode
+        cin, cout = int(rng.choice([64, 128, 256])), int(rng.choice([512, 768, 1024]))
+        tiles = int(np.ceil(1024 / (4 * (cout // 128)))) + int(rng.integers(0, 9))      # >= 1024 tiles of 128 x 128
+        N_, Lg = 32, 16
+        x = torch.randn(tiles, N_, Lg, cin, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5
+        bias = torch.randn(cout, generator=g)
+        xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1))
+        M = tiles * N_ * Lg
+        ref = bias.double().expand(M, cout).clone()
+        mag = bias.double().abs().expand(M, cout).clone()
+        for kh in range(3):
+            for kw in range(3):
+                xs = xp[:, kh:kh + N_, kw:kw + Lg, :].reshape(M, cin)
+                ref += xs @ w[:, :, kh, kw].double().t()
+                mag += xs.abs() @ w[:, :, kh, kw].double().abs().t()
+        wk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+        out = ops.gemm(x.reshape(-1, cin).to(DEV), wk.to(DEV), bias=bias.to(DEV), act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3,
+                       gn=N_, gl=Lg, cin=cin)
+        ref = torch.nn.functional.leaky_relu(ref, 0.01)
+        assert bool(((out.cpu().double() - ref).abs() <= 3e-6 * mag).all()), ("conv", cin, cout, tiles)

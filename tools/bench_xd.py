@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--windows", type=int, default=8, help="160-frame windows per frames step")
+    ap.add_argument("--head-only", action="store_true", help="skip the ViT leg (rocprof of the head alone)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -48,6 +49,9 @@ def main():
                     "gemm_frac_of_peak": round(gf / 1e9 / tot[0] / B.PEAK_TFLOPS[args.precision], 4) if tot[0] else None,
                     "kernel_ms_per_step": {"gemm": round(tot[0] / 3, 3), "attention": round(tot[1] / 3, 3),
                                            "norm_rows": round(tot[2] / 3, 3), "other": round(tot[3] / 3, 3)}}}
+    if args.head_only:
+        print(json.dumps(out))
+        return
     frames = torch.randn(160 * args.windows, 3, 224, 224, generator=g, device=dev)
 
     def enc():
