@@ -443,6 +443,10 @@ def hbm_kernel_legs(dev, copy_TBps):
     mean, var = torch.zeros(C1, device=dev), torch.ones(C1, device=dev)
     entry("selector_bn", 2 * rows * C1 * 4, _event_time(lambda: ops.selector_bn(nxt(raws), mean, var), 24),
           "1.7 MB in + out: launch-latency bound")
+    scs = [torch.rand(rows, generator=g, device=dev) for _ in range(8)]
+    entry("class_probs", (2 * rows * C1 + rows) * 4, _event_time(lambda: ops.class_probs(nxt(raws), nxt(scs)), 24),
+          "a11 eval post-processing softmax(similarity) * score: 3.5 MB, launch-latency bound")
+    del scs
     dls = ring(8, rows, C1)
     entry("bn_bwd_stats", 2 * rows * C1 * 4, _event_time(lambda: ops.bn_bwd_stats(nxt(raws), nxt(dls)), 24), "2 launches, 3.4 MB")
     # loss: (B*512, 13) logits + top-k gather + scores: one fused forward+backward pass
