@@ -383,6 +383,7 @@ class AnomalyCLIPModule(_Base):
             order = [self.net.prompt_learner.ctx, self.net.text_encoder.text_projection, self.net.selector_model.logit_scale]
             order += list(self.net.temporal_model.parameters())
             self._buckets = parallel.GradBuckets(order)
+            self.net.temporal_model.__dict__["_grad_sink"] = self._buckets     # graph-replayed backward: one accumulate launch
         self._buckets.zero()
         with torch.enable_grad():
             loss = self.training_step(batch, batch_idx)["loss"]

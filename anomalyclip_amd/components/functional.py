@@ -572,8 +572,14 @@ class TemporalGraphFn(torch.autograd.Function):
         # the graph's static gradient buffers are handed to autograd as they are: AccumulateGrad adds them into the
         # parameters' .grad (views of GradBuckets.flat) in place, or clones them itself when .grad is None (tg.outs keeps a
         # second reference, so it never adopts the static tensor) -- 34 clone launches per step less.  Only d_feats, which
-        # flows on into other autograd nodes, is copied out of the graph's memory
-        return tuple((o.clone() if i == 0 else o) if o is not None else None for i, o in enumerate(tg.outs))
+        # flows on into other autograd nodes, is copied out of the graph's memory.  With a gradient sink attached
+        # (parallel.GradBuckets of the module's train_batch) the 34 gradients are added into the flat buffer by ONE launch
+        # and reported ready there; autograd then gets None for them
+        d_feats = tg.outs[0].clone() if tg.outs[0] is not None else None
+        sink = getattr(ctx.tm, "_grad_sink", None)
+        if sink is not None and sink.accumulate(_temporal_param_list(ctx.tm), tg.outs[3:]):
+            return (d_feats, None, None) + (None,) * (len(tg.outs) - 3)
+        return (d_feats,) + tuple(tg.outs[1:])
 
 
 def temporal_train(tm, features, a_sub):

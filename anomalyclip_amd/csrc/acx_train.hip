@@ -1394,6 +1394,40 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSegs t, flo
   }
 }
 
+// Multi-tensor y += a * x: ONE launch accumulates a list of gradient tensors into their destinations (the views of
+// parallel.GradBuckets.flat) -- what autograd's AccumulateGrad does with one elementwise launch per parameter.
+constexpr int AXPY_MAX_SEG = 96;
+struct AxpySegs {
+  float* y[AXPY_MAX_SEG];
+  const float* x[AXPY_MAX_SEG];
+  long long n[AXPY_MAX_SEG];
+  int chunk0[AXPY_MAX_SEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void multi_axpy_kernel(const AxpySegs t, float a) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.chunk0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  float* __restrict__ y = t.y[lo];
+  const float* __restrict__ x = t.x[lo];
+  const long long n = t.n[lo];
+  const long long base = (long long)(b - t.chunk0[lo]) * 1024 + threadIdx.x;
+  float yv[4], xv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) { yv[k] = y[i]; xv[k] = x[i]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) y[i] = yv[k] + a * xv[k];
+  }
+}
+
 // d_ctx[c][t][:] = dx[c][1+t][:]  (or summed over classes when the context is shared)  (coop.py:74-90)
 __global__ __launch_bounds__(256) void ctx_grad_kernel(const float* __restrict__ dx, float* __restrict__ dctx, int C, int n_ctx,
                                                        int Lc, int W, int shared_ctx) {
@@ -1741,6 +1775,36 @@ extern "C" int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float
   hipLaunchKernelGGL(adamw_kernel, GRID1(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                      bc1, bc2s);
   ACX_CHECK_LAUNCH(ctx, "acx_adamw");
+  return ACX_OK;
+}
+
+extern "C" int acx_multi_axpy(acx_ctx* ctx, int32_t nseg, void* const* y, const void* const* x, const int64_t* n, float a,
+                              void* stream) {
+  if (nseg <= 0) return ACX_OK;
+  if (!y || !x || !n) return acx_fail(ctx, ACX_E_BADARG, "acx_multi_axpy: null pointer%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < nseg) {
+    AxpySegs t;
+    memset(&t, 0, sizeof(t));
+    long long chunks = 0;
+    int k = 0;
+    for (; i < nseg && k < AXPY_MAX_SEG; ++i) {
+      if (n[i] <= 0) continue;
+      if (!y[i] || !x[i]) return acx_fail(ctx, ACX_E_BADARG, "acx_multi_axpy: null tensor pointer%s");
+      t.y[k] = (float*)y[i]; t.x[k] = (const float*)x[i]; t.n[k] = n[i];
+      t.chunk0[k] = (int)chunks;
+      chunks += (n[i] + 1023) / 1024;
+      ++k;
+    }
+    if (k == 0) continue;
+    if (chunks > 0x7fffffffLL) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_multi_axpy: too many elements for one launch%s");
+    t.chunk0[k] = (int)chunks;
+    t.nseg = k;
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    hipLaunchKernelGGL(multi_axpy_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, a);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_multi_axpy");
   return ACX_OK;
 }
 

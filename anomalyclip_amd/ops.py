@@ -523,6 +523,17 @@ def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step) -> None:
                               weight_decay, step, _stream()), h)
 
 
+def multi_axpy_(ys, xs, a: float = 1.0) -> None:
+    """y_i += a * x_i for lists of equally sized contiguous f32 tensors, one launch."""
+    n = len(ys)
+    if n == 0:
+        return
+    assert all(y.numel() == x.numel() and y.is_contiguous() and x.is_contiguous() for y, x in zip(ys, xs))
+    h = _h(ys[0])
+    L.check(L.lib().acx_multi_axpy(h, n, (C.c_void_p * n)(*[y.data_ptr() for y in ys]), (C.c_void_p * n)(*[x.data_ptr() for x in xs]),
+                                   (C.c_int64 * n)(*[y.numel() for y in ys]), float(a), _stream()), h)
+
+
 def adamw_multi_(ps, gs, ms, vs, lrs, wds, beta1, beta2, eps, step) -> None:
     """one launch for all the tensors (lists of equal length; per-tensor lr / weight decay)."""
     n = len(ps)

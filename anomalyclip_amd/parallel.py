@@ -149,7 +149,8 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._handles = []
         self._fired = set()
-        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        self._hook_fns = [self._make_hook(i) for i in range(len(self.params))]
+        self._hooks = [p.register_post_accumulate_grad_hook(fn) for p, fn in zip(self.params, self._hook_fns)]
 
     def _make_hook(self, i):
         def hook(p):
@@ -165,6 +166,34 @@ class GradBuckets:
                 lo_b, hi_b = self.ranges[b]
                 self._handles.append(dist.all_reduce(self.flat[lo_b:hi_b], op=dist.ReduceOp.SUM, async_op=True))
         return hook
+
+    # ---- gradient sink: a backward function that already holds ALL gradients of a group of parameters (the graph-replayed
+    # temporal model) adds them into the flat buffer with ONE launch and reports them ready, instead of returning them to
+    # autograd (one AccumulateGrad launch + one hook per parameter)
+    def index_of(self, p):
+        if not hasattr(self, "_index"):
+            self._index = {id(q): i for i, q in enumerate(self.params)}
+        return self._index.get(id(p))
+
+    def accumulate(self, params, grads) -> bool:
+        """params[k].grad += grads[k] for every pair with a gradient, bucket bookkeeping included.  Returns False (and does
+        nothing) unless every such parameter is one of this buffer's and still points at its view."""
+        pairs = [(p, g) for p, g in zip(params, grads) if g is not None]
+        idx = [self.index_of(p) for p, _ in pairs]
+        if any(i is None for i in idx):
+            return False
+        views = []
+        for (p, g), i in zip(pairs, idx):
+            lo, hi = self._views[i]
+            if p.grad is None or p.grad.data_ptr() != self.flat[lo:hi].data_ptr() or not g.is_contiguous():
+                return False
+            views.append(self.flat[lo:hi])
+        from . import ops
+        ops.multi_axpy_(views, [g.reshape(-1) for _, g in pairs], 1.0)
+        hooks = self._hook_fns
+        for (p, _), i in zip(pairs, idx):
+            hooks[i](p)
+        return True
 
     def zero(self):
         self.flat.zero_()

@@ -341,6 +341,10 @@ int acx_mil_loss(acx_ctx* ctx, const float* sim, const float* sim_topk, const in
 /* acx_adamw: one torch.optim.AdamW step (decoupled weight decay, bias correction; step counts from 1). */
 int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* acx_multi_axpy: y_i += a * x_i for nseg tensors in ONE launch (HOST arrays of device pointers / sizes): the
+ * gradient accumulation autograd performs with one elementwise launch per parameter (AccumulateGrad). */
+int acx_multi_axpy(acx_ctx* ctx, int32_t nseg, void* const* y, const void* const* x, const int64_t* n, float a,
+                   void* stream);
 /* acx_adamw_multi: the same update for nseg parameter tensors in ONE launch (per-tensor lr / weight decay: the
  * reference's four param groups, anomaly_clip_module.py:693-746; common betas / eps / step).  The pointer and size
  * arrays are HOST arrays of length nseg; entries with n[i] <= 0 are skipped.  Hyper-parameters are doubles: the scalar
