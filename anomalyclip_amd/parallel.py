@@ -154,6 +154,10 @@ class GradBuckets:
 
     def _make_hook(self, i):
         def hook(p):
+            if i in self._fired:
+                # second report of the same parameter in one step: accumulate() reported it and autograd calls the
+                # post-accumulate hook of its AccumulateGrad node anyway (with an undefined gradient: nothing was added)
+                return
             lo, hi = self._views[i]
             if p.grad is not None and p.grad.data_ptr() != self.flat[lo:hi].data_ptr():
                 # autograd replaced the view (first accumulation into a None grad): copy back and re-point

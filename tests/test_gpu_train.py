@@ -638,8 +638,13 @@ def _nccl_worker(rank, world, port, q, backend):
             ma.train_batch(batch, oa)
             got = {n: p.grad for n, p in na.named_parameters() if p.grad is not None}
             ok &= set(got) == set(want)
+            if set(got) != set(want):
+                print("rank", rank, "step", step, "grad sets differ:", sorted(set(got) ^ set(want)), flush=True)
             for n in want:
-                e = ((got[n] - want[n]).abs().max() / (want[n].abs().max() + 1e-30)).item()
+                e = ((got[n] - want[n]).abs().max() / (want[n].abs().max() + 1e-30)).item() if n in got else float("inf")
+                if not e < 1e-5:
+                    print("rank", rank, "step", step, "gradient mismatch", n, e, float(got[n].abs().max()), float(want[n].abs().max()),
+                          float((got[n] * world - want[n]).abs().max()), flush=True)
                 ok &= e < 1e-5
             flat = ma._buckets.flat.clone()
             dist.broadcast(flat, 0)
