@@ -8,11 +8,11 @@
 //   * operands global -> LDS by global_load_lds_dwordx4 (inline asm: see acx_attn.hip for why), K-step = 128 B per row,
 //     row-linear LDS image with the bank swizzle on the SOURCE chunk (p ^ ((row >> 1) & 7)), two 64 KB stages; the
 //     K-steps of consecutive tiles form one DMA stream, so a tile starts with its first K-step already in LDS;
-//   * work units are 64-row x 256-column strips in column-major order (down M, then the next column tile); CU c owns the
-//     contiguous unit range [c U / n, (c + 1) U / n) and walks it in tiles of up to 4 units.  A short tile (1-3 units)
+//   * work units are 64-row x 256-column strips; a tile is 1-4 units of one column tile.  A short tile (1-3 units)
 //     switches off the waves of the missing 64-row groups (each SIMD hosts the four row groups of one column group), so
 //     its time shrinks with its height: the balance granularity is 64 rows, not a 256x256 tile (N = 768: 4.62 rounds of
-//     256x256 tiles would run at 92 %, 18.47 units per CU run at 97 %) and no separate tail launch exists;
+//     256x256 tiles would run at 92 %, 18.47 units per CU run at 97 %) and no separate tail launch exists.  The tile
+//     order is row-major inside an XCD (see "this CU's tiles" below);
 //   * epilogue: each wave transposes its accumulator tiles through a private 4 KB XOR-swizzled slice of the stage that
 //     was just consumed and goes to memory with 16-byte accesses (8 rows x 128 B per instruction); the next tile's
 //     first K-step is already resident, its second is issued right after the epilogue.
@@ -22,26 +22,27 @@ constexpr int P2_STAGE_B = 2 * P2_OP_B;          // A | W
 
 typedef __attribute__((address_space(3))) void p2_lds_t;
 
-struct P2Cursor {                                // position in this CU's unit range
-  long pos, end;
-  int RU;                                        // 64-row units per column tile
+struct P2Cursor {                                // position in this CU's tile list
+  int p, end, step;                              // tile index in the XCD's row-major list (column fastest), list length, CUs
+  int TN, u0, base, rem;                         // column tiles; the XCD's first row unit; block heights base + (b < rem)
   int col, ru, nun;                              // current tile: column tile, first row unit, units (1..4)
-  __device__ __forceinline__ bool valid() const { return pos < end; }
+  __device__ __forceinline__ bool valid() const { return p < end; }
   __device__ __forceinline__ void load() {
-    if (pos < end) {
-      col = (int)(pos / RU);
-      ru = (int)(pos - (long)col * RU);
-      long n = end - pos;
-      if (n > 4) n = 4;
-      if (n > RU - ru) n = RU - ru;
-      nun = (int)n;
+    if (p < end) {
+      const int b = p / TN;
+      col = p - b * TN;
+      ru = u0 + b * base + min(b, rem);
+      nun = base + (b < rem ? 1 : 0);
     }
   }
-  __device__ __forceinline__ void next() { pos += nun; load(); }
+  __device__ __forceinline__ void next() { p += step; load(); }
 };
 
 // RES != 0 is kept compilable (float4 residual per accumulator tile) but NOT dispatched: acx_gemm_takes_strip_stream()
-// sends problems with a residual to gemm_f32_w8_kernel (see the comment there and DESIGN.md section 4).
+// sends problems with a residual to gemm_f32_w8_kernel.  Round 3 also tried the residual INSIDE the K loop (four rows per
+// K-step LDS-DMA'd into a per-wave strip, added to the accumulators by packed FMAs behind the K-step's barrier): 124.7 /
+// 131.9 TFLOP/s on out-proj / proj against 126.4 / 132.0 for gemm_f32_w8_kernel and 133.2 / 135.8 without a residual --
+// the extra 310 MB cost the same 60-100 us per launch wherever they are read, so the simpler kernel keeps those shapes.
 // CV != 0: A is the implicit-GEMM operand of a 3x3 convolution over the (gn, gl) token grid (power-of-two grid, cin % 32
 // == 0): K-step kt reads channels [32 (kt % (cin/32)), +32) of the row shifted by tap kt / (cin/32); taps outside the grid
 // read the caller's zero page (g.zeros) -- a per-lane DMA source address, nothing else changes.
@@ -54,15 +55,25 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
   const int wm = wave >> 2, wn = wave & 3;
   const int li = lane & 31, hh = lane >> 5;
 
-  // ---- this CU's unit range.  Blocks of one XCD (bid % 8) take consecutive ranges: they share W panels in that XCD's L2.
+  // ---- this CU's tiles.  Each XCD (bid % 8, its own L2) owns a contiguous range of 64-row units, cut into row blocks of
+  // 3-4 units; its tiles are listed row-major (column tile fastest) and dealt round-robin to its CUs, so the TN column
+  // tiles of one row block run at the same time on TN CUs of one L2: the A rows come from HBM once, not TN times, and
+  // the W panels are shared by the CUs a row block apart.  S = tiles per CU; the block count B is the largest that fits
+  // S tiles per CU, the taller blocks come first (CU loads differ by at most one unit per step).
   const int TN = (d.N + P2_BN - 1) / P2_BN, RU = (d.M + 63) / 64;
-  const long U = (long)TN * RU;
   const int bid = blockIdx.x, nb = gridDim.x;
   const int xcd = bid & 7, qb = nb >> 3, rb = nb & 7;
-  const int cidx = (xcd < rb ? xcd * (qb + 1) : rb * (qb + 1) + (xcd - rb) * qb) + (bid >> 3);
+  const int nc = qb + (xcd < rb ? 1 : 0);                                 // CUs of this XCD in the launch
+  const int cb = xcd * qb + min(xcd, rb);                                 // CUs of the XCDs before it
+  const int u0 = (int)((long)RU * cb / nb), un = (int)((long)RU * (cb + nc) / nb) - u0;
+  if (un <= 0) return;
+  int S = (int)(((long)un * TN + 4L * nc - 1) / (4L * nc));
+  int B = min((int)((long)S * nc / TN), un);
+  while (B < (un + 3) / 4) { ++S; B = min((int)((long)S * nc / TN), un); }
   P2Cursor cc, dc;                               // compute cursor, DMA cursor
-  cc.pos = U * cidx / nb; cc.end = U * (cidx + 1) / nb; cc.RU = RU; cc.col = cc.ru = 0; cc.nun = 0;
-  if (cc.pos >= cc.end) return;
+  cc.p = bid >> 3; cc.end = B * TN; cc.step = nc; cc.TN = TN; cc.u0 = u0; cc.base = un / B; cc.rem = un % B;
+  cc.col = cc.ru = 0; cc.nun = 0;
+  if (!cc.valid()) return;
   cc.load();
   dc = cc;
   const int nk = d.K / 32;

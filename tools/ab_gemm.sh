@@ -4,7 +4,7 @@
 cd /root/repo/anomalyclip_amd/csrc
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags acx_api.hip acx_gemm.hip acx_norm.hip acx_attn.hip acx_head.hip acx_train.hip acx_metrics.hip -o /tmp/libacx_$name.so 2>/dev/null || { echo "build failed $name"; continue; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags acx_api.hip acx_gemm.hip acx_norm.hip acx_attn.hip acx_head.hip acx_train.hip acx_metrics.hip acx_probe.hip -o /tmp/libacx_$name.so 2>/dev/null || { echo "build failed $name"; continue; }
 done
 for rep in 1 2; do
 for spec in "$@"; do

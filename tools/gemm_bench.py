@@ -13,6 +13,7 @@ ap.add_argument("--shapes", default="qkv,out,fc,proj")
 ap.add_argument("--epi", type=int, default=0)   # 1: the in-model epilogues (residual on out/proj, QuickGELU on fc)
 ap.add_argument("--rounds", type=int, default=1)
 ap.add_argument("--cbf16", action="store_true")   # bf16 C (the in-model qkv / fc outputs of the bf16 mode)
+ap.add_argument("--inplace", action="store_true")   # residual aliases C (the in-model residual stream: x = x + linear(h))
 ap.add_argument("--custom", default="")   # e.g. 1536x768,4608x768  (NxK)
 args = ap.parse_args()
 M = 197 * args.frames
@@ -33,7 +34,7 @@ for name in names * args.rounds:
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if args.cbf16 else torch.float32)
     kw = {}
     if args.epi and name in ("out", "proj"):
-        kw["residual"] = torch.randn(M, N, device=dev)
+        kw["residual"] = out if args.inplace else torch.randn(M, N, device=dev)
     if args.epi and name == "fc":
         kw["act"] = L.ACT_QUICKGELU
     for _ in range(2):

@@ -4,14 +4,19 @@ import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from anomalyclip_amd import _lib as L, ops
-M, N, K = 197 * 512, 2304, 768
+M = 197 * 512
+N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2304, 768)
+RES = len(sys.argv) > 3 and sys.argv[3] == "res"
 a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; out = torch.empty(M, N, device="cuda")
+res = torch.randn(M, N, device="cuda") if RES else None
 h = L.ctx(0)
 def run(lda, ldw, tag):
     d = L.GemmDesc()
     d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldw, d.ldc = lda, ldw, N
+    if RES:
+        d.residual, d.ldr = res.data_ptr(), N
     d.a_dtype = d.c_dtype = L.ACX_F32; d.prec = L.PREC_F32
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(2): L.check(L.lib().acx_gemm(h, C.byref(d), st), h)
