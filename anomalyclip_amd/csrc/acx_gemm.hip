@@ -448,8 +448,9 @@ bool acx_gemm_takes_strip_stream(const acx_gemm_desc* d) {
   if (d->prec != ACX_PREC_F32 || d->a_dtype == ACX_BF16 || d->c_dtype == ACX_BF16) return false;
   if (d->a_sub || d->pos0 || d->K % 32 || d->residual) return false;
   if (d->amap == ACX_AMAP_CONV3X3) {
-    // implicit-GEMM convolutions: wide outputs only (N = 256 leaves half of the 256-column strip kernel's waves idle),
-    // power-of-two token grid, a caller-provided zero page for the taps outside the grid
+    // implicit-GEMM convolutions: wide outputs only (N = 256 at 32768 rows gives every CU one 128-row tile = 8 of its 16
+    // waves; measured 134-135 TFLOP/s against 133-136 for gemm_f32_w8_kernel, with and without the residual: a tie, so
+    // those stay where they were), power-of-two token grid, a caller-provided zero page for the taps outside the grid
     if (!d->zero_page || ((uintptr_t)d->zero_page & 15) || d->N < 512 || d->cin % 32 || d->act == ACX_ACT_QUICKGELU) return false;
     if ((d->gl & (d->gl - 1)) || ((d->gn * d->gl) & (d->gn * d->gl - 1)) || d->M % 64) return false;
   } else if (d->amap != ACX_AMAP_IDENTITY || d->act == ACX_ACT_LEAKYRELU) {

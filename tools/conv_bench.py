@@ -14,6 +14,10 @@ for rnd in range(2):
         b = torch.randn(cout, device=dev)
         out = torch.empty(M, cout, device=dev)
         kw = dict(bias=b, out=out, amap=L.AMAP_CONV3X3, gn=32, gl=16, cin=cin)
+        if os.environ.get("CB_RES") and name == "conv2":            # the forward conv2 carries the block's residual
+            kw["residual"] = torch.randn(M, cout, device=dev)
+        if os.environ.get("CB_ACT") and name == "conv1":
+            kw["act"] = L.ACT_LEAKYRELU
         for _ in range(2):
             ops.gemm(x, w, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
