@@ -50,6 +50,11 @@
 
 namespace {
 
+// QuickGELU of every epilogue: v * sigmoid(1.702 v) with v_exp_f32 + v_rcp_f32 (1 ulp).  "1.f / x" would be the IEEE division
+// sequence (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup): ten VALU instructions per element of a
+// 256 x 256 tile, with the MFMA pipe idle behind them.
+__device__ __forceinline__ float acx_quickgelu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v)); }
+
 constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 144;                // LDS row stride in bytes (128 data + 16 pad)
 constexpr int TILE_B = BM * ROWB;        // 18432
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
       for (int r = 0; r < 16; ++r) {
         float v = acc[mi][ni][r] + bias;
         const int act = FAST ? ACT : d.act;
-        if (act == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+        if (act == ACX_ACT_QUICKGELU) v = acx_quickgelu(v);
         else if (act == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
         outv[r] += v;
       }
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   float v = 0.f;
   for (int s = 0; s < splits; ++s) v += part[(size_t)s * total + i];
   if (d.bias) v += d.bias[col];
-  if (d.act == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+  if (d.act == ACX_ACT_QUICKGELU) v = acx_quickgelu(v);
   else if (d.act == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
   if (d.residual) v += d.residual[(size_t)row * d.ldr + col];
   if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
         const float4 a4 = *reinterpret_cast<const float4*>(sT + row_ * 32 + (tc ^ (4 * (row_ & 7)))); \
         float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};                         \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-          if constexpr (ACT == ACX_ACT_QUICKGELU) v[e] = v[e] * (1.f / (1.f + __expf(-1.702f * v[e]))); \
+          if constexpr (ACT == ACX_ACT_QUICKGELU) v[e] = acx_quickgelu(v[e]);                      \
           if constexpr (ACT == ACX_ACT_LEAKYRELU) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];          \
         }                                                                                          \
         float4 ov = make_float4(v[0], v[1], v[2], v[3]);                                           \
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
         const int row = m0 + wm * 64 + (mi) * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);                \
         float v = ACC[r] + bias;                                                                   \
-        if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));       \
+        if constexpr (ACT == ACX_ACT_QUICKGELU) v = acx_quickgelu(v);                              \
         if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;                       \
         if constexpr (RES != 0) v += d.residual[(size_t)min(row, d.M - 1) * d.ldr + colc];         \
         if (cok && row < d.M) ((float*)d.C)[(size_t)row * d.ldc + col] = v;                        \

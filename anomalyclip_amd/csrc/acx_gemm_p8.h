@@ -244,8 +244,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
               float4 v = *reinterpret_cast<const float4*>(scr + rr_ * 128 + ((cj ^ (rr_ & 7)) * 16));
               v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
               if constexpr (ACT == ACX_ACT_QUICKGELU) {
-                v.x = v.x * (1.f / (1.f + __expf(-1.702f * v.x))); v.y = v.y * (1.f / (1.f + __expf(-1.702f * v.y)));
-                v.z = v.z * (1.f / (1.f + __expf(-1.702f * v.z))); v.w = v.w * (1.f / (1.f + __expf(-1.702f * v.w)));
+                v.x = acx_quickgelu(v.x); v.y = acx_quickgelu(v.y);
+                v.z = acx_quickgelu(v.z); v.w = acx_quickgelu(v.w);
               }
               if constexpr (RES != 0) { v.x += res[u][ps].x; v.y += res[u][ps].y; v.z += res[u][ps].z; v.w += res[u][ps].w; }
               const int row = row0 + 8 * ps;

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
         float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if constexpr (ACT == ACX_ACT_QUICKGELU) v[e] = v[e] * (1.f / (1.f + __expf(-1.702f * v[e])));
+          if constexpr (ACT == ACX_ACT_QUICKGELU) v[e] = acx_quickgelu(v[e]);
           if constexpr (ACT == ACX_ACT_LEAKYRELU) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
         }
         ov[i] = make_float4(rs[i].x + v[0], rs[i].y + v[1], rs[i].z + v[2], rs[i].w + v[3]);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = acc[mi][r] + bias;
-      if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+      if constexpr (ACT == ACX_ACT_QUICKGELU) v = acx_quickgelu(v);
       if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
       outv[r] += v;
     }
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_s64_kernel(const Args g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float v = acc[r] + bias;
-    if constexpr (ACT == ACX_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+    if constexpr (ACT == ACX_ACT_QUICKGELU) v = acx_quickgelu(v);
     outv[r] += v;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
