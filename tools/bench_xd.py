@@ -2,7 +2,7 @@
 """BASELINE.json configs[4]: XD-Violence-shaped long segments, bf16.
   * head: features (1, 5 crops, 512*S, 512) f32 -> text encoder (bf16) + selector + axial temporal head with bf16 MFMA GEMMs /
     implicit-GEMM convolutions (XD config: C = 7, E = 128) -> scores; features/s, GEMM TFLOP/s of the step
-  * frames: 5-crop x 32-frame windows = 160 frames per ViT-B/16 launch in bf16 mode; frames/s
+  * frames: 5-crop x 32-frame windows, --chunk frames (default 640 = 4 windows) per ViT-B/16 launch in bf16 mode; frames/s
 One JSON line.   python tools/bench_xd.py [--S 16] [--steps 10] [--precision bf16|f32]"""
 import argparse, json, os, sys, time
 import torch
@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--windows", type=int, default=8, help="160-frame windows per frames step")
+    ap.add_argument("--chunk", type=int, default=640, help="frames per ViT launch (160 = one window)")
     ap.add_argument("--head-only", action="store_true", help="skip the ViT leg (rocprof of the head alone)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -27,7 +28,7 @@ def main():
     net = AnomalyCLIP(arch="ViT-B/16", labels_key="xd", emb_size=hc.emb_size, depth=hc.depth, heads=hc.heads, dim_heads=None,
                       num_segments=32, seg_length=16, concat_features=False, normal_id=hc.normal_id, stride=1,
                       load_from_features=True, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7, ncrops=hc.ncrops,
-                      num_topk=3, num_bottomk=3, precision=args.precision, vit_chunk=160)
+                      num_topk=3, num_bottomk=3, precision=args.precision, vit_chunk=args.chunk)
     net.load_state_dict(IW.init_anomalyclip_state_dict(IW.VIT_B16, hc, toks, seed=0), strict=True)
     net = net.to(dev).eval()
     timer, prof = B.Timer(None, dev), B.Prof(0)
@@ -60,7 +61,7 @@ def main():
     dt = timer.run(enc, max(2, args.steps // 3), 1, prof.start, prof.stop)
     n = max(2, args.steps // 3)
     gf, counts, tot = prof.collect()
-    out["frames"] = {"frames_per_launch": 160, "frames_per_s": round(160 * args.windows * n / dt, 1),
+    out["frames"] = {"frames_per_launch": args.chunk, "frames_per_s": round(160 * args.windows * n / dt, 1),
                      "gemm_tflops": round(gf / 1e9 / tot[0], 1) if tot[0] else None,
                      "gemm_frac_of_peak": round(gf / 1e9 / tot[0] / B.PEAK_TFLOPS[args.precision], 4) if tot[0] else None,
                      "kernel_ms_per_window": {"gemm": round(tot[0] / n / args.windows, 3), "attention": round(tot[1] / n / args.windows, 3),
