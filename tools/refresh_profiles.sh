@@ -13,8 +13,10 @@ for n in 2 4 8; do python tools/bench_head.py --steps 10 --emulate-world $n --te
 python tools/bench_head.py --steps 10 --emulate-world 8 > $OUT/bench_head_emulated_world8_eager.json 2>/dev/null
 python tools/bench_xd.py --steps 6 > $OUT/bench_xd_bf16.json 2>/dev/null
 python tools/bench_metrics.py > $OUT/bench_metrics.txt 2>&1
-python tools/gemm_bench.py --frames 512 --epi 1 > $OUT/gemm_f32.txt 2>&1
-python tools/gemm_bench.py --frames 512 --epi 1 --prec bf16 > $OUT/gemm_bf16.txt 2>&1
+# two rounds each: the first shapes of a process run on cold clocks, read the second round
+python tools/gemm_bench.py --frames 512 --epi 1 --inplace --rounds 2 > $OUT/gemm_f32.txt 2>&1
+python tools/gemm_bench.py --frames 512 --epi 1 --inplace --prec bf16 --rounds 2 > $OUT/gemm_bf16.txt 2>&1
+python tools/gemm_bench.py --frames 512 --epi 1 --prec bf16 --cbf16 --shapes qkv,fc --rounds 2 >> $OUT/gemm_bf16.txt 2>&1
 python tools/conv_bench.py > $OUT/conv_bench.txt 2>&1
 python tools/attn_bench.py > $OUT/attn.txt 2>&1
 python tools/attn_bf16_bench.py >> $OUT/attn.txt 2>&1
