@@ -614,7 +614,9 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     // combined in fixed order by splitk_reduce_kernel together with the epilogue
     const int tiles = tiles_m * g.tiles_n, nkt = d->K / ke;
     int split = 1;
-    while (tiles * split * 2 <= 512 && nkt / (split * 2) >= 4 && split < 16) split *= 2;
+    // bf16 pieces keep >= 8 K-steps: at the XD text tower's 539 rows x K = 512 a 2-way split + its 5 us reduce launch is
+    // slower than the unsplit launch (head step 1.64 -> 1.51 ms); 16 is worse again (1.59)
+    while (tiles * split * 2 <= 512 && nkt / (split * 2) >= (prec == ACX_PREC_BF16 ? 8 : 4) && split < 16) split *= 2;
     if (split > 1 && (size_t)split * d->M * d->N * sizeof(float) <= d->workspace_bytes) {
       g.ksplit = split;
       g.kchunk = (nkt + split - 1) / split;
