@@ -1151,6 +1151,88 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned cha
   out[i] = (v - mean) / sd;
 }
 
+// ---- fused variant: one workgroup per (frame, band of R output rows).  Phase 1 resamples the input rows the band needs
+// horizontally into an 8-bit image in LDS (thread = output column: its KS coefficients live in registers, a tap is ONE
+// unaligned dword load of the pixel's three bytes), phase 2 resamples vertically out of LDS (thread = four pixels x three
+// channels = three dwords per tap) and writes the normalised f32 planes with 16-byte stores.  The uint8 intermediate
+// never reaches memory; arithmetic and rounding are those of the two kernels above (bit-identical output).
+template <int KS>
+__global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
+                                                               const int* __restrict__ hb, const int* __restrict__ hk,
+                                                               const int* __restrict__ vb, const int* __restrict__ vk, int vks,
+                                                               int H, int W, int orows, int ocols, int R, int maxrows,
+                                                               float m0, float m1, float m2, float s0, float s1, float s2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ptmp[];
+  __shared__ float lut[3][256];                  // (v / 255 - mean[c]) / std[c] for v = 0..255: the float tail, evaluated once
+  const int f = blockIdx.y, yo0 = blockIdx.x * R, yo1 = min(orows, yo0 + R);
+  const int y0 = vb[2 * yo0];
+  const int nrows = min(vb[2 * (yo1 - 1)] + vb[2 * (yo1 - 1) + 1] - y0, maxrows);
+  const int rowb = ocols * 3;
+  const int t = threadIdx.x;
+  {
+    const float v = (float)t / 255.f;                                     // ToTensor: uint8 -> float32 / 255
+    lut[0][t] = (v - m0) / s0; lut[1][t] = (v - m1) / s1; lut[2][t] = (v - m2) / s2;
+  }
+  // ---- phase 1: tmp[yl][xo][c] = clip8(0.5 + sum_x in[f][y0 + yl][xmin + x][c] * k[xo][x])
+  // (24-bit multiplies: |k| < 2^23 -- a normalised bicubic weight lies in (-0.2, 1.2) x 2^22 -- and pixels are 8 bits)
+  for (int xo = t; xo < ocols; xo += 256) {
+    const int xmin = hb[2 * xo];
+    int k[KS], px[KS];                           // coefficients (zero beyond the window: host table), tap byte offsets in a row
+#pragma unroll
+    for (int x = 0; x < KS; ++x) { k[x] = hk[(size_t)xo * KS + x]; px[x] = 3 * min(xmin + x, W - 1); }
+    const unsigned char* rowp = in + ((size_t)f * H + y0) * (size_t)W * 3;
+    const bool first_row = f == 0 && y0 == 0;    // row 0 of the buffer: its pixel 0 has no byte in front of it
+#pragma unroll 4
+    for (int yl = 0; yl < nrows; ++yl, rowp += (size_t)W * 3) {
+      int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+#pragma unroll
+      for (int x = 0; x < KS; ++x) {
+        // the pixel's three bytes by ONE dword load that starts one byte early (never past the end of the buffer)
+        const int back = (first_row && yl == 0 && px[x] == 0) ? 0 : 1;
+        unsigned w;
+        __builtin_memcpy(&w, rowp + (px[x] - back), 4);
+        w >>= 8 * back;
+        a0 += __mul24((int)(w & 255u), k[x]);
+        a1 += __mul24((int)((w >> 8) & 255u), k[x]);
+        a2 += __mul24((int)((w >> 16) & 255u), k[x]);
+      }
+      unsigned char* q = ptmp + yl * rowb + 3 * xo;
+      q[0] = clip8_22(a0); q[1] = clip8_22(a1); q[2] = clip8_22(a2);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: out[f][c][yo][4 g ..] = lut[c][clip8(0.5 + sum_y tmp[ymin - y0 + y][..] * k[yo][y])]
+  const int ng = ocols >> 2;
+  for (int id = t; id < (yo1 - yo0) * ng; id += 256) {
+    const int yl = id / ng, g = id - yl * ng, yo = yo0 + yl;
+    const int ymin = vb[2 * yo] - y0, yn = vb[2 * yo + 1];
+    const int* kv = vk + (size_t)yo * vks;
+    int acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 1 << 21;
+    for (int y = 0; y < yn; ++y) {
+      const int row = min(ymin + y, maxrows - 1);
+      const unsigned* src = reinterpret_cast<const unsigned*>(ptmp + row * rowb + 12 * g);
+      const unsigned d0 = src[0], d1 = src[1], d2 = src[2];
+      const int kk_ = kv[y];
+      acc[0] += __mul24((int)(d0 & 255u), kk_);         acc[1] += __mul24((int)((d0 >> 8) & 255u), kk_);
+      acc[2] += __mul24((int)((d0 >> 16) & 255u), kk_); acc[3] += __mul24((int)(d0 >> 24), kk_);
+      acc[4] += __mul24((int)(d1 & 255u), kk_);         acc[5] += __mul24((int)((d1 >> 8) & 255u), kk_);
+      acc[6] += __mul24((int)((d1 >> 16) & 255u), kk_); acc[7] += __mul24((int)(d1 >> 24), kk_);
+      acc[8] += __mul24((int)(d2 & 255u), kk_);         acc[9] += __mul24((int)((d2 >> 8) & 255u), kk_);
+      acc[10] += __mul24((int)((d2 >> 16) & 255u), kk_); acc[11] += __mul24((int)(d2 >> 24), kk_);
+    }
+    float v[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) v[e] = lut[e % 3][clip8_22(acc[e])];
+    const size_t plane = (size_t)orows * ocols;
+    float* o = out + (size_t)f * 3 * plane + (size_t)yo * ocols + 4 * g;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[3], v[6], v[9]);
+    *reinterpret_cast<float4*>(o + plane) = make_float4(v[1], v[4], v[7], v[10]);
+    *reinterpret_cast<float4*>(o + 2 * plane) = make_float4(v[2], v[5], v[8], v[11]);
+  }
+}
+
 }  // namespace
 
 extern "C" int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, float* out, unsigned char* tmp,
@@ -1162,6 +1244,34 @@ extern "C" int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, 
     return acx_fail(ctx, ACX_E_BADARG, "acx_preprocess_frames: null pointer%s");
   if (F <= 0) return ACX_OK;
   hipStream_t s = (hipStream_t)stream;
+  // fused path: odd tap counts up to 15 (downscales up to 3.5x), whole float4 output rows, the band's rows in <= 96 KB of LDS.
+  // A band of R output rows needs at most (R - 1) * scale + vksize + 1 input rows, scale <= (vksize - 1) / 4.
+  if (ACX_DBG_SWITCH("PREPROCESS_FUSED", true) && hksize >= 5 && hksize <= 15 && (hksize & 1) && ocols % 4 == 0 &&
+      !((uintptr_t)out & 15) && F <= 65535) {
+    const int R = vksize <= 9 ? 32 : 16;
+    const int maxrows = (int)((R - 1) * ((vksize - 1) / 4.0) + vksize + 2);
+    const size_t lds = (size_t)maxrows * ocols * 3;
+    if (lds <= 96 * 1024) {
+      const dim3 grid((unsigned)((orows + R - 1) / R), (unsigned)F);
+#define ACX_PPF(KS)                                                                                 \
+  do {                                                                                              \
+    static bool attr_dev_[64] = {}; int dv_ = 0; (void)hipGetDevice(&dv_); bool& done_ = attr_dev_[dv_ & 63]; \
+    if (!done_) {                                                                                   \
+      (void)hipFuncSetAttribute((const void*)preprocess_fused_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      done_ = true;                                                                                 \
+    }                                                                                               \
+    hipLaunchKernelGGL(preprocess_fused_kernel<KS>, grid, dim3(256), lds, s, frames, out, hbounds, hcoef, vbounds, vcoef, vksize, \
+                       H, W, orows, ocols, R, maxrows, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);                  \
+  } while (0)
+      switch (hksize) {
+        case 5: ACX_PPF(5); break;   case 7: ACX_PPF(7); break;   case 9: ACX_PPF(9); break;
+        case 11: ACX_PPF(11); break; case 13: ACX_PPF(13); break; default: ACX_PPF(15); break;
+      }
+#undef ACX_PPF
+      ACX_CHECK_LAUNCH(ctx, "acx_preprocess_frames");
+      return ACX_OK;
+    }
+  }
   const int64_t t1 = (int64_t)F * H * ocols * 3;
   hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, frames, tmp, hbounds, hcoef, hksize, t1,
                      H, W, ocols);
