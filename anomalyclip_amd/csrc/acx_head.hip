@@ -1152,15 +1152,15 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned cha
 }
 
 // ---- fused variant: one workgroup per (frame, band of R output rows).  Phase 1 resamples the input rows the band needs
-// horizontally into an 8-bit image in LDS (thread = output column: its KS coefficients live in registers, a tap is ONE
-// unaligned dword load of the pixel's three bytes), phase 2 resamples vertically out of LDS (thread = four pixels x three
+// horizontally into an 8-bit image in LDS (thread = output column: its KS coefficients live in registers; the input rows
+// pass through LDS in chunks), phase 2 resamples vertically out of LDS (thread = four pixels x three
 // channels = three dwords per tap) and writes the normalised f32 planes with 16-byte stores.  The uint8 intermediate
 // never reaches memory; arithmetic and rounding are those of the two kernels above (bit-identical output).
 template <int KS>
 __global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
                                                                const int* __restrict__ hb, const int* __restrict__ hk,
                                                                const int* __restrict__ vb, const int* __restrict__ vk, int vks,
-                                                               int H, int W, int orows, int ocols, int R, int maxrows,
+                                                               int H, int W, int orows, int ocols, int R, int maxrows, int cr,
                                                                float m0, float m1, float m2, float s0, float s1, float s2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ptmp[];
   __shared__ float lut[3][256];                  // (v / 255 - mean[c]) / std[c] for v = 0..255: the float tail, evaluated once
@@ -1174,33 +1174,46 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned ch
     lut[0][t] = (v - m0) / s0; lut[1][t] = (v - m1) / s1; lut[2][t] = (v - m2) / s2;
   }
   // ---- phase 1: tmp[yl][xo][c] = clip8(0.5 + sum_x in[f][y0 + yl][xmin + x][c] * k[xo][x])
-  // (24-bit multiplies: |k| < 2^23 -- a normalised bicubic weight lies in (-0.2, 1.2) x 2^22 -- and pixels are 8 bits)
-  for (int xo = t; xo < ocols; xo += 256) {
+  // (24-bit multiplies: |k| < 2^23 -- a normalised bicubic weight lies in (-0.2, 1.2) x 2^22 -- and pixels are 8 bits).
+  // The input rows go through LDS in chunks of `cr` whole rows: 16-byte coalesced loads of the contiguous byte range
+  // (aligned down / up to 16 bytes: an aligned 16-byte block that holds a valid byte never leaves its page), then every
+  // tap is three ds_read_u8 -- per-lane windows 3.2 bytes apart cost the vector-memory path one access per lane, LDS
+  // serves them as broadcasts.
+  unsigned char* raw = ptmp + (size_t)maxrows * rowb;                     // [cr rows] + 32 bytes of alignment slack
+  const int xo = t;                                                       // ocols <= 256 (dispatch)
+  int k[KS], px[KS];
+  if (xo < ocols) {
     const int xmin = hb[2 * xo];
-    int k[KS], px[KS];                           // coefficients (zero beyond the window: host table), tap byte offsets in a row
 #pragma unroll
     for (int x = 0; x < KS; ++x) { k[x] = hk[(size_t)xo * KS + x]; px[x] = 3 * min(xmin + x, W - 1); }
-    const unsigned char* rowp = in + ((size_t)f * H + y0) * (size_t)W * 3;
-    const bool first_row = f == 0 && y0 == 0;    // row 0 of the buffer: its pixel 0 has no byte in front of it
-#pragma unroll 4
-    for (int yl = 0; yl < nrows; ++yl, rowp += (size_t)W * 3) {
-      int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
-#pragma unroll
-      for (int x = 0; x < KS; ++x) {
-        // the pixel's three bytes by ONE dword load that starts one byte early (never past the end of the buffer)
-        const int back = (first_row && yl == 0 && px[x] == 0) ? 0 : 1;
-        unsigned w;
-        __builtin_memcpy(&w, rowp + (px[x] - back), 4);
-        w >>= 8 * back;
-        a0 += __mul24((int)(w & 255u), k[x]);
-        a1 += __mul24((int)((w >> 8) & 255u), k[x]);
-        a2 += __mul24((int)((w >> 16) & 255u), k[x]);
-      }
-      unsigned char* q = ptmp + yl * rowb + 3 * xo;
-      q[0] = clip8_22(a0); q[1] = clip8_22(a1); q[2] = clip8_22(a2);
-    }
   }
-  __syncthreads();
+  const int roww = W * 3;
+  for (int c0 = 0; c0 < nrows; c0 += cr) {
+    const int nr = min(cr, nrows - c0);
+    const size_t g0 = ((size_t)f * H + y0 + c0) * (size_t)roww;
+    const size_t ga = g0 & ~(size_t)15;
+    const int phase = (int)(g0 - ga);
+    const int nvec = (phase + nr * roww + 15) >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(in + ga);
+    for (int i = t; i < nvec; i += 256) reinterpret_cast<uint4*>(raw)[i] = src[i];
+    __syncthreads();
+    if (xo < ocols) {
+#pragma unroll 2
+      for (int r = 0; r < nr; ++r) {
+        const unsigned char* rp = raw + phase + r * roww;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+#pragma unroll
+        for (int x = 0; x < KS; ++x) {
+          a0 += __mul24((int)rp[px[x]], k[x]);
+          a1 += __mul24((int)rp[px[x] + 1], k[x]);
+          a2 += __mul24((int)rp[px[x] + 2], k[x]);
+        }
+        unsigned char* q = ptmp + (c0 + r) * rowb + 3 * xo;
+        q[0] = clip8_22(a0); q[1] = clip8_22(a1); q[2] = clip8_22(a2);
+      }
+    }
+    __syncthreads();
+  }
   // ---- phase 2: out[f][c][yo][4 g ..] = lut[c][clip8(0.5 + sum_y tmp[ymin - y0 + y][..] * k[yo][y])]
   const int ng = ocols >> 2;
   for (int id = t; id < (yo1 - yo0) * ng; id += 256) {
@@ -1250,8 +1263,9 @@ extern "C" int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, 
       !((uintptr_t)out & 15) && F <= 65535) {
     const int R = vksize <= 9 ? 32 : 16;
     const int maxrows = (int)((R - 1) * ((vksize - 1) / 4.0) + vksize + 2);
-    const size_t lds = (size_t)maxrows * ocols * 3;
-    if (lds <= 96 * 1024) {
+    const int cr = std::max(1, std::min(16, 12288 / (W * 3)));              // input rows per LDS chunk (<= 12 KB)
+    const size_t lds = (size_t)maxrows * ocols * 3 + (size_t)cr * W * 3 + 32;
+    if (lds <= 96 * 1024 && ocols <= 256 && (maxrows * ocols * 3) % 16 == 0) {
       const dim3 grid((unsigned)((orows + R - 1) / R), (unsigned)F);
 #define ACX_PPF(KS)                                                                                 \
   do {                                                                                              \
@@ -1261,7 +1275,7 @@ extern "C" int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, 
       done_ = true;                                                                                 \
     }                                                                                               \
     hipLaunchKernelGGL(preprocess_fused_kernel<KS>, grid, dim3(256), lds, s, frames, out, hbounds, hcoef, vbounds, vcoef, vksize, \
-                       H, W, orows, ocols, R, maxrows, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);                  \
+                       H, W, orows, ocols, R, maxrows, cr, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);              \
   } while (0)
       switch (hksize) {
         case 5: ACX_PPF(5); break;   case 7: ACX_PPF(7); break;   case 9: ACX_PPF(9); break;

@@ -434,6 +434,13 @@ def hbm_kernel_legs(dev, copy_TBps):
     xv = torch.randn(512 * 197, 768, generator=g, device=dev)
     entry("layernorm_vit", 2 * xv.numel() * 4, _event_time(lambda: ops.layernorm(xv, lw, lb), 10), "(100864, 768) in + out")
     del xv
+    # row (f2): uint8 HWC frames -> bicubic resize 224 + centre crop + /255 + normalise -> the ViT's f32 input (one fused kernel)
+    from anomalyclip_amd.preprocess import preprocess_frames
+    fr = [torch.randint(0, 256, (FRAMES_PER_CLIP, 240, 320, 3), generator=g, device=dev, dtype=torch.uint8) for _ in range(5)]
+    entry("preprocess_frames", FRAMES_PER_CLIP * (240 * 320 * 3 + 3 * 224 * 224 * 4),
+          _event_time(lambda: preprocess_frames(nxt(fr)), 10),
+          "512 frames 240x320x3 u8 read + (512, 3, 224, 224) f32 written; Pillow-exact two-pass bicubic, 8-bit intermediate in LDS")
+    del fr
     x1s, x2s = ring(8, rows, E), ring(8, rows, E)
     cw, cb = torch.randn(1, E, generator=g, device=dev) * 0.1, torch.zeros(1, device=dev)
     l2w, l2b = torch.ones(E, device=dev), torch.zeros(E, device=dev)
