@@ -28,7 +28,53 @@ class FeatureStream:
         self._copied = [None, None]      # per slot: event recorded after the last H2D copy that READ the pinned buffer
         self.max_tiles = max_tiles
 
+    @staticmethod
+    def _npy_header(fh):
+        """(shape, fortran_order, dtype) of an open .npy file, positioned at its data (numpy.lib.format, versions 1-3)."""
+        from numpy.lib import format as NF
+        major, minor = NF.read_magic(fh)
+        if (major, minor) == (1, 0):
+            return NF.read_array_header_1_0(fh)
+        if (major, minor) == (2, 0):
+            return NF.read_array_header_2_0(fh)
+        return NF._read_array_header(fh, version=(major, minor))
+
+    def _slot_buffer(self, slot: int, need: int, D: int) -> torch.Tensor:
+        # The pinned buffer of this slot was the source of an asynchronous copy two videos ago: that copy must have
+        # finished reading it before the host overwrites it (the device-side wait_event in __iter__ orders the CONSUMER
+        # stream only, not the host).
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()
+            self._copied[slot] = None
+        buf = self._pinned[slot]
+        if buf is None or buf.numel() < need:
+            # pinning is slow (~1 GB/s): start at 16 tiles and grow by half so that a run re-pins a handful of times
+            grown = 0 if buf is None else buf.numel() * 3 // 2
+            buf = torch.empty(max(need, grown, self.ncrops * 16 * 512 * D), dtype=torch.float32).pin_memory()
+            self._pinned[slot] = buf
+        return buf
+
     def _host_tile(self, path: str, slot: int):
+        # Fast path (one crop, stride 1, C-ordered float32 file -- the reference's feature files): the tile is the file's
+        # rows in order followed by its first rows again (indices (s + i) % T, feature_dataset.py:362), so the file is READ
+        # STRAIGHT INTO the pinned buffer (one copy out of the page cache, no intermediate array, no index gather) and the
+        # wrap-around rows are copied inside it.
+        if self.ncrops == 1 and self.stride == 1:
+            with open(path, "rb") as fh:
+                shape, fortran, dtype = self._npy_header(fh)
+                if len(shape) == 2 and not fortran and dtype == np.dtype("<f4"):
+                    T, D = shape
+                    starts, S = FI.test_start_indices(T, self.N, self.L, self.stride)
+                    rows = len(starts) * self.L
+                    view = self._slot_buffer(slot, rows * D, D)[: rows * D].view(1, rows, D)
+                    dst = view.numpy()[0]
+                    got = fh.readinto(memoryview(dst[:T]).cast("B"))
+                    if got != T * D * 4:
+                        raise IOError(f"{path}: short read ({got} of {T * D * 4} bytes)")
+                    for r in range(T, rows, T):
+                        n = min(T, rows - r)
+                        dst[r:r + n] = dst[:n]
+                    return view, T, S
         arr = np.load(path, mmap_mode="r", allow_pickle=False)               # [T*ncrops, D] float32
         D = arr.shape[-1]
         T = arr.shape[0] // self.ncrops
@@ -36,36 +82,33 @@ class FeatureStream:
         idx = FI.frame_index_table(starts, self.L, self.stride, T)
         rows = idx.shape[0]
         need = self.ncrops * rows * D
-        # The pinned buffer of this slot was the source of an asynchronous copy two videos ago: that copy must have
-        # finished reading it before the host overwrites it (the device-side wait_event below orders the CONSUMER
-        # stream only, not the host).
-        if self._copied[slot] is not None:
-            self._copied[slot].synchronize()
-            self._copied[slot] = None
-        buf = self._pinned[slot]
-        if buf is None or buf.numel() < need:
-            buf = torch.empty(max(need, self.ncrops * 512 * D), dtype=torch.float32).pin_memory()
-            self._pinned[slot] = buf
-        view = buf[:need].view(self.ncrops, rows, D)
+        view = self._slot_buffer(slot, need, D)[:need].view(self.ncrops, rows, D)
         src = np.asarray(arr).reshape(T, self.ncrops, D)
         np.take(src, idx, axis=0, out=view.numpy().transpose(1, 0, 2)) if self.ncrops == 1 else \
             view.numpy().__setitem__(slice(None), src[idx].transpose(1, 0, 2))
         return view, T, S
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, int, int, str]]:
+        # One reader thread runs a video ahead: file i + 1 is read into its pinned slot (file I/O and large copies release
+        # the GIL) while this thread issues the copy of video i and the consumer launches its kernels.  Slot s is refilled
+        # for video i + 2 only after the copy of video i has finished reading it (_slot_buffer).
+        from concurrent.futures import ThreadPoolExecutor
         pending = None
-        for i, path in enumerate(self.paths):
-            slot = i & 1
-            view, T, S = self._host_tile(path, slot)
-            with torch.cuda.stream(self._copy_stream):
-                dev = view.to(self.device, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._copy_stream)
-            self._copied[slot] = ev
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(self._host_tile, self.paths[0], 0) if self.paths else None
+            for i, path in enumerate(self.paths):
+                slot = i & 1
+                view, T, S = fut.result()
+                fut = pool.submit(self._host_tile, self.paths[i + 1], (i + 1) & 1) if i + 1 < len(self.paths) else None
+                with torch.cuda.stream(self._copy_stream):
+                    dev = view.to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                self._copied[slot] = ev
+                if pending is not None:
+                    yield pending
+                torch.cuda.current_stream().wait_event(ev)          # consumer stream waits for this copy only
+                dev.record_stream(torch.cuda.current_stream())
+                pending = (dev.unsqueeze(0), T, S, path)
             if pending is not None:
                 yield pending
-            torch.cuda.current_stream().wait_event(ev)          # consumer stream waits for this copy only
-            dev.record_stream(torch.cuda.current_stream())
-            pending = (dev.unsqueeze(0), T, S, path)
-        if pending is not None:
-            yield pending
