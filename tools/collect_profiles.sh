@@ -16,6 +16,8 @@ cp $G/refresh/bench_head_emulated_world8_eager.json $P/${TAG}_bench_head_emulate
 cp $G/refresh/bench_xd_bf16.json $P/${TAG}_bench_xd_bf16.json
 cp $G/refresh/bench_gloo2_smoke.json $P/${TAG}_bench_gloo2_smoke.json
 cp $G/refresh/bench_metrics.txt $P/${TAG}_bench_metrics.txt
+cp $G/refresh/preprocess.json $P/${TAG}_preprocess.json
+cp $G/refresh/feature_stream.json $P/${TAG}_feature_stream.json
 { echo "# tools/gemm_bench.py --frames 512 --epi 1 --inplace --rounds 2 (f32; second round = warm clocks)"; grep -v amdgpu.ids $G/refresh/gemm_f32.txt;
   echo "# tools/gemm_bench.py --frames 512 --epi 1 --inplace --prec bf16 --rounds 2 (f32 C), then --cbf16 --shapes qkv,fc (the in-model bf16 outputs)"; grep -v amdgpu.ids $G/refresh/gemm_bf16.txt;
   echo "# tools/conv_bench.py"; grep -v amdgpu.ids $G/refresh/conv_bench.txt;

@@ -23,6 +23,9 @@ python tools/attn_bf16_bench.py >> $OUT/attn.txt 2>&1
 python tools/probes/selector_bench.py > $OUT/selector_bench.txt 2>&1
 python tools/text_gemm_bench.py > $OUT/text_gemm.txt 2>&1
 python tools/tn_bench.py > $OUT/tn_bench.txt 2>&1
+python tools/bench_preprocess.py 2>/dev/null | tail -1 > $OUT/preprocess.json
+python tools/bench_preprocess.py --hw 720x1280 --frames 64 --cpu-frames 8 2>/dev/null | tail -1 >> $OUT/preprocess.json
+python tools/bench_feature_stream.py 2>/dev/null | tail -1 > $OUT/feature_stream.json
 ACX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_gloo2_smoke.json 2> $OUT/bench_gloo2_smoke.err
 bash tools/profile_bench.sh f32 > $OUT/profile_bench.log 2>&1
 bash tools/profile_bench.sh bf16 > $OUT/profile_bench_bf16.log 2>&1
