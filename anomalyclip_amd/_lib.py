@@ -103,6 +103,7 @@ _SIGS = {
     "acx_prof_enable": (C.c_int, [c_void_p, C.c_int]),
     "acx_prof_gemm_flops": (C.c_int, [c_void_p, C.POINTER(C.c_double)]),
     "acx_prof_collect": (C.c_int, [c_void_p, C.POINTER(c_int32), C.POINTER(C.c_double)]),
+    "acx_prof_gemm_tn": (C.c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int32)]),
     "acx_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "acx_gemm_tn": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                               c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),

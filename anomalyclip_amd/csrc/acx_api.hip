@@ -43,6 +43,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->prof_on = false;
   c->prof_n = c->prof_created = 0;
   c->prof_gemm_flops = 0.0;
+  c->prof_tn_flops = c->prof_tn_ms = 0.0; c->prof_tn_count = 0;
   c->prof_ev = new (std::nothrow) hipEvent_t[2 * ACX_PROF_MAX];
   c->prof_kind = new (std::nothrow) unsigned char[ACX_PROF_MAX];
   *out = c;
@@ -60,7 +61,7 @@ extern "C" void acx_destroy(acx_ctx* ctx) {
 extern "C" int acx_prof_enable(acx_ctx* ctx, int on) {
   if (!ctx || !ctx->prof_ev || !ctx->prof_kind) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_enable: no context%s");
   ctx->prof_on = on != 0;
-  if (on) { ctx->prof_n = 0; ctx->prof_gemm_flops = 0.0; }
+  if (on) { ctx->prof_n = 0; ctx->prof_gemm_flops = 0.0; ctx->prof_tn_flops = 0.0; }
   return ACX_OK;
 }
 
@@ -70,9 +71,16 @@ extern "C" int acx_prof_gemm_flops(acx_ctx* ctx, double* flops) {
   return ACX_OK;
 }
 
+extern "C" int acx_prof_gemm_tn(acx_ctx* ctx, double* flops, double* total_ms, int32_t* launches) {
+  if (!ctx || !flops || !total_ms || !launches) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_gemm_tn: null pointer%s");
+  *flops = ctx->prof_tn_flops; *total_ms = ctx->prof_tn_ms; *launches = ctx->prof_tn_count;
+  return ACX_OK;
+}
+
 extern "C" int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms) {
   if (!ctx || !counts || !total_ms) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_collect: null pointer%s");
   for (int k = 0; k < ACX_K_COUNT; ++k) { counts[k] = 0; total_ms[k] = 0.0; }
+  ctx->prof_tn_ms = 0.0; ctx->prof_tn_count = 0;
   for (int i = 0; i < ctx->prof_n; ++i) {
     hipError_t e = hipEventSynchronize(ctx->prof_ev[2 * i + 1]);
     float ms = 0.f;
@@ -81,8 +89,10 @@ extern "C" int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms)
       snprintf(ctx->err, 512, "acx_prof_collect: %s", hipGetErrorString(e));
       return ACX_E_HIP;
     }
-    counts[ctx->prof_kind[i]]++;
-    total_ms[ctx->prof_kind[i]] += ms;
+    int kind = ctx->prof_kind[i];
+    if (kind == ACX_K_GEMM_TN) { ctx->prof_tn_ms += ms; ctx->prof_tn_count++; kind = ACX_K_GEMM; }
+    counts[kind]++;
+    total_ms[kind] += ms;
   }
   ctx->prof_n = 0;
   return ACX_OK;

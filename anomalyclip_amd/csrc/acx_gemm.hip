@@ -838,8 +838,8 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
     const size_t zoff = splits > 1 ? (size_t)splits * part : 0;
     if (zoff + TN_ZERO_B <= workspace_bytes && !(zoff & 15)) {
       hipStream_t s = (hipStream_t)stream;
-      AcxProfScope prof__(ctx, ACX_K_GEMM, s);
-      if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2;
+      AcxProfScope prof__(ctx, ACX_K_GEMM_TN, s);
+      if (ctx && ctx->prof_on) { ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2; ctx->prof_tn_flops += 2.0 * M * (double)N1 * N2; }
       float* zeros = (float*)((char*)workspace + zoff);
       // a KERNEL clears the page: as a hipMemsetAsync node inside a captured graph the clear was observed to run unordered
       // with the consumer (stale workspace bytes read as padding, run-to-run different gradients under graph replay)
@@ -888,8 +888,8 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
   }
   const size_t lds = 4 * 32 * TN_ROWF * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  AcxProfScope prof__(ctx, ACX_K_GEMM, s);
-  if (ctx && ctx->prof_on) ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2;
+  AcxProfScope prof__(ctx, ACX_K_GEMM_TN, s);
+  if (ctx && ctx->prof_on) { ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2; ctx->prof_tn_flops += 2.0 * M * (double)N1 * N2; }
   const int dev_slot = (ctx ? ctx->device : 0) & 63;            // kernel attributes are per device
   static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
   if (!attr_done) {

@@ -15,7 +15,8 @@ typedef unsigned short u16;
 
 // in-library launch timer (bench.py's roofline leg): HIP events recorded on the caller's stream
 // around every kernel launch of a kind, summed by acx_prof_collect.
-enum { ACX_K_GEMM = 0, ACX_K_ATTN = 1, ACX_K_NORM = 2, ACX_K_OTHER = 3, ACX_K_COUNT = 4 };
+enum { ACX_K_GEMM = 0, ACX_K_ATTN = 1, ACX_K_NORM = 2, ACX_K_OTHER = 3, ACX_K_COUNT = 4,
+       ACX_K_GEMM_TN = 4 };   // acx_gemm_tn launches: reported under ACX_K_GEMM by acx_prof_collect, alone by acx_prof_gemm_tn
 constexpr int ACX_PROF_MAX = 32768;
 
 // Development A/B switches.  The product library compiles them to their constant defaults; only a tools build with
@@ -44,6 +45,8 @@ struct acx_ctx {
   hipEvent_t* prof_ev; // [2 * ACX_PROF_MAX]
   unsigned char* prof_kind;
   double prof_gemm_flops;   // 2*M*N*K summed over acx_gemm / acx_gemm_tn launches while recording
+  double prof_tn_flops, prof_tn_ms;   // the acx_gemm_tn share of it; its summed launch time (filled by acx_prof_collect)
+  int prof_tn_count;
 };
 
 struct AcxProfScope {

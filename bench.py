@@ -177,6 +177,12 @@ class Prof:
         self.L.check(self.lib.acx_prof_collect(self.h, counts, tot), self.h)
         return gf.value, list(counts), list(tot)
 
+    def gemm_tn(self):
+        """(flops, summed launch ms, launches) of the acx_gemm_tn launches the last collect() consumed."""
+        gf, ms, n = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int32(0)
+        self.L.check(self.lib.acx_prof_gemm_tn(self.h, ctypes.byref(gf), ctypes.byref(ms), ctypes.byref(n)), self.h)
+        return gf.value, ms.value, n.value
+
 
 def head_batch(B_global, world, rank, dev, step_seed=1):
     """UCF-shaped synthetic batch: B videos x 512 x 512-d, first half abnormal (13 classes cycling),
@@ -275,6 +281,7 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
             timer.run(step, 1, 0)
             timer.run(step, psteps, 0, prof.start, prof.stop)
         gf, counts, tot = prof.collect()
+        tn_gf, tn_ms, tn_n = prof.gemm_tn()                      # the weight-gradient launches (acx_gemm_tn) of the profiled steps
         gf, counts, tot = gf * steps / psteps, [c * steps // psteps for c in counts], [t * steps / psteps for t in tot]
         feats = HEAD_BATCH * 512
         gemm_ms, n_gemm = tot[0], counts[0]
@@ -285,7 +292,14 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
             "train_gemm": {"tflops": round(gf / 1e9 / gemm_ms, 2) if gemm_ms > 0 else None,
                            "frac_of_f32_mfma_peak": round(gf / 1e9 / gemm_ms / PEAK_TFLOPS["f32"], 4) if gemm_ms > 0 else None,
                            "launches_per_step": n_gemm // steps, "ms_per_step": round(gemm_ms / steps, 3),
-                           "executed_gflop_per_step": round(gf / 1e9 / steps, 1)},
+                           "executed_gflop_per_step": round(gf / 1e9 / steps, 1),
+                           "gemm_tn": {"tflops": round(tn_gf / 1e9 / tn_ms, 2) if tn_ms > 0 else None,
+                                       "frac_of_f32_mfma_peak": round(tn_gf / 1e9 / tn_ms / PEAK_TFLOPS["f32"], 4) if tn_ms > 0 else None,
+                                       "launches_per_step": tn_n // psteps, "ms_per_step": round(tn_ms / psteps, 3),
+                                       "gflop_per_step": round(tn_gf / 1e9 / psteps, 1)},
+                           "gemm_nt": {"tflops": round((gf / steps - tn_gf / psteps) / 1e9 / (gemm_ms / steps - tn_ms / psteps), 2)
+                                       if gemm_ms / steps > tn_ms / psteps else None,
+                                       "ms_per_step": round(gemm_ms / steps - tn_ms / psteps, 3)}},
             "train_kernel_ms_per_step": {"gemm": round(tot[0] / steps, 3), "attention": round(tot[1] / steps, 3),
                                          "norm_rows": round(tot[2] / steps, 3), "other": round(tot[3] / steps, 3)},
         }

@@ -402,6 +402,9 @@ int acx_prof_enable(acx_ctx* ctx, int on);
 int acx_prof_collect(acx_ctx* ctx, int32_t* counts, double* total_ms);
 /* executed GEMM flops (2*M*N*K of every acx_gemm / acx_gemm_tn launch) since acx_prof_enable(ctx, 1) */
 int acx_prof_gemm_flops(acx_ctx* ctx, double* flops);
+/* the acx_gemm_tn share of the above: flops since acx_prof_enable(ctx, 1); summed launch time and launch count of the events the
+ * LAST acx_prof_collect consumed (call it after acx_prof_collect) */
+int acx_prof_gemm_tn(acx_ctx* ctx, double* flops, double* total_ms, int32_t* launches);
 
 /* ------------------------------------------------------------------------------------------
  * Measured roofline denominators (bench.py `peaks_measured`).  Not on the product path.
