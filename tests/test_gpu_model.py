@@ -283,7 +283,7 @@ def test_feature_stream_matches_reference_loop(tmp_path, prompts_table):
     from anomalyclip_amd.feature_stream import FeatureStream
     rng = np.random.default_rng(0)
     paths, raws = [], []
-    for i, T_ in enumerate((300, 513, 1000)):
+    for i, T_ in enumerate((300, 513, 1000, 100)):            # 100 frames: the 512-row tile wraps around five times
         a = (rng.standard_normal((T_, 128)) * 0.3).astype(np.float32)
         p = str(tmp_path / f"v{i}.npy")
         np.save(p, a)
