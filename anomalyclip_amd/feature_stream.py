@@ -79,6 +79,20 @@ class FeatureStream:
         D = arr.shape[-1]
         T = arr.shape[0] // self.ncrops
         starts, S = FI.test_start_indices(T, self.N, self.L, self.stride)
+        if self.stride == 1 and arr.dtype == np.float32 and arr.ndim == 2 and arr.flags.c_contiguous:
+            # several crops, stride 1: crop c of the tile is rows c, c + ncrops, ... of the file in order, then its first rows
+            # again -- one strided copy per crop straight out of the mapping into the pinned slot, no index gather
+            rows = len(starts) * self.L
+            need = self.ncrops * rows * D
+            view = self._slot_buffer(slot, need, D)[:need].view(self.ncrops, rows, D)
+            dst = view.numpy()
+            src = arr.reshape(T, self.ncrops, D)
+            for c in range(self.ncrops):
+                np.copyto(dst[c, :T], src[:, c, :])
+            for r in range(T, rows, T):
+                n = min(T, rows - r)
+                dst[:, r:r + n] = dst[:, :n]
+            return view, T, S
         idx = FI.frame_index_table(starts, self.L, self.stride, T)
         rows = idx.shape[0]
         need = self.ncrops * rows * D

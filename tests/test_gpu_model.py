@@ -304,6 +304,28 @@ def test_feature_stream_matches_reference_loop(tmp_path, prompts_table):
         assert relerr(sc[:T_], rc[:T_]) < TOL
 
 
+@pytest.mark.parametrize("ncrops,stride,T_", [(5, 1, 700), (5, 1, 90), (1, 2, 700), (5, 2, 1500)])
+def test_feature_stream_crops_and_stride(tmp_path, ncrops, stride, T_):
+    """row f1, the other loader branches: multi-crop files (XD-Violence: five crops interleaved per frame) through the
+    per-crop strided copy, strided sampling through the index gather -- both equal feature_index.gather_test_features,
+    the function pinned to the reference's tables (feature_dataset.py:347-376)."""
+    from anomalyclip_amd.feature_stream import FeatureStream
+    from anomalyclip_amd import feature_index as FI
+    rng = np.random.default_rng(T_ + ncrops)
+    paths, raws = [], []
+    for i in range(3):
+        a = rng.standard_normal(((T_ + 37 * i) * ncrops, 64)).astype(np.float32)
+        p = str(tmp_path / f"c{i}.npy")
+        np.save(p, a)
+        paths.append(p)
+        raws.append(a)
+    fs = FeatureStream(paths, stride=stride, ncrops=ncrops, device=torch.device(DEV))
+    for (feats, T, S, path), raw in zip(fs, raws):
+        ref, S_ref = FI.gather_test_features(raw, 32, 16, stride, ncrops)
+        assert T == raw.shape[0] // ncrops and S == S_ref and feats.shape == (1,) + ref.shape
+        assert np.array_equal(feats[0].cpu().numpy(), ref)
+
+
 def test_config0_shanghaitech_eval_from_feature_files(golden, prompts_table, tmp_path):
     """BASELINE.json configs[0] on the HIP path, end to end: eight `.npy` feature files (T = 300 ... 5000, up to S = 10
     tiles) -> FeatureStream (one gather into pinned memory, async copy) -> AnomalyCLIPModule.test_step (ShanghaiTech head:
