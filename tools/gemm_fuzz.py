@@ -1,12 +1,15 @@
 import sys; sys.path.insert(0, "/root/repo")
 import torch, random
 from anomalyclip_amd import ops, _lib as L
-random.seed(1)
-torch.manual_seed(1)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+CASES = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+random.seed(SEED)
+torch.manual_seed(SEED)
 bad = 0
-for it in range(14):
+for it in range(CASES):
     f32 = it % 2 == 0
-    M = random.choice([100864, 65536 + random.randrange(1, 4000), 40000 + random.randrange(0, 5000), 131072 + random.randrange(0, 999)])
+    M = random.choice([100864, 65536 + random.randrange(1, 4000), 40000 + random.randrange(0, 5000), 131072 + random.randrange(0, 999),
+                       16384 + random.randrange(0, 20000), 200000 + random.randrange(0, 3000)])
     N = random.choice([768, 1000, 2304, 2300, 3072, 1536, 516])
     K = random.choice([768, 256, 512, 1024, 3072]) if f32 else random.choice([768, 256, 512, 1024, 3072, 128])
     act = random.choice([0, 1]); res = random.choice([0, 1]) if not act else 0
