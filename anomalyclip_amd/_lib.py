@@ -136,6 +136,8 @@ _SIGS = {
     "acx_cast_bf16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_colsum": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_sort_workspace_bytes": (c_int64, [c_int64]),
+    "acx_sort_pairs_batched": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                         c_void_p, c_int64, c_void_p]),
     "acx_sort_pairs": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64,
                                  c_void_p]),
     "acx_clf_curve_workspace_bytes": (c_int64, [c_int64]),

@@ -22,11 +22,14 @@ __device__ __forceinline__ uint32_t key_decode(uint32_t u, int desc) {
 }
 
 // per-block digit histogram, written digit-major ([256][nblocks]) so one linear scan yields the scatter bases
+// (blockIdx.y = problem of a batched sort: keys kstride apart, histograms 256 * nblocks apart)
 __global__ __launch_bounds__(MT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ kin,
                                                                  uint32_t* __restrict__ hist, int n, int nblocks,
-                                                                 int shift, int first, int desc) {
+                                                                 int shift, int first, int desc, size_t kstride) {
   __shared__ uint32_t h[256];
   const int tid = threadIdx.x;
+  kin += blockIdx.y * kstride;
+  hist += (size_t)blockIdx.y * 256 * nblocks;
   h[tid] = 0;
   __syncthreads();
   const int base = blockIdx.x * MT_TILE;
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(MT_THREADS) void radix_hist_kernel(const uint32_t* 
 __global__ __launch_bounds__(256) void scan_rows_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ tot, int nblocks) {
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry_s;
+  hist += (size_t)blockIdx.y * 256 * nblocks;
+  tot += blockIdx.y * 256;
   uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) carry_s = 0;
@@ -85,11 +90,14 @@ __global__ __launch_bounds__(MT_THREADS) void radix_scatter_kernel(const uint32_
                                                                     const uint32_t* __restrict__ bases,
                                                                     const uint32_t* __restrict__ tot, int n,
                                                                     int nblocks, int shift, int first, int last,
-                                                                    int desc) {
+                                                                    int desc, size_t kstride, size_t vstride, size_t ostride) {
   __shared__ uint32_t cnt[4][256];
   __shared__ uint32_t dbase[256];
   __shared__ uint32_t dws[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  kin += blockIdx.y * kstride; vin += blockIdx.y * vstride;
+  kout += blockIdx.y * ostride; vout += blockIdx.y * ostride;
+  bases += (size_t)blockIdx.y * 256 * nblocks; tot += blockIdx.y * 256;
   {   // exclusive scan of the 256 digit totals (thread = digit)
     const uint32_t v = tot[tid];
     uint32_t inc = v;
@@ -486,6 +494,48 @@ extern "C" int64_t acx_sort_workspace_bytes(int64_t n) {
   return 2 * n * 4 + 256 * (nb > 0 ? nb : 1) * 4 + 256 * 4 + 256;
 }
 
+// `batch` independent sorts of n pairs each in ONE launch sequence (12 launches for any batch): keys of problem b at
+// keys + b * key_stride, payloads at vals + b * val_stride (val_stride = 0: every problem sorts the SAME payload array, the
+// metrics epilogue's one-vs-rest curves all carry the label vector), outputs dense [batch][n].  The workspace is `batch`
+// times acx_sort_workspace_bytes(n).
+extern "C" int acx_sort_pairs_batched(acx_ctx* ctx, const float* keys, int64_t key_stride, const uint32_t* vals,
+                                      int64_t val_stride, float* keys_out, uint32_t* vals_out, int64_t n, int32_t batch,
+                                      int32_t descending, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!ctx) return acx_fail(ctx, ACX_E_BADARG, "acx_sort_pairs_batched: null context");
+  if (n < 0 || n >= (1ll << 31) - MT_TILE) return acx_fail(ctx, ACX_E_BADARG, "acx_sort_pairs_batched: %sn=%ld out of range", "", (long)n);
+  if (batch < 0 || batch > 65535) return acx_fail(ctx, ACX_E_BADARG, "acx_sort_pairs_batched: %sbatch=%ld out of range", "", (long)batch);
+  if (n == 0 || batch == 0) return ACX_OK;
+  if (!keys || !vals || !keys_out || !vals_out || !workspace) return acx_fail(ctx, ACX_E_BADARG, "acx_sort_pairs_batched: null buffer");
+  if (key_stride < n || (val_stride != 0 && val_stride < n)) return acx_fail(ctx, ACX_E_BADARG, "acx_sort_pairs_batched: stride < n%s", "");
+  if ((const void*)keys == (void*)keys_out || (const void*)vals == (void*)vals_out)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_sort_pairs_batched: in-place sort is not supported");
+  if (workspace_bytes < (int64_t)batch * acx_sort_workspace_bytes(n))
+    return acx_fail(ctx, ACX_E_WORKSPACE, "acx_sort_pairs_batched: %sworkspace %ld < %ld bytes", "", (long)workspace_bytes,
+                    (long)((int64_t)batch * acx_sort_workspace_bytes(n)));
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((n + MT_TILE - 1) / MT_TILE);
+  uint32_t* tk = (uint32_t*)workspace;                       // [batch][n]
+  uint32_t* tv = tk + (size_t)batch * n;                     // [batch][n]
+  uint32_t* hist = tv + (size_t)batch * n;                   // [batch][256][nb]
+  uint32_t* tot = hist + (size_t)batch * 256 * nb;           // [batch][256]
+  // ping-pong: in -> tmp -> out -> tmp -> out
+  const uint32_t* sk[4] = {(const uint32_t*)keys, tk, (uint32_t*)keys_out, tk};
+  const uint32_t* sv[4] = {vals, tv, vals_out, tv};
+  uint32_t* dk[4] = {tk, (uint32_t*)keys_out, tk, (uint32_t*)keys_out};
+  uint32_t* dv[4] = {tv, vals_out, tv, vals_out};
+  AcxProfScope prof(ctx, ACX_K_OTHER, st);
+  for (int p = 0; p < 4; ++p) {
+    const size_t ks = p == 0 ? (size_t)key_stride : (size_t)n, vs = p == 0 ? (size_t)val_stride : (size_t)n;
+    radix_hist_kernel<<<dim3(nb, batch), MT_THREADS, 0, st>>>(sk[p], hist, (int)n, nb, 8 * p, p == 0, descending, ks);
+    scan_rows_kernel<<<dim3(256, batch), 256, 0, st>>>(hist, tot, nb);
+    radix_scatter_kernel<<<dim3(nb, batch), MT_THREADS, 0, st>>>(sk[p], sv[p], dk[p], dv[p], hist, tot, (int)n, nb, 8 * p,
+                                                                 p == 0, p == 3, descending, ks, vs, (size_t)n);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return acx_fail(ctx, ACX_E_HIP, "acx_sort_pairs_batched: %s", hipGetErrorString(e));
+  return ACX_OK;
+}
+
 extern "C" int acx_sort_pairs(acx_ctx* ctx, const float* keys, const uint32_t* vals, float* keys_out,
                               uint32_t* vals_out, int64_t n, int32_t descending, void* workspace,
                               int64_t workspace_bytes, void* stream) {
@@ -498,27 +548,7 @@ extern "C" int acx_sort_pairs(acx_ctx* ctx, const float* keys, const uint32_t* v
   if (workspace_bytes < acx_sort_workspace_bytes(n))
     return acx_fail(ctx, ACX_E_WORKSPACE, "acx_sort_pairs: %sworkspace %ld < %ld bytes", "", (long)workspace_bytes,
                     (long)acx_sort_workspace_bytes(n));
-  hipStream_t st = (hipStream_t)stream;
-  const int nb = (int)((n + MT_TILE - 1) / MT_TILE);
-  uint32_t* tk = (uint32_t*)workspace;
-  uint32_t* tv = tk + n;
-  uint32_t* hist = tv + n;
-  uint32_t* tot = hist + (size_t)256 * nb;
-  // ping-pong: in -> tmp -> out -> tmp -> out
-  const uint32_t* sk[4] = {(const uint32_t*)keys, tk, (uint32_t*)keys_out, tk};
-  const uint32_t* sv[4] = {vals, tv, vals_out, tv};
-  uint32_t* dk[4] = {tk, (uint32_t*)keys_out, tk, (uint32_t*)keys_out};
-  uint32_t* dv[4] = {tv, vals_out, tv, vals_out};
-  AcxProfScope prof(ctx, ACX_K_OTHER, st);
-  for (int p = 0; p < 4; ++p) {
-    radix_hist_kernel<<<nb, MT_THREADS, 0, st>>>(sk[p], hist, (int)n, nb, 8 * p, p == 0, descending);
-    scan_rows_kernel<<<256, 256, 0, st>>>(hist, tot, nb);
-    radix_scatter_kernel<<<nb, MT_THREADS, 0, st>>>(sk[p], sv[p], dk[p], dv[p], hist, tot, (int)n, nb, 8 * p, p == 0,
-                                                    p == 3, descending);
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return acx_fail(ctx, ACX_E_HIP, "acx_sort_pairs: %s", hipGetErrorString(e));
-  return ACX_OK;
+  return acx_sort_pairs_batched(ctx, keys, n, vals, n, keys_out, vals_out, n, 1, descending, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t acx_clf_curve_workspace_bytes(int64_t n) {

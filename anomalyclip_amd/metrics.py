@@ -47,18 +47,21 @@ def evaluate(abnormal_scores: torch.Tensor, labels: torch.Tensor, class_probs: t
     res = torch.zeros((Cn + 1) * ops.CURVE_RESULT_BYTES, dtype=torch.uint8, device=dev)
     rec = lambda i: res[i * ops.CURVE_RESULT_BYTES:(i + 1) * ops.CURVE_RESULT_BYTES]
 
-    # binary anomaly curve: target = labels != normal (:520-530)
-    ks, vs = ops.sort_pairs(s, lab32, descending=True)
-    cv = ops.clf_curve(ks, vs, normal_idx, True, rec(0), curves=curves)
-
-    # one-vs-rest curves over class_probs with the normal column (1 - score) inserted (:507-518, :583-584)
+    # All Cn + 1 score columns in one [Cn + 1, n] array: row 0 = the anomaly score (binary curve, target = labels != normal,
+    # :520-530), rows 1.. = class_probs with the normal column (1 - score) inserted (:507-518, :583-584); they are sorted by
+    # ONE batched launch sequence (the label vector is the shared payload) instead of Cn + 1 sorts of 12 launches each.
+    allc = torch.empty(Cn + 1, n, dtype=torch.float32, device=dev)
+    allc[0].copy_(s)
     cols = ops.transpose(probs)                                   # [C-1, n], one contiguous score column per class
-    normal_col = torch.ones_like(s)
+    allc[1:1 + normal_idx].copy_(cols[:normal_idx])
+    allc[2 + normal_idx:].copy_(cols[normal_idx:])
+    normal_col = allc[1 + normal_idx]
+    normal_col.fill_(1.0)
     ops.axpby_(normal_col, s, -1.0, 1.0)                          # 1 - s
+    ks, vs = ops.sort_pairs_batched(allc, lab32, descending=True)
+    cv = ops.clf_curve(ks[0], vs[0], normal_idx, True, rec(0), curves=curves)
     for c in range(Cn):
-        col = normal_col if c == normal_idx else cols[c if c < normal_idx else c - 1]
-        kc, vc = ops.sort_pairs(col, lab32, descending=True)
-        ops.clf_curve(kc, vc, c, False, rec(c + 1))
+        ops.clf_curve(ks[c + 1], vs[c + 1], c, False, rec(c + 1))
 
     out: Dict[str, object] = {}
     y_pred = counts = None

@@ -580,6 +580,25 @@ def sort_pairs(keys: torch.Tensor, vals: torch.Tensor, descending: bool = True):
     return ko, vo
 
 
+def sort_pairs_batched(keys: torch.Tensor, vals: torch.Tensor, descending: bool = True):
+    """keys [B, n] f32 (rows may be strided), vals [n] (shared by all rows) or [B, n] int32 -> (sorted keys [B, n], payloads [B, n]):
+    B stable radix sorts in one launch sequence (acx_sort_pairs_batched)."""
+    assert keys.dtype == torch.float32 and vals.dtype == torch.int32 and keys.dim() == 2 and keys.stride(1) == 1
+    B, n = keys.shape
+    shared = vals.dim() == 1
+    assert vals.is_contiguous() and (vals.shape == (n,) if shared else vals.shape == (B, n))
+    ko = torch.empty(B, n, dtype=torch.float32, device=keys.device)
+    vo = torch.empty(B, n, dtype=torch.int32, device=keys.device)
+    if n == 0 or B == 0:
+        return ko, vo
+    lib = L.lib()
+    ws = torch.empty(B * int(lib.acx_sort_workspace_bytes(n)), dtype=torch.uint8, device=keys.device)
+    h = _h(keys)
+    L.check(lib.acx_sort_pairs_batched(h, keys.data_ptr(), keys.stride(0), vals.data_ptr(), 0 if shared else n, ko.data_ptr(),
+                                       vo.data_ptr(), n, B, int(descending), ws.data_ptr(), ws.numel(), _stream()), h)
+    return ko, vo
+
+
 def clf_curve(sorted_scores: torch.Tensor, sorted_labels: torch.Tensor, cls: int, negate: bool,
               result: torch.Tensor, curves: bool = False):
     """Fills one 56-byte acx_curve_result record (`result`: uint8[56] device view); optionally returns the

@@ -367,6 +367,12 @@ int acx_scatter_rows(acx_ctx* ctx, const float* src, const int64_t* idx, float* 
 int64_t acx_sort_workspace_bytes(int64_t n);
 int acx_sort_pairs(acx_ctx* ctx, const float* keys, const uint32_t* vals, float* keys_out, uint32_t* vals_out,
                    int64_t n, int32_t descending, void* workspace, int64_t workspace_bytes, void* stream);
+/* `batch` independent sorts of n pairs in one launch sequence (12 launches for any batch).  Problem b reads keys + b * key_stride and
+ * vals + b * val_stride (val_stride = 0: all problems carry the SAME payload array); outputs are dense [batch][n].
+ * workspace_bytes >= batch * acx_sort_workspace_bytes(n).  Replaces the per-class loop of anomaly_clip_module.py:507-518. */
+int acx_sort_pairs_batched(acx_ctx* ctx, const float* keys, int64_t key_stride, const uint32_t* vals, int64_t val_stride,
+                           float* keys_out, uint32_t* vals_out, int64_t n, int32_t batch, int32_t descending, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 typedef struct acx_curve_result {   /* written to DEVICE memory */
   double auroc;          /* trapz(tpr, fpr) over the distinct thresholds; 0 when a class is absent (torchmetrics) */

@@ -35,6 +35,21 @@ def test_sort_pairs_is_a_stable_sort(n, desc):
     assert np.array_equal(ks.numpy().view(np.uint32), k.numpy()[order].view(np.uint32))
 
 
+@pytest.mark.parametrize("B,n,shared", [(15, 5000, True), (3, 2049, False), (1, 1, True), (4, 70000, True)])
+def test_sort_pairs_batched_equals_separate_sorts(B, n, shared):
+    """acx_sort_pairs_batched: B stable sorts in one launch sequence == B calls of acx_sort_pairs, bit for bit, with strided key
+    rows and a payload array that is either shared by all problems (the metrics epilogue) or one per problem."""
+    g = torch.Generator().manual_seed(B * 131 + n)
+    big = torch.randn(B, n + 7, generator=g)
+    big[:, : n // 2] = torch.round(big[:, : n // 2] * 20) / 20                # ties
+    keys = big.to(DEV)[:, :n]                                                  # row stride n + 7
+    vals = torch.randint(0, 1 << 20, (n,) if shared else (B, n), generator=g, dtype=torch.int32).to(DEV)
+    ks, vs = ops.sort_pairs_batched(keys, vals, descending=True)
+    for b in range(B):
+        k1, v1 = ops.sort_pairs(keys[b].contiguous(), vals if shared else vals[b].contiguous(), descending=True)
+        assert torch.equal(ks[b].view(torch.int32), k1.view(torch.int32)) and torch.equal(vs[b], v1)
+
+
 def _case(n, seed, ties, C=14, nid=7):
     rng = np.random.default_rng(seed)
     labels = rng.integers(0, C, n)
