@@ -141,6 +141,8 @@ _SIGS = {
     "acx_sort_pairs": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64,
                                  c_void_p]),
     "acx_clf_curve_workspace_bytes": (c_int64, [c_int64]),
+    "acx_clf_curve_batched": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, C.POINTER(c_int32),
+                                        C.POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_clf_curve": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_test_counts": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,

@@ -225,6 +225,13 @@ struct TileScan {
   int tsum;               // thread's positives
 };
 
+// per-problem parameters of a batched curve launch (blockIdx.y = problem): class id, "target = label != cls" flag
+struct CurveBatch {
+  int cls[64];
+  unsigned long long negate;
+  size_t sstride, lstride;      // elements between the problems' score / label arrays
+};
+
 __device__ __forceinline__ bool is_target(uint32_t label, int cls, int negate) {
   return negate ? ((int)label != cls) : ((int)label == cls);
 }
@@ -251,10 +258,12 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ s, const uin
 }
 
 __global__ __launch_bounds__(MT_THREADS) void curve_stats_kernel(const float* __restrict__ s,
-                                                                  const uint32_t* __restrict__ lab, int n, int cls,
-                                                                  int negate, CurveBlock* __restrict__ blk) {
+                                                                  const uint32_t* __restrict__ lab, int n,
+                                                                  const CurveBatch cb, CurveBlock* __restrict__ blk) {
   __shared__ int shi[4];
   __shared__ long long shl[4];
+  const int cls = cb.cls[blockIdx.y], negate = (int)((cb.negate >> blockIdx.y) & 1ull);
+  s += blockIdx.y * cb.sstride; lab += blockIdx.y * cb.lstride; blk += (size_t)blockIdx.y * gridDim.x;
   TileScan ts;
   tile_load(s, lab, n, cls, negate, ts);
   int total;
@@ -288,6 +297,7 @@ __global__ __launch_bounds__(1024) void curve_prefix_kernel(CurveBlock* __restri
   __shared__ int ps[1024], pc[1024];
   __shared__ long long pm[1024];
   const int tid = threadIdx.x;
+  blk += (size_t)blockIdx.x * nb; res += blockIdx.x;          // blockIdx.x = problem
   const int per = (nb + 1023) / 1024;
   const int lo = min(tid * per, nb), hi = min(lo + per, nb);
   int s = 0, c = 0;
@@ -329,14 +339,17 @@ __global__ __launch_bounds__(1024) void curve_prefix_kernel(CurveBlock* __restri
 }
 
 __global__ __launch_bounds__(MT_THREADS) void curve_points_kernel(const float* __restrict__ s,
-                                                                   const uint32_t* __restrict__ lab, int n, int cls,
-                                                                   int negate, CurveBlock* __restrict__ blk,
+                                                                   const uint32_t* __restrict__ lab, int n,
+                                                                   const CurveBatch cb, CurveBlock* __restrict__ blk,
                                                                    const CurveResultDev* __restrict__ res,
                                                                    int* __restrict__ ctps, int* __restrict__ cfps,
                                                                    float* __restrict__ cthr) {
   __shared__ int shi[4];
   __shared__ long long shl[4];
   __shared__ double shd[4];
+  const int cls = cb.cls[blockIdx.y], negate = (int)((cb.negate >> blockIdx.y) & 1ull);
+  s += blockIdx.y * cb.sstride; lab += blockIdx.y * cb.lstride; blk += (size_t)blockIdx.y * gridDim.x; res += blockIdx.y;
+  if (blockIdx.y != 0) ctps = nullptr;                        // the curve arrays belong to problem 0
   TileScan ts;
   tile_load(s, lab, n, cls, negate, ts);
   const CurveBlock b = blk[blockIdx.x];
@@ -395,10 +408,11 @@ __global__ __launch_bounds__(MT_THREADS) void curve_points_kernel(const float* _
 }
 
 __global__ __launch_bounds__(256) void curve_final_kernel(const float* __restrict__ s, const CurveBlock* __restrict__ blk,
-                                                           int nb, CurveResultDev* __restrict__ res) {
+                                                           int nb, CurveResultDev* __restrict__ res, size_t sstride) {
   __shared__ long long sa[256], sj[256], si[256];
   __shared__ double sp[256];
   const int tid = threadIdx.x;
+  s += blockIdx.x * sstride; blk += (size_t)blockIdx.x * nb; res += blockIdx.x;      // blockIdx.x = problem
   long long a = 0, bj = (long long)0x8000000000000000ll, bi = -1;
   double p = 0.0;
   for (int i = tid; i < nb; i += 256) {
@@ -557,30 +571,55 @@ extern "C" int64_t acx_clf_curve_workspace_bytes(int64_t n) {
   return (nb > 0 ? nb : 1) * (int64_t)sizeof(CurveBlock);
 }
 
+// `batch` curves in one launch sequence (4 launches for any batch <= 64): problem b reads sorted_scores + b * score_stride and
+// sorted_labels + b * label_stride with target = (label == cls[b]) or, where negate[b] != 0, (label != cls[b]); results[b] is its
+// record.  The optional curve arrays (all three or none) receive the points of problem 0 only.
+extern "C" int acx_clf_curve_batched(acx_ctx* ctx, const float* sorted_scores, int64_t score_stride,
+                                     const uint32_t* sorted_labels, int64_t label_stride, int64_t n, int32_t batch,
+                                     const int32_t* cls, const int32_t* negate, acx_curve_result* results, int32_t* curve_tps,
+                                     int32_t* curve_fps, float* curve_thresholds, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
+  static_assert(sizeof(CurveResultDev) == sizeof(acx_curve_result), "acx_curve_result layout");
+  if (!ctx) return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve_batched: null context");
+  if (n <= 0 || n >= (1ll << 31) - MT_TILE) return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve_batched: %sn=%ld out of range", "", (long)n);
+  if (batch < 1 || batch > 64) return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve_batched: %sbatch=%ld not in 1..64", "", (long)batch);
+  if (!sorted_scores || !sorted_labels || !cls || !negate || !results || !workspace)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve_batched: null buffer");
+  if ((curve_tps != nullptr) != (curve_fps != nullptr) || (curve_tps != nullptr) != (curve_thresholds != nullptr))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve_batched: pass all three curve arrays or none");
+  if (workspace_bytes < (int64_t)batch * acx_clf_curve_workspace_bytes(n))
+    return acx_fail(ctx, ACX_E_WORKSPACE, "acx_clf_curve_batched: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((n + MT_TILE - 1) / MT_TILE);
+  CurveBlock* blk = (CurveBlock*)workspace;                   // [batch][nb]
+  CurveResultDev* res = (CurveResultDev*)results;
+  CurveBatch cb;
+  memset(&cb, 0, sizeof(cb));
+  for (int b = 0; b < batch; ++b) { cb.cls[b] = cls[b]; if (negate[b]) cb.negate |= 1ull << b; }
+  cb.sstride = (size_t)score_stride; cb.lstride = (size_t)label_stride;
+  AcxProfScope prof(ctx, ACX_K_OTHER, st);
+  curve_stats_kernel<<<dim3(nb, batch), MT_THREADS, 0, st>>>(sorted_scores, sorted_labels, (int)n, cb, blk);
+  curve_prefix_kernel<<<batch, 1024, 0, st>>>(blk, nb, (long long)n, res);
+  curve_points_kernel<<<dim3(nb, batch), MT_THREADS, 0, st>>>(sorted_scores, sorted_labels, (int)n, cb, blk, res, curve_tps,
+                                                               curve_fps, curve_thresholds);
+  curve_final_kernel<<<batch, 256, 0, st>>>(sorted_scores, blk, nb, res, (size_t)score_stride);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return acx_fail(ctx, ACX_E_HIP, "acx_clf_curve_batched: %s", hipGetErrorString(e));
+  return ACX_OK;
+}
+
 extern "C" int acx_clf_curve(acx_ctx* ctx, const float* sorted_scores, const uint32_t* sorted_labels, int64_t n,
                              int32_t cls, int32_t negate, acx_curve_result* result, int32_t* curve_tps,
                              int32_t* curve_fps, float* curve_thresholds, void* workspace, int64_t workspace_bytes,
                              void* stream) {
-  static_assert(sizeof(CurveResultDev) == sizeof(acx_curve_result), "acx_curve_result layout");
   if (!ctx) return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve: null context");
   if (n <= 0 || n >= (1ll << 31) - MT_TILE) return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve: %sn=%ld out of range", "", (long)n);
   if (!sorted_scores || !sorted_labels || !result || !workspace) return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve: null buffer");
   if ((curve_tps != nullptr) != (curve_fps != nullptr) || (curve_tps != nullptr) != (curve_thresholds != nullptr))
     return acx_fail(ctx, ACX_E_BADARG, "acx_clf_curve: pass all three curve arrays or none");
   if (workspace_bytes < acx_clf_curve_workspace_bytes(n)) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_clf_curve: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  const int nb = (int)((n + MT_TILE - 1) / MT_TILE);
-  CurveBlock* blk = (CurveBlock*)workspace;
-  CurveResultDev* res = (CurveResultDev*)result;
-  AcxProfScope prof(ctx, ACX_K_OTHER, st);
-  curve_stats_kernel<<<nb, MT_THREADS, 0, st>>>(sorted_scores, sorted_labels, (int)n, cls, negate, blk);
-  curve_prefix_kernel<<<1, 1024, 0, st>>>(blk, nb, (long long)n, res);
-  curve_points_kernel<<<nb, MT_THREADS, 0, st>>>(sorted_scores, sorted_labels, (int)n, cls, negate, blk, res, curve_tps,
-                                                 curve_fps, curve_thresholds);
-  curve_final_kernel<<<1, 256, 0, st>>>(sorted_scores, blk, nb, res);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return acx_fail(ctx, ACX_E_HIP, "acx_clf_curve: %s", hipGetErrorString(e));
-  return ACX_OK;
+  return acx_clf_curve_batched(ctx, sorted_scores, n, sorted_labels, n, n, 1, &cls, &negate, result, curve_tps, curve_fps,
+                               curve_thresholds, workspace, workspace_bytes, stream);
 }
 
 extern "C" int acx_test_counts(acx_ctx* ctx, const float* scores, const float* probs, const int64_t* labels,

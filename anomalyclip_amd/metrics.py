@@ -59,9 +59,8 @@ def evaluate(abnormal_scores: torch.Tensor, labels: torch.Tensor, class_probs: t
     normal_col.fill_(1.0)
     ops.axpby_(normal_col, s, -1.0, 1.0)                          # 1 - s
     ks, vs = ops.sort_pairs_batched(allc, lab32, descending=True)
-    cv = ops.clf_curve(ks[0], vs[0], normal_idx, True, rec(0), curves=curves)
-    for c in range(Cn):
-        ops.clf_curve(ks[c + 1], vs[c + 1], c, False, rec(c + 1))
+    # ... and turned into their curves by ONE batched launch sequence: problem 0 = "label != normal", problem c + 1 = "label == c"
+    cv = ops.clf_curve_batched(ks, vs, [normal_idx] + list(range(Cn)), [True] + [False] * Cn, res, curves=curves)
 
     out: Dict[str, object] = {}
     y_pred = counts = None

@@ -619,6 +619,29 @@ def clf_curve(sorted_scores: torch.Tensor, sorted_labels: torch.Tensor, cls: int
     return tps, fps, thr
 
 
+def clf_curve_batched(sorted_scores: torch.Tensor, sorted_labels: torch.Tensor, cls, negate, results: torch.Tensor,
+                      curves: bool = False):
+    """B curves in one launch sequence: sorted_scores / sorted_labels [B, n] (dense rows), `cls` / `negate` length-B host
+    sequences, `results`: uint8[B * 56] device buffer (record b at byte 56 b).  With curves=True returns the (tps, fps,
+    thresholds) arrays of problem 0 (capacity n; the first n_distinct entries are valid)."""
+    B, n = sorted_scores.shape
+    assert sorted_labels.shape == (B, n) and sorted_scores.is_contiguous() and sorted_labels.is_contiguous()
+    assert len(cls) == B and len(negate) == B and results.numel() >= B * CURVE_RESULT_BYTES
+    lib = L.lib()
+    dev = sorted_scores.device
+    ws = torch.empty(B * int(lib.acx_clf_curve_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    tps = fps = thr = None
+    if curves:
+        tps = torch.empty(n, dtype=torch.int32, device=dev)
+        fps = torch.empty(n, dtype=torch.int32, device=dev)
+        thr = torch.empty(n, dtype=torch.float32, device=dev)
+    h = _h(sorted_scores)
+    ca, na = (C.c_int32 * B)(*[int(c) for c in cls]), (C.c_int32 * B)(*[int(bool(x)) for x in negate])
+    L.check(lib.acx_clf_curve_batched(h, sorted_scores.data_ptr(), n, sorted_labels.data_ptr(), n, n, B, ca, na, results.data_ptr(),
+                                      _ptr(tps), _ptr(fps), _ptr(thr), ws.data_ptr(), ws.numel(), _stream()), h)
+    return tps, fps, thr
+
+
 def eval_counts(scores, probs, labels, C: int, normal_idx: int, threshold_dev: torch.Tensor):
     """-> (y_pred int32 [n], counts int64 [3C + C*C + 30]); `threshold_dev` is a device f32 scalar view."""
     n = scores.numel()

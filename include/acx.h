@@ -390,6 +390,14 @@ int64_t acx_clf_curve_workspace_bytes(int64_t n);
 int acx_clf_curve(acx_ctx* ctx, const float* sorted_scores, const uint32_t* sorted_labels, int64_t n, int32_t cls,
                   int32_t negate, acx_curve_result* result, int32_t* curve_tps, int32_t* curve_fps,
                   float* curve_thresholds, void* workspace, int64_t workspace_bytes, void* stream);
+/* `batch` (1..64) curves in one launch sequence (4 launches): problem b reads sorted_scores + b * score_stride and
+ * sorted_labels + b * label_stride, target = (label == cls[b]), or (label != cls[b]) where negate[b] != 0; results[b] is its record;
+ * cls / negate are HOST arrays.  The optional curve arrays (all three or none) receive the points of problem 0 only.
+ * workspace_bytes >= batch * acx_clf_curve_workspace_bytes(n). */
+int acx_clf_curve_batched(acx_ctx* ctx, const float* sorted_scores, int64_t score_stride, const uint32_t* sorted_labels,
+                          int64_t label_stride, int64_t n, int32_t batch, const int32_t* cls, const int32_t* negate,
+                          acx_curve_result* results, int32_t* curve_tps, int32_t* curve_fps, float* curve_thresholds, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 /* anomaly_clip_module.py:538-581, 621-626, 673: y_pred and the integer counters behind top-1 / top-5 accuracy,
  * the confusion matrix and F1@{0.1..1.0}.  probs [n, C-1] (class_probs without the normal column), labels int64,
  * threshold = DEVICE pointer to the optimal threshold (e.g. &result->opt_threshold).  counts (int64, device,

@@ -50,6 +50,26 @@ def test_sort_pairs_batched_equals_separate_sorts(B, n, shared):
         assert torch.equal(ks[b].view(torch.int32), k1.view(torch.int32)) and torch.equal(vs[b], v1)
 
 
+def test_clf_curve_batched_equals_separate_curves():
+    """acx_clf_curve_batched: the records of B curves computed in one launch sequence are byte-identical to B acx_clf_curve calls
+    (exact int64 AUROC / threshold arithmetic, fixed-order f64 AP), and the curve arrays are those of problem 0."""
+    n, B = 30000, 6
+    g = torch.Generator().manual_seed(5)
+    keys = (torch.round(torch.rand(B, n, generator=g) * 500) / 500).to(DEV)
+    lab = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32).to(DEV)
+    ks, vs = ops.sort_pairs_batched(keys, lab, descending=True)
+    cls, neg = [2, 0, 1, 2, 3, 4], [True, False, False, False, False, False]
+    res = torch.zeros(B * ops.CURVE_RESULT_BYTES, dtype=torch.uint8, device=DEV)
+    tps, fps, thr = ops.clf_curve_batched(ks, vs, cls, neg, res, curves=True)
+    for b in range(B):
+        one = torch.zeros(ops.CURVE_RESULT_BYTES, dtype=torch.uint8, device=DEV)
+        t1, f1, h1 = ops.clf_curve(ks[b], vs[b], cls[b], neg[b], one, curves=b == 0)
+        assert torch.equal(one, res[b * ops.CURVE_RESULT_BYTES:(b + 1) * ops.CURVE_RESULT_BYTES])
+        if b == 0:
+            nd = int(one[32:40].view(torch.int64).item())                      # n_distinct
+            assert torch.equal(tps[:nd], t1[:nd]) and torch.equal(fps[:nd], f1[:nd]) and torch.equal(thr[:nd], h1[:nd])
+
+
 def _case(n, seed, ties, C=14, nid=7):
     rng = np.random.default_rng(seed)
     labels = rng.integers(0, C, n)

@@ -23,7 +23,15 @@ ev[0].record()
 for _ in range(10): ops.sort_pairs(ds, lab32)
 ev[1].record(); torch.cuda.synchronize()
 sort_ms = ev[0].elapsed_time(ev[1]) / 10
+# the epilogue's own sort: C + 1 score columns with the shared label payload, one batched launch sequence
+allc = torch.rand(C + 1, n, device=ds.device)
+ops.sort_pairs_batched(allc, lab32)
+ev[0].record()
+for _ in range(10): ops.sort_pairs_batched(allc, lab32)
+ev[1].record(); torch.cuda.synchronize()
+bsort_ms = ev[0].elapsed_time(ev[1]) / 10
 t0 = time.perf_counter(); w = MO.epilogue(s, labels, p, nid, C); cpu = time.perf_counter() - t0
 print({"n_frames": n, "gpu_epilogue_ms": round(gpu * 1e3, 2), "sort_pairs_ms": round(sort_ms, 3),
-       "sort_GBps_alg": round(n * 16 / sort_ms / 1e6, 1), "cpu_oracle_s": round(cpu, 2),
+       "sort_GBps_alg": round(n * 16 / sort_ms / 1e6, 1), "batched_sort_ms": round(bsort_ms, 3),
+       "batched_sort_GBps_alg": round((C + 1) * n * 16 / bsort_ms / 1e6, 1), "cpu_oracle_s": round(cpu, 2),
        "auc_roc": r["auc_roc"], "auc_roc_oracle": w["auc_roc"]})
