@@ -551,7 +551,10 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     // ~1300 rows -- 17-34 row tiles x 16 column tiles fill the chip where 64x64 tiles leave half of it idle
     // (profiles/r03_text_gemm.txt); wide outputs only up to the row limit
     const int sk_max_m = ctx ? ctx->opt_sk_max_m : ACX_SK_MAX_M;
-    if (sk_ok && (sk_fusion || d->M <= sk_max_m || (sk_max_m > 0 && d->N <= 512 && d->M <= 4 * sk_max_m))) {
+    // ... except long K at more than ~770 rows when the caller brought a split-K workspace: the 64x64 kernel with K split 2-4
+    // ways is ahead there (1078 rows, N = 512: K = 2048 37.1 vs 43.5 us, K = 1536 30.0 vs 33.2 us; at 539 rows it is not)
+    const bool sk_narrow = sk_max_m > 0 && d->N <= 512 && d->M <= 4 * sk_max_m && !(d->workspace && d->M > 768 && d->K >= 1536);
+    if (sk_ok && (sk_fusion || d->M <= sk_max_m || sk_narrow)) {
       const dim3 kgrid((unsigned)(((d->M + 31) / 32) * ((d->N + 31) / 32)));
 #define ACX_SKL(E, AG)                                                                              \
   do {                                                                                              \
@@ -591,7 +594,20 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const int st_m = (d->M + 63) / 64, st_n = (d->N + 63) / 64;
   if (s64 && fast && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16 && tiles_m * g.tiles_n <= 256 && st_m * st_n >= 96) {
     const size_t lds_s = 4 * TILE_S;
-    const dim3 sgrid((unsigned)(st_m * st_n));
+    dim3 sgrid((unsigned)(st_m * st_n));
+    // long K on few tiles (text tower: N = 512, K = 1536 / 2048 at 539-1078 rows = 72-136 tiles of 48-64 serial K-steps):
+    // split K so that the launch covers the chip about twice, at least 16 K-steps per piece
+    if (d->workspace && st_m * st_n <= 256 && d->K >= 1024) {
+      int split = 1;
+      const int nkt = d->K / 32;
+      while (st_m * st_n * split * 2 <= 1100 && nkt / (split * 2) >= 12 && split < 8) split *= 2;
+      if (split > 1 && (size_t)split * d->M * d->N * sizeof(float) <= d->workspace_bytes) {
+        g.kchunk = (nkt + split - 1) / split;
+        g.ksplit = (nkt + g.kchunk - 1) / g.kchunk;
+        g.partial = (float*)d->workspace;
+        sgrid.y = (unsigned)g.ksplit;
+      }
+    }
 #define ACX_S64L(ACT, RES)                                                                          \
   do {                                                                                              \
     static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
@@ -605,6 +621,11 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     if (d->act == ACX_ACT_QUICKGELU) { if (d->residual) ACX_S64L(1, 1); else ACX_S64L(1, 0); }
     else { if (d->residual) ACX_S64L(0, 1); else ACX_S64L(0, 0); }
 #undef ACX_S64L
+    if (g.ksplit > 1) {
+      const int64_t total = (int64_t)d->M * d->N;
+      hipLaunchKernelGGL((splitk_reduce_kernel<0>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)g.partial,
+                         g.ksplit, *d);
+    }
     ACX_CHECK_LAUNCH(ctx, "acx_gemm");
     return ACX_OK;
   }

@@ -328,10 +328,15 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_s64_kernel(const Args g) {
   const int m0 = tm * 64, n0 = tn * 64;
   const int t = threadIdx.x;
   const int chunk = t & 7, rbase = t >> 3;                  // 32 staged rows per pass, 2 passes per operand
-  const float* pa0 = (const float*)d.A + (size_t)min(m0 + rbase, d.M - 1) * d.lda + chunk * 4;
-  const float* pa1 = (const float*)d.A + (size_t)min(m0 + rbase + 32, d.M - 1) * d.lda + chunk * 4;
-  const float* pw0 = (const float*)d.W + (size_t)min(n0 + rbase, d.N - 1) * d.ldw + chunk * 4;
-  const float* pw1 = (const float*)d.W + (size_t)min(n0 + rbase + 32, d.N - 1) * d.ldw + chunk * 4;
+  // split-K (long-K problems that fill less than the chip: N = 512, K = 2048 at 1078 rows is 136 tiles): blockIdx.y takes
+  // K-steps [y * kchunk, ...) and leaves a raw partial tile for splitk_reduce_kernel
+  const int nk_total = d.K / 32;
+  const int kbeg = g.ksplit > 1 ? (int)blockIdx.y * g.kchunk * 32 : 0;
+  const int nk = g.ksplit > 1 ? min(g.kchunk, nk_total - (int)blockIdx.y * g.kchunk) : nk_total;
+  const float* pa0 = (const float*)d.A + (size_t)min(m0 + rbase, d.M - 1) * d.lda + chunk * 4 + kbeg;
+  const float* pa1 = (const float*)d.A + (size_t)min(m0 + rbase + 32, d.M - 1) * d.lda + chunk * 4 + kbeg;
+  const float* pw0 = (const float*)d.W + (size_t)min(n0 + rbase, d.N - 1) * d.ldw + chunk * 4 + kbeg;
+  const float* pw1 = (const float*)d.W + (size_t)min(n0 + rbase + 32, d.N - 1) * d.ldw + chunk * 4 + kbeg;
   float4 ra0, ra1, rw0, rw1;
 #define S64_LOAD(k0) do { ra0 = ld4(pa0 + (k0)); ra1 = ld4(pa1 + (k0)); rw0 = ld4(pw0 + (k0)); rw1 = ld4(pw1 + (k0)); } while (0)
 #define S64_STORE(stage, r)                                                            \
@@ -363,7 +368,6 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_s64_kernel(const Args g) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(SET##a.z, SET##b.z, acc, 0, 0, 0);                         \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(SET##a.w, SET##b.w, acc, 0, 0, 0);                         \
   } while (0)
-  const int nk = d.K / 32;
   S64_LOAD(0);
   S64_STORE(0, 0); S64_STORE(0, 1);
   __syncthreads();
@@ -392,9 +396,18 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_s64_kernel(const Args g) {
   const int col = n0 + wn * 32 + li;
   const bool cok = col < d.N;
   const int colc = cok ? col : d.N - 1;
+  const int rowb = m0 + wm * 32 + 4 * hh;
+  if (g.ksplit > 1) {          // raw partial tile; bias / activation / residual happen in splitk_reduce_kernel
+    float* P = g.partial + (size_t)blockIdx.y * d.M * d.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rowb + (r & 3) + 8 * (r >> 2);
+      if (cok && row < d.M) P[(size_t)row * d.N + col] = acc[r];
+    }
+    return;
+  }
   float bias = 0.f;
   if (d.bias) bias = d.bias[colc];
-  const int rowb = m0 + wm * 32 + 4 * hh;
   float outv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) outv[r] = 0.f;

@@ -126,7 +126,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     d.gelu_grad_of, d.ldg = _ptr(gelu_grad_of), (gelu_grad_of.stride(0) if gelu_grad_of is not None else 0)
     ws = None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    few_rows = ((M <= SK_MAX_ROWS or (N <= 512 and M <= 4 * SK_MAX_ROWS)) and K % 256 == 0 and prec == L.PREC_F32
+    few_rows = ((M <= SK_MAX_ROWS or (N <= 512 and M <= 4 * SK_MAX_ROWS and not (M > 768 and K >= 1536)))
+                and K % 256 == 0 and prec == L.PREC_F32
                 and amap == L.AMAP_IDENTITY and a_sub is None and pos0 is None
                 and act != L.ACT_LEAKYRELU)                                   # acx_gemm takes the few-row kernel: no split-K
     # split-K candidates: <= 128 output tiles, or up to 256 with a long K (the convolutions of a data-parallel rank's 4096

@@ -544,7 +544,7 @@ def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom):
                 if pb[n].grad is not None:
                     assert torch.equal(pa[n].grad, pb[n].grad), (step, n)
         assert torch.equal(mods[0][0].last_losses[0], mods[1][0].last_losses[0])
-    assert float(mods[0][1].selector_model.logit_scale) == float(np.float32(2.6592601))      # untouched by weight decay
+    assert float(mods[0][1].selector_model.logit_scale.detach()) == float(np.float32(2.6592601))      # untouched by weight decay
 
 
 @pytest.mark.parametrize("geom,B", [("tiny", 4), ("ViT-B/16", 4), ("ViT-B/16", 8)])
