@@ -102,6 +102,22 @@ def test_gemm_epilogues_and_asub():
     assert relerr(x, a @ w.t() + bias + res) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,res", [(1078, 512, 2048, True), (1078, 512, 1536, False), (900, 512, 2048, False), (1290, 500, 3072, True)])
+def test_gemm_small_tiles_split_k(M, N, K, res):
+    """the 64x64-tile kernel with K split 2-4 ways + the fixed-order reduce (long-K narrow outputs above 768 rows: the text
+    tower's proj / dX GEMMs of an undivided 14-class batch) against fp64."""
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV) if res else None
+    out = ops.gemm(a, w, bias=b, residual=r)
+    ref = a.double() @ w.double().t() + b.double() + (r.double() if res else 0.0)
+    assert relerr(out, ref) < 2e-6 * (K / 512) ** 0.5
+    out2 = ops.gemm(a, w, bias=b, residual=r)
+    assert torch.equal(out, out2)                                   # fixed summation order
+
+
 @pytest.mark.parametrize("cin,cout,tiles", [(64, 256, 2), (256, 64, 1)])
 def test_gemm_conv3x3(cin, cout, tiles):
     g = torch.Generator().manual_seed(cin)
