@@ -14,7 +14,7 @@ cp $G/refresh/bench_head_eager.json $P/${TAG}_bench_head_eager.json
 for n in 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_bench_head_emulated_world$n.json; done
 cp $G/refresh/bench_head_emulated_world8_eager.json $P/${TAG}_bench_head_emulated_world8_eager.json
 cp $G/refresh/bench_xd_bf16.json $P/${TAG}_bench_xd_bf16.json
-cp $G/refresh/bench_gloo2_smoke.json $P/${TAG}_bench_gloo2_smoke.json
+grep '^{' $G/refresh/bench_gloo2_smoke.json > $P/${TAG}_bench_gloo2_smoke.json   # gloo prints its own connection lines to stdout
 cp $G/refresh/bench_metrics.txt $P/${TAG}_bench_metrics.txt
 cp $G/refresh/preprocess.json $P/${TAG}_preprocess.json
 cp $G/refresh/feature_stream.json $P/${TAG}_feature_stream.json
