@@ -105,6 +105,50 @@ class MeanMetric:
         self.total, self.count = None, 0
 
 
+class _MeterBank:
+    """The eight loss meters of a training step as ONE device vector: the criterion returns its eight terms as views of one
+    tensor, so a step costs one add (not eight) and an epoch end one all-reduce (not eight).  `meter(i)` hands out objects with
+    MeanMetric's interface (the reference's per-loss attributes, anomaly_clip_module.py:77-84)."""
+
+    def __init__(self, n: int, device_fn):
+        self.n, self._device_fn = n, device_fn
+        self.total: Optional[torch.Tensor] = None
+        self.count = 0
+
+    def update(self, values):
+        base = getattr(values[0], "_base", None)
+        same = base is not None and base.shape == (self.n,) and all(getattr(v, "_base", None) is base for v in values)
+        vec = (base if same else torch.stack([torch.as_tensor(v).reshape(()) for v in values])).detach().float()
+        self.total = vec.clone() if self.total is None else self.total + vec
+        self.count += 1
+
+    def compute(self) -> torch.Tensor:
+        """[n] means; every rank takes part in the exchange, also one that saw no update (it contributes zeros)."""
+        if self.total is None:
+            t = torch.zeros(self.n + 1, dtype=torch.float32, device=self._device_fn())
+        else:
+            t = torch.cat([self.total, self.total.new_full((1,), float(self.count))])
+        if parallel.is_distributed():
+            parallel.all_reduce_sum_(t)
+        return t[: self.n] / t[self.n]           # nan when nobody updated, like torchmetrics' empty MeanMetric
+
+    def reset(self):
+        self.total, self.count = None, 0
+
+    def meter(self, i: int):
+        bank = self
+
+        class _View:
+            count = property(lambda _s: bank.count)
+
+            def compute(_s):
+                return bank.compute()[i]
+
+            def reset(_s):
+                bank.reset()
+        return _View()
+
+
 _LOSS_NAMES = ("train_loss", "dir_abn_loss", "dir_nor_loss", "topk_abn_loss", "bottomk_abn_loss", "topk_nor_loss",
                "smooth_loss", "sparse_loss")
 
@@ -129,8 +173,9 @@ class AnomalyCLIPModule(_Base):
         for p in self.net.token_embedding.parameters():
             p.requires_grad = False
         # for averaging loss across batches (:77-84)
-        for n in _LOSS_NAMES:
-            object.__setattr__(self, n, MeanMetric(lambda: self.device))
+        self._meters = _MeterBank(len(_LOSS_NAMES), lambda: self.device)
+        for i, n in enumerate(_LOSS_NAMES):
+            object.__setattr__(self, n, self._meters.meter(i))
         self.ncentroid: Optional[torch.Tensor] = None
         self.labels: List[torch.Tensor] = []
         self.abnormal_scores: List[torch.Tensor] = []
@@ -231,9 +276,9 @@ class AnomalyCLIPModule(_Base):
         sim, sim_topk, labels, scores, ia, in_, ba = self.model_step(batch)
         losses = self.criterion(sim, sim_topk, labels, scores, ia, in_, ba)
         self.last_losses = losses
-        for name, value in zip(_LOSS_NAMES, losses):                                # :244-293
+        self._meters.update(losses)                                                 # :244-293, all eight meters in one add
+        for name, value in zip(_LOSS_NAMES, losses):
             meter = getattr(self, name)
-            meter(value)
             # the reference logs the torchmetrics object and Lightning computes + resets it at epoch end.  Lightning's
             # self.log only accepts numbers / tensors / torchmetrics.Metric, so under a real Trainer the step value is
             # logged with on_epoch=True (Lightning's own epoch mean: the same number); the built-in loop keeps the meter
@@ -245,12 +290,11 @@ class AnomalyCLIPModule(_Base):
     def on_train_epoch_end(self):
         """Per-epoch means (the reference's torchmetrics are reset by Lightning after every epoch): compute -- every rank
         takes part in the exchange -- publish, reset."""
-        for name in _LOSS_NAMES:
-            meter = getattr(self, name)
-            mean = meter.compute()
-            if not _HAVE_LIGHTNING:
-                self.logged["train/" + ("loss" if name == "train_loss" else name)] = mean
-            meter.reset()
+        means = self._meters.compute()
+        if not _HAVE_LIGHTNING:
+            for i, name in enumerate(_LOSS_NAMES):
+                self.logged["train/" + ("loss" if name == "train_loss" else name)] = means[i]
+        self._meters.reset()
 
     # ------------------------------------------------------------------ evaluation (:301-337, :458-498)
     def _score_video(self, batch):

@@ -797,6 +797,43 @@ extern "C" int acx_selector_project(acx_ctx* ctx, const float* x, const float* n
   return ACX_OK;
 }
 
+// SyncBN exchange, the combine step (Chan et al.): gathered[r] = (mean[C], biased_var[C] * rows_r, rows_r) of rank r ->
+// mean, biased / unbiased variance over all rows and the total row count, in ONE launch (the dozen elementwise launches
+// of the torch expression sat on the critical path of every data-parallel forward).  Ranks are summed in order.
+namespace {
+__global__ __launch_bounds__(64) void bn_combine_kernel(const float* __restrict__ g, int R, int C, float* __restrict__ mean,
+                                                        float* __restrict__ var_b, float* __restrict__ var_u,
+                                                        float* __restrict__ total) {
+  const int c = threadIdx.x;
+  const int ld = 2 * C + 1;
+  float n = 0.f;
+  for (int r = 0; r < R; ++r) n += g[(size_t)r * ld + 2 * C];
+  if (c == 0) total[0] = n;
+  if (c >= C) return;
+  float m = 0.f;
+  for (int r = 0; r < R; ++r) m += g[(size_t)r * ld + c] * (g[(size_t)r * ld + 2 * C] / n);
+  float m2 = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float dm = g[(size_t)r * ld + c] - m;
+    m2 += g[(size_t)r * ld + C + c] + g[(size_t)r * ld + 2 * C] * (dm * dm);
+  }
+  mean[c] = m;
+  var_b[c] = m2 / n;
+  var_u[c] = m2 / fmaxf(n - 1.f, 1.f);
+}
+}  // namespace
+
+extern "C" int acx_bn_combine(acx_ctx* ctx, const float* gathered, int32_t ranks, int32_t C1, float* mean, float* var_biased,
+                              float* var_unbiased, float* total_rows, void* stream) {
+  if (!gathered || !mean || !var_biased || !var_unbiased || !total_rows) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_combine: null pointer%s");
+  if (ranks < 1 || C1 < 1 || C1 > 64) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_combine: need ranks >= 1 and 1 <= C1 <= 64%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, ranks, C1, mean, var_biased,
+                     var_unbiased, total_rows);
+  ACX_CHECK_LAUNCH(ctx, "acx_bn_combine");
+  return ACX_OK;
+}
+
 extern "C" int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_t C1, float* mean, float* var_biased,
                             float* var_unbiased, void* workspace, size_t workspace_bytes, void* stream) {
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);

@@ -194,6 +194,17 @@ def selector_project(x: torch.Tensor, ncentroid: torch.Tensor, dirs: torch.Tenso
     return raw
 
 
+def bn_combine(gathered: torch.Tensor, C1: int):
+    """SyncBN combine: gathered [R, 2 C1 + 1] (per rank: mean, biased var * rows, rows) -> (mean, var_biased, var_unbiased,
+    total rows as a device scalar [1]) in one launch."""
+    assert gathered.is_cuda and gathered.dtype == torch.float32 and gathered.is_contiguous() and gathered.shape[1] == 2 * C1 + 1
+    out = torch.empty(3 * C1 + 1, dtype=torch.float32, device=gathered.device)
+    h = _h(gathered)
+    L.check(L.lib().acx_bn_combine(h, gathered.data_ptr(), gathered.shape[0], C1, out.data_ptr(), out[C1:].data_ptr(),
+                                   out[2 * C1:].data_ptr(), out[3 * C1:].data_ptr(), _stream()), h)
+    return out[:C1], out[C1:2 * C1], out[2 * C1:3 * C1], out[3 * C1:]
+
+
 def _bn_workspace(t: torch.Tensor, rows: int, C1: int) -> torch.Tensor:
     return torch.empty(int(L.lib().acx_bn_workspace_bytes(rows, C1)) // 8, dtype=torch.float64, device=t.device)
 

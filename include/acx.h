@@ -197,6 +197,11 @@ int acx_selector_project(acx_ctx* ctx, const float* x, const float* ncentroid, c
  * stages (row slabs -> f64 partials in `workspace` -> fixed-order sum); C1 <= 64;
  * workspace >= acx_bn_workspace_bytes(rows, C1), 8-byte aligned. */
 size_t acx_bn_workspace_bytes(int64_t rows, int32_t C1);
+/* SyncBN (configs/trainer/ddp.yaml sync_batchnorm): combine the ranks' statistics.  gathered[ranks][2 * C1 + 1] holds, per rank,
+ * mean[C1], biased_var[C1] * rows, rows; outputs the statistics over all rows (Chan et al.) and the total row count (device
+ * scalar), one launch; C1 <= 64. */
+int acx_bn_combine(acx_ctx* ctx, const float* gathered, int32_t ranks, int32_t C1, float* mean, float* var_biased,
+                   float* var_unbiased, float* total_rows, void* stream);
 int acx_bn_stats(acx_ctx* ctx, const float* raw, int64_t rows, int32_t C1, float* mean,
                  float* var_biased, float* var_unbiased, void* workspace, size_t workspace_bytes,
                  void* stream);

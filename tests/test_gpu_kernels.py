@@ -102,6 +102,25 @@ def test_gemm_epilogues_and_asub():
     assert relerr(x, a @ w.t() + bias + res) < 1e-5
 
 
+@pytest.mark.parametrize("R,C1", [(1, 13), (2, 13), (8, 17), (3, 64)])
+def test_bn_combine_matches_chan_formula(R, C1):
+    """acx_bn_combine (SyncBN: the ranks' (mean, biased var x rows, rows) -> statistics over all rows) against the fp64
+    evaluation of the same formula (parallel.combine_bn_stats) and against the statistics of the concatenated rows."""
+    from anomalyclip_amd import parallel
+    g = torch.Generator().manual_seed(R * 100 + C1)
+    rows = [int(v) for v in torch.randint(200, 4000, (R,), generator=g)]
+    chunks = [torch.randn(n, C1, generator=g, dtype=torch.float64) * (1 + i) + i for i, n in enumerate(rows)]
+    gathered = torch.stack([torch.cat([c.mean(0), c.var(0, unbiased=False) * c.shape[0], torch.tensor([float(c.shape[0])], dtype=torch.float64)])
+                            for c in chunks])
+    m, vb, vu, n = ops.bn_combine(gathered.float().to(DEV).contiguous(), C1)
+    allrows = torch.cat(chunks)
+    assert float(n) == float(sum(rows))
+    assert relerr(m, allrows.mean(0)) < 1e-6 and relerr(vb, allrows.var(0, unbiased=False)) < 1e-5
+    assert relerr(vu, allrows.var(0, unbiased=True)) < 1e-5
+    rm, rvb, rvu, rn = parallel.combine_bn_stats(gathered[:, :C1], gathered[:, C1:2 * C1], gathered[:, 2 * C1])
+    assert relerr(m, rm) < 1e-6 and relerr(vb, rvb) < 1e-5 and relerr(vu, rvu) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K,res", [(1078, 512, 2048, True), (1078, 512, 1536, False), (900, 512, 2048, False), (1290, 500, 3072, True)])
 def test_gemm_small_tiles_split_k(M, N, K, res):
     """the 64x64-tile kernel with K split 2-4 ways + the fixed-order reduce (long-K narrow outputs above 768 rows: the text
