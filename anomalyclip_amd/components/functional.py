@@ -612,15 +612,20 @@ class MilLossFn(torch.autograd.Function):
                                                 ba.contiguous(), N, Lg, K, normal_id, lambdas)
         ctx.cfg = cfg
         ctx.save_for_backward(sim, sim_topk, scores, labels, ia, in_, ba)
-        return losses
+        # eight separate outputs (the reference's 8-tuple) with un-materialised gradients: returning ONE [8] tensor and unbinding it
+        # outside made autograd build seven zero scalars and stack them for the seven terms nobody differentiates
+        ctx.set_materialize_grads(False)
+        return tuple(losses.unbind(0))
 
     @staticmethod
-    def backward(ctx, d_losses):
+    def backward(ctx, d_total, *_unused):
         # Only the total cost (element 0) is meant to be differentiated (module.training_step returns it);
         # the upstream gradient is read on the device, no host sync.
         N, Lg, K, normal_id, lambdas = ctx.cfg
         sim, sim_topk, scores, labels, ia, in_, ba = ctx.saved_tensors
-        gout = d_losses.contiguous()[0:1]
+        if d_total is None:
+            return (None,) * 8
+        gout = d_total.reshape(1).contiguous()
         _, dsim, dtopk, dsc = ops.mil_loss(sim, sim_topk, labels, scores, ia.contiguous(), in_.contiguous(), ba.contiguous(),
                                            N, Lg, K, normal_id, lambdas, gout=gout)
         return dsim, dtopk, dsc, None, None, None, None, None

@@ -20,5 +20,4 @@ class ComputeLoss:
         lambdas = (self.lambda_dir_abn, self.lambda_dir_nor, self.lambda_topk_abn, self.lambda_bottomk_abn,
                    self.lambda_topk_nor, self.lambda_smooth, self.lambda_sparse)
         cfg = (self.num_segments, self.frames_per_segment, self.num_topk, self.normal_id, lambdas)
-        losses = MilLossFn.apply(similarity, similarity_topk, scores, labels, idx_topk_abn, idx_topk_nor, idx_bottomk_abn, cfg)
-        return tuple(losses.unbind(0))
+        return MilLossFn.apply(similarity, similarity_topk, scores, labels, idx_topk_abn, idx_topk_nor, idx_bottomk_abn, cfg)

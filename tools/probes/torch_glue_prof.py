@@ -14,6 +14,9 @@ dev = torch.device("cuda", 0)
 net, sd, eot, hc = B.build_net("f32", dev)
 net.load_from_features = True
 net.text_class_parallel = True
+if len(sys.argv) > 2 and sys.argv[2] == "graphs":
+    net.text_graph = True
+    net.temporal_model.graph = True
 crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
 mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(dev)
 mod.ncentroid = torch.zeros(512, device=dev)
@@ -27,7 +30,7 @@ def step(i):
     mt, mb = type(net.selector_model).generate_mask(net.selector_model, 64)
     net.selector_model.generate_mask = lambda b, mt=mt[idx], mb=mb[idx]: (mt, mb)
     mod.train_batch(batch, opt)
-for i in range(3):
+for i in range(4):
     step(i)
 torch.cuda.synchronize()
 import traceback
