@@ -106,6 +106,12 @@ class AnomalyCLIP(nn.Module):
                                             self.token_embedding.weight.detach(), bool(g("shared_context", False)), ctx_init)
         self.tokenized_prompts = self.prompt_learner.tokenized_prompts
         self.register_buffer("eot_index", tokenized.argmax(dim=-1).to(torch.int64), persistent=False)
+        # The text transformer is CAUSAL (clip/model.py:343-349) and only each class's EOT row is read (text_encoder.py:23): the
+        # positions behind the last EOT cannot influence any output or gradient, so the tower runs on the first `text_len`
+        # positions only ("X X X X X X X X <name>." ends at position 11-12 of CLIP's 77: 16 rows per class instead of 77).
+        # Results are those of the full-length evaluation; `text_truncate: false` restores it.
+        full = int(tokenized.shape[-1])
+        self.text_len = min(full, (int(tokenized.argmax(dim=-1).max()) + 1 + 3) // 4 * 4) if bool(g("text_truncate", True)) else full
         self.text_encoder = TextEncoder(geom.context_length, geom.transformer_width, geom.transformer_heads,
                                         geom.transformer_layers, geom.embed_dim, self.precision)
         self.image_encoder = VisionTransformer(geom.image_resolution, geom.vision_patch_size, geom.vision_width,
@@ -149,6 +155,8 @@ class AnomalyCLIP(nn.Module):
             if self._text_cache is not None and self._text_cache[0] == key:
                 return self._text_cache[1]
         x = self.prompt_learner(self.text_encoder.positional_embedding)
+        if self.text_len < x.shape[1]:
+            x = x[:, : self.text_len].contiguous()
         tf = self.text_encoder.encode(x, self.eot_index)
         if self.cache_text_features:
             self._text_cache = (key, tf)

@@ -36,6 +36,9 @@ def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int):
     cp = ctx_param.detach() if shared else ctx_param.detach()[lo:hi]
     x0 = ops.prompt_embed(pl.token_prefix[lo:hi], cp, pl.token_suffix[lo:hi], te.positional_embedding.detach(), pl.n_ctx)
     C = x0.shape[0]
+    Le = int(getattr(net, "text_len", Lc))
+    if Le < Lc:                                       # causal tower, EOT rows only: positions behind the last EOT are inert
+        x0, Lc = x0[:, :Le].contiguous(), Le
     x = x0.view(C * Lc, W)
     saved = []
     # few rows (a data-parallel rank's block of classes: 77 rows per class): acx_gemm runs the few-row kernel and the
@@ -212,7 +215,7 @@ class _TextGraphs:
         plist = te.__dict__.get("_acx_plist")
         if plist is None:
             plist = te.__dict__["_acx_plist"] = list(te.transformer.parameters())
-        return (lo, hi) + tuple((t.data_ptr(), tuple(t.shape)) for t in ts) + tuple(p.data_ptr() for p in plist)
+        return (lo, hi, int(getattr(net, "text_len", 0))) + tuple((t.data_ptr(), tuple(t.shape)) for t in ts) + tuple(p.data_ptr() for p in plist)
 
 
 class _NoTextRows:

@@ -796,15 +796,21 @@ def test_text_features_class_blocks_equal_full(prompts_table, geom):
         assert relerr(d_ctx, d_ctx_full) < 2e-5 and relerr(d_P, d_P_full) < 2e-5
 
 
+@pytest.mark.parametrize("truncate", [True, False])
 @pytest.mark.parametrize("c_local", [1, 2, 14])
-def test_text_tower_rows_vs_oracle(prompts_table, c_local):
+def test_text_tower_rows_vs_oracle(prompts_table, c_local, truncate):
     """The text tower of a data-parallel rank against the ORACLE directly (coop.py:74-90, text_encoder.py:14-25,
     clip/model.py:188-230): features of the first c_local classes and the gradients of ctx / text_projection for a random
     upstream gradient, against the oracle's fp64 autograd on the same weights.  c_local = 1, 2: the few-row kernels
     (gemm_f32_sk_kernel with the fused QuickGELU prologue / derivative epilogue, MFMA attention backward, LayerNorm backward
-    with the residual folded in); c_local = 14: the tile kernels with the separate activation launches."""
+    with the residual folded in); c_local = 14 at full length: the tile kernels with the separate activation launches.
+    truncate: the tower evaluated on the positions up to the last EOT only (net.text_len = 16 of CLIP's 77, the default --
+    the causal mask makes the rest inert) against the ORACLE'S FULL-LENGTH evaluation; False: all 77 positions."""
     from anomalyclip_amd.components import functional as Fn
     mod, net = _dp_module(prompts_table, seed=17, geom="ViT-B/16")
+    assert net.text_len == 16
+    if not truncate:
+        net.text_len = 77
     ctxp, P = net.prompt_learner.ctx, net.text_encoder.text_projection
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     eot = net.eot_index.cpu()
