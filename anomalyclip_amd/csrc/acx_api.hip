@@ -41,6 +41,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->opt_tn_p256_min_rows = 4096;
   c->err[0] = 0;
   c->prof_on = false;
+  c->prof_gemm_only = false;
   c->prof_n = c->prof_created = 0;
   c->prof_gemm_flops = 0.0;
   c->prof_tn_flops = c->prof_tn_ms = 0.0; c->prof_tn_count = 0;
@@ -61,6 +62,7 @@ extern "C" void acx_destroy(acx_ctx* ctx) {
 extern "C" int acx_prof_enable(acx_ctx* ctx, int on) {
   if (!ctx || !ctx->prof_ev || !ctx->prof_kind) return acx_fail(ctx, ACX_E_BADARG, "acx_prof_enable: no context%s");
   ctx->prof_on = on != 0;
+  ctx->prof_gemm_only = on == 2;
   if (on) { ctx->prof_n = 0; ctx->prof_gemm_flops = 0.0; ctx->prof_tn_flops = 0.0; }
   return ACX_OK;
 }

@@ -40,6 +40,7 @@ struct acx_ctx {
   int opt_tn_p256_min_rows; // ACX_OPT_TN_P256_MIN_ROWS
   char err[512];
   bool prof_on;
+  bool prof_gemm_only;   // acx_prof_enable(ctx, 2): event pairs around the GEMM launches only
   int prof_n;          // recorded pairs
   int prof_created;    // event pairs created so far
   hipEvent_t* prof_ev; // [2 * ACX_PROF_MAX]
@@ -55,6 +56,7 @@ struct AcxProfScope {
   int slot;
   AcxProfScope(acx_ctx* ctx, int kind, hipStream_t stream) : c(ctx), s(stream), slot(-1) {
     if (!c || !c->prof_on || c->prof_n >= ACX_PROF_MAX) return;
+    if (c->prof_gemm_only && kind != ACX_K_GEMM && kind != ACX_K_GEMM_TN) return;
     if (c->prof_n >= c->prof_created) {
       if (hipEventCreate(&c->prof_ev[2 * c->prof_created]) != hipSuccess) return;
       if (hipEventCreate(&c->prof_ev[2 * c->prof_created + 1]) != hipSuccess) return;
