@@ -587,13 +587,13 @@ def config4_leg(dev, timer, prof, world, steps):
         with torch.no_grad():
             net.image_encoder(frames)
     k = max(2, steps // 2)
-    dt = timer.run(enc, k, 1, prof.start, prof.stop)
+    dt = timer.run(enc, k, 1, prof.start_gemm_only, prof.stop)
     gf, counts, tot = prof.collect()
     out["frames"] = {"frames_per_launch": 160 * windows, "frames_per_s": round(160 * windows * k * world / dt, 1),
                      "gemm_tflops": round(gf / 1e9 / tot[0], 1) if tot[0] else None,
                      "gemm_frac_of_bf16_peak": round(gf / 1e9 / tot[0] / PEAK_TFLOPS["bf16"], 4) if tot[0] else None}
     net.image_encoder.chunk = 160
-    dt = timer.run(enc, k, 1, prof.start, prof.stop)
+    dt = timer.run(enc, k, 1, prof.start_gemm_only, prof.stop)
     gf, counts, tot = prof.collect()
     out["frames_160"] = {"frames_per_launch": 160, "frames_per_s": round(160 * windows * k * world / dt, 1),
                          "gemm_tflops": round(gf / 1e9 / tot[0], 1) if tot[0] else None,

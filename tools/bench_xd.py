@@ -58,7 +58,7 @@ def main():
     def enc():
         with torch.no_grad():
             net.image_encoder(frames)
-    dt = timer.run(enc, max(2, args.steps // 3), 1, prof.start, prof.stop)
+    dt = timer.run(enc, max(2, args.steps // 3), 1, prof.start_gemm_only, prof.stop)
     n = max(2, args.steps // 3)
     gf, counts, tot = prof.collect()
     out["frames"] = {"frames_per_launch": args.chunk, "frames_per_s": round(160 * args.windows * n / dt, 1),
