@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["acx_api.hip", "acx_gemm.hip", "acx_norm.hip", "acx_attn.hip", "acx_head.hip", "acx_train.hip", "acx_metrics.hip", "acx_probe.hip"]
+SOURCES = ["acx_api.hip", "acx_gemm.hip", "acx_norm.hip", "acx_attn.hip", "acx_head.hip", "acx_train.hip", "acx_metrics.hip", "acx_probe.hip", "acx_step.hip"]
 LIB = os.path.join(CSRC, "libacx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

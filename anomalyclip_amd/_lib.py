@@ -56,6 +56,11 @@ class CurveResult(C.Structure):          # == struct acx_curve_result (56 bytes,
                 ("n_distinct", c_int64), ("opt_index", c_int64), ("opt_threshold", c_float), ("pad", c_float)]
 
 
+class PrepSeg(C.Structure):            # == struct acx_prep_seg
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int32), ("cols", c_int32), ("src_ld", c_int32),
+                ("dst_ld", c_int32), ("transpose", c_int32), ("reserved", c_int32)]
+
+
 class VitDesc(C.Structure):
     _fields_ = [(n, c_int32) for n in ("resolution", "patch", "width", "layers", "heads", "embed_dim", "prec")]
 
@@ -97,7 +102,7 @@ _SIGS = {
                                       c_int32, c_void_p]),
     "acx_cls_head": (C.c_int, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acx_class_probs": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
-    "acx_prompt_embed": (C.c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_void_p]),
+    "acx_prompt_embed": (C.c_int, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p]),
     "acx_gather_rows": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_add_bcast": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "acx_concat_features": (C.c_int, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p]),
@@ -130,6 +135,20 @@ _SIGS = {
     "acx_multi_axpy": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int64), c_float, c_void_p]),
     "acx_adamw_multi": (C.c_int, [c_void_p, c_int32] + [C.POINTER(c_void_p)] * 4 + [C.POINTER(c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, c_int32, c_void_p]),
+    "acx_row_parts": (c_int64, [c_int64]),
+    "acx_prep_multi": (C.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "acx_multi_copy": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int64), c_void_p]),
+    "acx_adamw_hyper": (C.c_int, [c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, c_int32,
+                                  C.POINTER(c_float)]),
+    "acx_adamw_multi_dev": (C.c_int, [c_void_p, c_int32] + [C.POINTER(c_void_p)] * 4 + [C.POINTER(c_int64), c_void_p, c_float,
+                                      C.c_double, C.c_double, C.c_double, c_void_p]),
+    "acx_bn_pack": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "acx_bn_running_update": (C.c_int, [c_void_p] * 6 + [c_int32, c_float, c_float, c_void_p]),
+    "acx_fill_f32": (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "acx_colsum_fused_part_bytes": (c_size_t, [c_int64, c_int32]),
+    "acx_colsum_fused": (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "acx_gemm_tn_zp": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                 c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "acx_ctx_grad": (C.c_int, [c_void_p] * 3 + [c_int32] * 5 + [c_void_p]),
     "acx_scatter_rows": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
     "acx_preprocess_frames": (C.c_int, [c_void_p] * 6 + [c_int32, c_void_p, c_void_p, c_int32] + [c_int32] * 5 +

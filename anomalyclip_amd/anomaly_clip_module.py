@@ -114,12 +114,16 @@ class _MeterBank:
         self.n, self._device_fn = n, device_fn
         self.total: Optional[torch.Tensor] = None
         self.count = 0
+        self._attached = False
 
     def update(self, values):
         base = getattr(values[0], "_base", None)
         same = base is not None and base.shape == (self.n,) and all(getattr(v, "_base", None) is base for v in values)
         vec = (base if same else torch.stack([torch.as_tensor(v).reshape(()) for v in values])).detach().float()
-        self.total = vec.clone() if self.total is None else self.total + vec
+        if self._attached:
+            self.total += vec
+        else:
+            self.total = vec.clone() if self.total is None else self.total + vec
         self.count += 1
 
     def compute(self) -> torch.Tensor:
@@ -133,7 +137,20 @@ class _MeterBank:
         return t[: self.n] / t[self.n]           # nan when nobody updated, like torchmetrics' empty MeanMetric
 
     def reset(self):
-        self.total, self.count = None, 0
+        if self._attached:                       # the step graph's accumulator: zeroed in place, its address is captured
+            self.total.zero_()
+            self.count = 0
+        else:
+            self.total, self.count = None, 0
+
+    def attach(self, total: torch.Tensor):
+        """use `total` ([n] device tensor, accumulated inside the whole-step graph) as the running sums"""
+        if self.total is not None and self.total is not total:
+            total.copy_(self.total)
+        else:
+            total.zero_()
+            self.count = 0
+        self.total, self._attached = total, True
 
     def meter(self, i: int):
         bank = self
@@ -276,24 +293,30 @@ class AnomalyCLIPModule(_Base):
         sim, sim_topk, labels, scores, ia, in_, ba = self.model_step(batch)
         losses = self.criterion(sim, sim_topk, labels, scores, ia, in_, ba)
         self.last_losses = losses
-        self._meters.update(losses)                                                 # :244-293, all eight meters in one add
-        for name, value in zip(_LOSS_NAMES, losses):
-            meter = getattr(self, name)
-            # the reference logs the torchmetrics object and Lightning computes + resets it at epoch end.  Lightning's
-            # self.log only accepts numbers / tensors / torchmetrics.Metric, so under a real Trainer the step value is
-            # logged with on_epoch=True (Lightning's own epoch mean: the same number); the built-in loop keeps the meter
-            # and on_train_epoch_end turns it into the epoch mean
-            self.log("train/" + ("loss" if name == "train_loss" else name), value.detach() if _HAVE_LIGHTNING else meter,
-                     on_step=False, on_epoch=True, prog_bar=True)
+        if _HAVE_LIGHTNING:  # pragma: no cover - Lightning is not installed in the build image
+            # the reference logs torchmetrics MeanMetric objects, which Lightning computes (synchronised over ranks) and
+            # resets at epoch end.  self.log accepts numbers / tensors / torchmetrics.Metric only, so the step value is logged
+            # with on_epoch=True: Lightning's own epoch mean, rank-synchronised (sync_dist) like the reference's metric, one
+            # sample per step (batch_size=1: the (normal, abnormal) tuple has no unambiguous batch dimension)
+            for name, value in zip(_LOSS_NAMES, losses):
+                self.log("train/" + ("loss" if name == "train_loss" else name), value.detach(), on_step=False, on_epoch=True,
+                         prog_bar=True, sync_dist=True, batch_size=1)
+        else:
+            self._meters.update(losses)                                             # :244-293, all eight meters in one add
+            for name in _LOSS_NAMES:
+                # the built-in loop keeps the meter; on_train_epoch_end turns it into the epoch mean
+                self.log("train/" + ("loss" if name == "train_loss" else name), getattr(self, name), on_step=False,
+                         on_epoch=True, prog_bar=True)
         return {"loss": losses[0]}
 
     def on_train_epoch_end(self):
         """Per-epoch means (the reference's torchmetrics are reset by Lightning after every epoch): compute -- every rank
         takes part in the exchange -- publish, reset."""
+        if _HAVE_LIGHTNING:  # pragma: no cover - Lightning reduces and resets what training_step logged
+            return
         means = self._meters.compute()
-        if not _HAVE_LIGHTNING:
-            for i, name in enumerate(_LOSS_NAMES):
-                self.logged["train/" + ("loss" if name == "train_loss" else name)] = means[i]
+        for i, name in enumerate(_LOSS_NAMES):
+            self.logged["train/" + ("loss" if name == "train_loss" else name)] = means[i]
         self._meters.reset()
 
     # ------------------------------------------------------------------ evaluation (:301-337, :458-498)
@@ -419,19 +442,89 @@ class AnomalyCLIPModule(_Base):
         out.append(self.net.text_encoder.text_projection)
         return out
 
-    def train_batch(self, batch, optimizer, batch_idx: int = 0) -> torch.Tensor:
-        """forward, loss, backward (+ bucketed gradient all-reduce overlapped with it), AdamW: what Lightning's
-        automatic optimisation + DDP do around `training_step` (configs/trainer/ddp.yaml)."""
+    def _make_buckets(self):
         if self._buckets is None:
             # forward order: prompt/text first ... temporal last; buckets fill in reverse
             order = [self.net.prompt_learner.ctx, self.net.text_encoder.text_projection, self.net.selector_model.logit_scale]
             order += list(self.net.temporal_model.parameters())
-            self._buckets = parallel.GradBuckets(order)
-            self.net.temporal_model.__dict__["_grad_sink"] = self._buckets     # graph-replayed backward: one accumulate launch
-        self._buckets.zero()
-        with torch.enable_grad():
-            loss = self.training_step(batch, batch_idx)["loss"]
-            loss.backward()
-        self._buckets.finish()
+            # [text_projection, ctx] and the never-used logit_scale get buckets of their own: the step graph exchanges the
+            # text gradients on the text stream, ahead of the temporal model's buckets
+            self._buckets = parallel.GradBuckets(order, cuts=[order[2], order[1]])
+        return self._buckets
+
+    def _step_graph_for(self, batch, optimizer):
+        """The whole-step graph (components/step_graph.TrainStepGraph) for this batch geometry, captured on first use; None
+        when the step cannot run that way (training from frames, bf16, foreign optimizer state, capture failure ...) -- the
+        caller then takes the autograd path.  `net.step_graph = False` switches it off."""
+        net = self.net
+        if not getattr(net, "step_graph", True) or not getattr(net, "load_from_features", True) or self.criterion is None:
+            return None
+        (nf, nl), (af, al) = batch
+        if not (torch.is_tensor(af) and af.is_cuda and nf.is_cuda and af.dtype == torch.float32 and nf.dtype == torch.float32
+                and af.dim() == 4 and af.shape[1] == 1 and nf.shape[1:] == af.shape[1:] and torch.is_tensor(self.ncentroid)):
+            return None
+        from .components import step_graph as SG
+        key = SG.TrainStepGraph.make_key(self, optimizer, af.shape[0], nf.shape[0], af.shape[2])
+        cache = self.__dict__.setdefault("_step_graphs", {})
+        if key in cache:
+            return cache[key]
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        sg = None
+        try:
+            sg = SG.TrainStepGraph(self, optimizer, af.shape[0], nf.shape[0], af.shape[2])
+            # dry-run inputs: this batch and an all-ones mask -- NOT generate_mask(): the host RNG stream must advance exactly
+            # once per real step, like the reference's (selector_model.py:101-117)
+            ones = torch.ones(sg.B, self.net.selector_model.num_segments)
+            sg.load_inputs((af, al), (nf, nl), (ones, ones))
+            sg.capture()
+        except Exception as e:  # noqa: BLE001
+            import warnings
+            warnings.warn(f"whole-step training graph unavailable ({type(e).__name__}: {e}); using the autograd path")
+            self.step_graph_error = f"{type(e).__name__}: {e}"
+            sg = None
+        if parallel.is_distributed():
+            # all ranks take the same path: the graph path and the autograd path issue different collectives
+            flag = torch.tensor([1.0 if sg is not None else 0.0], device=self.device)
+            parallel.dist.all_reduce(flag, op=parallel.dist.ReduceOp.MIN)
+            if float(flag.item()) < 0.5:
+                sg = None
+        cache[key] = sg
+        return sg
+
+    def train_batch(self, batch, optimizer, batch_idx: int = 0) -> torch.Tensor:
+        """forward, loss, backward (+ bucketed gradient all-reduce overlapped with it), AdamW: what Lightning's
+        automatic optimisation + DDP do around `training_step` (configs/trainer/ddp.yaml).  Default: the whole step replayed
+        from HIP graphs (step_graph.TrainStepGraph); automatic fallback: the autograd path below, itself with the text tower /
+        temporal model as replayed graphs where they capture, eager otherwise."""
+        buckets = self._make_buckets()
+        sg = self._step_graph_for(batch, optimizer)
+        if sg is not None:
+            (nf, nl), (af, al) = batch
+            sg.load_inputs((af, al), (nf, nl), self.net.selector_model.generate_mask(sg.B))
+            if self._meters.total is not sg.meter_sum:
+                self._meters.attach(sg.meter_sum)        # before the step: the graph adds this step's terms to it
+            losses = sg.step()
+            self._after_step_graph(sg, losses)
+            return losses[0].detach()
+        tm = self.net.temporal_model
+        tm.__dict__["_grad_sink"] = buckets        # graph-replayed temporal backward: one accumulate launch, this step only
+        try:
+            buckets.zero()
+            with torch.enable_grad():
+                loss = self.training_step(batch, batch_idx)["loss"]
+                loss.backward()
+            buckets.finish()
+        finally:
+            tm.__dict__.pop("_grad_sink", None)
+            buckets._armed = False
         optimizer.step()
         return loss.detach()
+
+    def _after_step_graph(self, sg, losses):
+        vals = tuple(losses.unbind(0))
+        self.last_losses = vals
+        self._meters.count += 1                  # the sums are accumulated inside the graph
+        for name in _LOSS_NAMES:
+            self.log("train/" + ("loss" if name == "train_loss" else name), getattr(self, name), on_step=False, on_epoch=True,
+                     prog_bar=True)

@@ -26,19 +26,19 @@ def _parallel():
 
 
 # ====================================================================================================== text path
-def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int):
+def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int, tf_out=None):
     """Text features of classes [lo, hi) (coop.py:74-90, text_encoder.py:14-25): prompt assembly, the 12 frozen CLIP
-    text layers, EOT gather, ln_final, @ text_projection.  Returns (features [hi-lo, E], state for the backward)."""
+    text layers, EOT gather, ln_final, @ text_projection.  Returns (features [hi-lo, E], state for the backward).
+    tf_out: [hi-lo, E] destination (rows [lo, hi) of the class-parallel exchange buffer)."""
     te, pl = net.text_encoder, net.prompt_learner
     tr = te.transformer
     W, heads, Lc = tr.width, tr.heads, te.positional_embedding.shape[0]
     shared = ctx_param.dim() == 2
     cp = ctx_param.detach() if shared else ctx_param.detach()[lo:hi]
-    x0 = ops.prompt_embed(pl.token_prefix[lo:hi], cp, pl.token_suffix[lo:hi], te.positional_embedding.detach(), pl.n_ctx)
+    # causal tower, EOT rows only: positions behind the last EOT are inert -- the prompt kernel emits the first Le only
+    Lc = min(int(getattr(net, "text_len", Lc)), Lc)
+    x0 = ops.prompt_embed(pl.token_prefix[lo:hi], cp, pl.token_suffix[lo:hi], te.positional_embedding.detach(), pl.n_ctx, Lout=Lc)
     C = x0.shape[0]
-    Le = int(getattr(net, "text_len", Lc))
-    if Le < Lc:                                       # causal tower, EOT rows only: positions behind the last EOT are inert
-        x0, Lc = x0[:, :Le].contiguous(), Le
     x = x0.view(C * Lc, W)
     saved = []
     # few rows (a data-parallel rank's block of classes: 77 rows per class): acx_gemm runs the few-row kernel and the
@@ -59,20 +59,34 @@ def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int):
             x_next = ops.gemm(act, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid)
         saved.append((x, qkv, x_mid, pre))
         x = x_next
-    rows_idx = torch.arange(C, device=x.device, dtype=torch.int64) * Lc + net.eot_index[lo:hi]
+    rows_idx = _eot_rows(net, lo, hi, Lc)
     eot = ops.gather_rows(x, rows_idx)
     eln = ops.layernorm(eot, te.ln_final.weight, te.ln_final.bias)
-    tf = ops.gemm(eln, text_projection.detach().t().contiguous())
+    tf = ops.gemm(eln, ops.transpose(text_projection.detach()), out=tf_out)
     return tf, (saved, rows_idx, eot, eln, C, Lc, W, heads, shared)
 
 
-def _text_backward_rows(net, text_projection, state, d_tf):
+def _eot_rows(net, lo, hi, Lc):
+    """row index of every local class's EOT token in the [C_loc * Lc, W] activation matrix; built once per (block, length)"""
+    cache = net.__dict__.setdefault("_eot_rows_cache", {})
+    key = (lo, hi, Lc, net.eot_index.data_ptr())
+    r = cache.get(key)
+    if r is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.AcxError("text tower: the EOT row table must be built by an eager call before a HIP graph is captured")
+        dev = net.eot_index.device
+        r = cache[key] = (torch.arange(hi - lo, device=dev, dtype=torch.int64) * Lc + net.eot_index[lo:hi]).contiguous()
+    return r
+
+
+def _text_backward_rows(net, text_projection, state, d_tf, d_ctx_out=None, d_P_out=None):
     """d(features of the local classes) -> (d ctx for those classes [C_loc, n_ctx, W] (or [n_ctx, W] when shared),
-    d text_projection [W, E]); dX only through the frozen layers."""
+    d text_projection [W, E]); dX only through the frozen layers.  d_ctx_out / d_P_out: destinations to produce the two
+    gradients in (views of parallel.GradBuckets.flat)."""
     te, pl = net.text_encoder, net.prompt_learner
     saved, rows_idx, eot, eln, C, Lc, W, heads, shared = state
     d_tf = d_tf.contiguous()
-    d_P = ops.gemm_tn(eln, d_tf)                                             # [W, E]
+    d_P = ops.gemm_tn(eln, d_tf, out=d_P_out)                                # [W, E]
     d_eln = ops.gemm(d_tf, text_projection.detach().contiguous())            # d_tf @ P^T  (W_op = P [W,E])
     d_eot, _, _ = ops.layernorm_bwd(eot, te.ln_final.weight, d_eln, need_params=False)
     d_x = ops.scatter_rows(d_eot, rows_idx, C * Lc)
@@ -93,7 +107,7 @@ def _text_backward_rows(net, text_projection, state, d_tf):
         d_qkv = ops.seq_attention_bwd(qkv, d_att, C, 1, Lc, heads, 64, 1, causal=True)
         d_h1 = ops.gemm(d_qkv, t_in)
         d_x, _, _ = ops.layernorm_bwd(x, blk.ln_1.weight, d_h1, need_params=False, add=d_x_mid)      # d_x_mid + LN1'
-    d_ctx = ops.ctx_grad(d_x, C, pl.n_ctx, Lc, W, shared)
+    d_ctx = ops.ctx_grad(d_x, C, pl.n_ctx, Lc, W, shared, out=d_ctx_out)
     return d_ctx, d_P
 
 
@@ -389,10 +403,53 @@ def _temporal_param_list(tm) -> List[torch.nn.Parameter]:
     return plist
 
 
+_FORK_STREAMS: dict = {}
+
+
+class _Fork:
+    """Side branch for launches that only produce PARAMETER gradients (weight-gradient GEMMs, bias column sums, LayerNorm
+    parameter reductions, positional-embedding sums): nothing on the dX chain waits for them, so inside a stream capture
+    they are issued on a second stream and become a parallel branch of the captured graph -- a rank with few videos then
+    runs its chain of small latency-bound dX launches NEXT TO the fat weight-gradient GEMMs instead of in front of them
+    (the per-rank share of a data-parallel step: videos are not split, every kernel sees the same operands, results are
+    bit-identical to the in-order eager path).  Outside a capture (eager autograd path) everything stays on one stream.
+
+    Memory: a tensor produced on the main stream and read by the branch must outlive the branch -- `hold` keeps a reference
+    until join(), otherwise the capture's allocator could hand its block to a later main-stream allocation while the branch
+    (unordered with it) has not read it yet."""
+
+    def __init__(self, enable: bool = True):
+        self.on = bool(enable) and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        self.hold = []
+        if self.on:
+            self.main = torch.cuda.current_stream()
+            key = (self.main.device_index, self.main.cuda_stream)
+            side = _FORK_STREAMS.get(key)
+            if side is None:
+                side = _FORK_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
+            self.side = side
+            self._started = False
+
+    def run(self, fn, *reads):
+        """fn() after everything queued on the main stream so far; `reads`: main-stream tensors fn reads."""
+        if not self.on:
+            return fn()
+        self.side.wait_stream(self.main)
+        self._started = True
+        self.hold.extend(reads)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self):
+        if self.on and self._started:
+            self.main.wait_stream(self.side)
+        self.hold = []
+
+
 class TemporalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, a_sub, tm, *params):
-        P = tm.prepared()
+        P = tm.prepared(True)
         N, Lg, E, depth = tm.num_segments, tm.seg_length, tm.emb_size, tm.depth
         heads, e = tm.heads, tm.axial_attn.e
         x = feats.reshape(-1, feats.shape[-1]).contiguous()
@@ -433,17 +490,48 @@ class TemporalFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_scores):
+        """Returns (d_feats, None, None, *parameter gradients).  `ctx.grad_out` (optional; set by the step graph): a dict
+        parameter -> its dense gradient view in parallel.GradBuckets.flat -- the large gradients are then PRODUCED there (the
+        weight-gradient GEMMs write the view), the small ones are copied there by one acx_multi_copy launch, and None is
+        returned in their place."""
         tm = ctx.tm
         x, a_sub, x1, x2, scores, tiles, need_dfeats = ctx.misc
         N, Lg, E = tm.num_segments, tm.seg_length, tm.emb_size
         heads, e = tm.heads, tm.axial_attn.e
         blks = tm.axial_attn.layers.blocks
+        P = tm.prepared(True)
+        gout = getattr(ctx, "grad_out", None)
+        # OFF by default: measured on MI355X, the forked weight-gradient GEMMs (persistent 256 x 256 kernels, one workgroup per
+        # CU) starve the dX chain's small launches instead of hiding them, and ROCm spreads a forked graph over hardware
+        # queues that other streams need (profiles/r04_step_graph_notes.md); `tm.fork_weight_grads = True` re-enables it
+        fork = _Fork(enable=bool(getattr(tm, "fork_weight_grads", False)))
         grads = {}
         c = tm.classifier
-        dz, g_lnw, g_lnb, g_w, g_b = ops.cls_head_bwd(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight,
-                                                      scores, d_scores.contiguous().view(-1))
-        grads[c.layer_norm.weight], grads[c.layer_norm.bias] = g_lnw, g_lnb
-        grads[c.linear.weight], grads[c.linear.bias] = g_w.view(1, -1), g_b
+
+        def dest(p, shape2d):
+            """the [rows, cols] kernel-layout destination inside p's flat-buffer gradient view, or None"""
+            if gout is None or p not in gout:
+                return None
+            v = gout[p]
+            if p.dim() == 4:                                   # conv weight: channels-last view -> [Cout, 9 Cin]
+                v = v.permute(0, 2, 3, 1)
+                if not v.is_contiguous():
+                    return None
+            elif not v.is_contiguous():
+                return None
+            return v.reshape(shape2d)
+
+        def put(p, g, direct):
+            grads[p] = None if direct is not None else g
+
+        dz, part = ops.cls_head_bwd_parts(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight, scores,
+                                          d_scores.contiguous().view(-1))
+
+        def cls_params():
+            sred = ops.reduce_rows(part)
+            grads[c.layer_norm.weight], grads[c.layer_norm.bias] = sred[:E], sred[E:2 * E]
+            grads[c.linear.weight], grads[c.linear.bias] = sred[2 * E:3 * E].view(1, -1), sred[3 * E:3 * E + 1]
+        fork.run(cls_params, part)
         d1, d2 = dz, dz                                   # d(x1), d(x2) of the last block pair
 
         # every branch ends in a LayerNorm backward: the gradient of the residual path it joins (`add`) is summed in that
@@ -453,34 +541,53 @@ class TemporalFn(torch.autograd.Function):
             pn = getattr(blks[2 * d], fg).net.fn
             sa = pn.fn
             He = heads * e
-            grads[sa.to_out.weight] = ops.gemm_tn(d_out, o)                           # [E, He]
-            grads[sa.to_out.bias] = ops.colsum(d_out)
-            d_o = ops.gemm(d_out, ops.transpose(sa.to_out.weight.detach()))            # [rows, He]
+            w_dst = dest(sa.to_out.weight, (E, He))
+
+            def out_params():
+                put(sa.to_out.weight, ops.gemm_tn(d_out, o, out=w_dst), w_dst)          # [E, He]
+                grads[sa.to_out.bias] = ops.colsum(d_out)
+            fork.run(out_params, d_out, o)
+            d_o = ops.gemm(d_out, P[f"out_wT{d}{fg}"])                                   # [rows, He]
             d_qkv = ops.seq_attention_bwd(qkv, d_o, tiles, N, Lg, heads, e, axis)
-            g_qkv = ops.gemm_tn(d_qkv, h)                                              # [3He, E]
-            grads[sa.to_q.weight] = g_qkv[:He]
-            grads[sa.to_kv.weight] = g_qkv[He:]
-            qkv_w = tm.prepared()[f"qkv_w{d}{fg}"]
-            d_h = ops.gemm(d_qkv, ops.transpose(qkv_w))                                # [rows, E]
-            d_in, gw, gb = ops.layernorm_bwd(x_in, pn.norm.weight, d_h, add=add)
-            grads[pn.norm.weight], grads[pn.norm.bias] = gw, gb
+
+            def qkv_params():
+                g_qkv = ops.gemm_tn(d_qkv, h)                                            # [3He, E]
+                grads[sa.to_q.weight], grads[sa.to_kv.weight] = g_qkv[:He], g_qkv[He:]
+            fork.run(qkv_params, d_qkv, h)
+            d_h = ops.gemm(d_qkv, P[f"qkv_wT{d}{fg}"])                                   # [rows, E]
+            d_in, lpart = ops.layernorm_bwd_parts(x_in, pn.norm.weight, d_h, add=add)
+
+            def ln_params():
+                sred = ops.reduce_rows(lpart)
+                grads[pn.norm.weight], grads[pn.norm.bias] = sred[:E], sred[E:]
+            fork.run(ln_params, lpart)
             return d_in
 
         def ff_bwd(rec, d_out, add):
             _, d, fg, _, x_in, h, u, _ = rec
             f = getattr(blks[2 * d + 1], fg).net
-            P = tm.prepared()
-            grads[f[3].bias] = ops.colsum(d_out)
-            gw2 = ops.gemm_tn(d_out, u, conv=True, gn=N, gl=Lg, cin=4 * E)             # [E, 9*4E]  ([Cout][tap][Cin])
-            grads[f[3].weight] = gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2)
-            d_u = ops.gemm(d_out, ops.conv_weight_dx(f[3].weight.detach()), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
+            w2_dst, w1_dst = dest(f[3].weight, (E, 36 * E)), dest(f[1].weight, (4 * E, 9 * E))
+
+            def c2_params():
+                grads[f[3].bias] = ops.colsum(d_out)
+                gw2 = ops.gemm_tn(d_out, u, conv=True, gn=N, gl=Lg, cin=4 * E, out=w2_dst)    # [E, 9*4E]  ([Cout][tap][Cin])
+                put(f[3].weight, gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2), w2_dst)
+            fork.run(c2_params, d_out, u)
+            d_u = ops.gemm(d_out, P[f"c2_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
             d_pre = ops.act(u, d_u, 0)                                                 # LeakyReLU'
-            grads[f[1].bias] = ops.colsum(d_pre)
-            gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E)                 # [4E, 9E]
-            grads[f[1].weight] = gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2)
-            d_h = ops.gemm(d_pre, ops.conv_weight_dx(f[1].weight.detach()), amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
-            d_in, gg, gb = ops.layernorm_bwd(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN, add=add)
-            grads[f[0].g], grads[f[0].b] = gg.view(1, -1, 1, 1), gb.view(1, -1, 1, 1)
+
+            def c1_params():
+                grads[f[1].bias] = ops.colsum(d_pre)
+                gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E, out=w1_dst)        # [4E, 9E]
+                put(f[1].weight, gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2), w1_dst)
+            fork.run(c1_params, d_pre, h)
+            d_h = ops.gemm(d_pre, P[f"c1_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
+            d_in, lpart = ops.layernorm_bwd_parts(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN, add=add)
+
+            def ln_params():
+                sred = ops.reduce_rows(lpart)
+                grads[f[0].g], grads[f[0].b] = sred[:E].view(1, -1, 1, 1), sred[E:].view(1, -1, 1, 1)
+            fork.run(ln_params, lpart)
             return d_in
 
         recs = ctx.saved_acts
@@ -499,28 +606,50 @@ class TemporalFn(torch.autograd.Function):
             d1, d2 = d_x1, d_x2
         d_x0 = ops.add(d1, d2)
         pe = tm.axial_attn.pos_emb
-        g0, g1 = ops.pos_grad(d_x0, tiles, N, Lg)
-        grads[pe.param_0] = g0.t().reshape(1, E, N, 1)
-        grads[pe.param_1] = g1.t().reshape(1, E, 1, Lg)
         K = tm.input_size
-        gw = ops.gemm_tn(d_x0, x, b_sub=a_sub)                                         # [E, Kp]
-        grads[tm.projection.weight] = gw[:, :K]
-        grads[tm.projection.bias] = ops.colsum(d_x0)
+        pw_dst = dest(tm.projection.weight, (E, K)) if P["Kp"] == K else None
+
+        def x0_params():
+            g0, g1 = ops.pos_grad(d_x0, tiles, N, Lg)
+            grads[pe.param_0] = g0.t().reshape(1, E, N, 1)
+            grads[pe.param_1] = g1.t().reshape(1, E, 1, Lg)
+            gw = ops.gemm_tn(d_x0, x, b_sub=a_sub, out=pw_dst)                           # [E, Kp]
+            put(tm.projection.weight, gw[:, :K], pw_dst)
+            grads[tm.projection.bias] = ops.colsum(d_x0)
+        fork.run(x0_params, d_x0, x)
         d_feats = None
         if need_dfeats:
-            d_feats = ops.gemm(d_x0, ops.transpose(tm.prepared()["proj_w"]))           # [rows, Kp]
+            d_feats = ops.gemm(d_x0, P["proj_wT"])                                       # [rows, Kp]
+        fork.join()
         ctx.saved_acts = None
-        out = [grads.get(p) for p in _temporal_param_list(tm)]
-        out = [g.contiguous() if g is not None else None for g in out]
+        plist = _temporal_param_list(tm)
+        if gout is not None:
+            # the gradients that were not produced in place: ONE copy launch into their flat-buffer views
+            ys, xs = [], []
+            for p in plist:
+                g = grads.get(p)
+                if g is None:
+                    continue
+                if p not in gout:
+                    raise L.AcxError("TemporalFn.backward: grad_out lacks a parameter's gradient view")
+                ys.append(gout[p].reshape(-1))
+                xs.append(g.contiguous().reshape(-1))
+            ops.multi_copy_(ys, xs)
+            return (d_feats, None, None) + (None,) * len(plist)
+        out = [grads.get(p) for p in plist]
+        # contiguous in the PARAMETER's memory format (conv weights: channels-last, which their [Cout][tap][Cin] gradient
+        # views already are -- no copy)
+        out = [None if g is None else (g.contiguous() if p.is_contiguous() else
+                                       g.contiguous(memory_format=torch.channels_last)) for p, g in zip(plist, out)]
         return (d_feats, None, None, *out)
 
 
 class _TemporalGraphs:
     """TemporalFn.forward / .backward -- fixed sequences of library calls for a given input shape -- captured once as two
-    HIP graphs and replayed on the caller's stream: with few videos per GPU the step is bound by how fast the host can
-    issue these ~190 small launches.  Static buffers: a copy of the input features, the upstream gradient, every
-    activation, every returned gradient.  The weight-derived tensors of TemporalModel.prepared() are recomputed INSIDE
-    the forward graph (the optimizer rewrites the weights in place between replays)."""
+    HIP graphs and replayed on the caller's stream (the autograd path's accelerator; train_batch's whole-step graph,
+    step_graph.TrainStepGraph, supersedes it when it can run).  Static buffers: a copy of the input features, the upstream
+    gradient, every activation, every returned gradient.  The derived weight layouts (TemporalModel.refresh_prepared: one
+    launch) are rebuilt INSIDE the forward graph -- the optimizer rewrites the weights in place between replays."""
 
     def __init__(self, tm, feats, a_sub, need_dfeats):
         from types import SimpleNamespace
@@ -533,20 +662,22 @@ class _TemporalGraphs:
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(2):                                               # warm-up: lazy workspaces, function attributes
                 c = SimpleNamespace(needs_input_grad=(need_dfeats,))
+                tm.refresh_prepared(True)
                 sc = TemporalFn.forward(c, self.x, a_sub, tm, *params)
                 TemporalFn.backward(c, torch.zeros_like(sc))
         torch.cuda.synchronize()
-        tm._prep = None                                                      # prepared() runs inside the forward graph
+        cap = torch.cuda.Stream()
+        ops.prime_capture_stream(cap, self.x.device)
         self.cx = SimpleNamespace(needs_input_grad=(need_dfeats,))
         self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"), torch.no_grad():
+        with torch.cuda.graph(self.g_fwd, stream=cap, capture_error_mode="thread_local"), torch.no_grad():
+            tm.refresh_prepared(True)
             self.scores = TemporalFn.forward(self.cx, self.x, a_sub, tm, *params)
         self.d_scores = torch.zeros_like(self.scores)
         self.g_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), capture_error_mode="thread_local"), torch.no_grad():
+        with torch.cuda.graph(self.g_bwd, stream=cap, pool=self.g_fwd.pool(), capture_error_mode="thread_local"), torch.no_grad():
             self.outs = TemporalFn.backward(self.cx, self.d_scores)
         torch.cuda.synchronize()
-        tm._prep = None                                                      # eager callers must not pick up graph-pool tensors
 
     @staticmethod
     def make_key(tm, feats, a_sub, need_dfeats):
@@ -572,17 +703,15 @@ class TemporalGraphFn(torch.autograd.Function):
         tg = ctx.tm._graphs
         tg.d_scores.copy_(d_scores.reshape(tg.d_scores.shape))
         tg.g_bwd.replay()
-        # the graph's static gradient buffers are handed to autograd as they are: AccumulateGrad adds them into the
-        # parameters' .grad (views of GradBuckets.flat) in place, or clones them itself when .grad is None (tg.outs keeps a
-        # second reference, so it never adopts the static tensor) -- 34 clone launches per step less.  Only d_feats, which
-        # flows on into other autograd nodes, is copied out of the graph's memory.  With a gradient sink attached
-        # (parallel.GradBuckets of the module's train_batch) the 34 gradients are added into the flat buffer by ONE launch
-        # and reported ready there; autograd then gets None for them
+        # With a gradient sink attached for the duration of this backward (parallel.GradBuckets, armed by the module's
+        # train_batch) the graph's static gradient buffers are added into the flat buffer by ONE launch and reported ready
+        # there; autograd gets None for them.  Otherwise every gradient is COPIED out of the graph's memory: autograd may keep
+        # what a Function returns (torch.autograd.grad, hooks, retain_graph) and the next replay overwrites the static buffers.
         d_feats = tg.outs[0].clone() if tg.outs[0] is not None else None
         sink = getattr(ctx.tm, "_grad_sink", None)
         if sink is not None and sink.accumulate(_temporal_param_list(ctx.tm), tg.outs[3:]):
             return (d_feats, None, None) + (None,) * (len(tg.outs) - 3)
-        return (d_feats,) + tuple(tg.outs[1:])
+        return (d_feats, None, None) + tuple(g.clone() if g is not None else None for g in tg.outs[3:])
 
 
 def temporal_train(tm, features, a_sub):

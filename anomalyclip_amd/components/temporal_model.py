@@ -59,10 +59,24 @@ class _ChanLayerNorm(nn.Module):
 
 
 class _Conv3x3(nn.Module):
+    """nn.Conv2d(cin, cout, 3, padding=1)'s parameters.  `weight` has Conv2d's logical shape [cout, cin, 3, 3] (state_dict
+    compatible) but lives in channels-last MEMORY, i.e. physically [cout][kh][kw][cin] -- exactly the [Cout][tap][Cin]
+    operand of the implicit-GEMM kernels, so the forward reads the master weight as it stands, the weight gradient
+    [cout, 9 cin] of acx_gemm_tn is written straight into the parameter's gradient view and AdamW (elementwise on the
+    physical memory of p / g / m / v) needs no re-layout: 8 permute-copies of 9.4 MB per step less at the UCF config."""
+
     def __init__(self, cin, cout):
         super().__init__()
-        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3).normal_(std=(9 * cin) ** -0.5))
+        w = torch.empty(cout, cin, 3, 3).normal_(std=(9 * cin) ** -0.5)
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
         self.bias = nn.Parameter(torch.zeros(cout))
+
+    def kernel_weight(self) -> torch.Tensor:
+        """[cout, 9 cin] tap-major view of the master weight (a copy only if someone replaced the parameter's memory format)."""
+        w = self.weight.detach().permute(0, 2, 3, 1)
+        if not w.is_contiguous():
+            w = w.contiguous()
+        return w.reshape(w.shape[0], -1)
 
 
 def _ff(dim):
@@ -114,39 +128,103 @@ class TemporalModel(nn.Module):
         self.graph = False                 # training: replay forward / backward as HIP graphs (functional._TemporalGraphs)
         self._prep = None
 
-    # ---- derived weight layouts for the kernels (cached; rebuilt when a parameter changes)
-    def prepared(self):
-        key = (ops.WEIGHT_EPOCH[0], self.precision) + tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if self._prep is not None and self._prep[0] == key:
-            return self._prep[1]
-        with torch.no_grad():
-            P = {}
-            K = self.input_size
-            Kp = (K + 31) // 32 * 32
-            w = self.projection.weight.detach()
+    # ---- derived weight layouts for the kernels
+    def _derived(self, train: bool):
+        """Static buffers of every derived layout + the segment list that fills them (ops.prep_multi: ONE launch).  Allocated
+        once per (device, parameter addresses); views of the master parameters where no re-layout is needed."""
+        key = (bool(train),) + tuple(p.data_ptr() for p in self.parameters())
+        cur = self.__dict__.get("_drv")
+        if cur is not None and cur[0] == key:
+            return cur[1], cur[2]
+        if torch.cuda.is_current_stream_capturing():
+            raise L.AcxError("TemporalModel: derived weight buffers must be created by an eager call before a HIP graph is captured")
+        P, segs = {}, []
+        dev = self.projection.weight.device
+        E, N, Lg = self.emb_size, self.num_segments, self.seg_length
+        K = self.input_size
+        Kp = (K + 31) // 32 * 32
+        w = self.projection.weight.detach()
+        if Kp == K:
+            P["proj_w"] = w
+        else:                                              # zero-padded to a multiple of 32 columns (pad written once, here)
+            P["proj_w"] = torch.zeros(E, Kp, dtype=torch.float32, device=dev)
+            segs.append((w, P["proj_w"], E, K, K, Kp, 0))
+        P["Kp"] = Kp
+        pe = self.axial_attn.pos_emb
+        P["pos0"] = torch.empty(N, E, dtype=torch.float32, device=dev)            # param_0 (1, E, N, 1) -> [N, E]
+        P["pos1"] = torch.empty(Lg, E, dtype=torch.float32, device=dev)           # param_1 (1, E, 1, L) -> [L, E]
+        segs.append((pe.param_0.detach(), P["pos0"], E, N, N, E, 1))
+        segs.append((pe.param_1.detach(), P["pos1"], E, Lg, Lg, E, 1))
+        if train:
+            P["proj_wT"] = torch.empty(Kp, E, dtype=torch.float32, device=dev)
             if Kp != K:
-                w = torch.cat([w, w.new_zeros(w.shape[0], Kp - K)], dim=1)
-            P["proj_w"], P["Kp"] = w.contiguous(), Kp
-            pe = self.axial_attn.pos_emb
-            P["pos0"] = pe.param_0.detach()[0, :, :, 0].t().contiguous()   # [N, E]
-            P["pos1"] = pe.param_1.detach()[0, :, 0, :].t().contiguous()   # [L, E]
-            blks = self.axial_attn.layers.blocks
-            for d in range(self.depth):
-                for fg in ("f", "g"):
-                    sa = getattr(blks[2 * d], fg).net.fn.fn
-                    P[f"qkv_w{d}{fg}"] = torch.cat([sa.to_q.weight.detach(), sa.to_kv.weight.detach()], 0).contiguous()
-                    ff = getattr(blks[2 * d + 1], fg).net
-                    # conv weight [Cout, Cin, 3, 3] -> [Cout, tap=kh*3+kw, Cin]  (K = 9*Cin, tap-major)
-                    P[f"c1_w{d}{fg}"] = ff[1].weight.detach().permute(0, 2, 3, 1).reshape(ff[1].weight.shape[0], -1).contiguous()
-                    P[f"c2_w{d}{fg}"] = ff[3].weight.detach().permute(0, 2, 3, 1).reshape(ff[3].weight.shape[0], -1).contiguous()
-                    P[f"g{d}{fg}"] = ff[0].g.detach().reshape(-1).contiguous()
-                    P[f"b{d}{fg}"] = ff[0].b.detach().reshape(-1).contiguous()
-                    if self.precision == "bf16":
-                        P[f"out_w{d}{fg}"] = ops.cast_bf16(sa.to_out.weight.detach())
+                P["proj_wT"].zero_()
+            segs.append((w, P["proj_wT"], E, K, K, E, 1))
+        blks = self.axial_attn.layers.blocks
+        He = self.heads * self.axial_attn.e
+        for d in range(self.depth):
+            for fg in ("f", "g"):
+                sa = getattr(blks[2 * d], fg).net.fn.fn
+                tq, tkv, tout = sa.to_q.weight.detach(), sa.to_kv.weight.detach(), sa.to_out.weight.detach()
+                q = P[f"qkv_w{d}{fg}"] = torch.empty(3 * He, E, dtype=torch.float32, device=dev)      # [to_q ; to_kv]
+                segs.append((tq, q, He, E, E, E, 0))
+                segs.append((tkv, q[He:], 2 * He, E, E, E, 0))
+                ff = getattr(blks[2 * d + 1], fg).net
+                # conv weights: the channels-last master IS [Cout][tap = kh*3+kw][Cin] (K = 9 Cin, tap-major)
+                P[f"c1_w{d}{fg}"], P[f"c2_w{d}{fg}"] = ff[1].kernel_weight(), ff[3].kernel_weight()
+                P[f"g{d}{fg}"] = ff[0].g.detach().reshape(-1)
+                P[f"b{d}{fg}"] = ff[0].b.detach().reshape(-1)
+                if train:
+                    # operands of the dX GEMMs (dX = dY W needs W^T rows as the [N, K] operand)
+                    qT = P[f"qkv_wT{d}{fg}"] = torch.empty(E, 3 * He, dtype=torch.float32, device=dev)
+                    segs.append((tq, qT, He, E, E, 3 * He, 1))
+                    segs.append((tkv, qT[:, He:], 2 * He, E, E, 3 * He, 1))
+                    oT = P[f"out_wT{d}{fg}"] = torch.empty(He, E, dtype=torch.float32, device=dev)
+                    segs.append((tout, oT, E, He, He, He, 1))
+                    # dX of a 3x3 convolution = a 3x3 convolution of dY with flipped taps and swapped channels:
+                    # out[ci][tap'][co] = w[co][8 - tap'][ci], nine strided [Cout, Cin] -> [Cin, Cout] transposes per weight
+                    for name, conv in (("c1_dx", ff[1]), ("c2_dx", ff[3])):
+                        kw = conv.kernel_weight()
+                        Cout, Cin = kw.shape[0], kw.shape[1] // 9
+                        if kw.data_ptr() != conv.weight.data_ptr():
+                            raise L.AcxError("conv weights must stay in channels-last memory for training (see _Conv3x3)")
+                        o = P[f"{name}{d}{fg}"] = torch.empty(Cin, 9 * Cout, dtype=torch.float32, device=dev)
+                        for t in range(9):
+                            segs.append((kw.data_ptr() + 4 * t * Cin, o.data_ptr() + 4 * (8 - t) * Cout, Cout, Cin, 9 * Cin,
+                                         9 * Cout, 1))
+        self.__dict__["_drv"] = (key, P, segs)
+        return P, segs
+
+    def refresh_prepared(self, train: bool = True):
+        """(Re)build every derived layout from the current master weights: one acx_prep_multi launch on the current stream
+        (capturable -- the step graphs replay it after each optimizer update)."""
+        P, segs = self._derived(train)
+        ops.prep_multi(segs, device=self.projection.weight.device)
+        self._prep = (self._prep_key(train), P)
+        return P
+
+    def _prep_key(self, train: bool):
+        return (ops.WEIGHT_EPOCH[0], self.precision, bool(train)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def prepared(self, train: bool = False):
+        """Derived layouts, rebuilt when a parameter changed (cached by optimizer epoch / tensor versions).  `train` adds the
+        backward operands (transposes, flipped-tap conv weights); a training cache also serves inference callers."""
+        if self._prep is not None:
+            k = self._prep[0]
+            if k == self._prep_key(train) or (not train and k == self._prep_key(True)):
+                return self._prep[1]
+        with torch.no_grad():
+            P = dict(self.refresh_prepared(train))
             if self.precision == "bf16":
-                for k in [k for k in P if k == "proj_w" or k.startswith(("qkv_w", "c1_w", "c2_w"))]:
-                    P[k] = ops.cast_bf16(P[k])
-        self._prep = (key, P)
+                P = dict(P)
+                blks = self.axial_attn.layers.blocks
+                for d in range(self.depth):
+                    for fg in ("f", "g"):
+                        sa = getattr(blks[2 * d], fg).net.fn.fn
+                        P[f"out_w{d}{fg}"] = ops.cast_bf16(sa.to_out.weight.detach())
+                for k in [k for k in P if k == "proj_w" or k.startswith(("qkv_w", "c1_w", "c2_w")) and "T" not in k]:
+                    P[k] = ops.cast_bf16(P[k].contiguous())
+        self._prep = (self._prep_key(train), P)
         return P
 
     def _attn(self, x_in, resid, d, fg, tiles, axis, P):

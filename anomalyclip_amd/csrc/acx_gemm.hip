@@ -844,6 +844,12 @@ extern "C" size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2)
 extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                            int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
                            int32_t cin, void* workspace, size_t workspace_bytes, void* stream) {
+  return acx_gemm_tn_zp(ctx, A, lda, B, ldb, C, ldc, M, N1, N2, b_sub, conv, gn, gl, cin, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                              int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                              int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream) {
   if (!A || !B || !C) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: null pointer%s");
   if (M <= 0 || N1 <= 0 || N2 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: empty shape%s");
   if (N1 % 4 || N2 % 4 || lda % 4 || ldb % 4 || ldc != N2 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15))
@@ -855,16 +861,18 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     int splits = tn_p256_splits(M, N1, N2, ncu > 256 ? 256 : ncu);
     const size_t part = (size_t)N1 * N2 * sizeof(float);
-    while (splits > 1 && (size_t)splits * part + TN_ZERO_B > workspace_bytes) --splits;
+    const size_t ztail = zero_page ? 0 : TN_ZERO_B;      // a caller-owned zero page (>= 1 KB, never written) saves the clear launch
+    while (splits > 1 && (size_t)splits * part + ztail > workspace_bytes) --splits;
     const size_t zoff = splits > 1 ? (size_t)splits * part : 0;
-    if (zoff + TN_ZERO_B <= workspace_bytes && !(zoff & 15)) {
+    if (zoff + ztail <= workspace_bytes && !(zoff & 15) && !((uintptr_t)zero_page & 15)) {
       hipStream_t s = (hipStream_t)stream;
       AcxProfScope prof__(ctx, ACX_K_GEMM_TN, s);
       if (ctx && ctx->prof_on) { ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2; ctx->prof_tn_flops += 2.0 * M * (double)N1 * N2; }
-      float* zeros = (float*)((char*)workspace + zoff);
+      const float* zeros = zero_page ? (const float*)zero_page : (const float*)((char*)workspace + zoff);
       // a KERNEL clears the page: as a hipMemsetAsync node inside a captured graph the clear was observed to run unordered
       // with the consumer (stale workspace bytes read as padding, run-to-run different gradients under graph replay)
-      hipLaunchKernelGGL(tn_zero_page_kernel, dim3(1), dim3(TN_ZERO_B / 16), 0, s, reinterpret_cast<float4*>(zeros));
+      if (!zero_page)
+        hipLaunchKernelGGL(tn_zero_page_kernel, dim3(1), dim3(TN_ZERO_B / 16), 0, s, reinterpret_cast<float4*>(const_cast<float*>(zeros)));
       TnArgs g;
       g.A = A; g.B = B; g.C = splits > 1 ? (float*)workspace : C;
       g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -882,8 +890,7 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
         attr_done = true;
       }
       const int tiles = ((N1 + 255) / 256) * ((N2 + 255) / 256);
-      hipLaunchKernelGGL(gemm_tn_p256_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(1024), (size_t)TP_LDS_B, s, g,
-                         (const float*)zeros);
+      hipLaunchKernelGGL(gemm_tn_p256_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(1024), (size_t)TP_LDS_B, s, g, zeros);
       if (splits > 1) {
         const int64_t n4 = (int64_t)N1 * N2 / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, n4,

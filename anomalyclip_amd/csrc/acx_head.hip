@@ -586,14 +586,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void prompt_embed_kernel(const float* __restrict__ prefix, const float* __restrict__ ctxv,
                                                            const float* __restrict__ suffix, const float* __restrict__ pos,
                                                            float* __restrict__ out, int64_t total4, int n_ctx, int Lc, int W,
-                                                           int shared_ctx) {
+                                                           int shared_ctx, int Lout) {
+  // Lout <= Lc positions are written per class (the causal text tower is evaluated up to the last EOT only)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int W4 = W / 4;
   const int w4 = (int)(i % W4);
   const int64_t tokg = i / W4;
-  const int tkn = (int)(tokg % Lc);
-  const int64_t c = tokg / Lc;
+  const int tkn = (int)(tokg % Lout);
+  const int64_t c = tokg / Lout;
   const float* src;
   if (tkn == 0) src = prefix + c * W;
   else if (tkn <= n_ctx) src = ctxv + ((shared_ctx ? 0 : c * n_ctx) + (tkn - 1)) * (int64_t)W;
@@ -1084,14 +1085,15 @@ extern "C" int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows
 
 extern "C" int acx_prompt_embed(acx_ctx* ctx, const float* prefix, const float* ctxv, const float* suffix, const float* pos,
                                 float* out, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W, int32_t shared_ctx,
-                                void* stream) {
+                                int32_t Lout, void* stream) {
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!prefix || !ctxv || !suffix || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_prompt_embed: null pointer%s");
   if (C <= 0) return ACX_OK;
-  if (W % 4 || n_ctx < 0 || n_ctx + 1 >= Lc) return acx_fail(ctx, ACX_E_BADARG, "acx_prompt_embed: bad geometry%s");
-  const int64_t total4 = (int64_t)C * Lc * W / 4;
+  if (Lout <= 0) Lout = Lc;
+  if (W % 4 || n_ctx < 0 || n_ctx + 1 >= Lc || Lout > Lc) return acx_fail(ctx, ACX_E_BADARG, "acx_prompt_embed: bad geometry%s");
+  const int64_t total4 = (int64_t)C * Lout * W / 4;
   hipLaunchKernelGGL(prompt_embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prefix,
-                     ctxv, suffix, pos, out, total4, n_ctx, Lc, W, shared_ctx);
+                     ctxv, suffix, pos, out, total4, n_ctx, Lc, W, shared_ctx, Lout);
   ACX_CHECK_LAUNCH(ctx, "acx_prompt_embed");
   return ACX_OK;
 }

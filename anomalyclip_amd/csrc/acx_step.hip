@@ -1,0 +1,407 @@
+// Support kernels of the whole-step training graph (anomalyclip_amd/components/step_graph.py): everything a data-parallel
+// rank's optimisation step needs besides the forward / backward kernels, so that NO torch kernel runs between the first
+// and the last launch of a step and the whole step replays from HIP graphs:
+//   acx_prep_multi          every derived weight layout of the temporal model (q|kv concatenation, transposes for the dX
+//                           GEMMs, flipped-tap [Cin][tap][Cout] conv weights, padded projection weight, positional tables)
+//                           in ONE launch -- was ~20 copy / cat / transpose launches per step
+//   acx_adamw_multi_dev     multi-tensor AdamW whose per-tensor scalars (1 - lr wd, lr / bias correction) live in DEVICE
+//                           memory: lr schedules and the step count change without re-capturing the graph
+//   acx_multi_copy          y_i = x_i for a list of tensors (gradients that cannot be produced in place -> flat buffer)
+//   acx_bn_pack / acx_bn_running_update / acx_fill_f32   the selector's BatchNorm bookkeeping without torch elementwise ops
+#include "acx_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ strided copy / transpose
+constexpr int PREP_MAX_SEG = 72;
+struct PrepSegs {
+  const float* src[PREP_MAX_SEG];
+  float* dst[PREP_MAX_SEG];
+  int rows[PREP_MAX_SEG], cols[PREP_MAX_SEG];       // extent of the SOURCE block
+  int src_ld[PREP_MAX_SEG], dst_ld[PREP_MAX_SEG];
+  int tile0[PREP_MAX_SEG + 1];                      // first 32x32 tile of every segment
+  unsigned char transpose[PREP_MAX_SEG];
+  int nseg;
+};
+
+// one 32x32 tile per block: dst[r][c] = src[r][c] (copy) or dst[c][r] = src[r][c] (transpose), both sides coalesced
+__global__ __launch_bounds__(256) void prep_multi_kernel(const PrepSegs t) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.tile0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int R = t.rows[lo], Cn = t.cols[lo];
+  const int tc = (Cn + 31) >> 5;
+  const int tl = b - t.tile0[lo];
+  const int by = (tl / tc) * 32, bx = (tl % tc) * 32;
+  const float* __restrict__ src = t.src[lo];
+  float* __restrict__ dst = t.dst[lo];
+  const int sld = t.src_ld[lo], dld = t.dst_ld[lo];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (!t.transpose[lo]) {
+    for (int j = ty; j < 32; j += 8)
+      if (by + j < R && bx + tx < Cn) dst[(size_t)(by + j) * dld + bx + tx] = src[(size_t)(by + j) * sld + bx + tx];
+    return;
+  }
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < R && bx + tx < Cn) tile[j][tx] = src[(size_t)(by + j) * sld + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < Cn && by + tx < R) dst[(size_t)(bx + j) * dld + by + tx] = tile[tx][j];
+}
+
+// ------------------------------------------------------------------------------------------------ multi-tensor copy
+constexpr int COPY_MAX_SEG = 96;
+struct CopySegs {
+  float* y[COPY_MAX_SEG];
+  const float* x[COPY_MAX_SEG];
+  long long n[COPY_MAX_SEG];
+  int chunk0[COPY_MAX_SEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopySegs t) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.chunk0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  float* __restrict__ y = t.y[lo];
+  const float* __restrict__ x = t.x[lo];
+  const long long n = t.n[lo];
+  const long long base = (long long)(b - t.chunk0[lo]) * 1024 + threadIdx.x;
+  float xv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) xv[k] = x[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) y[i] = xv[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ AdamW, device-side scalars
+constexpr int ADAMW_DEV_MAX_SEG = 48;
+struct AdamwDevSegs {
+  float* p[ADAMW_DEV_MAX_SEG];
+  const float* g[ADAMW_DEV_MAX_SEG];
+  float* m[ADAMW_DEV_MAX_SEG];
+  float* v[ADAMW_DEV_MAX_SEG];
+  long long n[ADAMW_DEV_MAX_SEG];
+  int chunk0[ADAMW_DEV_MAX_SEG + 1];
+  int nseg, seg_base;                 // hyper index of segment k = seg_base + k
+};
+// hyper: [0] = sqrt(1 - beta2^step), then per tensor (decay = 1 - lr wd, step_size = lr / (1 - beta1^step)) pairs; the same
+// f32 values acx_adamw_multi forms on the host, so both entry points update bit-identically.  grad_scale multiplies every
+// gradient as it is read (1 / world size after a summing all-reduce; exactly 1.0f otherwise -- x * 1.0f == x).
+template <bool SCALE>
+__global__ __launch_bounds__(256) void adamw_multi_dev_kernel(const AdamwDevSegs t, const float* __restrict__ hyper, float b1, float b2,
+                                                              float omb1, float omb2, float eps, float grad_scale) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.chunk0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int sgi = lo;
+  float* __restrict__ p = t.p[sgi];
+  float* __restrict__ g = const_cast<float*>(t.g[sgi]);
+  float* __restrict__ m = t.m[sgi];
+  float* __restrict__ v = t.v[sgi];
+  const long long n = t.n[sgi];
+  const float bc2_sqrt = hyper[0];
+  const float decay = hyper[1 + 2 * (t.seg_base + sgi)], step_size = hyper[2 + 2 * (t.seg_base + sgi)];
+  const long long base = (long long)(b - t.chunk0[sgi]) * 1024 + threadIdx.x;
+  float pi[4], gi[4], mi[4], vi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) { pi[k] = p[i]; gi[k] = SCALE ? g[i] * grad_scale : g[i]; mi[k] = m[i]; vi[k] = v[i]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + 256 * k;
+    if (i < n) {
+      const float pw = pi[k] * decay;
+      const float mn = b1 * mi[k] + omb1 * gi[k];
+      const float vn = b2 * vi[k] + omb2 * gi[k] * gi[k];
+      m[i] = mn;
+      v[i] = vn;
+      p[i] = pw - step_size * (mn / (sqrtf(vn) / bc2_sqrt + eps));
+      if (SCALE) g[i] = gi[k];         // the flat gradient buffer is left holding the MEAN, as DDP leaves .grad
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fused column sums
+// out[c] = sum_r x[r][c] in ONE launch, deterministic: block (slab, column group of 64) writes its partial row, the LAST block
+// of a column group to arrive (device-scope counter) adds the slabs' partials in slab order.  The counter returns to zero,
+// so the launch is replayable from a HIP graph.  Replaces colsum_partials + reduce_rows (two launches per bias gradient).
+__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
+                                                           float* __restrict__ part, float* __restrict__ out,
+                                                           unsigned int* __restrict__ counters) {
+  __shared__ float4 red[16][16];
+  __shared__ bool last;
+  const int cg = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+  const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;          // 16 float4 columns x 16 row lanes
+  const int c = cg * 64 + 4 * tc;
+  const long long r0 = (long long)slab * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < D)
+    for (long long r = r0 + tr; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  red[tr][tc] = a;
+  __syncthreads();
+  if (tr == 0 && c < D) {
+    float4 s = red[0][tc];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { s.x += red[k][tc].x; s.y += red[k][tc].y; s.z += red[k][tc].z; s.w += red[k][tc].w; }
+    *reinterpret_cast<float4*>(part + (size_t)slab * D + c) = s;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&counters[cg], 1u) == (unsigned)nslab - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // last block of the column group: 64 columns x 4 slab lanes; lane l adds slabs l, l + 4, ... in order, the four lane sums are
+  // then added in lane order -- a fixed tree, whichever block happens to arrive last
+  __shared__ float fin[4][64];
+  {
+    const int cl = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int cc = cg * 64 + cl;
+    float s0 = 0.f;
+    if (cc < D) {
+      int p = l;
+      for (; p + 12 < nslab; p += 16) {
+        const float a0 = __builtin_nontemporal_load(part + (size_t)p * D + cc);
+        const float a1 = __builtin_nontemporal_load(part + (size_t)(p + 4) * D + cc);
+        const float a2 = __builtin_nontemporal_load(part + (size_t)(p + 8) * D + cc);
+        const float a3 = __builtin_nontemporal_load(part + (size_t)(p + 12) * D + cc);
+        s0 += a0; s0 += a1; s0 += a2; s0 += a3;
+      }
+      for (; p < nslab; p += 4) s0 += __builtin_nontemporal_load(part + (size_t)p * D + cc);
+    }
+    fin[l][cl] = s0;
+    __syncthreads();
+    if (l == 0 && cc < D) out[cc] = ((fin[0][cl] + fin[1][cl]) + fin[2][cl]) + fin[3][cl];
+  }
+  if (threadIdx.x == 0) counters[cg] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm bookkeeping
+// SyncBN payload of a rank: out = [mean (C) | biased var * rows (C) | rows]   (parallel.sync_bn_stats' torch.cat)
+__global__ void bn_pack_kernel(const float* __restrict__ mean, const float* __restrict__ var_b, float rows, int C,
+                               float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < C) { out[i] = mean[i]; out[C + i] = var_b[i] * rows; }
+  if (i == 0) out[2 * C] = rows;
+}
+// nn.BatchNorm1d's running statistics: r = (1 - momentum) r + momentum x (selector_model.py:30,65), batch counter + 1
+__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var_u, float* __restrict__ rm,
+                                  float* __restrict__ rv, long long* __restrict__ nbt, int C, float momentum, float om) {
+  const int i = threadIdx.x;
+  if (i < C) {
+    rm[i] = momentum * mean[i] + om * rm[i];
+    rv[i] = momentum * var_u[i] + om * rv[i];
+  }
+  if (i == 0 && nbt) *nbt += 1;
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long long n, float v) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" int acx_prep_multi(acx_ctx* ctx, int32_t nseg, const acx_prep_seg* segs, void* stream) {
+  if (nseg <= 0) return ACX_OK;
+  if (!segs) return acx_fail(ctx, ACX_E_BADARG, "acx_prep_multi: null segment table%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < nseg) {
+    PrepSegs t;
+    memset(&t, 0, sizeof(t));
+    long long tiles = 0;
+    int k = 0;
+    for (; i < nseg && k < PREP_MAX_SEG; ++i) {
+      const acx_prep_seg& g = segs[i];
+      if (g.rows <= 0 || g.cols <= 0) continue;
+      if (!g.src || !g.dst) return acx_fail(ctx, ACX_E_BADARG, "acx_prep_multi: null tensor pointer%s");
+      if (g.src_ld < g.cols || g.dst_ld < (g.transpose ? g.rows : g.cols))
+        return acx_fail(ctx, ACX_E_BADARG, "acx_prep_multi: leading dimension smaller than the row length%s");
+      t.src[k] = (const float*)g.src; t.dst[k] = (float*)g.dst;
+      t.rows[k] = g.rows; t.cols[k] = g.cols; t.src_ld[k] = g.src_ld; t.dst_ld[k] = g.dst_ld;
+      t.transpose[k] = g.transpose ? 1 : 0;
+      t.tile0[k] = (int)tiles;
+      tiles += (long long)((g.rows + 31) / 32) * ((g.cols + 31) / 32);
+      ++k;
+    }
+    if (k == 0) continue;
+    if (tiles > 0x7fffffffLL) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_prep_multi: too many tiles for one launch%s");
+    t.tile0[k] = (int)tiles;
+    t.nseg = k;
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    hipLaunchKernelGGL(prep_multi_kernel, dim3((unsigned)tiles), dim3(256), 0, s, t);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_prep_multi");
+  return ACX_OK;
+}
+
+extern "C" int acx_multi_copy(acx_ctx* ctx, int32_t nseg, void* const* y, const void* const* x, const int64_t* n, void* stream) {
+  if (nseg <= 0) return ACX_OK;
+  if (!y || !x || !n) return acx_fail(ctx, ACX_E_BADARG, "acx_multi_copy: null pointer%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < nseg) {
+    CopySegs t;
+    memset(&t, 0, sizeof(t));
+    long long chunks = 0;
+    int k = 0;
+    for (; i < nseg && k < COPY_MAX_SEG; ++i) {
+      if (n[i] <= 0) continue;
+      if (!y[i] || !x[i]) return acx_fail(ctx, ACX_E_BADARG, "acx_multi_copy: null tensor pointer%s");
+      t.y[k] = (float*)y[i]; t.x[k] = (const float*)x[i]; t.n[k] = n[i];
+      t.chunk0[k] = (int)chunks;
+      chunks += (n[i] + 1023) / 1024;
+      ++k;
+    }
+    if (k == 0) continue;
+    if (chunks > 0x7fffffffLL) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_multi_copy: too many elements for one launch%s");
+    t.chunk0[k] = (int)chunks;
+    t.nseg = k;
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_multi_copy");
+  return ACX_OK;
+}
+
+extern "C" int acx_adamw_hyper(int32_t nseg, const double* lr, const double* weight_decay, double beta1, double beta2, int32_t step,
+                               float* out) {
+  if (nseg < 0 || !out || (nseg > 0 && (!lr || !weight_decay)) || step <= 0) return ACX_E_BADARG;
+  // the scalar terms exactly as acx_adamw_multi forms them: f64 on the host, rounded ONCE (torch.optim.AdamW's Python floats)
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  out[0] = (float)sqrt(1.0 - pow(beta2, (double)step));
+  for (int i = 0; i < nseg; ++i) {
+    out[1 + 2 * i] = (float)(1.0 - lr[i] * weight_decay[i]);
+    out[2 + 2 * i] = (float)(lr[i] / bc1);
+  }
+  return ACX_OK;
+}
+
+extern "C" int acx_adamw_multi_dev(acx_ctx* ctx, int32_t nseg, void* const* p, const void* const* g, void* const* m, void* const* v,
+                                   const int64_t* n, const float* hyper_dev, float grad_scale, double beta1, double beta2, double eps,
+                                   void* stream) {
+  if (nseg <= 0) return ACX_OK;
+  if (!p || !g || !m || !v || !n || !hyper_dev) return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi_dev: null pointer%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < nseg) {
+    AdamwDevSegs t;
+    memset(&t, 0, sizeof(t));
+    long long chunks = 0;
+    int k = 0;
+    t.seg_base = i;
+    for (; i < nseg && k < ADAMW_DEV_MAX_SEG; ++i) {
+      // hyper is indexed by the CALLER's tensor index, so empty tensors are kept as zero-chunk segments, not skipped
+      if (n[i] > 0 && (!p[i] || !g[i] || !m[i] || !v[i]))
+        return acx_fail(ctx, ACX_E_BADARG, "acx_adamw_multi_dev: null tensor pointer%s");
+      t.p[k] = (float*)p[i]; t.g[k] = (const float*)g[i]; t.m[k] = (float*)m[i]; t.v[k] = (float*)v[i];
+      t.n[k] = n[i] > 0 ? n[i] : 0;
+      t.chunk0[k] = (int)chunks;
+      chunks += (t.n[k] + 1023) / 1024;
+      ++k;
+    }
+    if (chunks == 0) continue;
+    if (chunks > 0x7fffffffLL) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_adamw_multi_dev: too many elements for one launch%s");
+    // a zero-chunk segment shares its chunk0 with the next one: the search ("last segment with chunk0 <= b") then lands on the
+    // LAST of the equal entries, which is the non-empty one -- unless the empty ones trail; cut those off
+    while (k > 0 && t.n[k - 1] == 0) --k;
+    t.chunk0[k] = (int)chunks;
+    t.nseg = k;
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    if (grad_scale == 1.0f)
+      hipLaunchKernelGGL(adamw_multi_dev_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, s, t, hyper_dev, (float)beta1,
+                         (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale);
+    else
+      hipLaunchKernelGGL(adamw_multi_dev_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, s, t, hyper_dev, (float)beta1,
+                         (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_adamw_multi_dev");
+  return ACX_OK;
+}
+
+extern "C" int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_t rows, int32_t D, float* out, float* part,
+                                size_t part_bytes, uint32_t* counters, void* stream) {
+  if (!x || !out || !part || !counters) return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused: null pointer%s");
+  if (rows <= 0 || D <= 0) return ACX_OK;
+  if (D % 4 || ld % 4 || D > 64 * 256 || (((uintptr_t)x | (uintptr_t)part) & 15))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused: D / ld multiples of 4, D <= 16384, 16-byte aligned x / part%s");
+  // slabs: enough blocks to fill the chip a few times over, at least 64 rows each
+  const int cgs = (D + 63) / 64;
+  long long nslab = (512 + cgs - 1) / cgs;
+  if (nslab > 128) nslab = 128;
+  if (nslab * 32 > rows) nslab = (rows + 31) / 32;
+  if (nslab < 1) nslab = 1;
+  const int rpb = (int)((rows + nslab - 1) / nslab);
+  nslab = (rows + rpb - 1) / rpb;
+  if ((size_t)nslab * D * sizeof(float) > part_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_colsum_fused: partial buffer too small%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(colsum_fused_kernel, dim3((unsigned)cgs, (unsigned)nslab), dim3(256), 0, (hipStream_t)stream, x, ld,
+                     (long long)rows, D, rpb, part, out, counters);
+  ACX_CHECK_LAUNCH(ctx, "acx_colsum_fused");
+  return ACX_OK;
+}
+
+extern "C" size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D) {
+  if (rows <= 0 || D <= 0) return 0;
+  const int cgs = (D + 63) / 64;
+  long long nslab = (512 + cgs - 1) / cgs;
+  if (nslab > 128) nslab = 128;
+  if (nslab * 32 > rows) nslab = (rows + 31) / 32;
+  if (nslab < 1) nslab = 1;
+  return (size_t)(nslab + 1) * D * sizeof(float);
+}
+
+extern "C" int acx_bn_pack(acx_ctx* ctx, const float* mean, const float* var_biased, int64_t rows, int32_t C1, float* out,
+                           void* stream) {
+  if (!mean || !var_biased || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_pack: null pointer%s");
+  if (C1 <= 0 || C1 > 1024) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_bn_pack: 1 <= C1 <= 1024%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_pack_kernel, dim3(1), dim3((unsigned)((C1 + 63) / 64 * 64)), 0, (hipStream_t)stream, mean, var_biased,
+                     (float)rows, C1, out);
+  ACX_CHECK_LAUNCH(ctx, "acx_bn_pack");
+  return ACX_OK;
+}
+
+extern "C" int acx_bn_running_update(acx_ctx* ctx, const float* mean, const float* var_unbiased, float* running_mean,
+                                     float* running_var, int64_t* num_batches_tracked, int32_t C1, float momentum, float one_minus,
+                                     void* stream) {
+  if (!mean || !var_unbiased || !running_mean || !running_var)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_bn_running_update: null pointer%s");
+  if (C1 <= 0 || C1 > 1024) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_bn_running_update: 1 <= C1 <= 1024%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3((unsigned)((C1 + 63) / 64 * 64)), 0, (hipStream_t)stream, mean, var_unbiased,
+                     running_mean, running_var, (long long*)num_batches_tracked, C1, momentum, one_minus);
+  ACX_CHECK_LAUNCH(ctx, "acx_bn_running_update");
+  return ACX_OK;
+}
+
+extern "C" int acx_fill_f32(acx_ctx* ctx, float* p, int64_t n, float value, void* stream) {
+  if (n <= 0) return ACX_OK;
+  if (!p) return acx_fail(ctx, ACX_E_BADARG, "acx_fill_f32: null pointer%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, (long long)n, value);
+  ACX_CHECK_LAUNCH(ctx, "acx_fill_f32");
+  return ACX_OK;
+}

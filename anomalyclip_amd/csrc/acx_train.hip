@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const float* __restri
                                                            const float* __restrict__ lw, const float* __restrict__ lb,
                                                            const float* __restrict__ w, const float* __restrict__ scores,
                                                            const float* __restrict__ dscores, float* __restrict__ dx,
-                                                           float* __restrict__ part, int64_t rows) {
+                                                           float* __restrict__ part, int64_t rows, int rpw) {
   constexpr int E = 64 * VPL;
   constexpr float invD = 1.f / E;
   constexpr int PW = 3 * E + 4;
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const float* __restri
   float a_b = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) a_lw[i] = a_lb[i] = a_w[i] = 0.f;
-  const int64_t rbase = (int64_t)blockIdx.x * 64 + wave * 16;
-  for (int rr = 0; rr < 16; ++rr) {
+  const int64_t rbase = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+  for (int rr = 0; rr < rpw; ++rr) {
     const int64_t row = rbase + rr;
     if (row >= rows) break;
     float v[VPL], c[VPL];
@@ -1476,6 +1476,21 @@ extern "C" int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int3
   return ACX_OK;
 }
 
+// Rows one wave walks in the kernels that leave per-block parameter-gradient partials (LayerNorm backward, classifier
+// backward): 16 at >= 32 k rows (64 rows per block, 512 blocks), fewer below so that a data-parallel rank's 4096 rows still
+// fill the chip (rows / 2048 rounded down to a power of two: 4096 rows -> 2 rows per wave, 512 blocks; was 64 blocks of 16
+// sequential rows per wave = 28 us for a 4 MB pass).  acx_row_parts(rows) = the number of partial rows those kernels write.
+static inline int acx_rows_per_wave(int64_t rows) {
+  int r = 16;
+  while (r > 1 && rows < (int64_t)2048 * r) r >>= 1;
+  return r;
+}
+extern "C" int64_t acx_row_parts(int64_t rows) {
+  if (rows <= 0) return 0;
+  const int rpw = acx_rows_per_wave(rows);
+  return (rows + 4 * rpw - 1) / (4 * rpw);
+}
+
 extern "C" int acx_layernorm_bwd(acx_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* part,
                                  int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, const float* add,
                                  void* stream) {
@@ -1484,7 +1499,7 @@ extern "C" int acx_layernorm_bwd(acx_ctx* ctx, const float* x, const float* w, c
   if (rows <= 0) return ACX_OK;
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
-  const int rpw = part ? 16 : 1;
+  const int rpw = part ? acx_rows_per_wave(rows) : 1;
   const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), block(256);
   DISPATCH_VPL(D, layernorm_bwd_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x, w, dy, dx, part, rows, eps, mode, dx_scale, add, rpw));
   ACX_CHECK_LAUNCH(ctx, "acx_layernorm_bwd");
@@ -1499,8 +1514,9 @@ extern "C" int acx_cls_head_bwd(acx_ctx* ctx, const float* x1, const float* x2, 
   if (rows <= 0) return ACX_OK;
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
-  const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
-  DISPATCH_VPL(E, cls_head_bwd_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, scores, dscores, dx, part, rows));
+  const int rpw = acx_rows_per_wave(rows);
+  const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), block(256);
+  DISPATCH_VPL(E, cls_head_bwd_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, scores, dscores, dx, part, rows, rpw));
   ACX_CHECK_LAUNCH(ctx, "acx_cls_head_bwd");
   return ACX_OK;
 }

@@ -83,8 +83,30 @@ def _zero_page(device) -> torch.Tensor:
         if torch.cuda.is_current_stream_capturing():
             raise L.AcxError("the conv zero page must be created by an eager call before a HIP graph is captured "
                              "(run the op once outside the capture)")
-        z = _ZERO_PAGES[key] = torch.zeros(64, dtype=torch.float32, device=device)
+        z = _ZERO_PAGES[key] = torch.zeros(256, dtype=torch.float32, device=device)     # 1 KB: conv DMA padding + acx_gemm_tn_zp
     return z
+
+
+_COLSUM_COUNTERS: dict = {}
+
+
+def _colsum_counters(device) -> torch.Tensor:
+    """256 uint32 arrival counters per device AND stream for acx_colsum_fused (zero at rest: every launch resets its own)."""
+    key = (device.type, device.index, _stream())
+    c = _COLSUM_COUNTERS.get(key)
+    if c is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.AcxError("the column-sum counters must be created by an eager call before a HIP graph is captured")
+        c = _COLSUM_COUNTERS[key] = torch.zeros(256, dtype=torch.int32, device=device)
+    return c
+
+
+def prime_capture_stream(stream: "torch.cuda.Stream", device) -> None:
+    """Per-stream state that must exist BEFORE a HIP graph is captured on `stream` (zero-initialised buffers cannot be born
+    inside a capture): the column-sum arrival counters and the conv zero page."""
+    _zero_page(device)
+    with torch.cuda.stream(stream):
+        _colsum_counters(device)
 
 
 def cast_bf16(src: torch.Tensor) -> torch.Tensor:
@@ -280,13 +302,16 @@ def colsum_(acc: torch.Tensor, x: torch.Tensor) -> None:
     axpby_(acc, colsum(x), 1.0, 1.0)
 
 
-def prompt_embed(prefix, ctxv, suffix, pos: Optional[torch.Tensor], n_ctx: int) -> torch.Tensor:
+def prompt_embed(prefix, ctxv, suffix, pos: Optional[torch.Tensor], n_ctx: int, Lout: Optional[int] = None) -> torch.Tensor:
+    """[C, Lout, W] prompts (+ positional embedding); Lout < Lc keeps the first Lout positions only."""
     Cc, _, W = prefix.shape
     Lc = 1 + n_ctx + suffix.shape[1]
-    out = torch.empty(Cc, Lc, W, dtype=torch.float32, device=prefix.device)
+    Lout = Lc if Lout is None else min(int(Lout), Lc)
+    assert prefix.is_contiguous() and suffix.is_contiguous() and ctxv.is_contiguous()
+    out = torch.empty(Cc, Lout, W, dtype=torch.float32, device=prefix.device)
     h = _h(prefix)
     L.check(L.lib().acx_prompt_embed(h, prefix.data_ptr(), ctxv.data_ptr(), suffix.data_ptr(), _ptr(pos), out.data_ptr(),
-                                     Cc, n_ctx, Lc, W, int(ctxv.dim() == 2), _stream()), h)
+                                     Cc, n_ctx, Lc, W, int(ctxv.dim() == 2), Lout, _stream()), h)
     return out
 
 
@@ -319,19 +344,24 @@ def concat_features(logits: torch.Tensor, x: torch.Tensor, ncentroid: torch.Tens
 
 # ---------------------------------------------------------------------------------------------------
 # training-side wrappers
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, b_sub=None, conv=False, gn=0, gl=0, cin=0, N2: Optional[int] = None) -> torch.Tensor:
-    """C[N1,N2] = sum_m a[m,n1] * bmap(b)[m,n2]  (weight gradient dW = dY^T X)."""
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, b_sub=None, conv=False, gn=0, gl=0, cin=0, N2: Optional[int] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C[N1,N2] = sum_m a[m,n1] * bmap(b)[m,n2]  (weight gradient dW = dY^T X).  `out`: a dense [N1, N2] f32 destination (a
+    gradient view of parallel.GradBuckets.flat: the weight gradient is produced in place)."""
     assert a.dim() == 2 and b.dim() == 2 and a.is_contiguous() and b.is_contiguous() and a.shape[0] == b.shape[0]
     M, N1 = a.shape
     if N2 is None:
         N2 = 9 * cin if conv else b.shape[1]
-    out = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
+    else:
+        assert out.shape == (N1, N2) and out.is_contiguous() and out.dtype == torch.float32
     lib = L.lib()
     nbytes = lib.acx_gemm_tn_workspace_bytes(M, N1, N2)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=a.device)
     h = _h(a)
-    L.check(lib.acx_gemm_tn(h, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N2, M, N1, N2, _ptr(b_sub),
-                            int(conv), gn, gl, cin, ws.data_ptr(), ws.numel(), _stream()), h)
+    L.check(lib.acx_gemm_tn_zp(h, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N2, M, N1, N2, _ptr(b_sub),
+                               int(conv), gn, gl, cin, ws.data_ptr(), ws.numel(), _zero_page(a.device).data_ptr(), _stream()), h)
     return out
 
 
@@ -351,7 +381,7 @@ def layernorm_bwd(x, w, dy, *, eps=1e-5, mode=L.NORM_LAYER, need_dx=True, need_p
     assert x.is_contiguous() and dy.is_contiguous()
     rows = x.shape[0]
     dx = torch.empty_like(x) if need_dx else None
-    part = torch.empty((rows + 63) // 64, 2 * D, dtype=torch.float32, device=x.device) if need_params else None
+    part = torch.empty(int(L.lib().acx_row_parts(rows)), 2 * D, dtype=torch.float32, device=x.device) if need_params else None
     h = _h(x)
     if add is not None:
         add = add.reshape(-1, D)
@@ -364,11 +394,41 @@ def layernorm_bwd(x, w, dy, *, eps=1e-5, mode=L.NORM_LAYER, need_dx=True, need_p
     return dx, None, None
 
 
+def layernorm_bwd_parts(x, w, dy, *, eps=1e-5, mode=L.NORM_LAYER, dx_scale=1.0, add=None):
+    """layernorm_bwd with the parameter-gradient reduction left to the caller: returns (dx, part [acx_row_parts(rows), 2 D]);
+    reduce_rows(part) = [dw | db].  The step graph runs that reduction on its weight-gradient side branch."""
+    D = w.numel()
+    x = x.reshape(-1, D)
+    dy = dy.reshape(-1, D)
+    assert x.is_contiguous() and dy.is_contiguous()
+    rows = x.shape[0]
+    dx = torch.empty_like(x)
+    part = torch.empty(int(L.lib().acx_row_parts(rows)), 2 * D, dtype=torch.float32, device=x.device)
+    h = _h(x)
+    if add is not None:
+        add = add.reshape(-1, D)
+        assert add.is_contiguous() and add.shape == x.shape
+    L.check(L.lib().acx_layernorm_bwd(h, x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), part.data_ptr(), rows, D, eps, mode,
+                                      dx_scale, _ptr(add), _stream()), h)
+    return dx, part
+
+
+def cls_head_bwd_parts(x1, x2, ln_w, ln_b, lin_w, scores, dscores):
+    """cls_head_bwd without the final reduction: (dx, part [acx_row_parts(rows), 3 E + 4])."""
+    rows, E = x1.shape
+    dx = torch.empty_like(x1)
+    part = torch.empty(int(L.lib().acx_row_parts(rows)), 3 * E + 4, dtype=torch.float32, device=x1.device)
+    h = _h(x1)
+    L.check(L.lib().acx_cls_head_bwd(h, x1.data_ptr(), x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), lin_w.data_ptr(),
+                                     scores.data_ptr(), dscores.data_ptr(), dx.data_ptr(), part.data_ptr(), rows, E, _stream()), h)
+    return dx, part
+
+
 def cls_head_bwd(x1, x2, ln_w, ln_b, lin_w, scores, dscores):
     rows, E = x1.shape
     dx = torch.empty_like(x1)
     PW = 3 * E + 4
-    part = torch.empty((rows + 63) // 64, PW, dtype=torch.float32, device=x1.device)
+    part = torch.empty(int(L.lib().acx_row_parts(rows)), PW, dtype=torch.float32, device=x1.device)
     h = _h(x1)
     L.check(L.lib().acx_cls_head_bwd(h, x1.data_ptr(), x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), lin_w.data_ptr(),
                                      scores.data_ptr(), dscores.data_ptr(), dx.data_ptr(), part.data_ptr(), rows, E, _stream()), h)
@@ -442,7 +502,7 @@ def bn_bwd_apply(logits, dlogits, var_biased, sums, total_rows, eps=1e-5, pad_to
     int, or a device f32 scalar tensor (SyncBN: the all-gathered row count never visits the host)."""
     rows, C1 = logits.shape
     C1p = (C1 + pad_to - 1) // pad_to * pad_to
-    draw = torch.zeros(rows, C1p, dtype=torch.float32, device=logits.device)
+    draw = zeros(rows, C1p, device=logits.device)
     h = _h(logits)
     dev_n = total_rows if torch.is_tensor(total_rows) else None
     if dev_n is not None:
@@ -451,6 +511,96 @@ def bn_bwd_apply(logits, dlogits, var_biased, sums, total_rows, eps=1e-5, pad_to
                                      draw.data_ptr(), C1p, rows, 0 if dev_n is not None else int(total_rows), C1, eps,
                                      _ptr(dev_n), _stream()), h)
     return draw
+
+
+def row_parts(rows: int) -> int:
+    return int(L.lib().acx_row_parts(int(rows)))
+
+
+def fill_(t: torch.Tensor, value: float = 0.0) -> torch.Tensor:
+    """t[:] = value through a libacx kernel (capturable; hipMemsetAsync nodes and torch fill kernels stay out of the step graphs)."""
+    assert t.is_contiguous() and t.dtype == torch.float32
+    h = _h(t)
+    L.check(L.lib().acx_fill_f32(h, t.data_ptr(), t.numel(), float(value), _stream()), h)
+    return t
+
+
+def zeros(*shape, device) -> torch.Tensor:
+    return fill_(torch.empty(*shape, dtype=torch.float32, device=device), 0.0)
+
+
+def prep_multi(segs, device=None) -> None:
+    """segs: iterable of (src, dst, rows, cols, src_ld, dst_ld, transpose) with src / dst f32 device tensors (or data pointers):
+    every strided copy / transpose in ONE launch (acx_prep_multi)."""
+    segs = list(segs)
+    if not segs:
+        return
+    arr = (L.PrepSeg * len(segs))()
+    dev_t = None
+    for i, (src, dst, rows, cols, sld, dld, tr) in enumerate(segs):
+        if torch.is_tensor(src):
+            dev_t = src
+        arr[i].src = src.data_ptr() if torch.is_tensor(src) else int(src)
+        arr[i].dst = dst.data_ptr() if torch.is_tensor(dst) else int(dst)
+        arr[i].rows, arr[i].cols, arr[i].src_ld, arr[i].dst_ld, arr[i].transpose = int(rows), int(cols), int(sld), int(dld), int(bool(tr))
+    if device is not None:
+        if device.type != "cuda":
+            raise L.AcxError("libacx operates on device tensors only (no CPU fallback)")
+        h = L.ctx(device.index if device.index is not None else torch.cuda.current_device())
+    else:
+        h = _h(dev_t)
+    L.check(L.lib().acx_prep_multi(h, len(segs), C.cast(arr, C.c_void_p), _stream()), h)
+
+
+def multi_copy_(ys, xs) -> None:
+    """y_i = x_i for lists of equally sized contiguous f32 tensors, one launch."""
+    n = len(ys)
+    if n == 0:
+        return
+    assert all(y.numel() == x.numel() and y.is_contiguous() and x.is_contiguous() for y, x in zip(ys, xs))
+    h = _h(ys[0])
+    L.check(L.lib().acx_multi_copy(h, n, (C.c_void_p * n)(*[y.data_ptr() for y in ys]), (C.c_void_p * n)(*[x.data_ptr() for x in xs]),
+                                   (C.c_int64 * n)(*[y.numel() for y in ys]), _stream()), h)
+
+
+def adamw_hyper(lrs, wds, beta1, beta2, step: int, out: torch.Tensor) -> None:
+    """fills `out` (CPU float32 [1 + 2 n], typically pinned) with the scalars of one AdamW step (acx_adamw_hyper)."""
+    n = len(lrs)
+    assert out.dtype == torch.float32 and out.numel() >= 1 + 2 * n and not out.is_cuda and out.is_contiguous()
+    rc = L.lib().acx_adamw_hyper(n, (C.c_double * n)(*[float(x) for x in lrs]), (C.c_double * n)(*[float(x) for x in wds]),
+                                 float(beta1), float(beta2), int(step), C.cast(out.data_ptr(), C.POINTER(C.c_float)))
+    if rc != 0:
+        raise L.AcxError(f"acx_adamw_hyper failed [{rc}]")
+
+
+def adamw_multi_dev_(ps, gs, ms, vs, hyper_dev: torch.Tensor, grad_scale: float, beta1, beta2, eps) -> None:
+    """acx_adamw_multi with per-tensor scalars in device memory (`hyper_dev` f32 [1 + 2 n], see adamw_hyper)."""
+    n = len(ps)
+    if n == 0:
+        return
+    assert hyper_dev.is_cuda and hyper_dev.dtype == torch.float32 and hyper_dev.numel() >= 1 + 2 * n
+    h = _h(ps[0])
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])           # noqa: E731
+    L.check(L.lib().acx_adamw_multi_dev(h, n, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * n)(*[p.numel() for p in ps]),
+                                        hyper_dev.data_ptr(), float(grad_scale), beta1, beta2, eps, _stream()), h)
+
+
+def bn_pack(mean: torch.Tensor, var_b: torch.Tensor, rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    C1 = mean.numel()
+    if out is None:
+        out = torch.empty(2 * C1 + 1, dtype=torch.float32, device=mean.device)
+    h = _h(mean)
+    L.check(L.lib().acx_bn_pack(h, mean.data_ptr(), var_b.data_ptr(), int(rows), C1, out.data_ptr(), _stream()), h)
+    return out
+
+
+def bn_running_update_(bn, mean: torch.Tensor, var_u: torch.Tensor) -> None:
+    """nn.BatchNorm1d's running_mean / running_var / num_batches_tracked update in one launch."""
+    h = _h(mean)
+    nbt = bn.num_batches_tracked
+    assert nbt.dtype == torch.int64 and nbt.is_cuda
+    L.check(L.lib().acx_bn_running_update(h, mean.data_ptr(), var_u.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                          nbt.data_ptr(), mean.numel(), float(bn.momentum), float(1.0 - bn.momentum), _stream()), h)
 
 
 def axpby_(y: torch.Tensor, x: torch.Tensor, a: float, b: float) -> None:
@@ -463,6 +613,16 @@ def colsum(x: torch.Tensor, D: Optional[int] = None) -> torch.Tensor:
     assert x.dim() == 2 and x.is_contiguous()
     rows, ld = x.shape
     D = D or ld
+    if D % 4 == 0 and ld % 4 == 0 and D <= 16384 and x.data_ptr() % 16 == 0:
+        # one launch: slab partials + last-arriver reduce in slab order (acx_colsum_fused)
+        lib = L.lib()
+        nbytes = int(lib.acx_colsum_fused_part_bytes(rows, D))
+        part = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=x.device)
+        out = torch.empty(D, dtype=torch.float32, device=x.device)
+        h = _h(x)
+        L.check(lib.acx_colsum_fused(h, x.data_ptr(), ld, rows, D, out.data_ptr(), part.data_ptr(), part.numel() * 4,
+                                     _colsum_counters(x.device).data_ptr(), _stream()), h)
+        return out
     rpb = 128
     nb = (rows + rpb - 1) // rpb
     part = torch.empty(nb, D, dtype=torch.float32, device=x.device)
@@ -558,15 +718,19 @@ def adamw_multi_(ps, gs, ms, vs, lrs, wds, beta1, beta2, eps, step) -> None:
                                     beta1, beta2, eps, step, _stream()), h)
 
 
-def ctx_grad(dx, C, n_ctx, Lc, W, shared) -> torch.Tensor:
-    out = torch.empty((n_ctx, W) if shared else (C, n_ctx, W), dtype=torch.float32, device=dx.device)
+def ctx_grad(dx, C, n_ctx, Lc, W, shared, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    shape = (n_ctx, W) if shared else (C, n_ctx, W)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dx.device)
+    else:
+        assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.float32
     h = _h(dx)
     L.check(L.lib().acx_ctx_grad(h, dx.data_ptr(), out.data_ptr(), C, n_ctx, Lc, W, int(shared), _stream()), h)
     return out
 
 
 def scatter_rows(src, idx, rows) -> torch.Tensor:
-    out = torch.zeros(rows, src.shape[1], dtype=torch.float32, device=src.device)
+    out = zeros(rows, src.shape[1], device=src.device)
     h = _h(src)
     L.check(L.lib().acx_scatter_rows(h, src.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), src.shape[1], _stream()), h)
     return out
@@ -631,26 +795,36 @@ def clf_curve(sorted_scores: torch.Tensor, sorted_labels: torch.Tensor, cls: int
     return tps, fps, thr
 
 
+CURVE_BATCH_MAX = 64      # acx_clf_curve_batched: CurveBatch.cls[64] + a 64-bit negate mask per launch sequence
+
+
 def clf_curve_batched(sorted_scores: torch.Tensor, sorted_labels: torch.Tensor, cls, negate, results: torch.Tensor,
                       curves: bool = False):
-    """B curves in one launch sequence: sorted_scores / sorted_labels [B, n] (dense rows), `cls` / `negate` length-B host
-    sequences, `results`: uint8[B * 56] device buffer (record b at byte 56 b).  With curves=True returns the (tps, fps,
-    thresholds) arrays of problem 0 (capacity n; the first n_distinct entries are valid)."""
+    """B curves in one launch sequence per 64 problems: sorted_scores / sorted_labels [B, n] (dense rows), `cls` / `negate`
+    length-B host sequences, `results`: uint8[B * 56] device buffer (record b at byte 56 b).  With curves=True returns the (tps,
+    fps, thresholds) arrays of problem 0 (capacity n; the first n_distinct entries are valid).  More than 64 problems (a label
+    set with > 63 classes) are cut into groups of 64; only the first group carries the curve arrays."""
     B, n = sorted_scores.shape
     assert sorted_labels.shape == (B, n) and sorted_scores.is_contiguous() and sorted_labels.is_contiguous()
     assert len(cls) == B and len(negate) == B and results.numel() >= B * CURVE_RESULT_BYTES
     lib = L.lib()
     dev = sorted_scores.device
-    ws = torch.empty(B * int(lib.acx_clf_curve_workspace_bytes(n)), dtype=torch.uint8, device=dev)
     tps = fps = thr = None
     if curves:
         tps = torch.empty(n, dtype=torch.int32, device=dev)
         fps = torch.empty(n, dtype=torch.int32, device=dev)
         thr = torch.empty(n, dtype=torch.float32, device=dev)
     h = _h(sorted_scores)
-    ca, na = (C.c_int32 * B)(*[int(c) for c in cls]), (C.c_int32 * B)(*[int(bool(x)) for x in negate])
-    L.check(lib.acx_clf_curve_batched(h, sorted_scores.data_ptr(), n, sorted_labels.data_ptr(), n, n, B, ca, na, results.data_ptr(),
-                                      _ptr(tps), _ptr(fps), _ptr(thr), ws.data_ptr(), ws.numel(), _stream()), h)
+    for lo in range(0, B, CURVE_BATCH_MAX):
+        hi = min(B, lo + CURVE_BATCH_MAX)
+        k = hi - lo
+        ws = torch.empty(k * int(lib.acx_clf_curve_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        ca, na = (C.c_int32 * k)(*[int(c) for c in cls[lo:hi]]), (C.c_int32 * k)(*[int(bool(x)) for x in negate[lo:hi]])
+        first = lo == 0
+        L.check(lib.acx_clf_curve_batched(h, sorted_scores[lo:hi].data_ptr(), n, sorted_labels[lo:hi].data_ptr(), n, n, k, ca, na,
+                                          results[lo * CURVE_RESULT_BYTES:].data_ptr(), _ptr(tps) if first else None,
+                                          _ptr(fps) if first else None, _ptr(thr) if first else None, ws.data_ptr(), ws.numel(),
+                                          _stream()), h)
     return tps, fps, thr
 
 

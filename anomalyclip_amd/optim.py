@@ -7,6 +7,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .parallel import _is_dense as parallel_is_dense, same_layout
 
 
 class AcxAdamW(torch.optim.Optimizer):
@@ -31,12 +32,16 @@ class AcxAdamW(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    # moments in the PARAMETER's memory layout: the kernel walks the raw memory of (p, g, m, v) elementwise
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                if not p.is_contiguous():
-                    raise ops.L.AcxError("AcxAdamW updates parameters in place through raw pointers: contiguous parameters only")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not (p.is_contiguous() or parallel_is_dense(p)) or not same_layout(st["exp_avg"], p):
+                    raise ops.L.AcxError("AcxAdamW updates parameters in place through raw pointers: dense parameters only "
+                                         "(row-major, or a permuted-contiguous layout such as channels-last)")
+                g = p.grad
+                if not same_layout(g, p):             # same physical element order as the parameter
+                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                 key = (p.device, float(b1), float(b2), float(group["eps"]), int(st["step"]))
                 b = batches.setdefault(key, ([], [], [], [], [], []))
                 for lst, val in zip(b, (p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), float(group["weight_decay"]))):

@@ -78,6 +78,18 @@ def assemble_rows(local: torch.Tensor, lo: int, n: int) -> torch.Tensor:
     return all_reduce_sum_(full)
 
 
+def assemble_rows_into(full: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+    """assemble_rows on a STATIC buffer (the step graphs): rows [lo, hi) of `full` hold this rank's block, every other row is
+    zero; one in-place all-reduce leaves the complete tensor on every rank."""
+    return all_reduce_sum_(full)
+
+
+def all_gather_into(out: torch.Tensor, local: torch.Tensor) -> torch.Tensor:
+    """out[r] = rank r's `local` (out: [world, n] static buffer); the list form works on RCCL and on gloo alike"""
+    dist.all_gather(list(out.unbind(0)), local)
+    return out
+
+
 def combine_bn_stats(means: torch.Tensor, m2s: torch.Tensor, counts: torch.Tensor):
     """Chan et al. parallel variance: means/m2s [R, C], counts [R] -> (mean, var_biased, var_unbiased, n)."""
     n = counts.sum()
@@ -123,9 +135,16 @@ class GradBuckets:
     params: trainable parameters in FORWARD order; buckets are filled in reverse order (the order autograd
     produces gradients) and launched as soon as complete.  Every param.grad is a view into the flat buffer."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 16 << 20):
+    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 16 << 20, cuts: Sequence[torch.nn.Parameter] = ()):
+        """cuts: parameters at which a bucket must END (walking the list from the back, i.e. in the order gradients arrive):
+        [ctx, text_projection] get a bucket of their own, so the step graph can exchange the text gradients on the text
+        stream as soon as the text backward is done, independently of the temporal model's buckets."""
         self.params = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
+        cut_ids = {id(p) for p in cuts}
+        # every view starts on a 256-byte boundary: kernels that PRODUCE a gradient in its view (acx_gemm_tn's `C`, the step
+        # graph) need 16-byte alignment, and full-line starts cost 63 pad floats per tensor at most
+        ALIGN = 64
+        total = sum((p.numel() + ALIGN - 1) // ALIGN * ALIGN for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.buckets: List[List[int]] = []          # param indices per bucket
@@ -138,10 +157,11 @@ class GradBuckets:
         for i in reversed(range(len(self.params))):
             p = self.params[i]
             self._views[i] = (off, off + p.numel())
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            p.grad = self.view(i)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
             cur.append(i)
-            if (off - cur_start) * 4 >= bucket_bytes:
+            nxt = self.params[i - 1] if i > 0 else None
+            if (off - cur_start) * 4 >= bucket_bytes or (nxt is not None and id(nxt) in cut_ids):
                 self.buckets.append(cur)
                 self.ranges.append((cur_start, off))
                 cur, cur_start = [], off
@@ -152,11 +172,28 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._handles = []
         self._fired = set()
+        self._armed = False          # between zero() and finish(): the only window in which hooks / accumulate() act
         self._hook_fns = [self._make_hook(i) for i in range(len(self.params))]
         self._hooks = [p.register_post_accumulate_grad_hook(fn) for p, fn in zip(self.params, self._hook_fns)]
 
+    def view(self, i: int) -> torch.Tensor:
+        """Parameter i's slice of the flat buffer with the PARAMETER's strides: a dense parameter that is not row-major (the
+        channels-last conv weights of the temporal model) gets a gradient with the same physical element order, so AdamW's
+        elementwise pass over the raw memory of (p, g, m, v) lines up and a kernel can produce the gradient in place."""
+        p = self.params[i]
+        lo, hi = self._views[i]
+        if p.is_contiguous():
+            return self.flat[lo:hi].view_as(p)
+        if not _is_dense(p):
+            raise ValueError("GradBuckets: parameters must be dense (contiguous in some dimension order)")
+        return torch.as_strided(self.flat, p.shape, p.stride(), lo)
+
     def _make_hook(self, i):
         def hook(p):
+            if not self._armed:
+                # a backward outside zero() ... finish() (Lightning's automatic optimisation on the same module, a test calling
+                # training_step + backward): plain autograd semantics, no bucket bookkeeping, no collective
+                return
             if i in self._fired:
                 # second report of the same parameter in one step: accumulate() reported it and autograd calls the
                 # post-accumulate hook of its AccumulateGrad node anyway (with an undefined gradient: nothing was added)
@@ -164,8 +201,9 @@ class GradBuckets:
             lo, hi = self._views[i]
             if p.grad is not None and p.grad.data_ptr() != self.flat[lo:hi].data_ptr():
                 # autograd replaced the view (first accumulation into a None grad): copy back and re-point
-                self.flat[lo:hi].copy_(p.grad.reshape(-1))
-                p.grad = self.flat[lo:hi].view_as(p)
+                v = self.view(i)
+                v.copy_(p.grad)
+                p.grad = v
             self._fired.add(i)
             b = self._bucket_of[i]
             self._pending[b] -= 1
@@ -185,18 +223,22 @@ class GradBuckets:
     def accumulate(self, params, grads) -> bool:
         """params[k].grad += grads[k] for every pair with a gradient, bucket bookkeeping included.  Returns False (and does
         nothing) unless every such parameter is one of this buffer's and still points at its view."""
+        if not self._armed:
+            return False
         pairs = [(p, g) for p, g in zip(params, grads) if g is not None]
         idx = [self.index_of(p) for p, _ in pairs]
         if any(i is None for i in idx):
             return False
-        views = []
+        views, srcs = [], []
         for (p, g), i in zip(pairs, idx):
             lo, hi = self._views[i]
-            if p.grad is None or p.grad.data_ptr() != self.flat[lo:hi].data_ptr() or not g.is_contiguous():
+            # same PHYSICAL element order on both sides: the gradient must carry the parameter's (dense) strides
+            if p.grad is None or p.grad.data_ptr() != self.flat[lo:hi].data_ptr() or not same_layout(g, p.grad):
                 return False
             views.append(self.flat[lo:hi])
+            srcs.append(torch.as_strided(g, (g.numel(),), (1,), g.storage_offset()))
         from . import ops
-        ops.multi_axpy_(views, [g.reshape(-1) for _, g in pairs], 1.0)
+        ops.multi_axpy_(views, srcs, 1.0)
         hooks = self._hook_fns
         for (p, _), i in zip(pairs, idx):
             hooks[i](p)
@@ -204,21 +246,54 @@ class GradBuckets:
 
     def zero(self):
         self.flat.zero_()
+        self.arm()
+
+    def arm(self):
+        """start of a step WITHOUT zeroing the flat buffer (the whole-step graph overwrites every gradient it produces)"""
         self._pending = [len(b) for b in self.buckets]
         self._handles = []
         self._fired = set()
+        self._armed = True
         for i, p in enumerate(self.params):          # finish() detaches the grads of unused parameters
             if p.grad is None:
-                lo, hi = self._views[i]
-                p.grad = self.flat[lo:hi].view_as(p)
+                p.grad = self.view(i)
 
-    def finish(self):
+    def reduce_now(self, params) -> None:
+        """the gradients of `params` -- together exactly one or more WHOLE buckets -- are complete: all-reduce those buckets on
+        the CURRENT stream (blocking collective, stream-ordered) and settle their bookkeeping, so that neither the hooks nor
+        finish() touch them again"""
+        bs = set()
+        for p in params:
+            i = self.index_of(p)
+            if i is None:
+                raise ValueError("reduce_now: not a parameter of this buffer")
+            self._fired.add(i)
+            bs.add(self._bucket_of[i])
+        for b in sorted(bs):
+            if not set(self.buckets[b]) <= {self.index_of(p) for p in params}:
+                raise ValueError("reduce_now: the parameters do not cover their bucket")
+            self._pending[b] = 0
+            if is_distributed():
+                lo, hi = self.ranges[b]
+                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+
+    def mark_ready(self, params):
+        """the step graph produced these parameters' gradients in their views: bucket bookkeeping (and, under data
+        parallelism, the all-reduce of every bucket that became complete)"""
+        for p in params:
+            i = self.index_of(p)
+            if i is not None:
+                self._hook_fns[i](p)
+
+    def finish(self, average: bool = True):
         """Wait for the in-flight all-reduces, reduce buckets whose gradients never arrived (unused
-        parameters, e.g. selector_model.logit_scale), and average."""
+        parameters, e.g. selector_model.logit_scale), and average (average=False leaves the SUM: the step graph's AdamW
+        multiplies by 1 / world as it reads the gradients)."""
         # A parameter that received no gradient keeps grad = None, as under the reference's DDP
         # (find_unused_parameters: a globally unused parameter's .grad is left untouched), so AdamW skips it --
         # no weight decay on the never-used selector_model.logit_scale (selector_model.py:22).  The autograd graph
         # is the same on every rank, hence so is the set of unused parameters.
+        self._armed = False
         for i, p in enumerate(self.params):
             if i not in self._fired:
                 p.grad = None
@@ -230,8 +305,20 @@ class GradBuckets:
                 self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         for h in self._handles:
             h.wait()
-        self.flat.div_(world_size())
+        if average:
+            self.flat.div_(world_size())
         self._handles = []
+
+
+def _is_dense(t: torch.Tensor) -> bool:
+    """non-overlapping and dense: some permutation of the dimensions is contiguous"""
+    dims = sorted(range(t.dim()), key=lambda d: (t.stride(d), t.shape[d]), reverse=True)
+    return t.permute(*dims).is_contiguous() if t.dim() else True
+
+
+def same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """same shape and the same physical element order (strides compared on the dimensions that have more than one element)"""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
 
 
 def rank_zero_only(fn):

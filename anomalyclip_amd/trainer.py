@@ -71,23 +71,48 @@ class Trainer:
         the same dataset -- shuffling iff the original sampler shuffled -- re-seeded per epoch with set_epoch.  Without it
         every rank would iterate the full set: identical batches (redundant compute) or world-times the steps per epoch,
         and the per-epoch LR schedule would no longer line up with the reference's."""
-        from torch.utils.data import DataLoader, DistributedSampler, RandomSampler
+        from torch.utils.data import BatchSampler, DataLoader, DistributedSampler, RandomSampler, SequentialSampler
         if not parallel.is_distributed():
             return loader
         if not isinstance(loader, DataLoader):
+            if getattr(loader, "already_sharded", False):       # opt-in: an iterable that yields THIS rank's shard
+                return loader
             raise TypeError(f"data-parallel training needs torch DataLoaders to shard (got {type(loader).__name__}); "
-                            f"alternatively hand every rank its own shard and run with world size 1 semantics")
+                            f"an iterable that already yields this rank's shard may set `already_sharded = True`")
         if isinstance(loader.sampler, DistributedSampler):
             loader.sampler.set_epoch(epoch)
             return loader
+        if loader.batch_size is None or not isinstance(loader.batch_sampler, BatchSampler) or not isinstance(
+                loader.sampler, (RandomSampler, SequentialSampler)):
+            # what Lightning's replace_sampler refuses as well: a custom batch_sampler / sampler cannot be re-created around a
+            # DistributedSampler without knowing its constructor
+            raise TypeError("cannot shard a DataLoader built with a custom sampler / batch_sampler: construct it with a "
+                            "DistributedSampler (it is then only re-seeded per epoch)")
+        seed = os.environ.get("PL_GLOBAL_SEED")
+        if seed is None:
+            # no global seed: every rank must still agree on the permutation -- rank 0's torch seed, shared once per loader
+            seed = getattr(loader, "_acx_shard_seed", None)
+            if seed is None:
+                import torch.distributed as dist
+                t = torch.tensor([torch.initial_seed() % (1 << 31)], dtype=torch.int64)
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, 0)
+                seed = int(t.item())
+                try:
+                    loader._acx_shard_seed = seed
+                except Exception:  # noqa: BLE001
+                    pass
         sampler = DistributedSampler(loader.dataset, num_replicas=parallel.world_size(), rank=parallel.rank(),
-                                     shuffle=isinstance(loader.sampler, RandomSampler),
-                                     seed=int(os.environ.get("PL_GLOBAL_SEED", "0")))
+                                     shuffle=isinstance(loader.sampler, RandomSampler), seed=int(seed))
         sampler.set_epoch(epoch)
-        return DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers,
-                          collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=loader.drop_last,
-                          timeout=loader.timeout, worker_init_fn=loader.worker_init_fn,
-                          persistent_workers=loader.persistent_workers if loader.num_workers > 0 else False)
+        kw = dict(batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
+                  pin_memory=loader.pin_memory, drop_last=loader.drop_last, timeout=loader.timeout,
+                  worker_init_fn=loader.worker_init_fn, generator=loader.generator,
+                  multiprocessing_context=loader.multiprocessing_context)
+        if loader.num_workers > 0:
+            kw.update(persistent_workers=loader.persistent_workers, prefetch_factor=loader.prefetch_factor)
+        return DataLoader(loader.dataset, **kw)
 
     def _train_batches(self, loaders, epoch: int):
         """Lightning 1.8's default for a LIST of train loaders, multiple_trainloader_mode='max_size_cycle': the epoch has

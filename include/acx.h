@@ -236,10 +236,11 @@ int acx_class_probs(acx_ctx* ctx, const float* sim, const float* scores, float* 
 
 /* acx_prompt_embed: out[c,t,:] = cat(token_prefix, ctx, token_suffix)[c,t,:] + positional_embedding[t,:]
  * (coop.py:74-90 class_token_position "end" + text_encoder.py:15).  ctx is [C,n_ctx,W] or, when
- * shared_ctx != 0, [n_ctx,W] broadcast over classes (coop.py:76-77).  pos may be NULL (no add). */
+ * shared_ctx != 0, [n_ctx,W] broadcast over classes (coop.py:76-77).  pos may be NULL (no add).  Lout (0 = Lc): only the
+ * first Lout <= Lc positions of every class are written, out is [C, Lout, W] (the causal tower runs up to the last EOT). */
 int acx_prompt_embed(acx_ctx* ctx, const float* prefix, const float* ctxv, const float* suffix,
                      const float* pos, float* out, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
-                     int32_t shared_ctx, void* stream);
+                     int32_t shared_ctx, int32_t Lout, void* stream);
 /* acx_gather_rows: out[i,:] = x[idx[i],:]  (EOT-token gather, text_encoder.py:23). idx int64 on device. */
 int acx_gather_rows(acx_ctx* ctx, const float* x, const int64_t* idx, float* out, int64_t n,
                     int32_t W, void* stream);
@@ -281,13 +282,18 @@ size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2);
 int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                 int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
                 int32_t cin, void* workspace, size_t workspace_bytes, void* stream);
+/* the same with a caller-owned zero page (>= 1024 bytes of zeros, 16-byte aligned, never written; may be NULL): the
+ * 256 x 256 kernel then pads from it instead of clearing the tail of `workspace` with an extra launch per call */
+int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream);
 int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int32_t nparts, int32_t width, void* stream);
 /* LayerNorm / ChanLayerNorm backward.  dx (may be NULL) = [add +] dx_scale * dL/dx (add [rows, D] may be NULL: the
  * residual branch of a pre-norm block, clip/model.py:214-216, folded into the same pass); part (may be NULL)
- * receives ceil(rows/64) rows of [dw(D) | db(D)] partials. */
+ * receives acx_row_parts(rows) rows of [dw(D) | db(D)] partials. */
 int acx_layernorm_bwd(acx_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* part,
                       int64_t rows, int32_t D, float eps, int32_t mode, float dx_scale, const float* add, void* stream);
-/* backward of acx_cls_head (seg == 0): dx = dL/dx1 = dL/dx2; part: ceil(rows/64) rows of
+/* backward of acx_cls_head (seg == 0): dx = dL/dx1 = dL/dx2; part: acx_row_parts(rows) rows of
  * [d ln_w (E) | d ln_b (E) | d lin_w (E) | d lin_b (1) | pad 3]. */
 int acx_cls_head_bwd(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w, const float* ln_b,
                      const float* lin_w, const float* scores, const float* dscores, float* dx, float* part,
@@ -357,6 +363,50 @@ int acx_multi_axpy(acx_ctx* ctx, int32_t nseg, void* const* y, const void* const
 int acx_adamw_multi(acx_ctx* ctx, int32_t nseg, void* const* p, const void* const* g, void* const* m, void* const* v,
                     const int64_t* n, const double* lr, const double* weight_decay, double beta1, double beta2, double eps,
                     int32_t step, void* stream);
+/* ---- whole-step training graph support (anomalyclip_amd/components/step_graph.py; reference: what Lightning's automatic
+ * optimisation + DDP + torch.optim.AdamW do around training_step, anomaly_clip_module.py:203-293,693-746,
+ * configs/trainer/ddp.yaml:1-9).  Nothing here allocates; every call is capturable in a HIP graph. */
+/* number of per-block partial rows acx_layernorm_bwd (part != NULL) and acx_cls_head_bwd write for `rows` rows */
+int64_t acx_row_parts(int64_t rows);
+/* strided 2-D copies / transposes of f32 blocks, ALL in one launch: dst[r * dst_ld + c] = src[r * src_ld + c], or with
+ * `transpose` dst[c * dst_ld + r] = src[r * src_ld + c]; rows / cols are the SOURCE block's extent, leading dimensions
+ * in elements.  Builds every derived weight layout of the temporal model (temporal_model.py:18-40 parameters -> kernel
+ * operands: q|kv concatenation, W^T for the dX GEMMs, flipped-tap conv weights, padded projection, positional tables). */
+typedef struct acx_prep_seg {
+  const void* src;
+  void* dst;
+  int32_t rows, cols, src_ld, dst_ld;
+  int32_t transpose, reserved;
+} acx_prep_seg;
+int acx_prep_multi(acx_ctx* ctx, int32_t nseg, const acx_prep_seg* segs, void* stream);
+/* y_i = x_i for nseg contiguous f32 tensors, one launch */
+int acx_multi_copy(acx_ctx* ctx, int32_t nseg, void* const* y, const void* const* x, const int64_t* n, void* stream);
+/* HOST helper: the f32 scalars of one AdamW step, out[0] = sqrt(1 - beta2^step), out[1 + 2 i] = 1 - lr_i wd_i,
+ * out[2 + 2 i] = lr_i / (1 - beta1^step) -- formed in f64 and rounded once, exactly as acx_adamw_multi forms them. */
+int acx_adamw_hyper(int32_t nseg, const double* lr, const double* weight_decay, double beta1, double beta2, int32_t step,
+                    float* out);
+/* acx_adamw_multi with those scalars read from DEVICE memory (`hyper_dev`: 1 + 2 nseg floats, refreshed by the caller
+ * before each step), so a captured launch follows the LR schedule and the step count; every gradient is multiplied by
+ * `grad_scale` as it is read (1 / world size after a summing all-reduce, 1.0f otherwise).  torch.optim.AdamW semantics
+ * (anomaly_clip_module.py:693-746; wd 0.2 in the reference model configs). */
+int acx_adamw_multi_dev(acx_ctx* ctx, int32_t nseg, void* const* p, const void* const* g, void* const* m, void* const* v,
+                        const int64_t* n, const float* hyper_dev, float grad_scale, double beta1, double beta2, double eps,
+                        void* stream);
+/* SyncBatchNorm payload of a rank (configs/trainer/ddp.yaml:9): out[2 C1 + 1] = [mean | biased var * rows | rows] */
+int acx_bn_pack(acx_ctx* ctx, const float* mean, const float* var_biased, int64_t rows, int32_t C1, float* out,
+                void* stream);
+/* nn.BatchNorm1d running statistics (selector_model.py:30,65): r = one_minus * r + momentum * batch; counter += 1 */
+int acx_bn_running_update(acx_ctx* ctx, const float* mean, const float* var_unbiased, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, int32_t C1, float momentum, float one_minus,
+                          void* stream);
+int acx_fill_f32(acx_ctx* ctx, float* p, int64_t n, float value, void* stream);
+/* out[D] = column sums of x[rows, ld] in ONE launch, fixed summation order (bias gradients: the reference's autograd sums
+ * dY over rows for every nn.Linear / nn.Conv2d bias).  part: scratch of acx_colsum_fused_part_bytes(rows, D) bytes;
+ * counters: >= ceil(D / 64) uint32, ZERO before the first call and left zero by every call (caller-owned, reusable). */
+size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D);
+int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_t rows, int32_t D, float* out, float* part,
+                     size_t part_bytes, uint32_t* counters, void* stream);
+
 int acx_ctx_grad(acx_ctx* ctx, const float* dx, float* dctx, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
                  int32_t shared_ctx, void* stream);
 int acx_scatter_rows(acx_ctx* ctx, const float* src, const int64_t* idx, float* out, int64_t n, int32_t W,

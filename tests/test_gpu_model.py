@@ -42,7 +42,7 @@ def test_vit_tiny_golden(golden):
     g = golden("vit_tiny")
     vit, _ = make_vit(IW.TINY, int(g["seed"]))
     out = vit(torch.from_numpy(g["frames"]).to(DEV))
-    assert relerr(out, g["out"]) < TOL
+    assert relerr(out, g["out"]) < TOL and elem_ok(out, g["out"])
 
 
 def test_vit_b16_golden(golden):
@@ -50,7 +50,7 @@ def test_vit_b16_golden(golden):
     vit, sd = make_vit(IW.VIT_B16, int(g["seed"]))
     frames = R.vit_frames(int(g["seed"]), 2, 224)
     out = vit(frames.to(DEV))
-    assert relerr(out, g["out"]) < TOL
+    assert relerr(out, g["out"]) < TOL and elem_ok(out, g["out"])      # every one of the 2 x 512 features, element-wise
     # more frames than one chunk / ragged chunking gives the same rows.  Rows inside ONE launch are bit-identical
     # wherever they sit; across chunk sizes the library may pick a different K split for the GEMMs (64x64 tiles,
     # split-K for skinny problems and for the tail round of tiles), i.e. a different summation order: round-off only.
@@ -134,11 +134,11 @@ def test_text_golden(golden, prompts_table, tag, geom_name, key):
     net = net.to(DEV)
     with torch.no_grad():
         tf = net.get_text_features()
-    assert relerr(tf, g["out"]) < TOL
+    assert relerr(tf, g["out"]) < TOL and elem_ok(tf, g["out"])
     # reference-shaped API: PromptLearner() then TextEncoder(prompts, tokenized_prompts)
     with torch.no_grad():
         tf2 = net.text_encoder(net.prompt_learner(), net.tokenized_prompts)
-    assert relerr(tf2, g["out"]) < TOL
+    assert relerr(tf2, g["out"]) < TOL and elem_ok(tf2, g["out"])
 
 
 def test_temporal_golden(golden):
@@ -155,10 +155,11 @@ def test_temporal_golden(golden):
             f = torch.from_numpy(g[f"feats_S{S}"])
             fp = torch.cat([f, f.new_zeros(f.shape[0], Kp - in_size)], 1).to(DEV)
             out = tm(fp, S, True)
-            assert relerr(out, g[f"scores_test_S{S}"]) < TOL
+            assert relerr(out, g[f"scores_test_S{S}"]) < TOL and elem_ok(out, g[f"scores_test_S{S}"])
         f = torch.from_numpy(g["feats_train"])
         fp = torch.cat([f, f.new_zeros(f.shape[0], Kp - in_size)], 1).to(DEV)
-        assert relerr(tm(fp, 1, False), g["scores_train"]) < TOL
+        out = tm(fp, 1, False)
+        assert relerr(out, g["scores_train"]) < TOL and elem_ok(out, g["scores_train"])
 
 
 def test_e2e_tiny_golden_test_mode(golden, prompts_table):
@@ -301,7 +302,7 @@ def test_feature_stream_matches_reference_loop(tmp_path, prompts_table):
         with torch.no_grad():
             sim, sc = net(feats, None, nc, S, True)
             rs, rc = O.anomaly_clip_forward_test(sd, hc, torch.from_numpy(ref).view(1, 1, -1, 128), nc, eot, 2, S)
-        assert relerr(sc[:T_], rc[:T_]) < TOL
+        assert relerr(sc[:T_], rc[:T_]) < TOL and elem_ok(sc[:T_], rc[:T_])
 
 
 @pytest.mark.parametrize("ncrops,stride,T_", [(5, 1, 700), (5, 1, 90), (1, 2, 700), (5, 2, 1500)])
@@ -398,6 +399,7 @@ def test_lightning_checkpoint_load_then_score(tmp_path, prompts_table):
     sd_half = {k[4:]: (v.float() if v.is_floating_point() else v) for k, v in lsd.items() if k.startswith("net.")}
     rsim, rsc = O.anomaly_clip_forward_test(sd_half, hc, feats, ncl, eot, IW.TINY.transformer_heads, 2)
     assert relerr(sim, rsim) < TOL and relerr(sc, rsc) < TOL
+    assert elem_ok(sim, rsim) and elem_ok(sc, rsc)
 
 
 @pytest.mark.parametrize("S", [4, 8, 16])

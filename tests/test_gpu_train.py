@@ -199,6 +199,88 @@ def test_misc_train_kernels():
     assert relerr(gw, ps[4].grad.view(-1)) < 1e-5 and relerr(gb, ps[5].grad) < 1e-5
 
 
+@pytest.mark.parametrize("rows,D,ld", [(4096, 1024, 1024), (32768, 256, 256), (1000, 64, 64), (7, 132, 136), (70000, 2304, 2304), (512, 16384, 16384)])
+def test_colsum_fused_one_launch(rows, D, ld):
+    """acx_colsum_fused (slab partials + last-arriver reduce in slab order, one launch): every column within f32 round-off of
+    the fp64 sum, bit-identical from call to call (fixed order), the arrival counters back at zero."""
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, ld, generator=g) * 0.5 + 0.1).to(DEV)
+    a = ops.colsum(x, D)
+    b = ops.colsum(x, D)
+    ref = x[:, :D].double().sum(0)
+    bound = 2e-6 * x[:, :D].double().abs().sum(0)
+    assert a.shape == (D,) and bool(((a.double() - ref).abs() <= bound + 1e-12).all())
+    assert torch.equal(a, b)
+    assert int(ops._colsum_counters(x.device).abs().sum()) == 0
+
+
+def test_step_support_kernels():
+    """The whole-step graph's support launches against torch: acx_prep_multi (strided copies / transposes, incl. the
+    flipped-tap conv dX layout vs the single-purpose acx_conv_weight_dx), acx_multi_copy, acx_fill_f32, acx_bn_pack,
+    acx_bn_running_update, and acx_adamw_multi_dev == acx_adamw_multi bit for bit (device-side scalars, gradient scale)."""
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(37, 50, generator=g).to(DEV)
+    b = torch.randn(64, 96, generator=g).to(DEV)
+    t1 = torch.zeros(50, 40, device=DEV)
+    t2 = torch.zeros(64, 128, device=DEV)
+    t3 = torch.zeros(96, 64, device=DEV)
+    ops.prep_multi([(a, t1, 37, 50, 50, 40, 1), (b, t2[:, 16:], 64, 96, 96, 128, 0), (b, t3, 64, 96, 96, 64, 1)])
+    assert torch.equal(t1[:, :37], a.t()) and float(t1[:, 37:].abs().sum()) == 0
+    assert torch.equal(t2[:, 16:112], b) and float(t2[:, :16].abs().sum()) == 0 and float(t2[:, 112:].abs().sum()) == 0
+    assert torch.equal(t3, b.t())
+    # conv dX layout from a channels-last master == acx_conv_weight_dx of the logical [Cout, Cin, 3, 3] weight
+    Cout, Cin = 64, 32
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    kw = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    assert kw.data_ptr() == w.data_ptr()
+    o = torch.empty(Cin, 9 * Cout, device=DEV)
+    ops.prep_multi([(kw.data_ptr() + 4 * t * Cin, o.data_ptr() + 4 * (8 - t) * Cout, Cout, Cin, 9 * Cin, 9 * Cout, 1) for t in range(9)],
+                   device=w.device)
+    assert torch.equal(o, ops.conv_weight_dx(w.contiguous()))
+    # multi copy / fill
+    xs = [torch.randn(n, generator=g).to(DEV) for n in (1, 1023, 1024, 5000)]
+    ys = [torch.empty_like(t) for t in xs]
+    ops.multi_copy_(ys, xs)
+    assert all(torch.equal(y, t) for y, t in zip(ys, xs))
+    f = torch.empty(100003, device=DEV)
+    assert bool((ops.fill_(f, 2.5) == 2.5).all())
+    # BatchNorm bookkeeping
+    from types import SimpleNamespace
+    mean, vb, vu = (torch.randn(13, generator=g).to(DEV) for _ in range(3))
+    pk = ops.bn_pack(mean, vb, 4096)
+    assert torch.equal(pk, torch.cat([mean, vb * 4096.0, torch.tensor([4096.0], device=DEV)]))
+    bn = SimpleNamespace(running_mean=torch.randn(13, generator=g).to(DEV), running_var=torch.rand(13, generator=g).to(DEV),
+                         num_batches_tracked=torch.tensor(5, device=DEV), momentum=0.1)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    ops.axpby_(rm, mean, 0.1, 0.9)
+    ops.axpby_(rv, vu, 0.1, 0.9)
+    ops.bn_running_update_(bn, mean, vu)
+    assert torch.equal(bn.running_mean, rm) and torch.equal(bn.running_var, rv) and int(bn.num_batches_tracked) == 6
+    # AdamW with device-side scalars == the host-scalar entry point, bit for bit; grad_scale leaves the scaled gradient behind
+    sizes = [1, 77, 1024, 50001]
+    lrs, wds = [1e-3, 2e-3, 1e-3, 5e-4], [0.2, 0.2, 0.0, 0.2]
+    P0 = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    G0 = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    pa, pb = [t.clone() for t in P0], [t.clone() for t in P0]
+    ma, mb, va, vb_ = ([torch.zeros(n, device=DEV) for n in sizes] for _ in range(4))
+    hyper_host = torch.empty(1 + 2 * len(sizes))
+    hyper = torch.empty(1 + 2 * len(sizes), device=DEV)
+    for step in (1, 2, 3):
+        ops.adamw_multi_(pa, G0, ma, va, lrs, wds, 0.9, 0.999, 1e-8, step)
+        ops.adamw_hyper(lrs, wds, 0.9, 0.999, step, hyper_host)
+        hyper.copy_(hyper_host)
+        ops.adamw_multi_dev_(pb, G0, mb, vb_, hyper, 1.0, 0.9, 0.999, 1e-8)
+        assert all(torch.equal(x_, y_) for x_, y_ in zip(pa, pb)) and all(torch.equal(x_, y_) for x_, y_ in zip(va, vb_))
+    G2 = [t * 2.0 for t in G0]
+    pc, mc, vc = [t.clone() for t in P0], [torch.zeros(n, device=DEV) for n in sizes], [torch.zeros(n, device=DEV) for n in sizes]
+    pd, md, vd = [t.clone() for t in P0], [torch.zeros(n, device=DEV) for n in sizes], [torch.zeros(n, device=DEV) for n in sizes]
+    ops.adamw_hyper(lrs, wds, 0.9, 0.999, 1, hyper_host)
+    hyper.copy_(hyper_host)
+    ops.adamw_multi_dev_(pc, G0, mc, vc, hyper, 1.0, 0.9, 0.999, 1e-8)
+    ops.adamw_multi_dev_(pd, G2, md, vd, hyper, 0.5, 0.9, 0.999, 1e-8)          # (2 g) * 0.5 == g exactly
+    assert all(torch.equal(x_, y_) for x_, y_ in zip(pc, pd)) and all(torch.equal(x_, y_) for x_, y_ in zip(G2, G0))
+
+
 def test_selector_train_golden(golden):
     """a3/a4 against the REFERENCE's SelectorModel: logits, bit-exact MIL indices, gathered logits, running stats."""
     from anomalyclip_amd.components.selector_model import SelectorModel
@@ -254,6 +336,10 @@ def test_mil_loss_golden(golden):
     assert relerr(torch.stack(outs), g["losses"]) < 1e-5
     assert relerr(s1.grad, 2 * g["g_sim"]) < 1e-4 and relerr(s2.grad, 2 * g["g_sim_topk"]) < 1e-5
     assert relerr(s3.grad, 2 * g["g_scores"]) < 1e-4
+    # north_star's tolerance, element-wise: every loss term and every gradient element within 1e-3 |ref| + 1e-5 max|ref|
+    assert R.elem_excess(torch.stack(outs), g["losses"], afrac=1e-6) <= 1
+    assert R.elem_excess(s1.grad, 2 * g["g_sim"]) <= 1 and R.elem_excess(s2.grad, 2 * g["g_sim_topk"]) <= 1
+    assert R.elem_excess(s3.grad, 2 * g["g_scores"]) <= 1
 
 
 def test_adamw_matches_torch():
@@ -470,6 +556,9 @@ def test_full_config_train_step_vs_oracle(prompts_table, cfg, B):
     sd = sd64
     assert torch.equal(ia.cpu(), o[3]) and torch.equal(in_.cpu(), o[4]) and torch.equal(ba.cpu(), o[5])
     assert relerr(torch.stack(losses), torch.stack(ol)) < 1e-4
+    # element-wise (north_star: 1e-3 relative): each of the eight loss terms on its own, and every logit / score
+    assert R.elem_excess(torch.stack(losses), torch.stack(ol), afrac=1e-6) <= 1
+    assert R.elem_excess(lg, o[0]) <= 1 and R.elem_excess(lt, o[1]) <= 1 and R.elem_excess(sc, o[2]) <= 1
     params = dict(net.named_parameters())
     errs = sorted(((relerr(params[n].grad, sd[n].grad), n) for n in names), reverse=True)
     print("\n".join(f"{e:.2e} {n}" for e, n in errs[:8]))
@@ -482,46 +571,67 @@ def test_full_config_train_step_vs_oracle(prompts_table, cfg, B):
     for e, n in errs:
         tol = 2.5e-2 if (".net.1.weight" in n or ".net.1.bias" in n) else 2e-3
         assert e < tol, (e, n)
+    # element-wise gradient bounds against the fp64 ground truth: |g - g64| <= 1e-3 |g64| + afrac max|g64| per ELEMENT.  The
+    # prompt context and the text projection (UCF: no path through a LeakyReLU) get north_star's own floor; the temporal
+    # model's gradients sit behind LeakyReLU kink flips (see above; observed element-wise excess at the 1e-5 floor is
+    # printed): UCF (depth 1) holds them to a floor 20x under the norm-wise bound, ShanghaiTech (depth 2 + the logits concat,
+    # so every gradient including the text path is downstream of two levels of kinks) to half of it
+    ex = {n: R.elem_excess(params[n].grad, sd[n].grad, afrac=1e-5) for n in names}
+    print("elem_excess(1e-3, 1e-5), worst:", sorted(((round(v, 2), n) for n, v in ex.items()), reverse=True)[:6])
+    for n in names:
+        kink = ".net.1.weight" in n or ".net.1.bias" in n
+        text = n in ("prompt_learner.ctx", "text_encoder.text_projection")
+        if cfg == "ucf":
+            afrac = 1e-5 if text else (1.25e-3 if kink else 1e-4)
+        else:
+            afrac = 1.25e-2 if kink else 1e-3
+        assert R.elem_excess(params[n].grad, sd[n].grad, afrac=afrac) <= 1, (n, afrac)
 
 
 # ====================================================================================================== data parallel glue
-def _dp_module(prompts_table, seed=21, geom="tiny"):
+def _dp_module(prompts_table, seed=21, geom="tiny", key="ucf"):
     from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
-    hc = IW.HeadConfig(num_classes=14, normal_id=7, emb_size=64, heads=2, depth=1) if geom == "tiny" else IW.UCF_HEAD
-    net, sd, eot = build_net(geom if geom == "tiny" else "ViT-B/16", hc, "ucf", seed, prompts_table)
-    crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
-    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-3}).to(DEV)
+    C, nid = len(prompts_table[key]["classnames"]), int(prompts_table[key]["normal_id"])
+    hc = IW.HeadConfig(num_classes=C, normal_id=nid, emb_size=64, heads=2, depth=1) if geom == "tiny" else IW.UCF_HEAD
+    net, sd, eot = build_net(geom if geom == "tiny" else "ViT-B/16", hc, key, seed, prompts_table)
+    crit = ComputeLoss(nid, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=C, solver={"lr": 1e-3}).to(DEV)
     net.train()
     return mod, net
 
 
-def _dp_batch(B, D, seed):
+def _dp_batch(B, D, seed, n_cls=14, normal_id=7):
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(B, 1, 512, D, generator=g) * 0.3
-    labels = torch.tensor([1 + (i % 6) for i in range(B // 2)] + [7] * (B // 2))
+    abn = [c for c in range(n_cls) if c != normal_id]
+    labels = torch.tensor([abn[(1 + i) % len(abn)] for i in range(B // 2)] + [normal_id] * (B // 2))
     masks = [torch.bernoulli(torch.ones(B, 32) * 0.3, generator=g) for _ in range(2)]
     for m in masks:
         m[:, :3] = 1
     return feats, labels, masks
 
 
+@pytest.mark.parametrize("path", ["step_graph", "autograd"])
 @pytest.mark.parametrize("geom", ["tiny", "ViT-B/16"])
-def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom):
-    """AnomalyCLIPModule.train_batch with parallel.GradBuckets fed by LIBACX-produced gradients (autograd.Function
-    backward outputs accumulated into views of the flat buffer): two optimisation steps must leave exactly the same
-    parameters as plain `loss.backward(); opt.step()` without buckets, every p.grad must still alias the flat
-    buffer afterwards, and the never-used logit_scale must keep grad None (no weight decay on it, like the
-    reference's DDP)."""
+def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom, path):
+    """AnomalyCLIPModule.train_batch with parallel.GradBuckets fed by LIBACX-produced gradients: two optimisation steps must
+    leave exactly the same parameters as plain `loss.backward(); opt.step()` without buckets, every p.grad must still alias
+    the flat buffer afterwards, and the never-used logit_scale must keep grad None (no weight decay on it, like the
+    reference's DDP).  path "step_graph" = train_batch's default (the whole step replayed from HIP graphs, gradients
+    produced in their flat-buffer views, AdamW inside the graph); "autograd" = its fallback (autograd.Function backward
+    outputs accumulated into the views)."""
     D = IW.TINY.embed_dim if geom == "tiny" else 512
     B = 4
     mods = [_dp_module(prompts_table, geom=geom) for _ in range(2)]
+    mods[0][1].step_graph = path == "step_graph"
     opts = [m.configure_optimizers()["optimizer"] for m, _ in mods]
     for step in range(2):
         feats, labels, masks = _dp_batch(B, D, 100 + step)
         f, l = feats.to(DEV), labels.to(DEV)
         batch = ((f[B // 2:], l[B // 2:]), (f[:B // 2], l[:B // 2]))
         for (mod, net), opt, bucketed in zip(mods, opts, (True, False)):
-            mod.ncentroid = torch.zeros(D, device=DEV)
+            if mod.ncentroid is None:
+                mod.ncentroid = torch.zeros(D, device=DEV)
             net.selector_model.generate_mask = lambda b, m=masks: (m[0], m[1])
             if bucketed:
                 mod.train_batch(batch, opt)
@@ -545,6 +655,14 @@ def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom):
                     assert torch.equal(pa[n].grad, pb[n].grad), (step, n)
         assert torch.equal(mods[0][0].last_losses[0], mods[1][0].last_losses[0])
     assert float(mods[0][1].selector_model.logit_scale.detach()) == float(np.float32(2.6592601))      # untouched by weight decay
+    sgs = mods[0][0].__dict__.get("_step_graphs", {})
+    if path == "step_graph":
+        assert len(sgs) == 1 and all(v is not None for v in sgs.values()), getattr(mods[0][0], "step_graph_error", None)
+        bn_a, bn_b = mods[0][1].selector_model.bn_layer, mods[1][1].selector_model.bn_layer
+        assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+        assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 2
+    else:
+        assert not sgs
 
 
 @pytest.mark.parametrize("geom,B", [("tiny", 4), ("ViT-B/16", 4), ("ViT-B/16", 8)])
@@ -557,7 +675,10 @@ def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom, B):
     zero-page clear, split workspace and fixed-order reduce -- inside the captured graphs (a hipMemsetAsync node there once
     ran unordered with its consumer)."""
     D = IW.TINY.embed_dim if geom == "tiny" else 512
-    mods = [_dp_module(prompts_table, geom=geom) for _ in range(2)]
+    # module 0: autograd path with the text tower / temporal model as replayed graphs; module 1: eager autograd path;
+    # module 2: train_batch's default, the whole-step graph (step_graph.TrainStepGraph)
+    mods = [_dp_module(prompts_table, geom=geom) for _ in range(3)]
+    mods[0][1].step_graph = mods[1][1].step_graph = False
     mods[0][1].text_graph = True
     mods[0][1].temporal_model.graph = True                                    # + the temporal model's two graphs
     opts = [m.configure_optimizers()["optimizer"] for m, _ in mods]
@@ -566,8 +687,63 @@ def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom, B):
         f, l = feats.to(DEV), labels.to(DEV)
         batch = ((f[B // 2:], l[B // 2:]), (f[:B // 2], l[:B // 2]))
         for (mod, net), opt in zip(mods, opts):
-            mod.ncentroid = torch.zeros(D, device=DEV)
+            if mod.ncentroid is None:
+                mod.ncentroid = torch.zeros(D, device=DEV)
             net.selector_model.generate_mask = lambda b, m=masks: (m[0], m[1])
+            mod.train_batch(batch, opt)
+        torch.cuda.synchronize()
+        pb = dict(mods[1][1].named_parameters())
+        for which in (0, 2):
+            pa = dict(mods[which][1].named_parameters())
+            for a_, b_ in zip(mods[which][0].last_losses, mods[1][0].last_losses):
+                assert torch.equal(a_, b_), (which, step)
+            for n in pa:
+                if pa[n].requires_grad:
+                    assert (pa[n].grad is None) == (pb[n].grad is None), (which, step, n)
+                    if pb[n].grad is not None:
+                        assert torch.equal(pa[n].grad, pb[n].grad), (which, step, n)
+                    assert torch.equal(pa[n], pb[n]), (which, step, n)
+    tg = mods[0][1]._text_graphs
+    assert tg is not None and not hasattr(mods[1][1], "_text_graphs")
+    first = tg
+    mods[0][0].train_batch(batch, opts[0])
+    assert mods[0][1]._text_graphs is first                                   # captured once
+    sgs = mods[2][0].__dict__.get("_step_graphs", {})
+    assert len(sgs) == 1 and all(v is not None for v in sgs.values()), getattr(mods[2][0], "step_graph_error", None)
+    # the eight loss meters: accumulated inside the whole-step graph == accumulated by the eager path
+    ma, mb = mods[2][0]._meters.compute(), mods[1][0]._meters.compute()
+    assert torch.allclose(ma, mb, rtol=1e-6, atol=0) and mods[2][0]._meters.count == mods[1][0]._meters.count == 3
+
+
+@pytest.mark.parametrize("cfg,B", [("ucf", 8), ("sht", 4)])
+def test_step_graph_full_configs_bit_identical_to_autograd(prompts_table, cfg, B):
+    """The whole-step graph at the reference's head configurations -- UCF (no concat: the temporal backward runs as its own
+    graph beside the selector / text backward; B = 8 = a data-parallel rank's 4096 rows) and ShanghaiTech (concat on, depth
+    2: the temporal model sits between selector forward and backward, d_features flows back into the logits) -- against the
+    eager autograd path: three optimisation steps with an LR change in between (the in-graph AdamW reads lr from device
+    memory), bit-identical losses, gradients, parameters, AdamW moments and BatchNorm running statistics."""
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD}[cfg]
+    mods = []
+    for _ in range(2):
+        net, sd, eot = build_net("ViT-B/16", hc, cfg, 23, prompts_table)
+        crit = ComputeLoss(hc.normal_id, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+        mod = AnomalyCLIPModule(net, None, None, crit, num_classes=hc.num_classes, solver={"lr": 1e-3}).to(DEV)
+        net.train()
+        mods.append((mod, net))
+    mods[1][1].step_graph = False
+    opts = [m.configure_optimizers()["optimizer"] for m, _ in mods]
+    for step in range(3):
+        feats, labels, masks = _dp_batch(B, 512, 900 + step, hc.num_classes, hc.normal_id)
+        f, l = feats.to(DEV), labels.to(DEV)
+        batch = ((f[B // 2:], l[B // 2:]), (f[:B // 2], l[:B // 2]))
+        for (mod, net), opt in zip(mods, opts):
+            if mod.ncentroid is None:
+                mod.ncentroid = (torch.randn(512, generator=torch.Generator().manual_seed(3)) * 0.05).to(DEV)
+            net.selector_model.generate_mask = lambda b, m=masks: (m[0], m[1])
+            if step == 2:
+                for grp in opt.param_groups:
+                    grp["lr"] *= 0.5
             mod.train_batch(batch, opt)
         torch.cuda.synchronize()
         pa, pb = dict(mods[0][1].named_parameters()), dict(mods[1][1].named_parameters())
@@ -579,14 +755,40 @@ def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom, B):
                 if pb[n].grad is not None:
                     assert torch.equal(pa[n].grad, pb[n].grad), (step, n)
                 assert torch.equal(pa[n], pb[n]), (step, n)
-    tg = mods[0][1]._text_graphs
-    assert tg is not None and not hasattr(mods[1][1], "_text_graphs")
-    first = tg
-    mods[0][0].train_batch(batch, opts[0])
-    assert mods[0][1]._text_graphs is first                                   # captured once
+                if pa[n].grad is not None:
+                    sa, sb = opts[0].state[pa[n]], opts[1].state[pb[n]]
+                    assert sa["step"] == sb["step"] == step + 1
+                    assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (step, n)
+        bn_a, bn_b = mods[0][1].selector_model.bn_layer, mods[1][1].selector_model.bn_layer
+        assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+    sgs = mods[0][0].__dict__.get("_step_graphs", {})
+    assert len(sgs) == 1 and all(v is not None for v in sgs.values()), getattr(mods[0][0], "step_graph_error", None)
 
 
-def _nccl_worker(rank, world, port, q, backend):
+def test_temporal_graph_gradients_survive_the_next_replay(prompts_table):
+    """autograd path, temporal_model.graph = True: gradients handed to autograd must not alias the graph's static buffers --
+    torch.autograd.grad results of one step stay intact after the graphs are replayed for another input."""
+    mod, net = _dp_module(prompts_table, geom="tiny")
+    tm = net.temporal_model
+    tm.graph = True
+    D = IW.TINY.embed_dim
+    g = torch.Generator().manual_seed(4)
+    nc = torch.zeros(D, device=DEV)
+    params = [p for p in tm.parameters()]
+    outs = []
+    for k in range(2):
+        x = (torch.randn(2 * 512, D, generator=g) * 0.3).to(DEV)
+        with torch.enable_grad():
+            sc = tm(x, 1, False, a_sub=nc)
+            grads = torch.autograd.grad(sc.sum() * (k + 1), params)
+        outs.append((grads, [t.clone() for t in grads]))
+    torch.cuda.synchronize()
+    for a_, b_ in zip(outs[0][0], outs[0][1]):
+        assert torch.equal(a_, b_)                 # step 0's gradients were not overwritten by step 1's replay
+    assert any(not torch.equal(a_, b_) for a_, b_ in zip(outs[0][0], outs[1][0]))
+
+
+def _nccl_worker(rank, world, port, q, backend, key="ucf", B=8):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -605,21 +807,26 @@ def _nccl_worker(rank, world, port, q, backend):
         test_gpu_model.DEV = DEV
         table = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anomalyclip_amd",
                                             "data", "prompts.json")))
-        B, D = 8, IW.TINY.embed_dim
-        (ma, na), (mb, nb) = _dp_module(table), _dp_module(table)
-        na.text_graph = True              # graph-replayed text tower + class-parallel exchange vs the eager reference module
+        D = IW.TINY.embed_dim
+        n_cls, nid = len(table[key]["classnames"]), int(table[key]["normal_id"])
+        (ma, na), (mb, nb) = _dp_module(table, key=key), _dp_module(table, key=key)
+        # module A: train_batch's default, the whole-step graph (cut into segments at the exchange steps); for the 2-rank
+        # runs a second pass drives A's fallback -- the autograd path with graph-replayed text tower / temporal model
+        na.text_graph = True
         na.temporal_model.graph = True
+        na.step_graph = os.environ.get("ACX_TEST_STEP_GRAPH", "1") == "1"
         oa = ma.configure_optimizers()["optimizer"]
         ok = True
         for step in range(2):
-            feats, labels, masks = _dp_batch(B, D, 300 + step)
+            feats, labels, masks = _dp_batch(B, D, 300 + step, n_cls, nid)
             idx = parallel.shard_videos(B, world, rank)
             f, l = feats[idx].to(DEV), labels[idx].to(DEV)
             mk = [m[idx] for m in masks]
             h = len(idx) // 2
             batch = ((f[h:], l[h:]), (f[:h], l[:h]))
             for mod, net in ((ma, na), (mb, nb)):
-                mod.ncentroid = torch.zeros(D, device=DEV)
+                if mod.ncentroid is None:
+                    mod.ncentroid = torch.zeros(D, device=DEV)       # one persistent buffer (its address keys the graphs)
                 net.selector_model.generate_mask = lambda b, m=mk: (m[0], m[1])
             # reference for the exchange: module B's LOCAL gradients (SyncBN statistics exchanged inside, as in A),
             # summed over ranks and divided by the world size by hand.  lr = 0: both modules keep identical weights.
@@ -655,8 +862,9 @@ def _nccl_worker(rank, world, port, q, backend):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("path", ["step_graph", "autograd_graphs"])
 @pytest.mark.parametrize("backend", ["nccl", "gloo"])
-def test_train_batch_gradbuckets_world2(backend):
+def test_train_batch_gradbuckets_world2(backend, path):
     """two ranks: the bucketed asynchronous all-reduce of libacx-produced gradients equals the hand-averaged per-rank
     gradients, SyncBN statistics and the class-parallel text features are exchanged, and every rank ends with
     bit-identical gradient buffers.  "nccl" = RCCL, one GPU per rank (skips below 2 GPUs); "gloo" = the same device code
@@ -669,15 +877,75 @@ def test_train_batch_gradbuckets_world2(backend):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    os.environ["ACX_TEST_STEP_GRAPH"] = "1" if path == "step_graph" else "0"      # inherited by the spawned ranks
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        os.environ.pop("ACX_TEST_STEP_GRAPH", None)
+    assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_train_batch_more_ranks_than_classes_world8():
+    """XD-Violence has 7 classes: on 8 ranks the class-parallel text encoder leaves one rank without a class.  EIGHT
+    processes share the one GPU, collectives over gloo, the REAL libacx row functions (graph-replayed text tower on seven
+    ranks, the empty stand-in on the eighth), 16 videos = one abnormal + one normal per rank: averaged gradients equal the
+    hand-averaged per-rank gradients of the eager module and every rank ends with bit-identical buffers."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, "gloo", "xd", 16)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)], res
+    assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def test_bench_two_gpus_over_rccl_when_available():
+    """Self-arming multi-GPU evidence: on a box with >= 2 GPUs this runs the driver's own command at N = 2
+    (`python bench.py --gpus 2 --steps 3 --warmup 1`: one process per GPU over RCCL) and checks the line -- the backend really is
+    RCCL, the data-parallel training leg stepped (finite time, positive same-run efficiency), the headline value is finite.
+    The JSON line is also left under gpurun_out/ so the first multi-GPU box yields a record.  Skipped on one GPU."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL)")
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ACX_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    try:
+        os.makedirs(os.path.join(repo, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(repo, "gpurun_out", "bench_gpus2_rccl.json"), "w") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    assert out["n_gpus"] == 2 and out["world"]["size"] == 2 and out["world"]["backend"] == "rccl"
+    assert np.isfinite(out["value"]) and out["value"] > 0
+    dp = out["dp_train"]
+    assert "head_legs_error" not in out, out.get("head_legs_error")
+    assert dp["strong"]["efficiency_vs_t1_same_run"] > 0 and dp["weak"]["efficiency_vs_t1_same_run"] > 0
+    assert np.isfinite(dp["strong"]["ms_per_step"]) and dp["allreduce_grad_buffer_ms"] > 0
+    assert np.isfinite(dp["strong"].get("loss", 0.0))
 
 
 def test_train_batch_rccl_single_rank():

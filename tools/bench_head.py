@@ -47,12 +47,18 @@ def stub_collectives(world, net=None):
             return out
         parallel.assemble_rows = assemble_rows
 
+        def assemble_rows_into(buf, lo, hi):         # the step graph's static exchange buffer: foreign rows from the copy
+            buf[:lo].copy_(full[:lo])
+            buf[hi:].copy_(full[hi:])
+            return buf
+        parallel.assemble_rows_into = assemble_rows_into
+
     class _H:
         def wait(self):
             return None
 
     class _Dist:
-        ReduceOp = SimpleNamespace(SUM=0, MAX=1)
+        ReduceOp = SimpleNamespace(SUM=0, MAX=1, MIN=2)
 
         @staticmethod
         def all_reduce(t, op=None, async_op=False):
@@ -94,6 +100,7 @@ def main():
     ap.add_argument("--no-text-shard", action="store_true", help="replicate the text encoder on every rank (plain DP)")
     ap.add_argument("--text-graph", action="store_true", help="text tower as two replayed HIP graphs on a side stream")
     ap.add_argument("--temporal-graph", action="store_true", help="temporal model forward / backward as two replayed HIP graphs")
+    ap.add_argument("--no-step-graph", action="store_true", help="autograd path instead of train_batch's whole-step graph")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local_rank)
@@ -112,6 +119,7 @@ def main():
     net.text_class_parallel = not args.no_text_shard
     net.text_graph = bool(args.text_graph)
     net.temporal_model.graph = bool(args.temporal_graph)
+    net.step_graph = not args.no_step_graph
     crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
     mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(dev)
     mod.ncentroid = torch.zeros(512, device=dev)
@@ -143,7 +151,7 @@ def main():
         net.selector_model.generate_mask = lambda b, mt=mt[idx], mb=mb[idx]: (mt, mb)
         mod.train_batch(batch, opt)
         if len(loss_trace) < 4:
-            loss_trace.append(mod.last_losses[0].detach())
+            loss_trace.append(mod.last_losses[0].detach().clone())
 
     x = torch.cat((batch[1][0], batch[0][0]), 0).view(-1, 1, 512, 512)
 
@@ -167,7 +175,11 @@ def main():
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
     dt_train = timer.run(train_step, args.steps, args.warmup)
+    keep_sg = net.step_graph
+    net.step_graph = False                     # per-launch event pairs see library calls, not graph replays
+    timer.run(train_step, 1, 0)
     timer.run(train_step, 2, 0, prof.start, prof.stop)
+    net.step_graph = keep_sg
     gf, counts, tot = prof.collect()
     dt_fwd = timer.run(fwd_step, args.steps, args.warmup)
     # host-side cost of issuing one step (no device wait inside): launch-bound when close to ms_per_step
@@ -191,8 +203,10 @@ def main():
             "train_gemm_tflops": round(gf / 1e9 / tot[0], 2) if tot[0] > 0 else None,
             "n_gpus": world, "emulated_world": args.emulate_world or None, "videos_this_rank": len(idx),
             "text_class_parallel": bool(net.text_class_parallel), "text_graph": bool(net.text_graph), "temporal_graph": bool(net.temporal_model.graph),
+            "step_graph": bool(net.step_graph) and any(v is not None for v in mod.__dict__.get("_step_graphs", {}).values()),
+            "step_graph_error": getattr(mod, "step_graph_error", None),
             "global_batch_videos": B_global, "scaling": args.scaling, "dtype": "f32",
-            "loss": float(mod.last_losses[0]), "first_losses": [round(float(v), 6) for v in loss_trace], "data": "synthetic"}))
+            "loss": float(mod.last_losses[0].detach()), "first_losses": [round(float(v), 6) for v in loss_trace], "data": "synthetic"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
