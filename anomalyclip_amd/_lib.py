@@ -13,7 +13,7 @@ c_void_p, c_int32, c_int64, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_int64
 ACX_F32, ACX_BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
-AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE = 0, 1, 2
+AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1
 OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS = 1, 2, 3
 
@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("pos0", c_void_p), ("pos1", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("zero_page", c_void_p), ("a_act", c_int32), ("gelu_grad_of", c_void_p), ("ldg", c_int32),
+        ("tile_table", c_void_p),
     ]
 
 
@@ -101,6 +102,7 @@ _SIGS = {
     "acx_axial_attention": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, c_void_p]),
     "acx_cls_head": (C.c_int, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_cls_head_tiles": (C.c_int, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "acx_class_probs": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_prompt_embed": (C.c_int, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p]),
     "acx_gather_rows": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),

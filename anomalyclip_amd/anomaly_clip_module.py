@@ -331,6 +331,44 @@ class AnomalyCLIPModule(_Base):
         n = labels.shape[0]                                                          # remove padded frames
         return abnormal_scores[:n], labels, class_probs[:n]
 
+    def score_videos(self, batches: List[Any]):
+        """`_score_video` for SEVERAL test batches in one forward (AnomalyCLIP.forward_test_many): one selector / temporal /
+        post-processing launch sequence over all tiles, one text-tower evaluation, then split per video and truncated to the
+        real frames like anomaly_clip_module.py:474-483.  -> list of (abnormal_scores, labels, class_probs)."""
+        net = self.net
+        if len(batches) == 1 or not getattr(net, "load_from_features", True):
+            return [self._score_video(b) for b in batches]
+        dev = self.device
+        feats, rows_per_crop, segs, labs = [], [], [], []
+        for b in batches:
+            f, labels, S = b[0], b[1], int(b[3])
+            f = f.to(dev)
+            if f.dim() != 4 or f.shape[0] != 1 or f.shape[1] != net.ncrops:
+                return [self._score_video(bb) for bb in batches]
+            feats.append(f.reshape(-1, f.shape[-1]))
+            rows_per_crop.append(f.shape[2])
+            segs.append(S)
+            labs.append(torch.as_tensor(labels).squeeze(0).to(dev))
+        x = feats[0] if len(feats) == 1 else torch.cat(feats, 0)
+        with torch.no_grad():
+            sim, sc = net.forward_test_many(x, rows_per_crop, segs, self.ncentroid)
+            probs = ops.class_probs(sim.contiguous(), sc.contiguous())
+        out, r0 = [], 0
+        for rows, lab in zip(rows_per_crop, labs):
+            r1 = r0 + rows * net.ncrops
+            s_v, p_v = sc[r0:r1], probs[r0:r1]
+            if net.stride != 1:                                                      # anomaly_clip.py:149-150
+                s_v, p_v = s_v.repeat_interleave(net.stride, dim=0), p_v.repeat_interleave(net.stride, dim=0)
+            n = lab.shape[0]
+            out.append((s_v[:n], lab, p_v[:n]))
+            r0 = r1
+        return out
+
+    @parallel.rank_zero_only
+    def test_step_many(self, batches: List[Any], batch_idx: int = 0):
+        """test_step for a list of test batches (one video each): the per-video dicts test_epoch_end consumes"""
+        return [{"abnormal_scores": s, "labels": l, "class_probs": p} for s, l, p in self.score_videos(batches)]
+
     def validation_step(self, batch: Any, batch_idx: int = 0):
         save_dir = _get(self.hparams, "save_dir")
         f = Path(save_dir) / "ncentroid.pt" if save_dir else None

@@ -125,7 +125,11 @@ class AnomalyCLIP(nn.Module):
         self.temporal_model = TemporalModel(input_size, self.emb_size, 1, self.heads, self.dim_heads, self.depth,
                                             self.num_segments, self.seg_length)
         self.temporal_model.precision = self.precision
-        self.cache_text_features = bool(g("cache_text_features", False))
+        # evaluation: the prompt parameters are frozen under no_grad, so the per-video text tower of the reference
+        # (anomaly_clip.py:136: recomputed for every test video) returns the same tensor every time -- it is computed once and
+        # kept, keyed by the optimizer epoch and the version / address of every input of the text path (any edit of those
+        # recomputes it).  `cache_text_features: false` restores the per-call evaluation.
+        self.cache_text_features = bool(g("cache_text_features", True))
         # under data parallelism the (replicated) text encoder is evaluated class-parallel: every rank runs its block
         # of classes and the (C, E) features / their gradients are exchanged (functional.TextFeaturesFn)
         self.text_class_parallel = bool(g("text_class_parallel", True))
@@ -145,18 +149,23 @@ class AnomalyCLIP(nn.Module):
         key = None
         if self.cache_text_features:
             # every input of the text path: optimizer steps through raw pointers bump WEIGHT_EPOCH, load_state_dict /
-            # in-place edits bump _version, .to(device) changes data_ptr -- any of them invalidates the cache
-            key = (ops.WEIGHT_EPOCH[0],) + tuple(
+            # in-place edits bump _version, .to(device) changes data_ptr -- any of them invalidates the cache.  (The frozen
+            # layers' parameter OBJECTS are listed once: Module.parameters() walks the module tree, 0.4 ms per call.)
+            plist = self.text_encoder.__dict__.get("_acx_plist")
+            if plist is None:
+                plist = self.text_encoder.__dict__["_acx_plist"] = list(self.text_encoder.transformer.parameters())
+            key = (ops.WEIGHT_EPOCH[0], self.text_len) + tuple(
                 (t.data_ptr(), t._version) for t in (self.prompt_learner.ctx, self.prompt_learner.token_prefix,
                                                      self.prompt_learner.token_suffix,
                                                      self.text_encoder.text_projection,
-                                                     self.text_encoder.positional_embedding)
-            ) + tuple((p.data_ptr(), p._version) for p in self.text_encoder.transformer.parameters())
+                                                     self.text_encoder.positional_embedding,
+                                                     self.text_encoder.ln_final.weight, self.text_encoder.ln_final.bias)
+            ) + tuple((p.data_ptr(), p._version) for p in plist)
             if self._text_cache is not None and self._text_cache[0] == key:
                 return self._text_cache[1]
-        x = self.prompt_learner(self.text_encoder.positional_embedding)
-        if self.text_len < x.shape[1]:
-            x = x[:, : self.text_len].contiguous()
+        pl = self.prompt_learner
+        x = ops.prompt_embed(pl.token_prefix, pl.ctx.detach(), pl.token_suffix, self.text_encoder.positional_embedding.detach(),
+                             pl.n_ctx, Lout=self.text_len)
         tf = self.text_encoder.encode(x, self.eot_index)
         if self.cache_text_features:
             self._text_cache = (key, tf)
@@ -196,3 +205,39 @@ class AnomalyCLIP(nn.Module):
             return similarity, scores.view(-1)
         from . import functional as Fn
         return Fn.anomaly_clip_train_forward(self, image_features, labels, ncentroid)
+
+    @torch.no_grad()
+    def forward_test_many(self, features: torch.Tensor, rows_per_crop, segment_sizes, ncentroid):
+        """Test-mode forward of SEVERAL videos in one launch sequence (the reference scores one video per step,
+        configs/data/*.yaml:7 `batch_size_test: 1`, anomaly_clip_module.py:458-483; tiles of different videos are independent
+        in evaluation -- BatchNorm uses its running statistics -- so they batch).
+
+        features: [sum_v ncrops * 512 * S_v, D] rows, video after video, each video crop-major in frame order (what the
+        dataset's `(1, ncrops, 512 S, D)` tensor holds); rows_per_crop[v] = 512 * S_v; segment_sizes[v] = S_v.
+        Returns (similarity [rows, C-1], scores [rows]) in the same row order (stride expansion is left to the caller)."""
+        if not self.load_from_features:
+            raise ValueError("forward_test_many takes pre-extracted features")
+        dev = features.device
+        ncentroid = ncentroid.to(dev, torch.float32).contiguous()
+        N, Lg = self.num_segments, self.seg_length
+        x = features.reshape(-1, features.shape[-1]).contiguous().float()
+        # tile table (host ints -> one small H2D copy): video v, crop c, tile s gathers rows row0 + s L + n (S_v L) + l
+        base, stride = [], []
+        r0 = 0
+        for rows, S in zip(rows_per_crop, segment_sizes):
+            rows, S = int(rows), int(S)
+            if rows != N * Lg * S:
+                raise ValueError("rows_per_crop must equal num_segments * seg_length * segment_size")
+            for c in range(self.ncrops):
+                for s_ in range(S):
+                    base.append(r0 + s_ * Lg)
+                    stride.append(S * Lg)
+                r0 += rows
+        if r0 != x.shape[0]:
+            raise ValueError(f"features hold {x.shape[0]} rows, the video list describes {r0}")
+        table = torch.tensor(list(zip(base, stride)), dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        text_features = self.get_text_features()
+        similarity = self.selector_model(x, text_features, None, ncentroid, True)
+        feats, a_sub = self.get_temporal_model_input(x, similarity, ncentroid)
+        scores = self.temporal_model(feats, 1, True, a_sub=a_sub, tile_table=table)
+        return similarity, scores.view(-1)

@@ -249,9 +249,11 @@ class TemporalModel(nn.Module):
                         cin=4 * E, prec=prec)
 
     def forward(self, features: torch.Tensor, segment_size: int, test_mode: bool,
-                a_sub: Optional[torch.Tensor] = None) -> torch.Tensor:
+                a_sub: Optional[torch.Tensor] = None, tile_table: Optional[torch.Tensor] = None) -> torch.Tensor:
         """features [rows, input_size] -> scores [rows, 1] (temporal_model.py:42-77).  `a_sub` fuses the
-        caller's re-centring (anomaly_clip.py:143,201) into the projection GEMM's A staging."""
+        caller's re-centring (anomaly_clip.py:143,201) into the projection GEMM's A staging.  `tile_table` (test mode,
+        int32 [tiles, 2] on the device: base row, row stride between segments) replaces `segment_size` for a BATCH of videos
+        with different segment sizes: tile t gathers rows base + n * stride + l and its scores are scattered back there."""
         from . import functional as Fn
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if test_mode:
@@ -271,9 +273,12 @@ class TemporalModel(nn.Module):
         x = x.contiguous()
         tiles = rows // (N * Lg)
         seg = segment_size if test_mode else 0
-        x0 = ops.gemm(x, P["proj_w"], bias=self.projection.bias, a_sub=a_sub,
-                      amap=L.AMAP_TESTTILE if test_mode else L.AMAP_IDENTITY, gn=N, gl=Lg, seg=max(seg, 1),
-                      pos0=P["pos0"], pos1=P["pos1"], prec=L.PREC_BF16 if self.precision == "bf16" else L.PREC_F32)
+        if tile_table is not None and not test_mode:
+            raise ValueError("tile_table is a test-mode (no_grad) argument")
+        amap = L.AMAP_TILETABLE if tile_table is not None else (L.AMAP_TESTTILE if test_mode else L.AMAP_IDENTITY)
+        x0 = ops.gemm(x, P["proj_w"], bias=self.projection.bias, a_sub=a_sub, amap=amap, gn=N, gl=Lg, seg=max(seg, 1),
+                      pos0=P["pos0"], pos1=P["pos1"], prec=L.PREC_BF16 if self.precision == "bf16" else L.PREC_F32,
+                      tile_table=tile_table)
         x1 = x2 = x0
         for d in range(self.depth):
             y1 = self._attn(x2, x1, d, "f", tiles, 0, P)      # long-term: along the N segments
@@ -281,5 +286,6 @@ class TemporalModel(nn.Module):
             x1 = self._ff(y2, y1, d, "f", P)
             x2 = self._ff(x1, y2, d, "g", P)
         c = self.classifier
-        s = ops.cls_head(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight, c.linear.bias, N, Lg, seg)
+        s = ops.cls_head(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight, c.linear.bias, N, Lg, seg,
+                         tile_table=tile_table)
         return s.view(-1, 1)

@@ -29,11 +29,15 @@ class TextEncoder(nn.Module):
         prec = PRECISIONS[self.precision]
         x2 = x.view(Cc * Lc, W)
         self.transformer.forward_(x2, Cc, Lc, prec)                         # text_encoder.py:16-18
-        rows = torch.arange(Cc, device=x.device, dtype=torch.int64) * Lc + eot_index
+        cache = self.__dict__.setdefault("_eot_rows", {})                    # EOT row table: built once per geometry
+        key = (Cc, Lc, eot_index.data_ptr())
+        rows = cache.get(key)
+        if rows is None:
+            rows = cache[key] = (torch.arange(Cc, device=x.device, dtype=torch.int64) * Lc + eot_index).contiguous()
         eot = ops.gather_rows(x2, rows)                                      # text_encoder.py:23 (gather)
         eot = ops.layernorm(eot, self.ln_final.weight, self.ln_final.bias)   # :19 (row-wise, so gather first)
         # x @ text_projection == gemm with W = text_projection^T [E, W]; exact f32 always (tiny, trainable)
-        return ops.gemm(eot, self.text_projection.detach().t().contiguous(), prec=L.PREC_F32)
+        return ops.gemm(eot, ops.transpose(self.text_projection.detach()), prec=L.PREC_F32)
 
     def forward(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor) -> torch.Tensor:
         x = ops.add_bcast(prompts.contiguous(), self.positional_embedding)   # text_encoder.py:15

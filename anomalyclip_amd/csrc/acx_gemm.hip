@@ -129,6 +129,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
         const int sg = rem / grid_sz, rem2 = rem - sg * grid_sz;
         const int n = rem2 / d.gl, l = rem2 - n * d.gl;
         a_row[r] = (((long)b * d.gn + n) * d.seg + sg) * d.gl + l;
+      } else if (d.amap == ACX_AMAP_TILETABLE) {
+        // row (tile, n, l) reads source row table[2 tile] + n * table[2 tile + 1] + l: tiles of several videos, each with its
+        // own segment size S (base = video row0 + s L, stride = S L), in ONE launch
+        const int tile = m / grid_sz, rem = m - tile * grid_sz;
+        const int n = rem / d.gl, l = rem - n * d.gl;
+        a_row[r] = (long)d.tile_table[2 * tile] + (long)n * d.tile_table[2 * tile + 1] + l;
       } else if (d.amap == ACX_AMAP_CONV3X3) {
         const int tile = m / grid_sz, rem = m - tile * grid_sz;
         a_n[r] = rem / d.gl;
@@ -486,6 +492,9 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     if (d->cin <= 0 || d->K != 9 * d->cin || d->cin % ke || d->gn <= 0 || d->gl <= 0 || d->M % (d->gn * d->gl))
       return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: bad conv3x3 geometry%s");
     if (d->a_sub) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_sub with conv3x3%s");
+  } else if (d->amap == ACX_AMAP_TILETABLE) {
+    if (!d->tile_table || d->gn <= 0 || d->gl <= 0 || d->M % (d->gn * d->gl))
+      return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: TILETABLE needs tile_table and M %% (gn*gl) == 0%s");
   } else if (d->amap == ACX_AMAP_TESTTILE) {
     if (d->seg <= 0 || d->gn <= 0 || d->gl <= 0 || d->M % (d->gn * d->gl * d->seg))
       return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: bad test-tile geometry%s");

@@ -98,7 +98,8 @@ template <int VPL>
 __global__ __launch_bounds__(256) void cls_head_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                        const float* __restrict__ lw, const float* __restrict__ lb,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ scores, int64_t rows, int gn, int gl, int seg) {
+                                                       float* __restrict__ scores, int64_t rows, int gn, int gl, int seg,
+                                                       const int* __restrict__ tile_table) {
   constexpr int E = 64 * VPL;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -118,7 +119,13 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float* __restrict__
   dot = wave_sum(dot) + bias[0];
   if (lane == 0) {
     int64_t dst = row;
-    if (seg > 0) {  // row is ((b s) n l) -> write at ((b n s l))  (temporal_model.py:69-71)
+    if (tile_table) {   // batch of videos with their own segment sizes: row (tile, n, l) -> base + n * stride + l
+      const int grid_sz = gn * gl;
+      const int64_t tile = row / grid_sz;
+      const int rem = (int)(row - tile * grid_sz);
+      const int n = rem / gl, l = rem - n * gl;
+      dst = (int64_t)tile_table[2 * tile] + (int64_t)n * tile_table[2 * tile + 1] + l;
+    } else if (seg > 0) {  // row is ((b s) n l) -> write at ((b n s l))  (temporal_model.py:69-71)
       const int grid_sz = gn * gl;
       const int64_t per = (int64_t)grid_sz * seg;
       const int64_t bb = row / per, rem = row - bb * per;
@@ -186,7 +193,22 @@ extern "C" int acx_cls_head(acx_ctx* ctx, const float* x1, const float* x2, cons
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
-  DISPATCH_VPL(E, cls_head_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, lin_b, scores, rows, gn, gl, seg));
+  DISPATCH_VPL(E, cls_head_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, lin_b, scores, rows, gn, gl, seg, nullptr));
   ACX_CHECK_LAUNCH(ctx, "acx_cls_head");
+  return ACX_OK;
+}
+
+extern "C" int acx_cls_head_tiles(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w, const float* ln_b,
+                                  const float* lin_w, const float* lin_b, float* scores, int64_t rows, int32_t E, int32_t gn,
+                                  int32_t gl, const int32_t* tile_table, void* stream) {
+  if (!x1 || !x2 || !ln_w || !ln_b || !lin_w || !lin_b || !scores || !tile_table)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_cls_head_tiles: null pointer%s");
+  if (rows <= 0) return ACX_OK;
+  if (gn <= 0 || gl <= 0 || rows % ((int64_t)gn * gl)) return acx_fail(ctx, ACX_E_BADARG, "acx_cls_head_tiles: rows %% (gn*gl) != 0%s");
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_NORM, s);
+  DISPATCH_VPL(E, cls_head_kernel<V><<<grid COMMA block COMMA 0 COMMA s>>>(x1, x2, ln_w, ln_b, lin_w, lin_b, scores, rows, gn, gl, 0, tile_table));
+  ACX_CHECK_LAUNCH(ctx, "acx_cls_head_tiles");
   return ACX_OK;
 }

@@ -102,6 +102,93 @@ class FeatureStream:
             view.numpy().__setitem__(slice(None), src[idx].transpose(1, 0, 2))
         return view, T, S
 
+    # ---- several videos per batch (AnomalyCLIP.forward_test_many / AnomalyCLIPModule.score_videos)
+    def _geometry(self, path: str):
+        """(T, S, rows per crop, D) of a feature file from its header alone"""
+        with open(path, "rb") as fh:
+            shape, fortran, dtype = self._npy_header(fh)
+        T = shape[0] // self.ncrops
+        starts, S = FI.test_start_indices(T, self.N, self.L, self.stride)
+        return T, S, len(starts) * self.L, shape[-1]
+
+    def _fill(self, path: str, dst: np.ndarray, T: int, rows: int):
+        """test-mode tile of one video into dst [ncrops, rows, D] (pinned memory): same index semantics as _host_tile"""
+        D = dst.shape[-1]
+        if self.stride == 1:
+            if self.ncrops == 1:
+                with open(path, "rb") as fh:
+                    shape, fortran, dtype = self._npy_header(fh)
+                    if len(shape) == 2 and not fortran and dtype == np.dtype("<f4"):
+                        got = fh.readinto(memoryview(dst[0, :T]).cast("B"))
+                        if got != T * D * 4:
+                            raise IOError(f"{path}: short read ({got} of {T * D * 4} bytes)")
+                        for r in range(T, rows, T):
+                            n = min(T, rows - r)
+                            dst[0, r:r + n] = dst[0, :n]
+                        return
+            arr = np.load(path, mmap_mode="r", allow_pickle=False)
+            if arr.dtype == np.float32 and arr.ndim == 2 and arr.flags.c_contiguous:
+                src = arr.reshape(T, self.ncrops, D)
+                for c in range(self.ncrops):
+                    np.copyto(dst[c, :T], src[:, c, :])
+                for r in range(T, rows, T):
+                    n = min(T, rows - r)
+                    dst[:, r:r + n] = dst[:, :n]
+                return
+        arr = np.load(path, mmap_mode="r", allow_pickle=False)
+        starts, _ = FI.test_start_indices(T, self.N, self.L, self.stride)
+        idx = FI.frame_index_table(starts, self.L, self.stride, T)
+        src = np.asarray(arr).reshape(T, self.ncrops, D)
+        dst[:] = src[idx].transpose(1, 0, 2)
+
+    def _host_group(self, paths: Sequence[str], slot: int):
+        geo = [self._geometry(p) for p in paths]
+        D = geo[0][3]
+        need = sum(self.ncrops * g[2] * D for g in geo)
+        flat = self._slot_buffer(slot, need, D)[:need]
+        off = 0
+        for p, (T, S, rows, _) in zip(paths, geo):
+            n = self.ncrops * rows * D
+            self._fill(p, flat[off:off + n].view(self.ncrops, rows, D).numpy(), T, rows)
+            off += n
+        return flat.view(-1, D), [(T, S, rows, p) for p, (T, S, rows, _) in zip(paths, geo)]
+
+    def batched(self, videos: int = 8, max_tiles: int = 96):
+        """Iterates over GROUPS of consecutive videos: yields (features [sum_v ncrops * rows_v, D] on the device -- video after
+        video, each crop-major in frame order --, [(num_frames, segment_size, rows_per_crop, path), ...]).  A group holds up
+        to `videos` videos and `max_tiles` 512-frame tiles (per crop); one pinned slot, ONE host-to-device copy per group, the
+        next group read by the reader thread meanwhile."""
+        from concurrent.futures import ThreadPoolExecutor
+        groups, cur, tiles = [], [], 0
+        for p in self.paths:
+            S = self._geometry(p)[1]
+            if cur and (len(cur) >= videos or tiles + S > max_tiles):
+                groups.append(cur)
+                cur, tiles = [], 0
+            cur.append(p)
+            tiles += S
+        if cur:
+            groups.append(cur)
+        pending = None
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(self._host_group, groups[0], 0) if groups else None
+            for i in range(len(groups)):
+                slot = i & 1
+                view, meta = fut.result()
+                fut = pool.submit(self._host_group, groups[i + 1], (i + 1) & 1) if i + 1 < len(groups) else None
+                with torch.cuda.stream(self._copy_stream):
+                    dev = view.to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                self._copied[slot] = ev
+                if pending is not None:
+                    yield pending
+                torch.cuda.current_stream().wait_event(ev)
+                dev.record_stream(torch.cuda.current_stream())
+                pending = (dev, meta)
+            if pending is not None:
+                yield pending
+
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, int, int, str]]:
         # One reader thread runs a video ahead: file i + 1 is read into its pinned slot (file I/O and large copies release
         # the GIL) while this thread issues the copy of video i and the consumer launches its kernels.  Slot s is refilled

@@ -120,7 +120,7 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
 def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None, M: Optional[int] = None,
          bias=None, act=L.ACT_NONE, residual=None, a_sub=None, prec=L.PREC_F32, out_dtype=torch.float32,
          amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, seg=0, pos0=None, pos1=None, a_act=L.ACT_NONE,
-         gelu_grad_of=None) -> torch.Tensor:
+         gelu_grad_of=None, tile_table=None) -> torch.Tensor:
     """out[M,N] = epilogue(amap(a)[M,K] @ w[N,K]^T); see include/acx.h acx_gemm_desc."""
     assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
     N, K = w.shape
@@ -146,6 +146,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     if amap == L.AMAP_CONV3X3:
         d.zero_page = _zero_page(a.device).data_ptr()
     d.gelu_grad_of, d.ldg = _ptr(gelu_grad_of), (gelu_grad_of.stride(0) if gelu_grad_of is not None else 0)
+    if amap == L.AMAP_TILETABLE:
+        assert tile_table is not None and tile_table.dtype == torch.int32 and tile_table.is_cuda and tile_table.is_contiguous()
+        assert tile_table.numel() == 2 * (M // (gn * gl))
+        d.tile_table = tile_table.data_ptr()
     ws = None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     few_rows = ((M <= SK_MAX_ROWS or (N <= 512 and M <= 4 * SK_MAX_ROWS and not (M > 768 and K >= 1536)))
@@ -276,10 +280,15 @@ def axial_attention(qkv: torch.Tensor, tiles: int, gn: int, gl: int, heads: int,
     return out
 
 
-def cls_head(x1, x2, ln_w, ln_b, lin_w, lin_b, gn: int, gl: int, seg: int) -> torch.Tensor:
+def cls_head(x1, x2, ln_w, ln_b, lin_w, lin_b, gn: int, gl: int, seg: int, tile_table=None) -> torch.Tensor:
     rows, E = x1.shape
     scores = torch.empty(rows, dtype=torch.float32, device=x1.device)
     h = _h(x1)
+    if tile_table is not None:
+        assert tile_table.dtype == torch.int32 and tile_table.is_cuda and tile_table.numel() == 2 * (rows // (gn * gl))
+        L.check(L.lib().acx_cls_head_tiles(h, x1.data_ptr(), x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), lin_w.data_ptr(),
+                                           lin_b.data_ptr(), scores.data_ptr(), rows, E, gn, gl, tile_table.data_ptr(), _stream()), h)
+        return scores
     L.check(L.lib().acx_cls_head(h, x1.data_ptr(), x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), lin_w.data_ptr(),
                                  lin_b.data_ptr(), scores.data_ptr(), rows, E, gn, gl, seg, _stream()), h)
     return scores

@@ -171,6 +171,30 @@ class Trainer:
             self.ckpt_path = ckpt_path
         model.net.eval()
         model.on_test_start()
-        outputs = [model.test_step(_to_device(batch, dev), i) for i, batch in enumerate(self.datamodule.test_dataloader())]
+        # the reference scores one video per step (batch_size_test: 1); tiles of different videos are independent in
+        # evaluation, so `eval_batch_videos` consecutive test batches go through ONE forward (test_step_many) -- bounded by
+        # `eval_batch_tiles` 512-frame tiles so that a run of long videos does not blow up the activation memory
+        outputs, group, tiles = [], [], 0
+        kmax, tmax = int(getattr(self, "eval_batch_videos", 8)), int(getattr(self, "eval_batch_tiles", 96))
+        many = getattr(model, "test_step_many", None) if kmax > 1 else None
+
+        def flush():
+            if group:
+                res = many([_to_device(b, dev) for b in group], len(outputs))
+                outputs.extend(res if res is not None else [None] * len(group))
+                group.clear()
+        for i, batch in enumerate(self.datamodule.test_dataloader()):
+            if many is None or not isinstance(batch, (tuple, list)) or len(batch) < 4:
+                flush()
+                tiles = 0
+                outputs.append(model.test_step(_to_device(batch, dev), i))
+                continue
+            t = int(batch[3])
+            if group and (len(group) >= kmax or tiles + t > tmax):
+                flush()
+                tiles = 0
+            group.append(batch)
+            tiles += t
+        flush()
         m = model.test_epoch_end(outputs)
         return [m] if m is not None else []

@@ -38,7 +38,7 @@ enum {
 enum { ACX_F32 = 0, ACX_BF16 = 1 };                 /* storage dtypes */
 enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1 };       /* MFMA arithmetic: exact f32 (v_mfma_f32_32x32x2_f32) or bf16 in / f32 acc */
 enum { ACX_ACT_NONE = 0, ACX_ACT_QUICKGELU = 1, ACX_ACT_LEAKYRELU = 2 };
-enum { ACX_AMAP_IDENTITY = 0, ACX_AMAP_CONV3X3 = 1, ACX_AMAP_TESTTILE = 2 };
+enum { ACX_AMAP_IDENTITY = 0, ACX_AMAP_CONV3X3 = 1, ACX_AMAP_TESTTILE = 2, ACX_AMAP_TILETABLE = 3 };
 enum { ACX_NORM_LAYER = 0, ACX_NORM_CHAN = 1 };     /* nn.LayerNorm vs axial_attention ChanLayerNorm (eps added to std) */
 
 typedef struct acx_ctx acx_ctx;
@@ -100,6 +100,10 @@ typedef struct acx_gemm_desc {
   int32_t a_act;          /* ACX_ACT_QUICKGELU: the activation is applied to A as it is read (x_next = gelu(pre) @ W^T) */
   const float* gelu_grad_of; /* [M, ldg] saved pre-activation p: C = (A W^T + bias) * d gelu(p)/dp  (no act / residual) */
   int32_t ldg;
+  const int32_t* tile_table; /* TILETABLE: [M / (gn gl)][2] device ints (base row, row stride between segments): output row
+                                (tile, n, l) reads source row base + n * stride + l -- the test-mode tiling of
+                                temporal_model.py:46-53 for a batch of videos with DIFFERENT segment sizes (video v, tile s:
+                                base = row0_v + s gl, stride = S_v gl) */
 } acx_gemm_desc;
 int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
 
@@ -231,6 +235,11 @@ int acx_cls_head(acx_ctx* ctx, const float* x1, const float* x2, const float* ln
                  int64_t rows, int32_t E, int32_t gn, int32_t gl, int32_t seg, void* stream);
 
 /* acx_class_probs: softmax(similarity, dim=1) * score  (anomaly_clip_module.py:474-477). */
+/* acx_cls_head with the scores scattered through a tile table (see acx_gemm_desc.tile_table): row (tile, n, l) is
+ * written at base + n * stride + l -- the inverse tiling of temporal_model.py:67-73 for a batch of videos. */
+int acx_cls_head_tiles(acx_ctx* ctx, const float* x1, const float* x2, const float* ln_w, const float* ln_b,
+                       const float* lin_w, const float* lin_b, float* scores, int64_t rows, int32_t E, int32_t gn,
+                       int32_t gl, const int32_t* tile_table, void* stream);
 int acx_class_probs(acx_ctx* ctx, const float* sim, const float* scores, float* probs,
                     int64_t rows, int32_t C1, void* stream);
 

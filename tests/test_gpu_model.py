@@ -360,7 +360,40 @@ def test_config0_shanghaitech_eval_from_feature_files(golden, prompts_table, tmp
         ps = float(out["class_probs"].double().sum())
         assert abs(ps - float(g[f"probsum{i}"])) < 1e-5 * abs(float(g[f"probsum{i}"]))
         outs.append(out)
+    # ---- the same eight videos BATCHED: FeatureStream.batched (groups of consecutive videos, one H2D copy each) ->
+    # test_step_many -> AnomalyCLIP.forward_test_many (ONE selector / temporal launch sequence over all tiles of a group, a
+    # per-tile gather table instead of one segment size, text features once).  Against the reference-produced fixture with
+    # the same bounds as above; against the one-video path to summation-order round-off (NOT bit-identical: the library
+    # picks its GEMM kernels -- few-row, 64x64 tiles, split-K -- by the launch's row count, hence a different f32 summation
+    # order); and position-independent: a video gives bit-identical rows wherever it sits inside a group.
+    fs = FeatureStream(paths, device=torch.device(DEV))
+    bouts = []
+    for feats, meta in fs.batched(videos=3, max_tiles=16):
+        i0 = len(bouts)
+        batches, r0 = [], 0
+        for k, (T_, S, rows, path) in enumerate(meta):
+            i = i0 + k
+            assert T_ == R.CONFIG0_LENGTHS[i] and S == int(g[f"S{i}"]) and rows == 512 * S
+            batches.append((feats[r0:r0 + rows].view(1, 1, rows, 512), torch.from_numpy(labels[i]).unsqueeze(0),
+                            int(labels[i].min()), S, path))
+            r0 += rows
+        assert r0 == feats.shape[0]
+        bouts.extend(mod.test_step_many(batches, i0))
+    assert len(bouts) == 8
+    for i, (a_, b_) in enumerate(zip(bouts, outs)):
+        assert a_["abnormal_scores"].shape == b_["abnormal_scores"].shape and a_["class_probs"].shape == b_["class_probs"].shape
+        assert relerr(a_["abnormal_scores"], g[f"scores{i}"]) < TOL and elem_ok(a_["abnormal_scores"], g[f"scores{i}"])
+        assert elem_ok(a_["class_probs"][::8], g[f"probs8_{i}"])
+        assert relerr(a_["abnormal_scores"], b_["abnormal_scores"]) < 5e-6 and relerr(a_["class_probs"], b_["class_probs"]) < 5e-6
+        assert torch.equal(a_["labels"], b_["labels"])
+    mk = lambda i: (torch.from_numpy(np.ascontiguousarray(np.resize(arrays[i], (512 * int(g[f"S{i}"]), 512)))).view(1, 1, -1, 512).to(DEV),
+                    torch.from_numpy(labels[i]).unsqueeze(0), int(labels[i].min()), int(g[f"S{i}"]), paths[i])
+    twice = mod.test_step_many([mk(2), mk(0), mk(2)], 0)            # video 2 (S = 2) at two positions of one group
+    assert torch.equal(twice[0]["abnormal_scores"], twice[2]["abnormal_scores"])
+    assert torch.equal(twice[0]["class_probs"], twice[2]["class_probs"])
     m = mod.test_epoch_end(outs)
+    mb = mod.test_epoch_end(bouts)
+    assert abs(mb["auc_roc"] - m["auc_roc"]) < 1e-4
     from oracle import metrics_oracle as MO
     ref_scores = np.concatenate([g[f"scores{i}"] for i in range(8)])
     ref_bin = (np.concatenate(labels) != hc.normal_id).astype(np.int64)
@@ -428,6 +461,48 @@ def test_xd_long_segments_bf16_head(prompts_table, S):
     err = (sc.double().cpu() - rsc.double()).abs().max().item()
     print(f"bf16 head, S={S}: max |score - oracle| = {err:.3e}, similarity rel = {relerr(sim, rsim):.3e}")
     assert err < 2e-2 and relerr(sim, rsim) < 2e-2
+
+
+def test_forward_test_many_crops_and_text_cache(prompts_table):
+    """AnomalyCLIP.forward_test_many with several crops (XD-Violence: 5) and different segment sizes in one batch against the
+    per-video forward (same rows to summation-order round-off, element-wise within north_star's bound), and the evaluation
+    text-feature cache: on by default, returns the SAME tensor for consecutive videos, bit-identical to an uncached
+    evaluation, recomputed after an optimizer step / an in-place edit of the context."""
+    hc = IW.XD_HEAD
+    net, sd, eot = build_net("ViT-B/16", hc, "xd", 29, prompts_table)
+    net.eval()
+    g = torch.Generator().manual_seed(12)
+    nc = (torch.randn(512, generator=g) * 0.05).to(DEV)
+    vids = [(torch.randn(1, hc.ncrops, 512 * S, 512, generator=g) * 0.3 + 0.02).to(DEV) for S in (2, 1, 3)]
+    segs = [2, 1, 3]
+    with torch.no_grad():
+        singles = [net(v, None, nc, S, True) for v, S in zip(vids, segs)]
+        x = torch.cat([v.reshape(-1, 512) for v in vids], 0)
+        sim, sc = net.forward_test_many(x, [512 * S for S in segs], segs, nc)
+    r0 = 0
+    for (rs, rc), S in zip(singles, segs):
+        r1 = r0 + hc.ncrops * 512 * S
+        assert relerr(sim[r0:r1], rs) < 5e-6 and relerr(sc[r0:r1], rc) < 5e-6
+        assert elem_ok(sim[r0:r1], rs) and elem_ok(sc[r0:r1], rc)
+        r0 = r1
+    assert r0 == sim.shape[0]
+    # ---- text-feature cache
+    assert net.cache_text_features
+    with torch.no_grad():
+        t1 = net.get_text_features()
+        t2 = net.get_text_features()
+        assert t2 is t1
+        net.cache_text_features = False
+        t3 = net.get_text_features()
+        net.cache_text_features = True
+        assert t3 is not t1 and torch.equal(t3, t1)
+        from anomalyclip_amd import ops as OPS
+        OPS.WEIGHT_EPOCH[0] += 1                     # what an optimizer step through raw pointers does
+        t4 = net.get_text_features()
+        assert t4 is not t1 and torch.equal(t4, t1)
+        net.prompt_learner.ctx.mul_(1.5)             # an in-place edit bumps the tensor version
+        t5 = net.get_text_features()
+        assert t5 is not t4 and not torch.equal(t5, t4)
 
 
 def test_vit_bf16_160_frame_window(golden):
