@@ -57,6 +57,11 @@ class CurveResult(C.Structure):          # == struct acx_curve_result (56 bytes,
                 ("n_distinct", c_int64), ("opt_index", c_int64), ("opt_threshold", c_float), ("pad", c_float)]
 
 
+class TnProblem(C.Structure):          # == struct acx_tn_problem
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("b_sub", c_void_p), ("M", c_int32), ("N1", c_int32),
+                ("N2", c_int32), ("lda", c_int32), ("ldb", c_int32), ("reserved", c_int32)]
+
+
 class PrepSeg(C.Structure):            # == struct acx_prep_seg
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int32), ("cols", c_int32), ("src_ld", c_int32),
                 ("dst_ld", c_int32), ("transpose", c_int32), ("reserved", c_int32)]
@@ -147,8 +152,14 @@ _SIGS = {
     "acx_bn_pack": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "acx_bn_running_update": (C.c_int, [c_void_p] * 6 + [c_int32, c_float, c_float, c_void_p]),
     "acx_fill_f32": (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "acx_gemm_tn_group_workspace_bytes": (c_size_t, [c_int32, c_void_p]),
+    "acx_gemm_tn_group": (C.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "acx_colsum_fused_part_bytes": (c_size_t, [c_int64, c_int32]),
     "acx_colsum_fused": (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "acx_colsum_fused_group": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32), C.POINTER(c_int64),
+                                         C.POINTER(c_int32), C.POINTER(c_void_p), C.POINTER(c_void_p), c_void_p, c_int32, c_void_p]),
+    "acx_reduce_rows_group": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int32),
+                                        C.POINTER(c_int32), c_void_p]),
     "acx_gemm_tn_zp": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                  c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "acx_ctx_grad": (C.c_int, [c_void_p] * 3 + [c_int32] * 5 + [c_void_p]),

@@ -403,49 +403,6 @@ def _temporal_param_list(tm) -> List[torch.nn.Parameter]:
     return plist
 
 
-_FORK_STREAMS: dict = {}
-
-
-class _Fork:
-    """Side branch for launches that only produce PARAMETER gradients (weight-gradient GEMMs, bias column sums, LayerNorm
-    parameter reductions, positional-embedding sums): nothing on the dX chain waits for them, so inside a stream capture
-    they are issued on a second stream and become a parallel branch of the captured graph -- a rank with few videos then
-    runs its chain of small latency-bound dX launches NEXT TO the fat weight-gradient GEMMs instead of in front of them
-    (the per-rank share of a data-parallel step: videos are not split, every kernel sees the same operands, results are
-    bit-identical to the in-order eager path).  Outside a capture (eager autograd path) everything stays on one stream.
-
-    Memory: a tensor produced on the main stream and read by the branch must outlive the branch -- `hold` keeps a reference
-    until join(), otherwise the capture's allocator could hand its block to a later main-stream allocation while the branch
-    (unordered with it) has not read it yet."""
-
-    def __init__(self, enable: bool = True):
-        self.on = bool(enable) and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-        self.hold = []
-        if self.on:
-            self.main = torch.cuda.current_stream()
-            key = (self.main.device_index, self.main.cuda_stream)
-            side = _FORK_STREAMS.get(key)
-            if side is None:
-                side = _FORK_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
-            self.side = side
-            self._started = False
-
-    def run(self, fn, *reads):
-        """fn() after everything queued on the main stream so far; `reads`: main-stream tensors fn reads."""
-        if not self.on:
-            return fn()
-        self.side.wait_stream(self.main)
-        self._started = True
-        self.hold.extend(reads)
-        with torch.cuda.stream(self.side):
-            return fn()
-
-    def join(self):
-        if self.on and self._started:
-            self.main.wait_stream(self.side)
-        self.hold = []
-
-
 class TemporalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, a_sub, tm, *params):
@@ -501,10 +458,6 @@ class TemporalFn(torch.autograd.Function):
         blks = tm.axial_attn.layers.blocks
         P = tm.prepared(True)
         gout = getattr(ctx, "grad_out", None)
-        # OFF by default: measured on MI355X, the forked weight-gradient GEMMs (persistent 256 x 256 kernels, one workgroup per
-        # CU) starve the dX chain's small launches instead of hiding them, and ROCm spreads a forked graph over hardware
-        # queues that other streams need (profiles/r04_step_graph_notes.md); `tm.fork_weight_grads = True` re-enables it
-        fork = _Fork(enable=bool(getattr(tm, "fork_weight_grads", False)))
         grads = {}
         c = tm.classifier
 
@@ -524,14 +477,19 @@ class TemporalFn(torch.autograd.Function):
         def put(p, g, direct):
             grads[p] = None if direct is not None else g
 
+        # Parameter gradients that are NOT fat -- the small weight-gradient GEMMs (to_out, to_q|to_kv, projection), the bias column
+        # sums, the LayerNorm / classifier parameter reductions -- are only RECORDED while the dX chain runs and issued at the end
+        # as three grouped launches (acx_gemm_tn_group / acx_colsum_fused_group / acx_reduce_rows_group) instead of ~30 latency-
+        # bound ones; each group member computes exactly what its single launch computes.
+        tn_jobs, cs_jobs, rr_jobs = [], [], []
+
         dz, part = ops.cls_head_bwd_parts(x1, x2, c.layer_norm.weight, c.layer_norm.bias, c.linear.weight, scores,
                                           d_scores.contiguous().view(-1))
 
-        def cls_params():
-            sred = ops.reduce_rows(part)
+        def cls_params(sred):
             grads[c.layer_norm.weight], grads[c.layer_norm.bias] = sred[:E], sred[E:2 * E]
             grads[c.linear.weight], grads[c.linear.bias] = sred[2 * E:3 * E].view(1, -1), sred[3 * E:3 * E + 1]
-        fork.run(cls_params, part)
+        rr_jobs.append((part, cls_params))
         d1, d2 = dz, dz                                   # d(x1), d(x2) of the last block pair
 
         # every branch ends in a LayerNorm backward: the gradient of the residual path it joins (`add`) is summed in that
@@ -542,52 +500,40 @@ class TemporalFn(torch.autograd.Function):
             sa = pn.fn
             He = heads * e
             w_dst = dest(sa.to_out.weight, (E, He))
-
-            def out_params():
-                put(sa.to_out.weight, ops.gemm_tn(d_out, o, out=w_dst), w_dst)          # [E, He]
-                grads[sa.to_out.bias] = ops.colsum(d_out)
-            fork.run(out_params, d_out, o)
+            tn_jobs.append((d_out, o, w_dst, None, lambda g, w=sa.to_out.weight, dd=w_dst: put(w, g, dd)))     # [E, He]
+            cs_jobs.append((d_out, lambda g, b=sa.to_out.bias: grads.__setitem__(b, g)))
             d_o = ops.gemm(d_out, P[f"out_wT{d}{fg}"])                                   # [rows, He]
             d_qkv = ops.seq_attention_bwd(qkv, d_o, tiles, N, Lg, heads, e, axis)
 
-            def qkv_params():
-                g_qkv = ops.gemm_tn(d_qkv, h)                                            # [3He, E]
+            def qkv_params(g_qkv, sa=sa, He=He):                                         # [3He, E]
                 grads[sa.to_q.weight], grads[sa.to_kv.weight] = g_qkv[:He], g_qkv[He:]
-            fork.run(qkv_params, d_qkv, h)
+            tn_jobs.append((d_qkv, h, None, None, qkv_params))
             d_h = ops.gemm(d_qkv, P[f"qkv_wT{d}{fg}"])                                   # [rows, E]
             d_in, lpart = ops.layernorm_bwd_parts(x_in, pn.norm.weight, d_h, add=add)
 
-            def ln_params():
-                sred = ops.reduce_rows(lpart)
+            def ln_params(sred, pn=pn):
                 grads[pn.norm.weight], grads[pn.norm.bias] = sred[:E], sred[E:]
-            fork.run(ln_params, lpart)
+            rr_jobs.append((lpart, ln_params))
             return d_in
 
         def ff_bwd(rec, d_out, add):
             _, d, fg, _, x_in, h, u, _ = rec
             f = getattr(blks[2 * d + 1], fg).net
             w2_dst, w1_dst = dest(f[3].weight, (E, 36 * E)), dest(f[1].weight, (4 * E, 9 * E))
-
-            def c2_params():
-                grads[f[3].bias] = ops.colsum(d_out)
-                gw2 = ops.gemm_tn(d_out, u, conv=True, gn=N, gl=Lg, cin=4 * E, out=w2_dst)    # [E, 9*4E]  ([Cout][tap][Cin])
-                put(f[3].weight, gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2), w2_dst)
-            fork.run(c2_params, d_out, u)
+            cs_jobs.append((d_out, lambda g, b=f[3].bias: grads.__setitem__(b, g)))
+            gw2 = ops.gemm_tn(d_out, u, conv=True, gn=N, gl=Lg, cin=4 * E, out=w2_dst)        # [E, 9*4E]  ([Cout][tap][Cin])
+            put(f[3].weight, gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2), w2_dst)
             d_u = ops.gemm(d_out, P[f"c2_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
             d_pre = ops.act(u, d_u, 0)                                                 # LeakyReLU'
-
-            def c1_params():
-                grads[f[1].bias] = ops.colsum(d_pre)
-                gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E, out=w1_dst)        # [4E, 9E]
-                put(f[1].weight, gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2), w1_dst)
-            fork.run(c1_params, d_pre, h)
+            cs_jobs.append((d_pre, lambda g, b=f[1].bias: grads.__setitem__(b, g)))
+            gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E, out=w1_dst)            # [4E, 9E]
+            put(f[1].weight, gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2), w1_dst)
             d_h = ops.gemm(d_pre, P[f"c1_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
             d_in, lpart = ops.layernorm_bwd_parts(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN, add=add)
 
-            def ln_params():
-                sred = ops.reduce_rows(lpart)
+            def ln_params(sred, f=f):
                 grads[f[0].g], grads[f[0].b] = sred[:E].view(1, -1, 1, 1), sred[E:].view(1, -1, 1, 1)
-            fork.run(ln_params, lpart)
+            rr_jobs.append((lpart, ln_params))
             return d_in
 
         recs = ctx.saved_acts
@@ -608,19 +554,21 @@ class TemporalFn(torch.autograd.Function):
         pe = tm.axial_attn.pos_emb
         K = tm.input_size
         pw_dst = dest(tm.projection.weight, (E, K)) if P["Kp"] == K else None
-
-        def x0_params():
-            g0, g1 = ops.pos_grad(d_x0, tiles, N, Lg)
-            grads[pe.param_0] = g0.t().reshape(1, E, N, 1)
-            grads[pe.param_1] = g1.t().reshape(1, E, 1, Lg)
-            gw = ops.gemm_tn(d_x0, x, b_sub=a_sub, out=pw_dst)                           # [E, Kp]
-            put(tm.projection.weight, gw[:, :K], pw_dst)
-            grads[tm.projection.bias] = ops.colsum(d_x0)
-        fork.run(x0_params, d_x0, x)
+        g0, g1 = ops.pos_grad(d_x0, tiles, N, Lg)
+        grads[pe.param_0] = g0.t().reshape(1, E, N, 1)
+        grads[pe.param_1] = g1.t().reshape(1, E, 1, Lg)
+        tn_jobs.append((d_x0, x, pw_dst, a_sub, lambda gw: put(tm.projection.weight, gw[:, :K], pw_dst)))        # [E, Kp]
+        cs_jobs.append((d_x0, lambda g: grads.__setitem__(tm.projection.bias, g)))
         d_feats = None
         if need_dfeats:
             d_feats = ops.gemm(d_x0, P["proj_wT"])                                       # [rows, Kp]
-        fork.join()
+        # ---- the deferred parameter gradients: three grouped launches (+ one grouped split reduce)
+        for job, res in zip(tn_jobs, ops.gemm_tn_group([(a, b, o, bs) for a, b, o, bs, _ in tn_jobs])):
+            job[4](res)
+        for job, res in zip(cs_jobs, ops.colsum_group([xx for xx, _ in cs_jobs])):
+            job[1](res)
+        for job, res in zip(rr_jobs, ops.reduce_rows_group([pp for pp, _ in rr_jobs])):
+            job[1](res)
         ctx.saved_acts = None
         plist = _temporal_param_list(tm)
         if gout is not None:

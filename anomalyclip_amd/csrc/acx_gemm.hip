@@ -839,6 +839,79 @@ static int tn_p256_splits(int64_t M, int64_t N1, int64_t N2, int ncu) {
 }
 constexpr size_t TN_ZERO_B = 1024;               // zero page at the end of the workspace (the DMA kernel's padding source)
 
+// ---- grouped small weight gradients (identity row map, no conv): see gemm_tn_w8_group_kernel
+extern "C" size_t acx_gemm_tn_group_workspace_bytes(int32_t nprob, const acx_tn_problem* probs) {
+  size_t need = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const int splits = tn_choose_splits(probs[i].M, probs[i].N1, probs[i].N2);
+    if (splits > 1) need += ((size_t)splits * probs[i].N1 * probs[i].N2 * sizeof(float) + 255) / 256 * 256;
+  }
+  return need;
+}
+
+extern "C" int acx_gemm_tn_group(acx_ctx* ctx, int32_t nprob, const acx_tn_problem* probs, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (nprob <= 0) return ACX_OK;
+  if (!probs) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_group: null problem table%s");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = 4 * 32 * TN_ROWF * sizeof(float);
+  const int dev_slot = (ctx ? ctx->device : 0) & 63;
+  static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_w8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  int i = 0;
+  size_t woff = 0;
+  while (i < nprob) {
+    TnGroup G;
+    TnReduceGroup R;
+    memset(&G, 0, sizeof(G));
+    memset(&R, 0, sizeof(R));
+    int k = 0, blocks = 0, rblocks = 0, nr = 0;
+    double flops = 0.0;
+    for (; i < nprob && k < TN_GROUP_MAX; ++i, ++k) {
+      const acx_tn_problem& q = probs[i];
+      if (!q.A || !q.B || !q.C) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_group: null pointer%s");
+      if (q.M <= 0 || q.N1 <= 0 || q.N2 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_group: empty shape%s");
+      if (q.N1 % 4 || q.N2 % 4 || q.lda % 4 || q.ldb % 4 || (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15) ||
+          (q.b_sub && ((uintptr_t)q.b_sub & 15)))
+        return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_group: N1/N2/lda/ldb multiples of 4, 16-byte aligned pointers%s");
+      const int splits = tn_choose_splits(q.M, q.N1, q.N2);
+      const int tiles = ((q.N1 + 127) / 128) * ((q.N2 + 127) / 128);
+      float* dst = (float*)q.C;
+      if (splits > 1) {
+        const size_t need = ((size_t)splits * q.N1 * q.N2 * sizeof(float) + 255) / 256 * 256;
+        if (!workspace || woff + need > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_gemm_tn_group: workspace too small%s");
+        dst = (float*)((char*)workspace + woff);
+        woff += need;
+        R.part[nr] = dst; R.out[nr] = (float*)q.C; R.n4[nr] = (long long)q.N1 * q.N2 / 4; R.splits[nr] = splits;
+        R.blk0[nr] = rblocks;
+        rblocks += (int)((R.n4[nr] + 255) / 256);
+        ++nr;
+      }
+      TnArgs& g = G.p[k];
+      g.A = (const float*)q.A; g.B = (const float*)q.B; g.C = dst;
+      g.M = q.M; g.N1 = q.N1; g.N2 = q.N2; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.N2;
+      g.b_sub = (const float*)q.b_sub; g.conv = 0; g.gn = g.gl = g.cin = 0;
+      g.m_per_split = ((q.M + splits - 1) / splits + 31) / 32 * 32;
+      g.sh_gl = g.sh_grid = -1;
+      G.tiles[k] = tiles;
+      G.blk0[k] = blocks;
+      blocks += tiles * splits;
+      flops += 2.0 * q.M * (double)q.N1 * q.N2;
+    }
+    G.blk0[k] = blocks; G.n = k;
+    R.blk0[nr] = rblocks; R.n = nr;
+    AcxProfScope prof__(ctx, ACX_K_GEMM_TN, s);
+    if (ctx && ctx->prof_on) { ctx->prof_gemm_flops += flops; ctx->prof_tn_flops += flops; }
+    hipLaunchKernelGGL(gemm_tn_w8_group_kernel, dim3((unsigned)blocks), dim3(512), lds, s, G);
+    if (nr > 0) hipLaunchKernelGGL(tn_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, R);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_gemm_tn_group");
+  return ACX_OK;
+}
+
 extern "C" size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2) {
   const int splits = tn_choose_splits(M, N1, N2);
   size_t need = splits > 1 ? (size_t)splits * N1 * N2 * sizeof(float) : 0;

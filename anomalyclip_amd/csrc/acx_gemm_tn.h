@@ -175,14 +175,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const TnArgs g) {
 }
 
 // 8-wave variant (64 x 32 of C per wave, four waves per SIMD with two resident blocks): same LDS image and K-step.
-__global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) {
+// body of the 8-wave weight-gradient kernel for output tile `bx_` and m-split `by_` (shared by the single-problem and the
+// grouped launch)
+__device__ __forceinline__ void tn_w8_body(const TnArgs& g, const int bx_, const int by_) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem);           // [stage][A|B][32][TN_ROWF]
   constexpr int TILE_F = 32 * TN_ROWF;
   const int tiles_n2 = (g.N2 + 127) / 128;
-  const int tm = blockIdx.x / tiles_n2, tn = blockIdx.x % tiles_n2;
+  const int tm = bx_ / tiles_n2, tn = bx_ % tiles_n2;
   const int n1_0 = tm * 128, n2_0 = tn * 128;
-  const int split = blockIdx.y;
+  const int split = by_;
   const int m_begin = split * g.m_per_split;
   const int m_end = min(g.M, m_begin + g.m_per_split);
 
@@ -331,6 +333,58 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) {
   }
 #undef TN_LOAD_ROW
 #undef TN_STORE_ROW
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_w8_kernel(const TnArgs g) { tn_w8_body(g, (int)blockIdx.x, (int)blockIdx.y); }
+
+// Several small weight-gradient problems in ONE launch (the temporal model's to_out / to_q|kv / projection gradients of a
+// data-parallel rank: 0.5-1.6 GFLOP each, 22-25 us per launch + a 6 us reduce when issued one by one): the flat block index
+// is cut by a prefix table into (problem, tile, split); every problem runs exactly the blocks -- and therefore the arithmetic --
+// of its own single launch.
+constexpr int TN_GROUP_MAX = 8;
+struct TnGroup {
+  TnArgs p[TN_GROUP_MAX];
+  int tiles[TN_GROUP_MAX];
+  int blk0[TN_GROUP_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(512, 2) void gemm_tn_w8_group_kernel(const TnGroup G) {
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < TN_GROUP_MAX; ++i)
+    if (i < G.n && G.blk0[i] <= b) k = i;
+  const int local = b - G.blk0[k];
+  const int tiles = G.tiles[k];
+  const int by = local / tiles;
+  tn_w8_body(G.p[k], local - by * tiles, by);
+}
+
+struct TnReduceGroup {
+  const float* part[TN_GROUP_MAX];
+  float* out[TN_GROUP_MAX];
+  long long n4[TN_GROUP_MAX];
+  int splits[TN_GROUP_MAX];
+  int blk0[TN_GROUP_MAX + 1];
+  int n;
+};
+// out_k[i] = sum_s part_k[s][i] for every problem of a group, one launch (fixed order)
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(const TnReduceGroup G) {
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < TN_GROUP_MAX; ++i)
+    if (i < G.n && G.blk0[i] <= b) k = i;
+  const long long i = (long long)(b - G.blk0[k]) * 256 + threadIdx.x;
+  const long long n4 = G.n4[k];
+  if (i >= n4) return;
+  const float4* part = reinterpret_cast<const float4*>(G.part[k]);
+  float4 s = part[i];
+  for (int q = 1; q < G.splits[k]; ++q) {
+    const float4 v = part[(long long)q * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(G.out[k])[i] = s;
 }
 
 // ---- 256 x 256 tiles, one 16-wave workgroup per CU, operands by LDS-DMA ("strip" geometry of gemm_f32_p256_kernel)

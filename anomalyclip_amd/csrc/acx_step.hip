@@ -143,58 +143,131 @@ __global__ __launch_bounds__(256) void adamw_multi_dev_kernel(const AdamwDevSegs
 // out[c] = sum_r x[r][c] in ONE launch, deterministic: block (slab, column group of 64) writes its partial row, the LAST block
 // of a column group to arrive (device-scope counter) adds the slabs' partials in slab order.  The counter returns to zero,
 // so the launch is replayable from a HIP graph.  Replaces colsum_partials + reduce_rows (two launches per bias gradient).
-__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
-                                                           float* __restrict__ part, float* __restrict__ out,
-                                                           unsigned int* __restrict__ counters) {
-  __shared__ float4 red[16][16];
+__device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
+                                                  float* __restrict__ part, float* __restrict__ out,
+                                                  unsigned int* __restrict__ counters, const int cg, const int slab, const int nslab) {
+  // block = 256 columns (64 float4 lanes: one wave-level load covers 1 KB of ONE row) x 4 row slices (the four waves);
+  // slice k adds rows r0 + k, r0 + k + 4, ... in order, the four slices are added in slice order
+  __shared__ float4 red[4][64];
   __shared__ bool last;
-  const int cg = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
-  const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;          // 16 float4 columns x 16 row lanes
-  const int c = cg * 64 + 4 * tc;
+  const int q = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = cg * 256 + 4 * q;
   const long long r0 = (long long)slab * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < D)
-    for (long long r = r0 + tr; r < r1; r += 16) {
+  if (c < D) {
+    long long r = r0 + sl;
+    for (; r + 12 < r1; r += 16) {                 // four rows in flight per lane (independent loads, fixed add order)
+      const float4 v0 = *reinterpret_cast<const float4*>(x + r * ld + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(x + (r + 4) * ld + c);
+      const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 8) * ld + c);
+      const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 12) * ld + c);
+      a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+      a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+      a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+      a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+    }
+    for (; r < r1; r += 4) {
       const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-  red[tr][tc] = a;
-  __syncthreads();
-  if (tr == 0 && c < D) {
-    float4 s = red[0][tc];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) { s.x += red[k][tc].x; s.y += red[k][tc].y; s.z += red[k][tc].z; s.w += red[k][tc].w; }
-    *reinterpret_cast<float4*>(part + (size_t)slab * D + c) = s;
   }
-  __threadfence();
+  red[sl][q] = a;
+  __syncthreads();
+  if (sl == 0 && c < D) {
+    float4 t = red[0][q];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
+    *reinterpret_cast<float4*>(part + (size_t)slab * D + c) = t;
+    __threadfence();                               // the partial row is visible device-wide before this block's arrival
+  }
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(&counters[cg], 1u) == (unsigned)nslab - 1;
   __syncthreads();
   if (!last) return;
   __threadfence();
-  // last block of the column group: 64 columns x 4 slab lanes; lane l adds slabs l, l + 4, ... in order, the four lane sums are
-  // then added in lane order -- a fixed tree, whichever block happens to arrive last
-  __shared__ float fin[4][64];
+  // last block of the column group to arrive: thread t adds the slabs' partials of column cg * 256 + t in slab order
   {
-    const int cl = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const int cc = cg * 64 + cl;
-    float s0 = 0.f;
+    const int cc = cg * 256 + threadIdx.x;
     if (cc < D) {
-      int p = l;
-      for (; p + 12 < nslab; p += 16) {
-        const float a0 = __builtin_nontemporal_load(part + (size_t)p * D + cc);
-        const float a1 = __builtin_nontemporal_load(part + (size_t)(p + 4) * D + cc);
-        const float a2 = __builtin_nontemporal_load(part + (size_t)(p + 8) * D + cc);
-        const float a3 = __builtin_nontemporal_load(part + (size_t)(p + 12) * D + cc);
-        s0 += a0; s0 += a1; s0 += a2; s0 += a3;
+      float s0 = 0.f;
+      int p = 0;
+      for (; p + 7 < nslab; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(part + (size_t)(p + k) * D + cc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s0 += v[k];
       }
-      for (; p < nslab; p += 4) s0 += __builtin_nontemporal_load(part + (size_t)p * D + cc);
+      for (; p < nslab; ++p) s0 += __builtin_nontemporal_load(part + (size_t)p * D + cc);
+      out[cc] = s0;
     }
-    fin[l][cl] = s0;
-    __syncthreads();
-    if (l == 0 && cc < D) out[cc] = ((fin[0][cl] + fin[1][cl]) + fin[2][cl]) + fin[3][cl];
   }
   if (threadIdx.x == 0) counters[cg] = 0;
+}
+
+__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
+                                                           float* __restrict__ part, float* __restrict__ out,
+                                                           unsigned int* __restrict__ counters) {
+  colsum_fused_body(x, ld, rows, D, rpb, part, out, counters, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// several column sums in one launch (the bias gradients of a backward pass): flat block index -> (problem, column group, slab)
+constexpr int COLSUM_GROUP_MAX = 12;
+struct ColsumGroup {
+  const float* x[COLSUM_GROUP_MAX];
+  float* part[COLSUM_GROUP_MAX];
+  float* out[COLSUM_GROUP_MAX];
+  long long rows[COLSUM_GROUP_MAX];
+  int ld[COLSUM_GROUP_MAX], D[COLSUM_GROUP_MAX], rpb[COLSUM_GROUP_MAX], cgs[COLSUM_GROUP_MAX], nslab[COLSUM_GROUP_MAX];
+  int ctr0[COLSUM_GROUP_MAX];                       // first arrival counter of the problem
+  int blk0[COLSUM_GROUP_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_fused_group_kernel(const ColsumGroup G, unsigned int* __restrict__ counters) {
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < COLSUM_GROUP_MAX; ++i)
+    if (i < G.n && G.blk0[i] <= b) k = i;
+  const int local = b - G.blk0[k];
+  const int cgs = G.cgs[k];
+  const int slab = local / cgs;
+  colsum_fused_body(G.x[k], G.ld[k], G.rows[k], G.D[k], G.rpb[k], G.part[k], G.out[k], counters + G.ctr0[k], local - slab * cgs, slab,
+                    G.nslab[k]);
+}
+
+// out_k[c] = sum_p part_k[p][c] for several partial tables in one launch (LayerNorm / classifier parameter gradients): fixed
+// order, the same tree as reduce_rows_kernel (16 slices of the parts, then the slices in order)
+constexpr int RR_GROUP_MAX = 12;
+struct ReduceRowsGroup {
+  const float* part[RR_GROUP_MAX];
+  float* out[RR_GROUP_MAX];
+  int nparts[RR_GROUP_MAX], width[RR_GROUP_MAX];
+  int blk0[RR_GROUP_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void reduce_rows_group_kernel(const ReduceRowsGroup G) {
+  __shared__ float red[16][17];
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < RR_GROUP_MAX; ++i)
+    if (i < G.n && G.blk0[i] <= b) k = i;
+  const float* __restrict__ part = G.part[k];
+  const int nparts = G.nparts[k], width = G.width[k];
+  const int ci = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = (b - G.blk0[k]) * 16 + ci;
+  float s = 0.f;
+  if (c < width)
+    for (int p = sl; p < nparts; p += 16) s += part[(size_t)p * width + c];
+  red[sl][ci] = s;
+  __syncthreads();
+  if (sl == 0 && c < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][ci];
+    G.out[k][c] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm bookkeeping
@@ -343,13 +416,13 @@ extern "C" int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_
                                 size_t part_bytes, uint32_t* counters, void* stream) {
   if (!x || !out || !part || !counters) return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused: null pointer%s");
   if (rows <= 0 || D <= 0) return ACX_OK;
-  if (D % 4 || ld % 4 || D > 64 * 256 || (((uintptr_t)x | (uintptr_t)part) & 15))
+  if (D % 4 || ld % 4 || D > 256 * 256 || (((uintptr_t)x | (uintptr_t)part) & 15))
     return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused: D / ld multiples of 4, D <= 16384, 16-byte aligned x / part%s");
   // slabs: enough blocks to fill the chip a few times over, at least 64 rows each
-  const int cgs = (D + 63) / 64;
-  long long nslab = (512 + cgs - 1) / cgs;
-  if (nslab > 128) nslab = 128;
-  if (nslab * 32 > rows) nslab = (rows + 31) / 32;
+  const int cgs = (D + 255) / 256;
+  long long nslab = (768 + cgs - 1) / cgs;        // ~3 blocks per CU
+  if (nslab > 256) nslab = 256;
+  if (nslab * 16 > rows) nslab = (rows + 15) / 16;
   if (nslab < 1) nslab = 1;
   const int rpb = (int)((rows + nslab - 1) / nslab);
   nslab = (rows + rpb - 1) / rpb;
@@ -361,12 +434,81 @@ extern "C" int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_
   return ACX_OK;
 }
 
+static inline void colsum_geometry(int64_t rows, int32_t D, int* cgs, int* nslab, int* rpb) {
+  const int c = (D + 255) / 256;
+  long long ns = (768 + c - 1) / c;
+  if (ns > 256) ns = 256;
+  if (ns * 16 > rows) ns = (rows + 15) / 16;
+  if (ns < 1) ns = 1;
+  const int r = (int)((rows + ns - 1) / ns);
+  *cgs = c; *rpb = r; *nslab = (int)((rows + r - 1) / r);
+}
+
+extern "C" int acx_colsum_fused_group(acx_ctx* ctx, int32_t nprob, const void* const* x, const int32_t* ld, const int64_t* rows,
+                                      const int32_t* D, void* const* out, void* const* part, uint32_t* counters, int32_t ncounters,
+                                      void* stream) {
+  if (nprob <= 0) return ACX_OK;
+  if (!x || !ld || !rows || !D || !out || !part || !counters) return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused_group: null pointer%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < nprob) {
+    ColsumGroup G;
+    memset(&G, 0, sizeof(G));
+    int k = 0, blocks = 0, ctr = 0;
+    for (; i < nprob && k < COLSUM_GROUP_MAX; ++i) {
+      if (rows[i] <= 0 || D[i] <= 0) continue;
+      if (!x[i] || !out[i] || !part[i] || D[i] % 4 || ld[i] % 4 || (((uintptr_t)x[i] | (uintptr_t)part[i]) & 15))
+        return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused_group: D / ld multiples of 4, 16-byte aligned x / part%s");
+      int cgs, nslab, rpb;
+      colsum_geometry(rows[i], D[i], &cgs, &nslab, &rpb);
+      if (ctr + cgs > ncounters) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_colsum_fused_group: not enough arrival counters%s");
+      G.x[k] = (const float*)x[i]; G.part[k] = (float*)part[i]; G.out[k] = (float*)out[i];
+      G.rows[k] = rows[i]; G.ld[k] = ld[i]; G.D[k] = D[i]; G.rpb[k] = rpb; G.cgs[k] = cgs; G.nslab[k] = nslab;
+      G.ctr0[k] = ctr; ctr += cgs;
+      G.blk0[k] = blocks; blocks += cgs * nslab;
+      ++k;
+    }
+    if (k == 0) continue;
+    G.blk0[k] = blocks; G.n = k;
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    hipLaunchKernelGGL(colsum_fused_group_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, counters);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_colsum_fused_group");
+  return ACX_OK;
+}
+
+extern "C" int acx_reduce_rows_group(acx_ctx* ctx, int32_t nprob, const void* const* part, void* const* out, const int32_t* nparts,
+                                     const int32_t* width, void* stream) {
+  if (nprob <= 0) return ACX_OK;
+  if (!part || !out || !nparts || !width) return acx_fail(ctx, ACX_E_BADARG, "acx_reduce_rows_group: null pointer%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < nprob) {
+    ReduceRowsGroup G;
+    memset(&G, 0, sizeof(G));
+    int k = 0, blocks = 0;
+    for (; i < nprob && k < RR_GROUP_MAX; ++i) {
+      if (nparts[i] <= 0 || width[i] <= 0) continue;
+      if (!part[i] || !out[i]) return acx_fail(ctx, ACX_E_BADARG, "acx_reduce_rows_group: null tensor pointer%s");
+      G.part[k] = (const float*)part[i]; G.out[k] = (float*)out[i]; G.nparts[k] = nparts[i]; G.width[k] = width[i];
+      G.blk0[k] = blocks; blocks += (width[i] + 15) / 16;
+      ++k;
+    }
+    if (k == 0) continue;
+    G.blk0[k] = blocks; G.n = k;
+    AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+    hipLaunchKernelGGL(reduce_rows_group_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_reduce_rows_group");
+  return ACX_OK;
+}
+
 extern "C" size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D) {
   if (rows <= 0 || D <= 0) return 0;
-  const int cgs = (D + 63) / 64;
-  long long nslab = (512 + cgs - 1) / cgs;
-  if (nslab > 128) nslab = 128;
-  if (nslab * 32 > rows) nslab = (rows + 31) / 32;
+  const int cgs = (D + 255) / 256;
+  long long nslab = (768 + cgs - 1) / cgs;        // ~3 blocks per CU
+  if (nslab > 256) nslab = 256;
+  if (nslab * 16 > rows) nslab = (rows + 15) / 16;
   if (nslab < 1) nslab = 1;
   return (size_t)(nslab + 1) * D * sizeof(float);
 }

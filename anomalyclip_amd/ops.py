@@ -374,6 +374,70 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, b_sub=None, conv=False, gn=0, g
     return out
 
 
+def gemm_tn_group(problems):
+    """problems: list of (a [M, N1], b [M, N2], out or None, b_sub or None) -> list of C_k = a_k^T (b_k - b_sub_k); ONE launch
+    (+ one reduce) for all of them, bit-identical to separate gemm_tn calls (acx_gemm_tn_group)."""
+    n = len(problems)
+    if n == 0:
+        return []
+    arr = (L.TnProblem * n)()
+    outs = []
+    for i, (a, b, out, b_sub) in enumerate(problems):
+        assert a.dim() == 2 and b.dim() == 2 and a.is_contiguous() and b.is_contiguous() and a.shape[0] == b.shape[0]
+        M, N1 = a.shape
+        N2 = b.shape[1]
+        if out is None:
+            out = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
+        else:
+            assert out.shape == (N1, N2) and out.is_contiguous() and out.dtype == torch.float32
+        outs.append(out)
+        arr[i].A, arr[i].B, arr[i].C, arr[i].b_sub = a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(b_sub)
+        arr[i].M, arr[i].N1, arr[i].N2, arr[i].lda, arr[i].ldb = M, N1, N2, a.stride(0), b.stride(0)
+    lib = L.lib()
+    pa = C.cast(arr, C.c_void_p)
+    nbytes = int(lib.acx_gemm_tn_group_workspace_bytes(n, pa))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=problems[0][0].device)
+    h = _h(problems[0][0])
+    L.check(lib.acx_gemm_tn_group(h, n, pa, ws.data_ptr(), ws.numel(), _stream()), h)
+    return outs
+
+
+def colsum_group(xs):
+    """column sums of several [rows_i, D_i] matrices in ONE launch (acx_colsum_fused_group) -> list of [D_i] tensors;
+    bit-identical to colsum() of each."""
+    n = len(xs)
+    if n == 0:
+        return []
+    lib = L.lib()
+    dev = xs[0].device
+    outs, parts = [], []
+    for x in xs:
+        assert x.dim() == 2 and x.is_contiguous() and x.shape[1] % 4 == 0 and x.data_ptr() % 16 == 0
+        rows, D = x.shape
+        outs.append(torch.empty(D, dtype=torch.float32, device=dev))
+        parts.append(torch.empty(max(int(lib.acx_colsum_fused_part_bytes(rows, D)) // 4, 4), dtype=torch.float32, device=dev))
+    ctr = _colsum_counters(dev)
+    h = _h(xs[0])
+    vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])            # noqa: E731
+    L.check(lib.acx_colsum_fused_group(h, n, vp(xs), (C.c_int32 * n)(*[x.stride(0) for x in xs]),
+                                       (C.c_int64 * n)(*[x.shape[0] for x in xs]), (C.c_int32 * n)(*[x.shape[1] for x in xs]),
+                                       vp(outs), vp(parts), ctr.data_ptr(), ctr.numel(), _stream()), h)
+    return outs
+
+
+def reduce_rows_group(parts):
+    """reduce_rows of several partial tables in ONE launch -> list of [width_i] tensors (same summation tree)."""
+    n = len(parts)
+    if n == 0:
+        return []
+    outs = [torch.empty(p.shape[1], dtype=torch.float32, device=p.device) for p in parts]
+    h = _h(parts[0])
+    vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])            # noqa: E731
+    L.check(L.lib().acx_reduce_rows_group(h, n, vp(parts), vp(outs), (C.c_int32 * n)(*[p.shape[0] for p in parts]),
+                                          (C.c_int32 * n)(*[p.shape[1] for p in parts]), _stream()), h)
+    return outs
+
+
 def reduce_rows(part: torch.Tensor) -> torch.Tensor:
     nparts, width = part.shape
     out = torch.empty(width, dtype=torch.float32, device=part.device)

@@ -291,6 +291,16 @@ size_t acx_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2);
 int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                 int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
                 int32_t cin, void* workspace, size_t workspace_bytes, void* stream);
+/* Several small weight gradients C_k[N1_k, N2_k] = A_k^T (B_k - b_sub_k) (identity row map, dense C_k) in ONE launch (+ one
+ * reduce launch): each problem runs the blocks of its own acx_gemm_tn launch, so results are bit-identical to separate calls.
+ * The temporal model's to_out / to_q|to_kv / projection gradients of a step (0.5-1.6 GFLOP each) are issued this way. */
+typedef struct acx_tn_problem {
+  const void* A; const void* B; void* C; const void* b_sub;
+  int32_t M, N1, N2, lda, ldb, reserved;
+} acx_tn_problem;
+size_t acx_gemm_tn_group_workspace_bytes(int32_t nprob, const acx_tn_problem* probs);
+int acx_gemm_tn_group(acx_ctx* ctx, int32_t nprob, const acx_tn_problem* probs, void* workspace, size_t workspace_bytes,
+                      void* stream);
 /* the same with a caller-owned zero page (>= 1024 bytes of zeros, 16-byte aligned, never written; may be NULL): the
  * 256 x 256 kernel then pads from it instead of clearing the tail of `workspace` with an extra launch per call */
 int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
@@ -411,10 +421,18 @@ int acx_bn_running_update(acx_ctx* ctx, const float* mean, const float* var_unbi
 int acx_fill_f32(acx_ctx* ctx, float* p, int64_t n, float value, void* stream);
 /* out[D] = column sums of x[rows, ld] in ONE launch, fixed summation order (bias gradients: the reference's autograd sums
  * dY over rows for every nn.Linear / nn.Conv2d bias).  part: scratch of acx_colsum_fused_part_bytes(rows, D) bytes;
- * counters: >= ceil(D / 64) uint32, ZERO before the first call and left zero by every call (caller-owned, reusable). */
+ * counters: >= ceil(D / 256) uint32, ZERO before the first call and left zero by every call (caller-owned, reusable). */
 size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D);
 int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_t rows, int32_t D, float* out, float* part,
                      size_t part_bytes, uint32_t* counters, void* stream);
+/* nprob column sums in ONE launch (part[i]: acx_colsum_fused_part_bytes(rows[i], D[i]) bytes each; `counters`: ncounters
+ * zero-at-rest uint32, at least sum_i ceil(D[i] / 256)); and nprob row-partial tables reduced in one launch
+ * (out_i[width_i] = sum_p part_i[p][:], the summation tree of acx_reduce_rows). */
+int acx_colsum_fused_group(acx_ctx* ctx, int32_t nprob, const void* const* x, const int32_t* ld, const int64_t* rows,
+                           const int32_t* D, void* const* out, void* const* part, uint32_t* counters, int32_t ncounters,
+                           void* stream);
+int acx_reduce_rows_group(acx_ctx* ctx, int32_t nprob, const void* const* part, void* const* out, const int32_t* nparts,
+                          const int32_t* width, void* stream);
 
 int acx_ctx_grad(acx_ctx* ctx, const float* dx, float* dctx, int32_t C, int32_t n_ctx, int32_t Lc, int32_t W,
                  int32_t shared_ctx, void* stream);

@@ -214,6 +214,34 @@ def test_colsum_fused_one_launch(rows, D, ld):
     assert int(ops._colsum_counters(x.device).abs().sum()) == 0
 
 
+def test_grouped_gradient_launches_equal_single_launches():
+    """acx_gemm_tn_group / acx_colsum_fused_group / acx_reduce_rows_group: every member of a group computes bit for bit what
+    its own launch computes (the temporal backward issues its small parameter gradients as three grouped launches)."""
+    g = torch.Generator().manual_seed(31)
+    shapes = [(4096, 256, 256), (4096, 768, 256), (4096, 256, 512), (1024, 64, 64), (32768, 256, 256), (512, 128, 64),
+              (4096, 768, 256), (2048, 256, 1024), (999 * 4, 16, 132)]                    # nine problems: two group launches
+    probs = []
+    for i, (M, N1, N2) in enumerate(shapes):
+        a = torch.randn(M, N1, generator=g).to(DEV)
+        b = torch.randn(M, N2, generator=g).to(DEV)
+        sub = (torch.randn(N2, generator=g) * 0.1).to(DEV) if i % 3 == 2 else None
+        probs.append((a, b, None, sub))
+    outs = ops.gemm_tn_group(probs)
+    for (a, b, _, sub), o in zip(probs, outs):
+        assert torch.equal(o, ops.gemm_tn(a, b, b_sub=sub))
+        ref = a.double().t() @ (b.double() - (sub.double() if sub is not None else 0.0))
+        assert relerr(o, ref) < 3e-6
+    dst = torch.zeros(256, 256, device=DEV)
+    assert ops.gemm_tn_group([(probs[0][0], probs[0][1], dst, None)])[0] is dst and torch.equal(dst, outs[0])
+    xs = [torch.randn(r, d, generator=g).to(DEV) for r, d in ((4096, 256), (4096, 1024), (32768, 256), (7, 64), (4096, 16), (1000, 2304))]
+    for x, o in zip(xs, ops.colsum_group(xs)):
+        assert torch.equal(o, ops.colsum(x))
+    assert int(ops._colsum_counters(xs[0].device).abs().sum()) == 0
+    parts = [torch.randn(n, w, generator=g).to(DEV) for n, w in ((512, 512), (64, 772), (1, 16), (2048, 512), (33, 100))]
+    for p_, o in zip(parts, ops.reduce_rows_group(parts)):
+        assert torch.equal(o, ops.reduce_rows(p_))
+
+
 def test_step_support_kernels():
     """The whole-step graph's support launches against torch: acx_prep_multi (strided copies / transposes, incl. the
     flipped-tap conv dX layout vs the single-purpose acx_conv_weight_dx), acx_multi_copy, acx_fill_f32, acx_bn_pack,
