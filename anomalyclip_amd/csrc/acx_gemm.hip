@@ -444,9 +444,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   if (d.bias) v += d.bias[col];
   if (d.act == ACX_ACT_QUICKGELU) v = acx_quickgelu(v);
   else if (d.act == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
-  if (d.residual) v += d.residual[(size_t)row * d.ldr + col];
-  if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(v);
-  else ((float*)d.C)[(size_t)row * d.ldc + col] = v;
+  // same order as the unsplit kernel's epilogue: (residual + (pos0 + pos1)) + activation(acc + bias)
+  float o = d.residual ? d.residual[(size_t)row * d.ldr + col] : 0.f;
+  if (d.pos0) {
+    const int l = row % d.gl, n = (row / d.gl) % d.gn;
+    o += d.pos0[(size_t)n * d.N + col] + d.pos1[(size_t)l * d.N + col];
+  }
+  o += v;
+  if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(o);
+  else ((float*)d.C)[(size_t)row * d.ldc + col] = o;
 }
 
 }  // namespace
@@ -639,7 +645,11 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     return ACX_OK;
   }
   const bool w8 = ACX_DBG_SWITCH("W8", true);   // ACX_W8=0 (debug builds) keeps the 4-wave kernels
-  if ((fast || (w8_conv && w8)) && d->workspace) {
+  // ... and f32 problems on the generic row-mapped path (a_sub / positional epilogue / test tilings: the temporal model's input
+  // projection, 64 tiles at a data-parallel rank's 4096 rows = a quarter of the chip for 59 us): same split, same reduce
+  const bool gen_split = !fast && prec == ACX_PREC_F32 && !a_bf16 && !c_bf16 && d->amap != ACX_AMAP_CONV3X3 && d->K % ke == 0 &&
+                         d->act != ACX_ACT_LEAKYRELU;
+  if ((fast || (w8_conv && w8) || gen_split) && d->workspace) {
     // skinny problems (few tiles, long K): split K over gridDim.y so the chip is filled; partial sums are
     // combined in fixed order by splitk_reduce_kernel together with the epilogue
     const int tiles = tiles_m * g.tiles_n, nkt = d->K / ke;

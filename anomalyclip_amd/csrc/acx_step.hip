@@ -173,18 +173,27 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
   }
   red[sl][q] = a;
   __syncthreads();
+  // Publishing the partial row WITHOUT a release fence: `__threadfence()` at device scope writes back every dirty line of this
+  // XCD's L2 -- after a fat GEMM that is megabytes, and it made this kernel take 33-124 us inside a training step.  The
+  // partials go out as agent-scope (write-through, sc1) stores, `s_waitcnt vmcnt(0)` waits for their acknowledgement, the
+  // arrival counter is a relaxed agent-scope atomic, and the last arriver reads the partials with agent-scope loads
+  // (MI355X_MICROARCH.md, hand-off price list: publish-large / handoff-flag).
   if (sl == 0 && c < D) {
     float4 t = red[0][q];
 #pragma unroll
     for (int k = 1; k < 4; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
-    *reinterpret_cast<float4*>(part + (size_t)slab * D + c) = t;
-    __threadfence();                               // the partial row is visible device-wide before this block's arrival
+    float* dst = part + (size_t)slab * D + c;
+    __hip_atomic_store(dst + 0, t.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 1, t.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 2, t.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 3, t.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(&counters[cg], 1u) == (unsigned)nslab - 1;
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(&counters[cg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nslab - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
   // last block of the column group to arrive: thread t adds the slabs' partials of column cg * 256 + t in slab order
   {
     const int cc = cg * 256 + threadIdx.x;
@@ -194,15 +203,15 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
       for (; p + 7 < nslab; p += 8) {
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(part + (size_t)(p + k) * D + cc);
+        for (int k = 0; k < 8; ++k) v[k] = __hip_atomic_load(part + (size_t)(p + k) * D + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s0 += v[k];
       }
-      for (; p < nslab; ++p) s0 += __builtin_nontemporal_load(part + (size_t)p * D + cc);
+      for (; p < nslab; ++p) s0 += __hip_atomic_load(part + (size_t)p * D + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out[cc] = s0;
     }
   }
-  if (threadIdx.x == 0) counters[cg] = 0;
+  if (threadIdx.x == 0) __hip_atomic_store(&counters[cg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, int ld, long long rows, int D, int rpb,

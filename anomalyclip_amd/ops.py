@@ -158,8 +158,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
                 and act != L.ACT_LEAKYRELU)                                   # acx_gemm takes the few-row kernel: no split-K
     # split-K candidates: <= 128 output tiles, or up to 256 with a long K (the convolutions of a data-parallel rank's 4096
     # rows: 256 tiles = ONE 8-wave block per CU; two K halves put two blocks on every CU for the price of a 12 us reduce)
-    if ((tiles <= 128 and K >= 256 or tiles <= 256 and K >= 1024) and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3)
-            and a_sub is None and pos0 is None and not few_rows):
+    generic_f32 = (a_sub is not None or pos0 is not None or amap in (L.AMAP_TESTTILE, L.AMAP_TILETABLE)) and prec == L.PREC_F32 \
+        and a.dtype == torch.float32 and out.dtype == torch.float32
+    if ((tiles <= 128 and K >= 256 or tiles <= 256 and K >= 1024) and not few_rows
+            and ((amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and a_sub is None and pos0 is None) or generic_f32)):
         ws = _splitk_workspace(a.device, min(16, 512 // tiles) * M * N * 4)     # skinny problem: let the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a)
