@@ -155,7 +155,7 @@ _SIGS = {
     "acx_gemm_tn_group_workspace_bytes": (c_size_t, [c_int32, c_void_p]),
     "acx_gemm_tn_group": (C.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "acx_colsum_fused_part_bytes": (c_size_t, [c_int64, c_int32]),
-    "acx_colsum_fused": (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "acx_colsum_fused": (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),
     "acx_colsum_fused_group": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32), C.POINTER(c_int64),
                                          C.POINTER(c_int32), C.POINTER(c_void_p), C.POINTER(c_void_p), c_void_p, c_int32, c_void_p]),
     "acx_reduce_rows_group": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int32),

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void adamw_multi_dev_kernel(const AdamwDevSegs
 // so the launch is replayable from a HIP graph.  Replaces colsum_partials + reduce_rows (two launches per bias gradient).
 __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
                                                   float* __restrict__ part, float* __restrict__ out,
-                                                  unsigned int* __restrict__ counters, const int cg, const int slab, const int nslab) {
+                                                  unsigned int* __restrict__ counters, const int cg, const int slab, const int nslab,
+                                                  const float beta) {
   // block = 256 columns (64 float4 lanes: one wave-level load covers 1 KB of ONE row) x 4 row slices (the four waves);
   // slice k adds rows r0 + k, r0 + k + 4, ... in order, the four slices are added in slice order
   __shared__ float4 red[4][64];
@@ -156,15 +157,12 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < D) {
     long long r = r0 + sl;
-    for (; r + 12 < r1; r += 16) {                 // four rows in flight per lane (independent loads, fixed add order)
-      const float4 v0 = *reinterpret_cast<const float4*>(x + r * ld + c);
-      const float4 v1 = *reinterpret_cast<const float4*>(x + (r + 4) * ld + c);
-      const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 8) * ld + c);
-      const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 12) * ld + c);
-      a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
-      a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
-      a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
-      a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+    for (; r + 28 < r1; r += 32) {                 // eight rows in flight per lane (independent loads, fixed add order)
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(x + (r + 4 * k) * ld + c);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
     }
     for (; r < r1; r += 4) {
       const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
@@ -194,21 +192,40 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
     last = __hip_atomic_fetch_add(&counters[cg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nslab - 1;
   __syncthreads();
   if (!last) return;
-  // last block of the column group to arrive: thread t adds the slabs' partials of column cg * 256 + t in slab order
+  // last block of the column group to arrive: 64 float4 columns x 4 slab lanes; lane l adds slabs l, l + 4, ... in order (four
+  // slabs = sixteen scalar loads in flight), the four lane sums are then added in lane order -- a fixed tree
   {
-    const int cc = cg * 256 + threadIdx.x;
-    if (cc < D) {
-      float s0 = 0.f;
-      int p = 0;
-      for (; p + 7 < nslab; p += 8) {
-        float v[8];
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D) {
+      int p = sl;
+      for (; p + 12 < nslab; p += 16) {
+        float v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = __hip_atomic_load(part + (size_t)(p + k) * D + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s0 += v[k];
+          for (int j = 0; j < 4; ++j)
+            v[4 * k + j] = __hip_atomic_load(part + (size_t)(p + 4 * k) * D + c + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0.x += v[4 * k]; s0.y += v[4 * k + 1]; s0.z += v[4 * k + 2]; s0.w += v[4 * k + 3]; }
       }
-      for (; p < nslab; ++p) s0 += __hip_atomic_load(part + (size_t)p * D + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out[cc] = s0;
+      for (; p < nslab; p += 4) {
+        s0.x += __hip_atomic_load(part + (size_t)p * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s0.y += __hip_atomic_load(part + (size_t)p * D + c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s0.z += __hip_atomic_load(part + (size_t)p * D + c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s0.w += __hip_atomic_load(part + (size_t)p * D + c + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    red[sl][q] = s0;
+    __syncthreads();
+    if (sl == 0 && c < D) {
+      float4 t = red[0][q];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
+      if (beta != 0.f) {
+        const float4 o = *reinterpret_cast<const float4*>(out + c);
+        t.x += beta * o.x; t.y += beta * o.y; t.z += beta * o.z; t.w += beta * o.w;
+      }
+      *reinterpret_cast<float4*>(out + c) = t;
     }
   }
   if (threadIdx.x == 0) __hip_atomic_store(&counters[cg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -216,8 +233,8 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
 
 __global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
                                                            float* __restrict__ part, float* __restrict__ out,
-                                                           unsigned int* __restrict__ counters) {
-  colsum_fused_body(x, ld, rows, D, rpb, part, out, counters, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+                                                           unsigned int* __restrict__ counters, float beta) {
+  colsum_fused_body(x, ld, rows, D, rpb, part, out, counters, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, beta);
 }
 
 // several column sums in one launch (the bias gradients of a backward pass): flat block index -> (problem, column group, slab)
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(256) void colsum_fused_group_kernel(const ColsumGro
   const int cgs = G.cgs[k];
   const int slab = local / cgs;
   colsum_fused_body(G.x[k], G.ld[k], G.rows[k], G.D[k], G.rpb[k], G.part[k], G.out[k], counters + G.ctr0[k], local - slab * cgs, slab,
-                    G.nslab[k]);
+                    G.nslab[k], 0.f);
 }
 
 // out_k[c] = sum_p part_k[p][c] for several partial tables in one launch (LayerNorm / classifier parameter gradients): fixed
@@ -302,6 +319,17 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long l
 }
 
 }  // namespace
+
+static inline void colsum_geometry(int64_t rows, int32_t D, int* cgs, int* nslab, int* rpb) {
+  // at most 64 slabs of >= 64 rows: the last arriver walks the slabs' partials with memory-latency-bound batches (~1 us per
+  // four slabs per lane), so the slab count, not the block count, sets the kernel's tail (512 slabs: 32 batches = 30 us)
+  const int c = (D + 255) / 256;
+  long long ns = rows / 64;
+  if (ns > 64) ns = 64;
+  if (ns < 1) ns = 1;
+  const int r = (int)((rows + ns - 1) / ns);
+  *cgs = c; *rpb = r; *nslab = (int)((rows + r - 1) / r);
+}
 
 extern "C" int acx_prep_multi(acx_ctx* ctx, int32_t nseg, const acx_prep_seg* segs, void* stream) {
   if (nseg <= 0) return ACX_OK;
@@ -422,35 +450,21 @@ extern "C" int acx_adamw_multi_dev(acx_ctx* ctx, int32_t nseg, void* const* p, c
 }
 
 extern "C" int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_t rows, int32_t D, float* out, float* part,
-                                size_t part_bytes, uint32_t* counters, void* stream) {
+                                size_t part_bytes, uint32_t* counters, float beta, void* stream) {
   if (!x || !out || !part || !counters) return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused: null pointer%s");
   if (rows <= 0 || D <= 0) return ACX_OK;
   if (D % 4 || ld % 4 || D > 256 * 256 || (((uintptr_t)x | (uintptr_t)part) & 15))
     return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused: D / ld multiples of 4, D <= 16384, 16-byte aligned x / part%s");
   // slabs: enough blocks to fill the chip a few times over, at least 64 rows each
-  const int cgs = (D + 255) / 256;
-  long long nslab = (768 + cgs - 1) / cgs;        // ~3 blocks per CU
-  if (nslab > 256) nslab = 256;
-  if (nslab * 16 > rows) nslab = (rows + 15) / 16;
-  if (nslab < 1) nslab = 1;
-  const int rpb = (int)((rows + nslab - 1) / nslab);
-  nslab = (rows + rpb - 1) / rpb;
+  int cgs, nslab_i, rpb;
+  colsum_geometry(rows, D, &cgs, &nslab_i, &rpb);
+  long long nslab = nslab_i;
   if ((size_t)nslab * D * sizeof(float) > part_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_colsum_fused: partial buffer too small%s");
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   hipLaunchKernelGGL(colsum_fused_kernel, dim3((unsigned)cgs, (unsigned)nslab), dim3(256), 0, (hipStream_t)stream, x, ld,
-                     (long long)rows, D, rpb, part, out, counters);
+                     (long long)rows, D, rpb, part, out, counters, beta);
   ACX_CHECK_LAUNCH(ctx, "acx_colsum_fused");
   return ACX_OK;
-}
-
-static inline void colsum_geometry(int64_t rows, int32_t D, int* cgs, int* nslab, int* rpb) {
-  const int c = (D + 255) / 256;
-  long long ns = (768 + c - 1) / c;
-  if (ns > 256) ns = 256;
-  if (ns * 16 > rows) ns = (rows + 15) / 16;
-  if (ns < 1) ns = 1;
-  const int r = (int)((rows + ns - 1) / ns);
-  *cgs = c; *rpb = r; *nslab = (int)((rows + r - 1) / r);
 }
 
 extern "C" int acx_colsum_fused_group(acx_ctx* ctx, int32_t nprob, const void* const* x, const int32_t* ld, const int64_t* rows,
@@ -514,11 +528,8 @@ extern "C" int acx_reduce_rows_group(acx_ctx* ctx, int32_t nprob, const void* co
 
 extern "C" size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D) {
   if (rows <= 0 || D <= 0) return 0;
-  const int cgs = (D + 255) / 256;
-  long long nslab = (768 + cgs - 1) / cgs;        // ~3 blocks per CU
-  if (nslab > 256) nslab = 256;
-  if (nslab * 16 > rows) nslab = (rows + 15) / 16;
-  if (nslab < 1) nslab = 1;
+  int cgs, nslab, rpb;
+  colsum_geometry(rows, D, &cgs, &nslab, &rpb);
   return (size_t)(nslab + 1) * D * sizeof(float);
 }
 

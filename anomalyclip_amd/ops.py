@@ -310,7 +310,7 @@ def colsum_(acc: torch.Tensor, x: torch.Tensor) -> None:
     256-row slab -- serialises 65 k atomics on 512 addresses at the benchmark shape: 78 us for 67 MB, order-dependent bits.)"""
     x = x.reshape(-1, x.shape[-1])
     assert x.is_contiguous()
-    axpby_(acc, colsum(x), 1.0, 1.0)
+    colsum(x, acc=acc)
 
 
 def prompt_embed(prefix, ctxv, suffix, pos: Optional[torch.Tensor], n_ctx: int, Lout: Optional[int] = None) -> torch.Tensor:
@@ -683,21 +683,25 @@ def axpby_(y: torch.Tensor, x: torch.Tensor, a: float, b: float) -> None:
     L.check(L.lib().acx_axpby(h, x.data_ptr(), y.data_ptr(), y.numel(), a, b, _stream()), h)
 
 
-def colsum(x: torch.Tensor, D: Optional[int] = None) -> torch.Tensor:
-    """deterministic column sums of x[rows, ld] (first D columns)."""
+def colsum(x: torch.Tensor, D: Optional[int] = None, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """deterministic column sums of x[rows, ld] (first D columns); `acc` [D]: acc += sums in the same launch."""
     assert x.dim() == 2 and x.is_contiguous()
     rows, ld = x.shape
     D = D or ld
-    if D % 4 == 0 and ld % 4 == 0 and D <= 16384 and x.data_ptr() % 16 == 0:
+    if D % 4 == 0 and ld % 4 == 0 and D <= 16384 and x.data_ptr() % 16 == 0 and (acc is None or acc.data_ptr() % 16 == 0):
         # one launch: slab partials + last-arriver reduce in slab order (acx_colsum_fused)
         lib = L.lib()
         nbytes = int(lib.acx_colsum_fused_part_bytes(rows, D))
         part = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=x.device)
-        out = torch.empty(D, dtype=torch.float32, device=x.device)
+        out = acc if acc is not None else torch.empty(D, dtype=torch.float32, device=x.device)
         h = _h(x)
         L.check(lib.acx_colsum_fused(h, x.data_ptr(), ld, rows, D, out.data_ptr(), part.data_ptr(), part.numel() * 4,
-                                     _colsum_counters(x.device).data_ptr(), _stream()), h)
+                                     _colsum_counters(x.device).data_ptr(), 1.0 if acc is not None else 0.0, _stream()), h)
         return out
+    if acc is not None:
+        s_ = colsum(x, D)
+        axpby_(acc, s_, 1.0, 1.0)
+        return acc
     rpb = 128
     nb = (rows + rpb - 1) // rpb
     part = torch.empty(nb, D, dtype=torch.float32, device=x.device)

@@ -421,10 +421,11 @@ int acx_bn_running_update(acx_ctx* ctx, const float* mean, const float* var_unbi
 int acx_fill_f32(acx_ctx* ctx, float* p, int64_t n, float value, void* stream);
 /* out[D] = column sums of x[rows, ld] in ONE launch, fixed summation order (bias gradients: the reference's autograd sums
  * dY over rows for every nn.Linear / nn.Conv2d bias).  part: scratch of acx_colsum_fused_part_bytes(rows, D) bytes;
- * counters: >= ceil(D / 256) uint32, ZERO before the first call and left zero by every call (caller-owned, reusable). */
+ * counters: >= ceil(D / 256) uint32, ZERO before the first call and left zero by every call (caller-owned, reusable).
+ * out = sums + beta * out (beta = 0: overwrite; 1: the ncentroid accumulation of anomaly_clip_module.py:145-171). */
 size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D);
 int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_t rows, int32_t D, float* out, float* part,
-                     size_t part_bytes, uint32_t* counters, void* stream);
+                     size_t part_bytes, uint32_t* counters, float beta, void* stream);
 /* nprob column sums in ONE launch (part[i]: acx_colsum_fused_part_bytes(rows[i], D[i]) bytes each; `counters`: ncounters
  * zero-at-rest uint32, at least sum_i ceil(D[i] / 256)); and nprob row-partial tables reduced in one launch
  * (out_i[width_i] = sum_p part_i[p][:], the summation tree of acx_reduce_rows). */
