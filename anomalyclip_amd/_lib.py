@@ -138,6 +138,7 @@ _SIGS = {
     "acx_gather_segments": (C.c_int, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "acx_scatter_segments": (C.c_int, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "acx_mil_loss": (C.c_int, [c_void_p] * 13 + [c_size_t] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p]),
+    "acx_mil_loss_one": (C.c_int, [c_void_p] * 13 + [c_size_t] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "acx_adamw": (C.c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int32, c_void_p]),
     "acx_multi_axpy": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int64), c_float, c_void_p]),
     "acx_adamw_multi": (C.c_int, [c_void_p, c_int32] + [C.POINTER(c_void_p)] * 4 + [C.POINTER(c_int64), C.POINTER(C.c_double),

@@ -1208,11 +1208,12 @@ struct LossArgs {
   float l_dir_abn, l_dir_nor, l_topk_abn, l_bottomk_abn, l_topk_nor, l_smooth, l_sparse;
   const float* gout_ptr;   // device scalar: upstream gradient of the total cost (NULL -> 1)
 };
-// thread per frame row; block partial sums of the 7 terms -> part[blk][8]
-__global__ __launch_bounds__(256) void loss_rows_kernel(const LossArgs a) {
-  __shared__ float red[4];
+// thread per frame row; block partial sums of the 7 terms -> part[blk][8].  PUBLISH: the partials leave as agent-scope
+// (write-through) stores for the one-launch form, whose last-arriving block adds them up (see loss_fused_kernel)
+template <bool PUBLISH>
+__device__ __forceinline__ void loss_rows_body(const LossArgs& a, const int blk, float* red) {
   const int64_t R = (int64_t)a.B * a.N * a.Lg;
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = (int64_t)blk * 256 + threadIdx.x;
   const float gout = a.gout_ptr ? a.gout_ptr[0] : 1.f;
   float t_dir_nor = 0.f, t_topk_abn = 0.f, t_bot_abn = 0.f, t_topk_nor = 0.f, t_smooth = 0.f, t_sparse = 0.f;
   if (r < R) {
@@ -1278,15 +1279,22 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(const LossArgs a) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const float tot = block_sum(vals[k], red);
-    if (threadIdx.x == 0) a.part[(size_t)blockIdx.x * 8 + k] = tot;
+    if (threadIdx.x == 0) {
+      if (PUBLISH) __hip_atomic_store(a.part + (size_t)blk * 8 + k, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else a.part[(size_t)blk * 8 + k] = tot;
+    }
   }
 }
-// thread per row of sim_topk (abnormal part only contributes): ldir_abn = -mean(own-class logit)
-__global__ __launch_bounds__(256) void loss_topk_kernel(const LossArgs a, float* __restrict__ part2) {
+__global__ __launch_bounds__(256) void loss_rows_kernel(const LossArgs a) {
   __shared__ float red[4];
+  loss_rows_body<false>(a, (int)blockIdx.x, red);
+}
+// thread per row of sim_topk (abnormal part only contributes): ldir_abn = -mean(own-class logit)
+template <bool PUBLISH>
+__device__ __forceinline__ void loss_topk_body(const LossArgs& a, float* __restrict__ part2, const int blk, float* red) {
   const int64_t RT = (int64_t)a.B * a.K * a.Lg;
   const int64_t RA = (int64_t)(a.B / 2) * a.K * a.Lg;
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = (int64_t)blk * 256 + threadIdx.x;
   const float gout = a.gout_ptr ? a.gout_ptr[0] : 1.f;
   float t = 0.f;
   if (r < RT) {
@@ -1300,7 +1308,14 @@ __global__ __launch_bounds__(256) void loss_topk_kernel(const LossArgs a, float*
     }
   }
   const float tot = block_sum(t, red);
-  if (threadIdx.x == 0) part2[blockIdx.x] = tot;
+  if (threadIdx.x == 0) {
+    if (PUBLISH) __hip_atomic_store(part2 + blk, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else part2[blk] = tot;
+  }
+}
+__global__ __launch_bounds__(256) void loss_topk_kernel(const LossArgs a, float* __restrict__ part2) {
+  __shared__ float red[4];
+  loss_topk_body<false>(a, part2, (int)blockIdx.x, red);
 }
 // final: losses[8] = (cost, ldir_abn, ldir_nor, ltopk_abn, lbottomk_abn, ltopk_nor, lsmooth, lsparse)
 __global__ void loss_final_kernel(const LossArgs a, const float* __restrict__ part, int nparts, const float* __restrict__ part2,
@@ -1321,6 +1336,58 @@ __global__ void loss_final_kernel(const LossArgs a, const float* __restrict__ pa
   losses[1] = ldir_abn; losses[2] = ldir_nor; losses[3] = ltopk_abn; losses[4] = lbot_abn;
   losses[5] = ltopk_nor; losses[6] = lsmooth; losses[7] = lsparse;
   losses[0] = ldir_abn + ldir_nor + ltopk_abn + lbot_abn + ltopk_nor + lsmooth + lsparse;
+}
+
+// The three launches above as ONE: blocks [0, np1) run the frame rows, blocks [np1, np1 + np2) the top-k rows; every block
+// publishes its partial sums write-through (no release fence: a device-scope fence would write back the whole L2 of its
+// XCD), bumps a relaxed arrival counter, and the last block to arrive forms the eight loss terms: 7 x 32 lanes add the parts
+// p = lane, lane + 32, ... in f64, the 32 lane sums of a term are added in lane order -- a fixed tree.
+__global__ __launch_bounds__(256) void loss_fused_kernel(const LossArgs a, float* __restrict__ part2, int np1, int np2,
+                                                         float* __restrict__ losses, unsigned int* __restrict__ counter) {
+  __shared__ float red[4];
+  __shared__ double fin[7][32];
+  __shared__ bool last;
+  const int b = (int)blockIdx.x;
+  if (b < np1) loss_rows_body<true>(a, b, red);
+  else loss_topk_body<true>(a, part2, b - np1, red);
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(np1 + np2) - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  const int k = threadIdx.x >> 5, j = threadIdx.x & 31;
+  if (k < 7) {
+    double acc = 0.0;
+    if (k < 6) {
+      for (int p = j; p < np1; p += 32)
+        acc += (double)__hip_atomic_load(a.part + (size_t)p * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (int p = j; p < np2; p += 32) acc += (double)__hip_atomic_load(part2 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    fin[k][j] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double t[7];
+  for (int q = 0; q < 7; ++q) {
+    double sacc = 0.0;
+    for (int l = 0; l < 32; ++l) sacc += fin[q][l];
+    t[q] = sacc;
+  }
+  const double d = t[6];
+  const double per = (double)a.N * a.Lg, Bh = a.B / 2, Bn = a.B - a.B / 2;
+  const float ldir_abn = (float)(-a.l_dir_abn * d / (Bh * a.K * a.Lg));
+  const float ldir_nor = (float)(a.l_dir_nor * t[0] / (Bn * per));
+  const float ltopk_abn = (float)(a.l_topk_abn * t[1] / (Bh * a.K * a.Lg));
+  const float lbot_abn = (float)(a.l_bottomk_abn * t[2] / (Bh * a.K * a.Lg));
+  const float ltopk_nor = (float)(a.l_topk_nor * t[3] / (Bn * a.K * a.Lg));
+  const float lsmooth = (float)(a.l_smooth * t[4]);
+  const float lsparse = (float)(a.l_sparse * t[5] / (Bh * per));
+  losses[1] = ldir_abn; losses[2] = ldir_nor; losses[3] = ltopk_abn; losses[4] = lbot_abn;
+  losses[5] = ltopk_nor; losses[6] = lsmooth; losses[7] = lsparse;
+  losses[0] = ldir_abn + ldir_nor + ltopk_abn + lbot_abn + ltopk_nor + lsmooth + lsparse;
+  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ AdamW (torch.optim.AdamW, no amsgrad)
@@ -1754,6 +1821,15 @@ extern "C" int acx_mil_loss(acx_ctx* ctx, const float* sim, const float* sim_top
                             float* dsim, float* dsim_topk, float* dscores, float* losses, float* workspace,
                             size_t workspace_floats, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K, int32_t normal_id,
                             const float* lambdas /* [7] */, const float* gout, void* stream) {
+  return acx_mil_loss_one(ctx, sim, sim_topk, labels, scores, idx_topk_abn, idx_topk_nor, idx_bottomk_abn, dsim, dsim_topk, dscores,
+                          losses, workspace, workspace_floats, B, N, Lg, C1, K, normal_id, lambdas, gout, nullptr, stream);
+}
+
+extern "C" int acx_mil_loss_one(acx_ctx* ctx, const float* sim, const float* sim_topk, const int64_t* labels, const float* scores,
+                                const int64_t* idx_topk_abn, const int64_t* idx_topk_nor, const int64_t* idx_bottomk_abn,
+                                float* dsim, float* dsim_topk, float* dscores, float* losses, float* workspace,
+                                size_t workspace_floats, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K, int32_t normal_id,
+                                const float* lambdas /* [7] */, const float* gout, uint32_t* counter, void* stream) {
   if (!sim || !sim_topk || !labels || !scores || !idx_topk_abn || !idx_topk_nor || !idx_bottomk_abn || !dsim || !dsim_topk ||
       !dscores || !losses || !workspace || !lambdas)
     return acx_fail(ctx, ACX_E_BADARG, "acx_mil_loss: null pointer%s");
@@ -1772,6 +1848,11 @@ extern "C" int acx_mil_loss(acx_ctx* ctx, const float* sim, const float* sim_top
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_OTHER, s);
   float* part2 = workspace + (size_t)np1 * 8;
+  if (counter) {
+    hipLaunchKernelGGL(loss_fused_kernel, dim3(np1 + np2), dim3(256), 0, s, a, part2, np1, np2, losses, counter);
+    ACX_CHECK_LAUNCH(ctx, "acx_mil_loss");
+    return ACX_OK;
+  }
   hipLaunchKernelGGL(loss_rows_kernel, dim3(np1), dim3(256), 0, s, a);
   hipLaunchKernelGGL(loss_topk_kernel, dim3(np2), dim3(256), 0, s, a, part2);
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, a, (const float*)workspace, np1, (const float*)part2, np2, losses);

@@ -761,10 +761,11 @@ def mil_loss(sim, sim_topk, labels, scores, idx_topk_abn, idx_topk_nor, idx_bott
     ws = torch.empty(nws, dtype=torch.float32, device=dev)
     lam = (ctypes.c_float * 7)(*[float(x) for x in lambdas])
     h = _h(sim)
-    L.check(L.lib().acx_mil_loss(h, sim.data_ptr(), sim_topk.data_ptr(), labels.data_ptr(), scores.data_ptr(),
-                                 idx_topk_abn.data_ptr(), idx_topk_nor.data_ptr(), idx_bottomk_abn.data_ptr(), dsim.data_ptr(),
-                                 dtopk.data_ptr(), dsc.data_ptr(), losses.data_ptr(), ws.data_ptr(), nws, B, N, Lg, C1, K,
-                                 normal_id, ctypes.cast(lam, ctypes.c_void_p), _ptr(gout), _stream()), h)
+    ctr = _colsum_counters(dev)[255:]                       # the last arrival counter of the stream's table: the loss's own
+    L.check(L.lib().acx_mil_loss_one(h, sim.data_ptr(), sim_topk.data_ptr(), labels.data_ptr(), scores.data_ptr(),
+                                     idx_topk_abn.data_ptr(), idx_topk_nor.data_ptr(), idx_bottomk_abn.data_ptr(), dsim.data_ptr(),
+                                     dtopk.data_ptr(), dsc.data_ptr(), losses.data_ptr(), ws.data_ptr(), nws, B, N, Lg, C1, K,
+                                     normal_id, ctypes.cast(lam, ctypes.c_void_p), _ptr(gout), ctr.data_ptr(), _stream()), h)
     return losses, dsim, dtopk, dsc
 
 

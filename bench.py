@@ -398,11 +398,17 @@ def peaks_measured(dev, local_rank):
     out["hbm_copy_TBps"] = {"measured": round(2 * n / dt / 1e12, 3), "nominal": HBM_PEAK_TBPS,
                             "ratio": round(2 * n / dt / 1e12 / HBM_PEAK_TBPS, 4),
                             "note": "read + write bytes of a 1 GiB float4 grid-stride copy"}
+    # write-only stream (acx_fill_f32 over the same GiB): the roof of the write-heavy kernels (frame preprocessing writes
+    # 2.6x what it reads) is not the copy rate
+    from anomalyclip_amd import ops as _ops
+    dstf = dst.view(torch.float32)
+    dtf = _event_time(lambda: _ops.fill_(dstf, 1.0), 10, 2)
+    out["hbm_fill_TBps"] = {"measured": round(n / dtf / 1e12, 3), "note": "bytes written by a 1 GiB fill (write-only stream)"}
     del src, dst            # stays in torch's cache: torch.cuda.empty_cache() here, with the training legs' HIP graphs alive, made
     return out              # every later allocation of the process a fresh hipMalloc (configs[4] head leg: 1.7 -> 12.7 ms per step)
 
 
-def hbm_kernel_legs(dev, copy_TBps):
+def hbm_kernel_legs(dev, copy_TBps, fill_TBps=None):
     """The HBM-bound kernels of the path at their benchmark shapes (UCF, B = 64; ViT LayerNorm at 512 frames): algorithmic
     bytes / HIP-event time, as a fraction of the nominal 8 TB/s and of the copy rate measured on this box.  Inputs
     smaller than the 256 MiB Infinity Cache are ROTATED over >= 512 MB of distinct buffers so that a repeat does not read
@@ -448,6 +454,11 @@ def hbm_kernel_legs(dev, copy_TBps):
     entry("preprocess_frames", FRAMES_PER_CLIP * (240 * 320 * 3 + 3 * 224 * 224 * 4),
           _event_time(lambda: preprocess_frames(nxt(fr)), 10),
           "512 frames 240x320x3 u8 read + (512, 3, 224, 224) f32 written; Pillow-exact two-pass bicubic, 8-bit intermediate in LDS")
+    if fill_TBps:
+        wb, rb = FRAMES_PER_CLIP * 3 * 224 * 224 * 4, FRAMES_PER_CLIP * 240 * 320 * 3
+        floor_us = (wb / (fill_TBps * 1e12) + rb / (copy_TBps * 1e12)) * 1e6
+        out["preprocess_frames"]["frac_of_write_read_floor"] = round(floor_us / out["preprocess_frames"]["us"], 4)
+        out["preprocess_frames"]["write_read_floor_us"] = round(floor_us, 1)
     del fr
     x1s, x2s = ring(8, rows, E), ring(8, rows, E)
     cw, cb = torch.randn(1, E, generator=g, device=dev) * 0.1, torch.zeros(1, device=dev)
@@ -732,7 +743,7 @@ def main():
                 try:
                     pk = peaks_measured(dev, local_rank)
                     extra["peaks_measured"] = pk
-                    extra["hbm_kernels"] = hbm_kernel_legs(dev, pk["hbm_copy_TBps"]["measured"])
+                    extra["hbm_kernels"] = hbm_kernel_legs(dev, pk["hbm_copy_TBps"]["measured"], pk.get("hbm_fill_TBps", {}).get("measured"))
                 except Exception as e:  # noqa: BLE001
                     extra["peaks_measured_error"] = f"{type(e).__name__}: {e}"[:300]
             try:

@@ -368,6 +368,14 @@ int acx_mil_loss(acx_ctx* ctx, const float* sim, const float* sim_topk, const in
                  float* dsim, float* dsim_topk, float* dscores, float* losses, float* workspace,
                  size_t workspace_floats, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K, int32_t normal_id,
                  const float* lambdas, const float* gout /* device scalar or NULL (=1) */, void* stream);
+/* acx_mil_loss as ONE launch: `counter` = one uint32, zero before the first call and left zero by every call (caller-owned;
+ * NULL = the three-launch form above).  The block partials are added in a different (fixed) order than the three-launch
+ * form's serial sum, in f64 either way. */
+int acx_mil_loss_one(acx_ctx* ctx, const float* sim, const float* sim_topk, const int64_t* labels, const float* scores,
+                 const int64_t* idx_topk_abn, const int64_t* idx_topk_nor, const int64_t* idx_bottomk_abn,
+                 float* dsim, float* dsim_topk, float* dscores, float* losses, float* workspace,
+                 size_t workspace_floats, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K, int32_t normal_id,
+                 const float* lambdas, const float* gout, uint32_t* counter, void* stream);
 /* acx_adamw: one torch.optim.AdamW step (decoupled weight decay, bias correction; step counts from 1). */
 int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int32_t step, void* stream);
