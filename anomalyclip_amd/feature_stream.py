@@ -19,7 +19,7 @@ class FeatureStream:
     """Iterates over videos: yields (features [1, ncrops, 512*S, D] on `device`, num_frames, segment_size, path)."""
 
     def __init__(self, paths: Sequence[str], num_segments: int = 32, seg_length: int = 16, stride: int = 1,
-                 ncrops: int = 1, device: Optional[torch.device] = None, max_tiles: int = 64):
+                 ncrops: int = 1, device: Optional[torch.device] = None, max_tiles: int = 64, readers: int = 4):
         self.paths = list(paths)
         self.N, self.L, self.stride, self.ncrops = num_segments, seg_length, stride, ncrops
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -27,6 +27,7 @@ class FeatureStream:
         self._pinned = [None, None]
         self._copied = [None, None]      # per slot: event recorded after the last H2D copy that READ the pinned buffer
         self.max_tiles = max_tiles
+        self.readers = max(1, int(readers))       # threads that fill the videos of one batched() group concurrently
 
     @staticmethod
     def _npy_header(fh):
@@ -146,12 +147,26 @@ class FeatureStream:
         D = geo[0][3]
         need = sum(self.ncrops * g[2] * D for g in geo)
         flat = self._slot_buffer(slot, need, D)[:need]
-        off = 0
+        jobs, off = [], 0
         for p, (T, S, rows, _) in zip(paths, geo):
             n = self.ncrops * rows * D
-            self._fill(p, flat[off:off + n].view(self.ncrops, rows, D).numpy(), T, rows)
+            jobs.append((p, flat[off:off + n].view(self.ncrops, rows, D).numpy(), T, rows))
             off += n
+        # the videos of a group land in disjoint slices of the pinned slot: filled by `self.readers` threads at once (one
+        # thread copies out of the page cache at ~8-10 GB/s; file reads and large numpy copies release the GIL)
+        if self.readers > 1 and len(jobs) > 1:
+            list(self._fill_pool().map(lambda j: self._fill(*j), jobs))
+        else:
+            for j in jobs:
+                self._fill(*j)
         return flat.view(-1, D), [(T, S, rows, p) for p, (T, S, rows, _) in zip(paths, geo)]
+
+    def _fill_pool(self):
+        pool = self.__dict__.get("_pool")
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self.__dict__["_pool"] = ThreadPoolExecutor(max_workers=self.readers)
+        return pool
 
     def batched(self, videos: int = 8, max_tiles: int = 96):
         """Iterates over GROUPS of consecutive videos: yields (features [sum_v ncrops * rows_v, D] on the device -- video after
