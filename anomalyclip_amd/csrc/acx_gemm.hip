@@ -760,6 +760,27 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
 #undef ACX_RING_SEL
 #undef ACX_RING_L
   } else
+  if (prec == ACX_PREC_BF16 && a_bf16 && !no_dma && d->amap == ACX_AMAP_CONV3X3 && g.ksplit == 1 && d->zero_page &&
+      !((uintptr_t)d->zero_page & 15) && d->cin % 64 == 0 && d->M % 128 == 0 && d->lda % 8 == 0 && d->ldw % 8 == 0 && !d->a_sub &&
+      !d->pos0 && d->act != ACX_ACT_QUICKGELU && !(d->act == ACX_ACT_LEAKYRELU && d->residual)) {
+    // bf16 implicit-GEMM convolutions (the XD-Violence head): the 128x128 LDS-DMA kernel with a per-tap source row
+    const size_t dlds = 2 * DMA_STAGE_B;
+    g.zeros = (const float*)d->zero_page;
+#define ACX_DMAC(CB, ACT, RES)                                                                      \
+  do {                                                                                              \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<CB, ACT, RES, 1>,                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);             \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<CB, ACT, RES, 1>), grid, block, dlds, s, g);           \
+  } while (0)
+    if (d->act == ACX_ACT_LEAKYRELU) { if (c_bf16) ACX_DMAC(1, 2, 0); else ACX_DMAC(0, 2, 0); }
+    else if (d->residual) { if (c_bf16) ACX_DMAC(1, 0, 1); else ACX_DMAC(0, 0, 1); }
+    else { if (c_bf16) ACX_DMAC(1, 0, 0); else ACX_DMAC(0, 0, 0); }
+#undef ACX_DMAC
+  } else
   if (fast && g.ksplit == 1 && prec == ACX_PREC_BF16 && a_bf16 && !no_dma && d->lda % 8 == 0 && d->ldw % 8 == 0) {
     const size_t dlds = 2 * DMA_STAGE_B;
 #define ACX_DMA(CB, ACT, RES)                                                                       \

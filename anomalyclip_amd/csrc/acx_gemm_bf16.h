@@ -21,7 +21,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <int C_BF16, int ACT, int RES>
+// CV = 1: implicit-GEMM 3x3 convolution over the (gn, gl) token grid (K = 9 cin, W laid out [N][tap][cin], cin % 64 == 0 so a
+// K-step lies inside one tap): the DMA source of an A row becomes the row SHIFTED by the K-step's tap, or the caller's zero
+// page when the tap falls outside the grid -- no im2col buffer, no LDS-side predicate.  (The XD-Violence head's bf16
+// convolutions ran on the register-staged generic kernel at 435-520 TFLOP/s.)
+template <int C_BF16, int ACT, int RES, int CV = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -48,16 +52,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(const Args g
   } while (0)
   DMA_SRC(0); DMA_SRC(1); DMA_SRC(2); DMA_SRC(3);
 #undef DMA_SRC
+  // conv: grid coordinates of this lane's four A rows (tiles hold whole rows of the token grid: M % 128 == 0)
+  int cn0 = 0, cn1 = 0, cn2 = 0, cn3 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cl3 = 0;
+  const char* zsrc = nullptr;
+  int kt_per_tap = 1;
+  if constexpr (CV != 0) {
+    const int grid_sz = d.gn * d.gl;
+#define DMA_CRD(j)                                                                                 \
+  do {                                                                                             \
+    const int rem_ = (m0 + (4 * wave + (j)) * 8 + (lane >> 3)) % grid_sz;                          \
+    cn##j = rem_ / d.gl; cl##j = rem_ - cn##j * d.gl;                                              \
+  } while (0)
+    DMA_CRD(0); DMA_CRD(1); DMA_CRD(2); DMA_CRD(3);
+#undef DMA_CRD
+    zsrc = (const char*)g.zeros + (lane & 7) * 16;
+    kt_per_tap = d.cin / 64;
+  }
   const int dma_off = 4 * wave * 1024;             // this wave's 4 KB slice of each operand image
+  // A source of instruction j at K-step kt_: identity -> row + kt_ * 128 B; conv -> the row shifted by the tap, channel block kc_
+#define DMA_ASRC(j, kt_, tap_, kc_, dn_, dl_)                                                      \
+  (CV == 0 ? ga##j + (size_t)(kt_) * 128                                                           \
+           : (((unsigned)(cn##j + (dn_)) < (unsigned)d.gn && (unsigned)(cl##j + (dl_)) < (unsigned)d.gl)                \
+                  ? ga##j + ((ptrdiff_t)((dn_) * d.gl + (dl_)) * d.lda) * 2 + (size_t)(kc_) * 128 : zsrc))
 #define DMA_ISSUE(stage, kt_)                                                                      \
   do {                                                                                             \
     char* sA_ = smem + (stage) * DMA_STAGE_B + dma_off;                                            \
     char* sW_ = sA_ + DMA_OP_B;                                                                    \
     const size_t ko_ = (size_t)(kt_) * 128;                                                        \
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga0 + ko_), (lds_void_t*)(sA_), 16, 0, 0);       \
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga1 + ko_), (lds_void_t*)(sA_ + 1024), 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga2 + ko_), (lds_void_t*)(sA_ + 2048), 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga3 + ko_), (lds_void_t*)(sA_ + 3072), 16, 0, 0); \
+    const int tap_ = CV ? (kt_) / kt_per_tap : 0, kc_ = CV ? (kt_) - tap_ * kt_per_tap : 0;        \
+    const int dn_ = CV ? tap_ / 3 - 1 : 0, dl_ = CV ? tap_ - (tap_ / 3) * 3 - 1 : 0;               \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(DMA_ASRC(0, kt_, tap_, kc_, dn_, dl_)), (lds_void_t*)(sA_), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(DMA_ASRC(1, kt_, tap_, kc_, dn_, dl_)), (lds_void_t*)(sA_ + 1024), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(DMA_ASRC(2, kt_, tap_, kc_, dn_, dl_)), (lds_void_t*)(sA_ + 2048), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(DMA_ASRC(3, kt_, tap_, kc_, dn_, dl_)), (lds_void_t*)(sA_ + 3072), 16, 0, 0); \
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw0 + ko_), (lds_void_t*)(sW_), 16, 0, 0);       \
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw1 + ko_), (lds_void_t*)(sW_ + 1024), 16, 0, 0); \
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw2 + ko_), (lds_void_t*)(sW_ + 2048), 16, 0, 0); \
@@ -119,6 +146,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(const Args g
     __builtin_amdgcn_s_barrier();                            // stage `cur` is free for the DMA of tile kt + 2
   }
 #undef DMA_ISSUE
+#undef DMA_ASRC
 
   // ---- epilogue (same structure as gemm_kernel's: compute everything, then store)
 #pragma unroll
@@ -145,6 +173,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(const Args g
       for (int r = 0; r < 16; ++r) {
         float v = acc[mi][ni][r] + bias;
         if constexpr (ACT == ACX_ACT_QUICKGELU) v = acx_quickgelu(v);
+        if constexpr (ACT == ACX_ACT_LEAKYRELU) v = v > 0.f ? v : 0.01f * v;
         outv[r] += v;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
