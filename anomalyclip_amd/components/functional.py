@@ -555,8 +555,8 @@ class TemporalFn(torch.autograd.Function):
         K = tm.input_size
         pw_dst = dest(tm.projection.weight, (E, K)) if P["Kp"] == K else None
         g0, g1 = ops.pos_grad(d_x0, tiles, N, Lg)
-        grads[pe.param_0] = g0.t().reshape(1, E, N, 1)
-        grads[pe.param_1] = g1.t().reshape(1, E, 1, Lg)
+        grads[pe.param_0] = ops.transpose(g0).view(1, E, N, 1)         # [N, E] -> (1, E, N, 1), a libacx launch (no torch copy)
+        grads[pe.param_1] = ops.transpose(g1).view(1, E, 1, Lg)
         tn_jobs.append((d_x0, x, pw_dst, a_sub, lambda gw: put(tm.projection.weight, gw[:, :K], pw_dst)))        # [E, Kp]
         cs_jobs.append((d_x0, lambda g: grads.__setitem__(tm.projection.bias, g)))
         d_feats = None

@@ -68,6 +68,7 @@ struct Args {
   int ksplit, kchunk;      // split-K (FAST path, skinny problems): gridDim.y splits of kchunk K-steps each
   float* partial;          // [ksplit][M][N] raw partial sums (epilogue applied by splitk_reduce_kernel)
   const float* zeros;      // acx_gemm_desc.zero_page (conv taps outside the grid on the LDS-DMA kernels)
+  unsigned int* counters;  // acx_gemm_desc.counters (few-row kernel's cross-workgroup K split: one arrival counter per tile)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -520,7 +521,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   g.trace = nullptr;
 #endif
   dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
-  g.ksplit = 1; g.kchunk = 0; g.partial = nullptr;
+  g.ksplit = 1; g.kchunk = 0; g.partial = nullptr; g.counters = nullptr;
   g.zeros = (const float*)d->zero_page;
   const size_t lds = 4 * TILE_B;
   hipStream_t s = (hipStream_t)stream;
@@ -570,7 +571,20 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     // ways is ahead there (1078 rows, N = 512: K = 2048 37.1 vs 43.5 us, K = 1536 30.0 vs 33.2 us; at 539 rows it is not)
     const bool sk_narrow = sk_max_m > 0 && d->N <= 512 && d->M <= 4 * sk_max_m && !(d->workspace && d->M > 768 && d->K >= 1536);
     if (sk_ok && (sk_fusion || d->M <= sk_max_m || sk_narrow)) {
-      const dim3 kgrid((unsigned)(((d->M + 31) / 32) * ((d->N + 31) / 32)));
+      dim3 kgrid((unsigned)(((d->M + 31) / 32) * ((d->N + 31) / 32)));
+      // long K on few tiles: pieces of two chunks (512 floats = resident in one DMA burst) across workgroups, when the caller
+      // brought the partial workspace and the arrival counters
+      g.counters = (unsigned int*)d->counters;
+      if (d->workspace && d->counters && d->K >= 1024 && d->K % 512 == 0) {
+        const int pieces = d->K / 512;
+        if ((int)kgrid.x * pieces <= 512 && (int)kgrid.x <= d->n_counters &&
+            (size_t)pieces * kgrid.x * 4096 <= d->workspace_bytes && !((uintptr_t)d->workspace & 15)) {
+          g.ksplit = pieces;
+          g.kchunk = 2;
+          g.partial = (float*)d->workspace;
+          kgrid.y = (unsigned)pieces;
+        }
+      }
 #define ACX_SKL(E, AG)                                                                              \
   do {                                                                                              \
     static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                                                                 \

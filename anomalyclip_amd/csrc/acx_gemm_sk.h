@@ -38,7 +38,11 @@ __global__ __launch_bounds__(512) void gemm_f32_sk_kernel(const Args g) {
   const int tiles_n = (d.N + 31) / 32;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;     // n fastest: neighbours share the A rows in L2
   const int m0 = tm * 32, n0 = tn * 32;
-  const int nch = d.K / SK_CH;
+  // cross-workgroup K split (gridDim.y pieces of `kchunk` chunks): long-K problems on few tiles -- the text tower's K = 2048
+  // GEMMs at a rank's 32-224 rows are 16-112 workgroups streaming 4 MB of weights, 16-17 us each -- see the tail of the kernel
+  const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
+  const int c_lo = ksplit > 1 ? (int)blockIdx.y * g.kchunk : 0;
+  const int nch = ksplit > 1 ? min(g.kchunk, d.K / SK_CH - c_lo) : d.K / SK_CH;
 
   // ---- DMA: this wave's 8 KB of a chunk = k-block `wave` of A and of W, 4 row groups of 8 rows each.
   // wave-instruction rg: lane l -> row 8 rg + l/8, LDS position l%8 holds source chunk (l%8) ^ ((row >> 1) & 7)
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(512) void gemm_f32_sk_kernel(const Args g) {
 #define SK_ISSUE(c)                                                                                \
   do {                                                                                             \
     const unsigned s_ = lds0 + ((c) & 1) * SK_STAGE_B + wave * 4096;                               \
-    const int k0_ = (c) * SK_CH;                                                                   \
+    const int k0_ = (c_lo + (c)) * SK_CH;                                                          \
     _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                             \
       SK_DMA1((const float*)d.A + (size_t)(aoff[rg] + k0_), s_ + rg * 1024);                       \
       SK_DMA1((const float*)d.W + (size_t)(woff[rg] + k0_), s_ + SK_OP_B + rg * 1024);             \
@@ -119,6 +123,30 @@ __global__ __launch_bounds__(512) void gemm_f32_sk_kernel(const Args g) {
   for (int w = 1; w < 8; ++w) {
     const float2 p = *reinterpret_cast<const float2*>(r0 + w * 1024);
     v.x += p.x; v.y += p.y;
+  }
+  if (ksplit > 1) {
+    // The pieces' partial tiles meet through memory WITHOUT a release fence (a device-scope fence writes back the whole L2 of
+    // the XCD): agent-scope write-through stores, s_waitcnt vmcnt(0), a relaxed arrival counter per tile; the last piece to
+    // arrive adds the pieces in piece order -- its own from registers -- and runs the epilogue.  The counter returns to zero.
+    __shared__ bool last;
+    const int tile = (int)blockIdx.x, ntile = (int)gridDim.x;
+    float* mine = g.partial + ((size_t)blockIdx.y * ntile + tile) * 1024 + 2 * t;
+    __hip_atomic_store(mine, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) last = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ksplit - 1;
+    __syncthreads();
+    if (!last) return;
+    float2 tot = make_float2(0.f, 0.f);
+    for (int q = 0; q < ksplit; ++q) {
+      if (q == (int)blockIdx.y) { tot.x += v.x; tot.y += v.y; continue; }
+      const float* pq = g.partial + ((size_t)q * ntile + tile) * 1024 + 2 * t;
+      tot.x += __hip_atomic_load(pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot.y += __hip_atomic_load(pq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    v = tot;
+    if (t == 0) __hip_atomic_store(g.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const int gm = m0 + row, gn = n0 + c2;
   if (gm >= d.M || gn >= d.N) return;                                        // N % 4 == 0: a pair is in range or not

@@ -15,8 +15,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   const int ci = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + ci;
   float s = 0.f;
-  if (c < width)
-    for (int p = sl; p < nparts; p += 16) s += part[(size_t)p * width + c];
+  if (c < width) {
+    int p = sl;
+    for (; p + 112 < nparts; p += 128) {            // eight loads in flight per thread, added in part order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + 16 * u) * width + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nparts; p += 16) s += part[(size_t)p * width + c];
+  }
   red[sl][ci] = s;
   __syncthreads();
   if (sl == 0 && c < width) {

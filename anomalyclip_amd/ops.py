@@ -164,6 +164,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
             and ((amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and a_sub is None and pos0 is None) or generic_f32)):
         ws = _splitk_workspace(a.device, min(16, 512 // tiles) * M * N * 4)     # skinny problem: let the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    if few_rows and K >= 1024 and K % 512 == 0 and ((M + 31) // 32) * ((N + 31) // 32) * (K // 512) <= 512:
+        # long K on few tiles (the text tower's K = 2048 GEMMs): K split across workgroups, last-arriver reduction in-kernel
+        tiles32 = ((M + 31) // 32) * ((N + 31) // 32)
+        ws = _splitk_workspace(a.device, (K // 512) * tiles32 * 4096)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        ctr = _colsum_counters(a.device)
+        d.counters, d.n_counters = ctr.data_ptr(), 255                      # entry 255 belongs to the loss kernel
     h = _h(a)
     L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)
     return out

@@ -100,6 +100,10 @@ typedef struct acx_gemm_desc {
   int32_t a_act;          /* ACX_ACT_QUICKGELU: the activation is applied to A as it is read (x_next = gelu(pre) @ W^T) */
   const float* gelu_grad_of; /* [M, ldg] saved pre-activation p: C = (A W^T + bias) * d gelu(p)/dp  (no act / residual) */
   int32_t ldg;
+  uint32_t* counters;     /* optional: n_counters uint32, ZERO before the first call and left zero by every call (caller-owned,
+                             one table per stream).  With it and `workspace`, few-row problems with K >= 1024 split K across
+                             workgroups whose partial tiles meet through a last-arriver reduction (no second launch). */
+  int32_t n_counters;
   const int32_t* tile_table; /* TILETABLE: [M / (gn gl)][2] device ints (base row, row stride between segments): output row
                                 (tile, n, l) reads source row base + n * stride + l -- the test-mode tiling of
                                 temporal_model.py:46-53 for a batch of videos with DIFFERENT segment sizes (video v, tile s:

@@ -53,6 +53,10 @@ def stub_collectives(world, net=None):
             return buf
         parallel.assemble_rows_into = assemble_rows_into
 
+    # SyncBN all-gather of the step graph: ONE collective on real hardware -> one broadcast copy here (the list form of the stub
+    # below is eight copies)
+    parallel.all_gather_into = lambda out, local: out.copy_(local.unsqueeze(0).expand_as(out))
+
     class _H:
         def wait(self):
             return None
