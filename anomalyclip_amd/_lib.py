@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("pos0", c_void_p), ("pos1", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("zero_page", c_void_p), ("a_act", c_int32), ("gelu_grad_of", c_void_p), ("ldg", c_int32),
+        ("a_norm_w", c_void_p), ("a_norm_b", c_void_p), ("a_norm_eps", c_float),
         ("counters", c_void_p), ("n_counters", c_int32),
         ("tile_table", c_void_p),
     ]

@@ -44,13 +44,24 @@ def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int, tf_out
     # few rows (a data-parallel rank's block of classes: 77 rows per class): acx_gemm runs the few-row kernel and the
     # activation / its derivative ride in its prologue / epilogue instead of separate launches
     few = C * Lc <= ops.SK_MAX_ROWS and (4 * W) % 256 == 0 and W % 256 == 0
+    # ... and the two LayerNorms of a block ride in the A prologue of the GEMM that consumes them (K == 512: the whole row is
+    # resident in the kernel's two stages; LN(x) is never materialised -- the backward recomputes it from x anyway)
+    norm_fused = few and W == 512
     for blk in tr.resblocks:
-        h1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
-        qkv = ops.gemm(h1, blk.attn.in_proj_weight.detach(), bias=blk.attn.in_proj_bias.detach())
+        if norm_fused:
+            qkv = ops.gemm(x, blk.attn.in_proj_weight.detach(), bias=blk.attn.in_proj_bias.detach(),
+                           a_norm=(blk.ln_1.weight.detach(), blk.ln_1.bias.detach()))
+        else:
+            h1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+            qkv = ops.gemm(h1, blk.attn.in_proj_weight.detach(), bias=blk.attn.in_proj_bias.detach())
         att = ops.attention(qkv, C, Lc, heads, True)
         x_mid = ops.gemm(att, blk.attn.out_proj.weight.detach(), bias=blk.attn.out_proj.bias.detach(), residual=x)
-        h2 = ops.layernorm(x_mid, blk.ln_2.weight, blk.ln_2.bias)
-        pre = ops.gemm(h2, blk.mlp.c_fc.weight.detach(), bias=blk.mlp.c_fc.bias.detach())
+        if norm_fused:
+            pre = ops.gemm(x_mid, blk.mlp.c_fc.weight.detach(), bias=blk.mlp.c_fc.bias.detach(),
+                           a_norm=(blk.ln_2.weight.detach(), blk.ln_2.bias.detach()))
+        else:
+            h2 = ops.layernorm(x_mid, blk.ln_2.weight, blk.ln_2.bias)
+            pre = ops.gemm(h2, blk.mlp.c_fc.weight.detach(), bias=blk.mlp.c_fc.bias.detach())
         if few:                                       # QuickGELU applied as the few-row GEMM reads its A operand
             x_next = ops.gemm(pre, blk.mlp.c_proj.weight.detach(), bias=blk.mlp.c_proj.bias.detach(), residual=x_mid,
                               a_act=L.ACT_QUICKGELU)

@@ -554,7 +554,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   } while (0)
   // few-row f32 problems (and every problem that asks for the few-row fusions): 32x32 tiles, K split over the waves
   {
-    const bool sk_fusion = d->a_act != ACX_ACT_NONE || d->gelu_grad_of != nullptr;
+    const bool a_norm = d->a_norm_w != nullptr;
+    const bool sk_fusion = d->a_act != ACX_ACT_NONE || d->gelu_grad_of != nullptr || a_norm;
     const bool sk_ok = fast && prec == ACX_PREC_F32 && !c_bf16 && !a_bf16 && d->K % SK_CH == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 &&
                        !((uintptr_t)d->C & 15) && (!d->residual || (d->ldr % 4 == 0 && !((uintptr_t)d->residual & 15))) &&
                        (!d->gelu_grad_of || (d->ldg % 4 == 0 && !((uintptr_t)d->gelu_grad_of & 15) && !d->residual &&
@@ -562,7 +563,10 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
                        !(d->act == ACX_ACT_QUICKGELU && d->residual) && (d->a_act == ACX_ACT_NONE || d->a_act == ACX_ACT_QUICKGELU) &&
                        (size_t)d->M * d->lda < ((size_t)1 << 31) && (size_t)d->N * d->ldw < ((size_t)1 << 31);
     if (sk_fusion && !sk_ok)
-      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_act / gelu_grad_of need the few-row f32 kernel (see acx_gemm_desc)%s");
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_act / gelu_grad_of / a_norm need the few-row f32 kernel (see acx_gemm_desc)%s");
+    if (a_norm && (d->K != 512 || !d->a_norm_b || d->a_act != ACX_ACT_NONE || d->residual || d->gelu_grad_of || d->act != ACX_ACT_NONE ||
+                   (((uintptr_t)d->a_norm_w | (uintptr_t)d->a_norm_b) & 15)))
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_norm needs K == 512, weight and bias, and no other fusion%s");
     // narrow outputs (N <= 512: out-proj, proj and the dX chain of the text tower) stay ahead of the 64x64-tile kernel up to
     // ~1300 rows -- 17-34 row tiles x 16 column tiles fill the chip where 64x64 tiles leave half of it idle
     // (profiles/r03_text_gemm.txt); wide outputs only up to the row limit
@@ -595,6 +599,17 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     }                                                                                               \
     hipLaunchKernelGGL((gemm_f32_sk_kernel<E, AG>), kgrid, dim3(512), (size_t)SK_LDS_B, s, g);      \
   } while (0)
+      if (a_norm) {
+        static bool attrn_dev_[64] = {}; bool& attrn_done = attrn_dev_[dev_slot];
+        if (!attrn_done) {
+          (void)hipFuncSetAttribute((const void*)gemm_f32_sk_kernel<SK_EPI_PLAIN, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)SK_LDS_B);
+          attrn_done = true;
+        }
+        hipLaunchKernelGGL((gemm_f32_sk_kernel<SK_EPI_PLAIN, 0, 1>), kgrid, dim3(512), (size_t)SK_LDS_B, s, g);
+        ACX_CHECK_LAUNCH(ctx, "acx_gemm");
+        return ACX_OK;
+      }
       const int epi = d->gelu_grad_of ? SK_EPI_GELUGRAD : d->residual ? SK_EPI_RES : d->act == ACX_ACT_QUICKGELU ? SK_EPI_QUICKGELU : SK_EPI_PLAIN;
       if (d->a_act == ACX_ACT_QUICKGELU) {
         switch (epi) {

@@ -28,7 +28,10 @@ enum { SK_EPI_PLAIN = 0, SK_EPI_QUICKGELU = 1, SK_EPI_RES = 2, SK_EPI_GELUGRAD =
 __device__ __forceinline__ float sk_sigmoid1702(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v)); }
 __device__ __forceinline__ float sk_quickgelu(float v) { return v * sk_sigmoid1702(v); }
 
-template <int EPI, int A_GELU>
+// A_NORM: LayerNorm over K applied to the A rows as they leave LDS (K == 512 = the whole row resident in the two stages):
+// y = LN(x) W^T + b without a LayerNorm launch and without materialising LN(x) (clip/model.py:214-216: ln_1 -> attention in-proj,
+// ln_2 -> c_fc).  Two-pass statistics (mean, then centred sum of squares) exchanged between the eight waves through LDS.
+template <int EPI, int A_GELU, int A_NORM = 0>
 __global__ __launch_bounds__(512) void gemm_f32_sk_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -79,6 +82,62 @@ __global__ __launch_bounds__(512) void gemm_f32_sk_kernel(const Args g) {
   if (nch > 1) SK_ISSUE(1);
   const int sw = (li >> 1) & 7;
   const int fr = wave * 4096 + li * 128;                                     // this lane's row in the wave's k-block
+  if constexpr (A_NORM != 0) {
+    // K == 512, no K split: both chunks are in flight; wait for all of it, normalise the A fragments, then the MFMAs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float4 xa[2][4], xb[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int o = ((2 * cc + hh) ^ sw) * 16;
+        xa[c][cc] = *reinterpret_cast<const float4*>(smem + c * SK_STAGE_B + fr + o);
+        xb[c][cc] = *reinterpret_cast<const float4*>(smem + c * SK_STAGE_B + SK_OP_B + fr + o);
+      }
+    __shared__ float nst[2][8][32];                                          // [pass][wave][row]
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) s1 += (xa[c][cc].x + xa[c][cc].y) + (xa[c][cc].z + xa[c][cc].w);
+    s1 += __shfl_xor(s1, 32, 64);                                            // the two half-rows of the wave's k-blocks
+    if (hh == 0) nst[0][wave][li] = s1;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) mean += nst[0][w][li];
+    mean *= (1.f / 512.f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        xa[c][cc].x -= mean; xa[c][cc].y -= mean; xa[c][cc].z -= mean; xa[c][cc].w -= mean;
+        s2 += (xa[c][cc].x * xa[c][cc].x + xa[c][cc].y * xa[c][cc].y) + (xa[c][cc].z * xa[c][cc].z + xa[c][cc].w * xa[c][cc].w);
+      }
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hh == 0) nst[1][wave][li] = s2;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) var += nst[1][w][li];
+    const float rstd = 1.f / sqrtf(var * (1.f / 512.f) + d.a_norm_eps);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        // the fragment at position (2 cc + hh) holds k = 256 c + 32 wave + 4 (2 cc + hh) .. + 3 of this lane's row
+        const int k0 = 256 * c + 32 * wave + 4 * (2 * cc + hh);
+        const float4 gw = *reinterpret_cast<const float4*>(d.a_norm_w + k0), gb = *reinterpret_cast<const float4*>(d.a_norm_b + k0);
+        xa[c][cc].x = xa[c][cc].x * rstd * gw.x + gb.x; xa[c][cc].y = xa[c][cc].y * rstd * gw.y + gb.y;
+        xa[c][cc].z = xa[c][cc].z * rstd * gw.z + gb.z; xa[c][cc].w = xa[c][cc].w * rstd * gw.w + gb.w;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[c][cc].x, xb[c][cc].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[c][cc].y, xb[c][cc].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[c][cc].z, xb[c][cc].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[c][cc].w, xb[c][cc].w, acc, 0, 0, 0);
+      }
+    __syncthreads();                                                         // every wave is done reading the stages
+  } else
   for (int c = 0; c < nch; ++c) {
     if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // chunk c landed; chunk c+1 may be in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

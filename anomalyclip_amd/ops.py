@@ -120,7 +120,7 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
 def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None, M: Optional[int] = None,
          bias=None, act=L.ACT_NONE, residual=None, a_sub=None, prec=L.PREC_F32, out_dtype=torch.float32,
          amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, seg=0, pos0=None, pos1=None, a_act=L.ACT_NONE,
-         gelu_grad_of=None, tile_table=None) -> torch.Tensor:
+         gelu_grad_of=None, tile_table=None, a_norm=None, a_norm_eps=1e-5) -> torch.Tensor:
     """out[M,N] = epilogue(amap(a)[M,K] @ w[N,K]^T); see include/acx.h acx_gemm_desc."""
     assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
     N, K = w.shape
@@ -146,6 +146,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
     if amap == L.AMAP_CONV3X3:
         d.zero_page = _zero_page(a.device).data_ptr()
     d.gelu_grad_of, d.ldg = _ptr(gelu_grad_of), (gelu_grad_of.stride(0) if gelu_grad_of is not None else 0)
+    if a_norm is not None:                                   # (weight, bias): LayerNorm over K in the few-row kernel's A prologue
+        d.a_norm_w, d.a_norm_b, d.a_norm_eps = a_norm[0].data_ptr(), a_norm[1].data_ptr(), float(a_norm_eps)
     if amap == L.AMAP_TILETABLE:
         assert tile_table is not None and tile_table.dtype == torch.int32 and tile_table.is_cuda and tile_table.is_contiguous()
         assert tile_table.numel() == 2 * (M // (gn * gl))

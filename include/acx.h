@@ -100,6 +100,11 @@ typedef struct acx_gemm_desc {
   int32_t a_act;          /* ACX_ACT_QUICKGELU: the activation is applied to A as it is read (x_next = gelu(pre) @ W^T) */
   const float* gelu_grad_of; /* [M, ldg] saved pre-activation p: C = (A W^T + bias) * d gelu(p)/dp  (no act / residual) */
   int32_t ldg;
+  const float* a_norm_w;  /* LayerNorm over K applied to the A rows as they are read (y = LN(A) W^T + bias): weight / bias [K], or
+                             NULL.  Few-row f32 kernel only, K == 512, no a_act / residual / gelu_grad_of / activation
+                             (clip/model.py:214-216 ln_1 -> in_proj, ln_2 -> c_fc of the text tower); ACX_E_UNSUPPORTED otherwise */
+  const float* a_norm_b;
+  float a_norm_eps;
   uint32_t* counters;     /* optional: n_counters uint32, ZERO before the first call and left zero by every call (caller-owned,
                              one table per stream).  With it and `workspace`, few-row problems with K >= 1024 split K across
                              workgroups whose partial tiles meet through a last-arriver reduction (no second launch). */

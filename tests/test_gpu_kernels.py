@@ -69,6 +69,34 @@ def test_gemm_few_rows_kernel(M, K, N):
     assert bool(((out.cpu().double() - (ga @ w64.t() + bias.double() + res.double())).abs() <= 2 * bound_g).all())
 
 
+@pytest.mark.parametrize("M", [1, 16, 32, 33, 100, 224, 320, 1000])
+@pytest.mark.parametrize("N", [1536, 2048, 36])
+def test_gemm_few_rows_layernorm_prologue(M, N):
+    """a_norm: LayerNorm over K = 512 applied to the A rows inside the few-row kernel (the text tower's ln_1 -> in_proj and
+    ln_2 -> c_fc, clip/model.py:214-216) against LayerNorm-then-GEMM in fp64, element-wise; rows with a large common offset
+    (|mean| >> std, the case a one-pass variance would lose) included; refused for K != 512 or together with another fusion."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, 512, generator=g)
+    a[::3] += 40.0                                           # |mean| = 40 std: two-pass statistics keep the centred values exact
+    a[:, 7] *= 25.0                                          # an outlier channel, as CLIP text activations have
+    w = torch.randn(N, 512, generator=g) * 0.05 + torch.arange(N).view(-1, 1) * 1e-4
+    bias = torch.randn(N, generator=g)
+    lw, lb = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g) * 0.1
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), a_norm=(lw.to(DEV), lb.to(DEV)))
+    h = torch.nn.functional.layer_norm(a.double(), (512,), lw.double(), lb.double(), 1e-5)
+    ref = h @ w.double().t() + bias.double()
+    bound = 4e-6 * (h.abs() @ w.double().abs().t() + bias.abs().double()) + 1e-30
+    assert bool(((out.cpu().double() - ref).abs() <= bound).all())
+    # the unfused pair (LayerNorm launch + GEMM) agrees to round-off
+    h32 = ops.layernorm(a.to(DEV), lw.to(DEV), lb.to(DEV))
+    assert relerr(out, ops.gemm(h32, w.to(DEV), bias=bias.to(DEV))) < 5e-6
+    if M == 32 and N == 36:
+        with pytest.raises(L.AcxError, match="a_norm"):
+            ops.gemm(a[:, :256].contiguous().to(DEV), w[:, :256].contiguous().to(DEV), a_norm=(lw[:256].to(DEV), lb[:256].to(DEV)))
+        with pytest.raises(L.AcxError, match="a_norm"):
+            ops.gemm(a.to(DEV), w.to(DEV), a_norm=(lw.to(DEV), lb.to(DEV)), act=L.ACT_QUICKGELU)
+
+
 def test_gemm_few_row_fusions_are_refused_elsewhere():
     """a_act / gelu_grad_of exist in the few-row kernel only: a shape it cannot take fails loudly, and the row limit is an
     option of the context (above it the tile kernels run and give the same result)."""
