@@ -728,6 +728,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     }                                                                                               \
     hipLaunchKernelGGL((gemm_f32_w8_kernel<ACT, RES, CV>), grid, dim3(512), lds, s, g);             \
   } while (0)
+    // split pieces meet inside the kernel (last-arriver reduction) when the caller brought arrival counters; else a reduce launch
+    g.counters = (g.ksplit > 1 && d->counters && (int)grid.x <= d->n_counters) ? (unsigned int*)d->counters : nullptr;
     if (w8_conv) {
       if (d->act == ACX_ACT_LEAKYRELU) { if (d->residual) ACX_W8L(2, 1, 1); else ACX_W8L(2, 0, 1); }
       else if (d->act == ACX_ACT_QUICKGELU) { if (d->residual) ACX_W8L(1, 1, 1); else ACX_W8L(1, 0, 1); }
@@ -737,7 +739,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       else { if (d->residual) ACX_W8L(0, 1, 0); else ACX_W8L(0, 0, 0); }
     }
 #undef ACX_W8L
-    if (g.ksplit > 1) {
+    if (g.ksplit > 1 && !g.counters) {
       const int64_t total = (int64_t)d->M * d->N;
       hipLaunchKernelGGL((splitk_reduce_kernel<0>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)g.partial,
                          g.ksplit, *d);

@@ -214,14 +214,57 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
   const bool cok = col < d.N;
   if (g.ksplit > 1) {
     float* P = g.partial + (size_t)blockIdx.y * d.M * d.N;
+    if (!g.counters) {                 // partial tiles for splitk_reduce_kernel (second launch)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mi * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+          if (cok && row < d.M) P[(size_t)row * d.N + col] = acc[mi][r];
+        }
+      return;
+    }
+    // In-kernel reduction, no second launch: the K pieces publish their raw tiles with agent-scope (write-through) stores --
+    // no release fence, which would write back the XCD's whole L2 --, bump the tile's relaxed arrival counter, and the LAST
+    // piece to arrive adds the pieces in piece order (its own from registers: (0 + p0) + p1 + ..., the reduce kernel's
+    // order, bit for bit) and falls through into the normal epilogue.  The counter returns to zero.
+    __shared__ bool last_piece;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + mi * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
-        if (cok && row < d.M) P[(size_t)row * d.N + col] = acc[mi][r];
+        if (cok && row < d.M) __hip_atomic_store(P + (size_t)row * d.N + col, acc[mi][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-    return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      last_piece = __hip_atomic_fetch_add(g.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.ksplit - 1;
+    __syncthreads();
+    if (!last_piece) return;
+    float tot[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[mi][r] = 0.f;
+    for (int q = 0; q < g.ksplit; ++q) {
+      const float* Pq = g.partial + (size_t)q * d.M * d.N;
+      const bool own = q == (int)blockIdx.y;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mi * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+          float pv = acc[mi][r];
+          if (!own) pv = (cok && row < d.M) ? __hip_atomic_load(Pq + (size_t)row * d.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          tot[mi][r] += pv;
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = tot[mi][r];
+    if (threadIdx.x == 0) __hip_atomic_store(g.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- vector epilogue.  In the 32x32 C layout a lane holds ONE column and 16 rows, so the natural store is 32 x
   // global_store_dword per lane (64 instructions of 2 x 128 B per wave and tile, plus as many residual loads): the store

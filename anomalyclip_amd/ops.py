@@ -88,16 +88,19 @@ def _zero_page(device) -> torch.Tensor:
 
 
 _COLSUM_COUNTERS: dict = {}
+_CTR_N = 4096            # arrival counters per (device, stream): last-arriver reductions (column sums, split-K pieces, the loss)
 
 
 def _colsum_counters(device) -> torch.Tensor:
-    """256 uint32 arrival counters per device AND stream for acx_colsum_fused (zero at rest: every launch resets its own)."""
+    """4096 uint32 arrival counters per device AND stream for the in-kernel last-arriver reductions (acx_colsum_fused, the
+    split-K pieces of acx_gemm, acx_mil_loss_one): zero at rest, every launch resets its own; launches of one stream are
+    sequential, so they share the table.  The LAST entry belongs to the loss kernel."""
     key = (device.type, device.index, _stream())
     c = _COLSUM_COUNTERS.get(key)
     if c is None:
         if torch.cuda.is_current_stream_capturing():
             raise L.AcxError("the column-sum counters must be created by an eager call before a HIP graph is captured")
-        c = _COLSUM_COUNTERS[key] = torch.zeros(256, dtype=torch.int32, device=device)
+        c = _COLSUM_COUNTERS[key] = torch.zeros(_CTR_N, dtype=torch.int32, device=device)
     return c
 
 
@@ -166,13 +169,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
             and ((amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and a_sub is None and pos0 is None) or generic_f32)):
         ws = _splitk_workspace(a.device, min(16, 512 // tiles) * M * N * 4)     # skinny problem: let the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        if amap == L.AMAP_CONV3X3 and prec == L.PREC_F32:
+            # f32 convolutions: the split pieces are reduced INSIDE the kernel (last-arriver, no second launch)
+            ctr = _colsum_counters(a.device)
+            d.counters, d.n_counters = ctr.data_ptr(), _CTR_N - 1
     if few_rows and K >= 1024 and K % 512 == 0 and ((M + 31) // 32) * ((N + 31) // 32) * (K // 512) <= 512:
         # long K on few tiles (the text tower's K = 2048 GEMMs): K split across workgroups, last-arriver reduction in-kernel
         tiles32 = ((M + 31) // 32) * ((N + 31) // 32)
         ws = _splitk_workspace(a.device, (K // 512) * tiles32 * 4096)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         ctr = _colsum_counters(a.device)
-        d.counters, d.n_counters = ctr.data_ptr(), 255                      # entry 255 belongs to the loss kernel
+        d.counters, d.n_counters = ctr.data_ptr(), _CTR_N - 1               # the last entry belongs to the loss kernel
     h = _h(a)
     L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)
     return out
@@ -432,7 +439,7 @@ def colsum_group(xs):
     vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])            # noqa: E731
     L.check(lib.acx_colsum_fused_group(h, n, vp(xs), (C.c_int32 * n)(*[x.stride(0) for x in xs]),
                                        (C.c_int64 * n)(*[x.shape[0] for x in xs]), (C.c_int32 * n)(*[x.shape[1] for x in xs]),
-                                       vp(outs), vp(parts), ctr.data_ptr(), ctr.numel(), _stream()), h)
+                                       vp(outs), vp(parts), ctr.data_ptr(), ctr.numel() - 1, _stream()), h)
     return outs
 
 
@@ -770,7 +777,7 @@ def mil_loss(sim, sim_topk, labels, scores, idx_topk_abn, idx_topk_nor, idx_bott
     ws = torch.empty(nws, dtype=torch.float32, device=dev)
     lam = (ctypes.c_float * 7)(*[float(x) for x in lambdas])
     h = _h(sim)
-    ctr = _colsum_counters(dev)[255:]                       # the last arrival counter of the stream's table: the loss's own
+    ctr = _colsum_counters(dev)[_CTR_N - 1:]                # the last arrival counter of the stream's table: the loss's own
     L.check(L.lib().acx_mil_loss_one(h, sim.data_ptr(), sim_topk.data_ptr(), labels.data_ptr(), scores.data_ptr(),
                                      idx_topk_abn.data_ptr(), idx_topk_nor.data_ptr(), idx_bottomk_abn.data_ptr(), dsim.data_ptr(),
                                      dtopk.data_ptr(), dsc.data_ptr(), losses.data_ptr(), ws.data_ptr(), nws, B, N, Lg, C1, K,
