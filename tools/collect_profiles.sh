@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copies what tools/refresh_profiles.sh left under gpurun_out/ into profiles/<tag>_* (run in the development container after
-# the gpurun call merged its outputs back).  usage: tools/collect_profiles.sh [tag]   (default r03)
+# the gpurun call merged its outputs back).  usage: tools/collect_profiles.sh [tag]   (default r04)
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 G=$R/gpurun_out
 P=$R/profiles
@@ -11,8 +11,10 @@ cp $G/refresh/bench_f32.json $P/${TAG}_bench_f32.json
 cp $G/refresh/bench_bf16.json $P/${TAG}_bench_bf16.json
 cp $G/refresh/bench_head.json $P/${TAG}_bench_head.json
 cp $G/refresh/bench_head_eager.json $P/${TAG}_bench_head_eager.json
-for n in 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_bench_head_emulated_world$n.json; done
+for n in 1 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_bench_head_emulated_world$n.json; done
 cp $G/refresh/bench_head_emulated_world8_eager.json $P/${TAG}_bench_head_emulated_world8_eager.json
+for v in world8_autograd_graphs world8_main_chain_only world1_main_chain_only; do cp $G/refresh/bench_head_emulated_$v.json $P/${TAG}_bench_head_emulated_$v.json; done
+cp $G/refresh/dp8_step_timeline.txt $P/${TAG}_dp8_step_timeline.txt
 cp $G/refresh/bench_xd_bf16.json $P/${TAG}_bench_xd_bf16.json
 grep '^{' $G/refresh/bench_gloo2_smoke.json > $P/${TAG}_bench_gloo2_smoke.json   # gloo prints its own connection lines to stdout
 cp $G/refresh/bench_metrics.txt $P/${TAG}_bench_metrics.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One pass over everything profiles/r03_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
+# One pass over everything profiles/r04_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
 set -x
 R=/root/repo
 OUT=$R/gpurun_out/refresh
@@ -7,10 +7,18 @@ rm -rf $OUT; mkdir -p $OUT
 cd $R
 python bench.py --steps 10 --warmup 3 > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 python bench.py --steps 10 --warmup 3 --precision bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
-python tools/bench_head.py --steps 10 --text-graph --temporal-graph > $OUT/bench_head.json 2>/dev/null
-python tools/bench_head.py --steps 10 > $OUT/bench_head_eager.json 2>/dev/null
-for n in 2 4 8; do python tools/bench_head.py --steps 10 --emulate-world $n --text-graph --temporal-graph > $OUT/bench_head_emulated_world$n.json 2>/dev/null; done
-python tools/bench_head.py --steps 10 --emulate-world 8 > $OUT/bench_head_emulated_world8_eager.json 2>/dev/null
+# train_batch's default = the whole-step graph; --no-step-graph = its autograd fallback (with / without its own graphs)
+python tools/bench_head.py --steps 40 --warmup 5 > $OUT/bench_head.json 2>/dev/null
+python tools/bench_head.py --steps 20 --no-step-graph > $OUT/bench_head_eager.json 2>/dev/null
+for n in 1 2 4 8; do python tools/bench_head.py --steps 40 --warmup 5 --emulate-world $n > $OUT/bench_head_emulated_world$n.json 2>/dev/null; done
+python tools/bench_head.py --steps 20 --emulate-world 8 --no-step-graph > $OUT/bench_head_emulated_world8_eager.json 2>/dev/null
+python tools/bench_head.py --steps 20 --emulate-world 8 --no-step-graph --text-graph --temporal-graph > $OUT/bench_head_emulated_world8_autograd_graphs.json 2>/dev/null
+ACX_STEP_SKIP_TEXT=1 python tools/bench_head.py --steps 40 --warmup 5 --emulate-world 8 > $OUT/bench_head_emulated_world8_main_chain_only.json 2>/dev/null
+ACX_STEP_SKIP_TEXT=1 python tools/bench_head.py --steps 40 --warmup 5 --emulate-world 1 > $OUT/bench_head_emulated_world1_main_chain_only.json 2>/dev/null
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp8 -o dp8 -- python $R/tools/bench_head.py --emulate-world 8 --steps 10 --warmup 2 > /dev/null 2>&1; cp $(find /tmp/pp8 -name '*kernel_stats.csv' | head -1) $OUT/dp8_rank_share_kernel_stats.csv)
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp1 -o tr -- python $R/tools/bench_head.py --steps 10 --warmup 2 > /dev/null 2>&1; cp $(find /tmp/pp1 -name '*kernel_stats.csv' | head -1) $OUT/train_step_kernel_stats.csv)
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d /tmp/tl8 -o t -- python $R/tools/bench_head.py --emulate-world 8 --steps 8 --warmup 2 > /dev/null 2>&1; python $R/tools/step_timeline.py $(find /tmp/tl8 -name '*kernel_trace.csv' | head -1) --delim prep_multi_kernel --step 5 --out $OUT/dp8_step_timeline.txt)
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/xd -o xd -- python $R/tools/bench_xd.py --head-only --steps 20 > /dev/null 2>&1; cp $(find /tmp/xd -name '*kernel_stats.csv' | head -1) $OUT/xd_bf16_kernel_stats.csv)
 python tools/bench_xd.py --steps 6 > $OUT/bench_xd_bf16.json 2>/dev/null
 python tools/bench_metrics.py > $OUT/bench_metrics.txt 2>&1
 # two rounds each: the first shapes of a process run on cold clocks, read the second round
