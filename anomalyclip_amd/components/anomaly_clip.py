@@ -130,6 +130,7 @@ class AnomalyCLIP(nn.Module):
         # kept, keyed by the optimizer epoch and the version / address of every input of the text path (any edit of those
         # recomputes it).  `cache_text_features: false` restores the per-call evaluation.
         self.cache_text_features = bool(g("cache_text_features", True))
+        self.text_eval_graph = bool(g("text_eval_graph", True))            # uncached evaluation: the tower replayed from a HIP graph
         # under data parallelism the (replicated) text encoder is evaluated class-parallel: every rank runs its block
         # of classes and the (C, E) features / their gradients are exchanged (functional.TextFeaturesFn)
         self.text_class_parallel = bool(g("text_class_parallel", True))
@@ -163,13 +164,61 @@ class AnomalyCLIP(nn.Module):
             ) + tuple((p.data_ptr(), p._version) for p in plist)
             if self._text_cache is not None and self._text_cache[0] == key:
                 return self._text_cache[1]
-        pl = self.prompt_learner
-        x = ops.prompt_embed(pl.token_prefix, pl.ctx.detach(), pl.token_suffix, self.text_encoder.positional_embedding.detach(),
-                             pl.n_ctx, Lout=self.text_len)
-        tf = self.text_encoder.encode(x, self.eot_index)
+        if not self.cache_text_features and self.text_eval_graph:
+            tf = self._text_features_replayed()
+            if tf is not None:
+                return tf
+        tf = self._text_features_eager()
         if self.cache_text_features:
             self._text_cache = (key, tf)
         return tf
+
+    def _text_features_eager(self) -> torch.Tensor:
+        pl = self.prompt_learner
+        x = ops.prompt_embed(pl.token_prefix, pl.ctx.detach(), pl.token_suffix, self.text_encoder.positional_embedding.detach(),
+                             pl.n_ctx, Lout=self.text_len)
+        return self.text_encoder.encode(x, self.eot_index)
+
+    def _text_features_replayed(self):
+        """Evaluation with `cache_text_features = False` (the reference's per-call text tower, anomaly_clip.py:136): the ~170
+        launches of the tower are a fixed sequence over parameters that stay where they are, so they are captured once as a
+        HIP graph and replayed -- one launch from the host per call instead of ~1.4 ms of launch calls.  The layers keep derived
+        weight layouts keyed by (optimizer epoch, address, version) of their parameters, so the graph is keyed the same way:
+        any edit of a text-path parameter re-captures it.  Returns None where a graph cannot be used (no GPU stream capture inside another
+        capture; a failed capture disables the path for this module)."""
+        dev = self.prompt_learner.ctx.device
+        if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return None
+        plist = self.text_encoder.__dict__.get("_acx_plist")
+        if plist is None:
+            plist = self.text_encoder.__dict__["_acx_plist"] = list(self.text_encoder.transformer.parameters())
+        te = self.text_encoder
+        key = (self.text_len, te.precision, ops.WEIGHT_EPOCH[0]) + tuple(
+            (t.data_ptr(), t._version) for t in (self.prompt_learner.ctx, self.prompt_learner.token_prefix,
+                                                 self.prompt_learner.token_suffix, te.text_projection, te.positional_embedding,
+                                                 te.ln_final.weight, te.ln_final.bias)
+        ) + tuple((p.data_ptr(), p._version) for p in plist)
+        g = self.__dict__.get("_text_graph")
+        if g is None or g[0] != key:
+            try:
+                with torch.no_grad():
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream())
+                    ops.prime_capture_stream(side, dev)
+                    with torch.cuda.stream(side):
+                        self._text_features_eager()                      # lazy workspaces, function attributes
+                    torch.cuda.synchronize(dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                        out = self._text_features_eager()
+                    torch.cuda.synchronize(dev)
+            except Exception as e:                                       # noqa: BLE001 -- capture support is best effort
+                self.text_eval_graph = False
+                self.__dict__["_text_graph_error"] = repr(e)
+                return None
+            g = self.__dict__["_text_graph"] = (key, graph, out)
+        g[1].replay()
+        return g[2].clone()                                              # the static buffer is rewritten by the next replay
 
     def get_temporal_model_input(self, image_features, similarity, ncentroid):
         """anomaly_clip.py:223-233; returns (features, a_sub): the re-centring is either folded into

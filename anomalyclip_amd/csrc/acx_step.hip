@@ -334,7 +334,10 @@ static inline void colsum_geometry(int64_t rows, int32_t D, int* cgs, int* nslab
   // four slabs per lane), so the slab count, not the block count, sets the kernel's tail (512 slabs: 32 batches = 30 us)
   const int c = (D + 255) / 256;
   long long ns = rows / 64;
-  if (ns > 64) ns = 64;
+  static int probe = -2;
+  if (probe == -2) { const char* e = getenv("ACX_OPT_COLSUM_SLABS"); probe = e ? atoi(e) : -1; }
+  const long long cap = probe > 0 ? probe : 64;
+  if (ns > cap) ns = cap;
   if (ns < 1) ns = 1;
   const int r = (int)((rows + ns - 1) / ns);
   *cgs = c; *rpb = r; *nslab = (int)((rows + r - 1) / r);

@@ -168,23 +168,26 @@ class FeatureStream:
             pool = self.__dict__["_pool"] = ThreadPoolExecutor(max_workers=self.readers)
         return pool
 
-    def batched(self, videos: int = 8, max_tiles: int = 96):
+    def batched(self, videos: int = 8, max_tiles: int = 96, first: int = 2):
         """Iterates over GROUPS of consecutive videos: yields (features [sum_v ncrops * rows_v, D] on the device -- video after
         video, each crop-major in frame order --, [(num_frames, segment_size, rows_per_crop, path), ...]).  A group holds up
         to `videos` videos and `max_tiles` 512-frame tiles (per crop); one pinned slot, ONE host-to-device copy per group, the
-        next group read by the reader thread meanwhile."""
+        next group read by the reader thread meanwhile.  The FIRST group holds at most `first` videos: nothing overlaps its
+        read + copy, so it is kept short (the consumer starts after ~1 ms instead of a full group's ~5 ms)."""
         from concurrent.futures import ThreadPoolExecutor
         groups, cur, tiles = [], [], 0
         for p in self.paths:
             S = self._geometry(p)[1]
-            if cur and (len(cur) >= videos or tiles + S > max_tiles):
+            if cur and (len(cur) >= (videos if groups else max(1, min(first, videos))) or tiles + S > max_tiles):
                 groups.append(cur)
                 cur, tiles = [], 0
             cur.append(p)
             tiles += S
         if cur:
             groups.append(cur)
-        pending = None
+        # group i is handed to the consumer as soon as its copy is ENQUEUED (the consumer's stream waits for the copy on the
+        # device); the reader thread fills the other slot with group i + 1 meanwhile, and that group's copy overlaps
+        # whatever the consumer queued for group i
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(self._host_group, groups[0], 0) if groups else None
             for i in range(len(groups)):
@@ -196,13 +199,9 @@ class FeatureStream:
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
                 self._copied[slot] = ev
-                if pending is not None:
-                    yield pending
                 torch.cuda.current_stream().wait_event(ev)
                 dev.record_stream(torch.cuda.current_stream())
-                pending = (dev, meta)
-            if pending is not None:
-                yield pending
+                yield dev, meta
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, int, int, str]]:
         # One reader thread runs a video ahead: file i + 1 is read into its pinned slot (file I/O and large copies release

@@ -225,6 +225,16 @@ int acx_selector_project_stats(acx_ctx* ctx, const float* x, const float* ncentr
                                const float* dirs, float* raw, int64_t rows, int32_t D, int32_t C1,
                                float* mean, float* var_biased, float* var_unbiased,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* acx_selector_project_stats_one: the same in ONE launch where the shape allows it (rows >= 256,
+ * C-1 <= 32, D in {128, 256, 512, 768, 1024}; two launches otherwise): the last workgroup to
+ * arrive adds the per-workgroup partials in acx_selector_project_stats's order (bit-identical
+ * statistics).  `counter`: one uint32 owned by the caller, ZERO when the call is enqueued and
+ * zero again when it completes; calls that may run concurrently need distinct counters. */
+int acx_selector_project_stats_one(acx_ctx* ctx, const float* x, const float* ncentroid,
+                                   const float* dirs, float* raw, int64_t rows, int32_t D, int32_t C1,
+                                   float* mean, float* var_biased, float* var_unbiased,
+                                   void* workspace, size_t workspace_bytes, uint32_t* counter,
+                                   void* stream);
 /* acx_selector_bn: logits = (raw - mean) / sqrt(var + eps)  (BatchNorm1d(C-1, affine=False),
  * selector_model.py:30,65).  mean/var [C1] (running stats in eval, batch stats in train). */
 int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean, const float* var,
