@@ -104,8 +104,6 @@ _SIGS = {
     "acx_bn_stats": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "acx_selector_project_stats": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "acx_selector_project_stats_one": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "acx_selector_bn": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                   c_float, c_void_p]),
     "acx_axial_attention": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -222,18 +222,10 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
 // during the stores), one workgroup of eight waves per CU.
 typedef __attribute__((address_space(3))) void selm_lds_t;
 constexpr int SELD_ST = 2;                      // ring stages per wave (three measured no faster: 16.6 vs 15.5 us)
-// STATS with fin.counter != nullptr: the batch statistics are FINISHED by the last workgroup to arrive (no bn_finalize launch):
-// partials published with agent-scope stores + s_waitcnt vmcnt(0), a relaxed arrival counter (zero at rest, reset by the last
-// arriver), partials read back with agent-scope loads in bn_finalize_kernel's order -- the same bits as the two-launch path.
-struct SelFin {
-  unsigned int* counter;
-  float *mean, *var_b, *var_u;
-};
-__device__ __forceinline__ double bn_pair_total_agent(const double* part, int nblocks, int CP, int C1, double* red);
 template <int D, int NT, bool STATS>
 __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* __restrict__ x, const float* __restrict__ nc,
                                                                    const float* __restrict__ dirs, float* __restrict__ raw,
-                                                                   int64_t rows, int C1, double* __restrict__ part, const SelFin fin) {
+                                                                   int64_t rows, int C1, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int LD = D + 4;
   constexpr int NCK = D / 64;                    // 64-float chunks per row
@@ -361,37 +353,7 @@ __global__ __launch_bounds__(512) void selector_project_dma_kernel(const float* 
       const int k = threadIdx.x / (16 * NT), c = threadIdx.x - k * 16 * NT;
       double v = 0.0;
       for (int w = 0; w < 8; ++w) v += red[(w * 2 + k) * 16 * NT + c];
-      if (fin.counter) {
-        __hip_atomic_store(&part[(size_t)blockIdx.x * 2 * 16 * NT + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        part[(size_t)blockIdx.x * 2 * 16 * NT + threadIdx.x] = v;
-      }
-    }
-    if (fin.counter) {
-      __shared__ bool last;
-      __syncthreads();
-      if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-      __syncthreads();
-      if (!last) return;
-      double* fred = reinterpret_cast<double*>(smem) + 1024;             // [256] + [128] behind the per-wave table above
-      double* tot = fred + 256;
-      double v = 0.0;
-      v = bn_pair_total_agent(part, (int)gridDim.x, 16 * NT, C1, fred);  // threads >= 256 take no blocks
-      if ((int)threadIdx.x < 2 * C1) tot[threadIdx.x] = v;
-      __syncthreads();
-      const int c = threadIdx.x;
-      if (c < C1) {
-        const double sm = tot[c], qq = tot[C1 + c];
-        const double n = (double)rows, m = sm / n;
-        double m2 = qq - sm * m;
-        if (m2 < 0.0) m2 = 0.0;
-        fin.mean[c] = (float)m;
-        fin.var_b[c] = (float)(m2 / n);
-        fin.var_u[c] = rows > 1 ? (float)(m2 / (n - 1.0)) : 0.f;
-      }
-      if (threadIdx.x == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      part[(size_t)blockIdx.x * 2 * 16 * NT + threadIdx.x] = v;
     }
   }
 }
@@ -454,32 +416,6 @@ __device__ __forceinline__ double bn_pair_total(const double* __restrict__ part,
   if ((int)threadIdx.x < P)
     for (int gg = 0; gg < G; ++gg) tot += red[gg * P + threadIdx.x];
   return tot;                                                          // valid for threadIdx.x < 2*C1: pair (k = t / C1, c = t % C1)
-}
-// bn_pair_total for partials published by OTHER workgroups of the running kernel (agent-scope loads; same order, same bits)
-__device__ __forceinline__ double bn_pair_total_agent(const double* part, int nblocks, int CP, int C1, double* red) {
-  const int P = 2 * C1, G = 256 / P;
-  const int p = threadIdx.x % P, g = threadIdx.x / P;
-  double v = 0.0;
-  if (g < G) {
-    const int k = p / C1, c = p - k * C1;
-    const double* src = part + (size_t)k * CP + c;
-    const size_t bs = (size_t)2 * CP;
-    int b = g;
-    for (; b + 7 * G < nblocks; b += 8 * G) {
-      double t8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t8[u] = __hip_atomic_load(src + (size_t)(b + u * G) * bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += t8[u];
-    }
-    for (; b < nblocks; b += G) v += __hip_atomic_load(src + (size_t)b * bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (threadIdx.x < 256) red[threadIdx.x] = v;
-  __syncthreads();
-  double tot = 0.0;
-  if ((int)threadIdx.x < P)
-    for (int gg = 0; gg < G; ++gg) tot += red[gg * P + threadIdx.x];
-  return tot;
 }
 // mean / biased / unbiased variance from the (sum, sum of squares) partials: var = E[x^2] - mean^2 in f64 (the column
 // values are O(1): 53 bits leave ~1e-13 after the cancellation)
@@ -745,9 +681,7 @@ extern "C" size_t acx_bn_workspace_bytes(int64_t rows, int32_t C1) {
 
 // shared launcher: projection (+ optional fused batch statistics); returns false when the shape does not fit the MFMA kernel
 static bool launch_selector_mfma(const float* x, const float* nc, const float* dirs, float* raw, int64_t rows, int D, int C1,
-                                 double* part, int* nblocks, int ncu, hipStream_t s, SelFin fin = SelFin{nullptr, nullptr, nullptr, nullptr},
-                                 bool* finalized = nullptr) {
-  if (finalized) *finalized = false;
+                                 double* part, int* nblocks, int ncu, hipStream_t s) {
   const int NT = (C1 + 15) / 16;
   const size_t lds = ((size_t)16 * NT * (D + 4) + D) * 4;
   if ((D != 64 && D != 128 && D != 256 && D != 512 && D != 768 && D != 1024) || lds > 160 * 1024) return false;
@@ -758,19 +692,17 @@ static bool launch_selector_mfma(const float* x, const float* nc, const float* d
     int64_t nbd = (ng + 7) / 8;
     if (nbd > ncu) nbd = ncu;
     *nblocks = (int)nbd;
-    if (finalized && part && fin.counter) *finalized = true;
-    else fin.counter = nullptr;
     const dim3 dgrid((unsigned)nbd), dblock(512);
 #define ACX_SELDMA(DD, N_)                                                                                                \
   do {                                                                                                                    \
     if (part) {                                                                                                           \
       (void)hipFuncSetAttribute((const void*)selector_project_dma_kernel<DD, N_, true>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);                                \
-      hipLaunchKernelGGL((selector_project_dma_kernel<DD, N_, true>), dgrid, dblock, lds_dma, s, x, nc, dirs, raw, rows, C1, part, fin); \
+      hipLaunchKernelGGL((selector_project_dma_kernel<DD, N_, true>), dgrid, dblock, lds_dma, s, x, nc, dirs, raw, rows, C1, part); \
     } else {                                                                                                              \
       (void)hipFuncSetAttribute((const void*)selector_project_dma_kernel<DD, N_, false>,                                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);                                \
-      hipLaunchKernelGGL((selector_project_dma_kernel<DD, N_, false>), dgrid, dblock, lds_dma, s, x, nc, dirs, raw, rows, C1, part, fin); \
+      hipLaunchKernelGGL((selector_project_dma_kernel<DD, N_, false>), dgrid, dblock, lds_dma, s, x, nc, dirs, raw, rows, C1, part); \
     }                                                                                                                     \
   } while (0)
 #define ACX_SELDMA_D(DD) do { if (NT == 1) ACX_SELDMA(DD, 1); else ACX_SELDMA(DD, 2); } while (0)
@@ -944,10 +876,9 @@ extern "C" int acx_bn_bwd_stats(acx_ctx* ctx, const float* logits, const float* 
   return ACX_OK;
 }
 
-static int selector_project_stats_impl(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
-                                       int64_t rows, int32_t D, int32_t C1, float* mean, float* var_biased,
-                                       float* var_unbiased, void* workspace, size_t workspace_bytes, uint32_t* counter,
-                                       void* stream) {
+extern "C" int acx_selector_project_stats(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
+                                          int64_t rows, int32_t D, int32_t C1, float* mean, float* var_biased,
+                                          float* var_unbiased, void* workspace, size_t workspace_bytes, void* stream) {
   if (!mean || !var_biased || !var_unbiased || !workspace)
     return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project_stats: null pointer%s");
   if (rows <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project_stats: empty%s");
@@ -961,17 +892,11 @@ static int selector_project_stats_impl(acx_ctx* ctx, const float* x, const float
   int nb = 0;
   {
     AcxProfScope prof__(ctx, ACX_K_OTHER, s);
-    bool finalized = false;
-    if (!launch_selector_mfma(x, ncentroid, dirs, raw, rows, D, C1, (double*)workspace, &nb, ncu, s,
-                              SelFin{counter, mean, var_biased, var_unbiased}, &finalized)) {
+    if (!launch_selector_mfma(x, ncentroid, dirs, raw, rows, D, C1, (double*)workspace, &nb, ncu, s)) {
       // shape outside the MFMA kernel: projection, then the stand-alone statistics
       int rc = acx_selector_project(ctx, x, ncentroid, dirs, raw, rows, D, C1, stream);
       if (rc != ACX_OK) return rc;
       return acx_bn_stats(ctx, raw, rows, C1, mean, var_biased, var_unbiased, workspace, workspace_bytes, stream);
-    }
-    if (finalized) {                                                   // the last workgroup finished the statistics
-      ACX_CHECK_LAUNCH(ctx, "acx_selector_project_stats");
-      return ACX_OK;
     }
   }
   AcxProfScope prof2__(ctx, ACX_K_OTHER, s);
@@ -980,22 +905,6 @@ static int selector_project_stats_impl(acx_ctx* ctx, const float* x, const float
                      var_unbiased);
   ACX_CHECK_LAUNCH(ctx, "acx_selector_project_stats");
   return ACX_OK;
-}
-
-extern "C" int acx_selector_project_stats(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
-                                          int64_t rows, int32_t D, int32_t C1, float* mean, float* var_biased,
-                                          float* var_unbiased, void* workspace, size_t workspace_bytes, void* stream) {
-  return selector_project_stats_impl(ctx, x, ncentroid, dirs, raw, rows, D, C1, mean, var_biased, var_unbiased, workspace,
-                                     workspace_bytes, nullptr, stream);
-}
-
-extern "C" int acx_selector_project_stats_one(acx_ctx* ctx, const float* x, const float* ncentroid, const float* dirs, float* raw,
-                                              int64_t rows, int32_t D, int32_t C1, float* mean, float* var_biased,
-                                              float* var_unbiased, void* workspace, size_t workspace_bytes, uint32_t* counter,
-                                              void* stream) {
-  if (!counter || ((uintptr_t)counter & 3)) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_project_stats_one: null or misaligned counter%s");
-  return selector_project_stats_impl(ctx, x, ncentroid, dirs, raw, rows, D, C1, mean, var_biased, var_unbiased, workspace,
-                                     workspace_bytes, counter, stream);
 }
 
 extern "C" int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean, const float* var, float* logits,
@@ -1286,7 +1195,11 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned cha
 // pass through LDS in chunks), phase 2 resamples vertically out of LDS (thread = four pixels x three
 // channels = three dwords per tap) and writes the normalised f32 planes with 16-byte stores.  The uint8 intermediate
 // never reaches memory; arithmetic and rounding are those of the two kernels above (bit-identical output).
-template <int KS>
+// ALLIN: the band's input rows span at most FOUR chunks and every chunk's 16-byte blocks are requested up front (4 x 4
+// registers per thread): the workgroup waits for HBM ONCE instead of once per chunk -- the chunk loop's arithmetic is ~0.3 us
+// per chunk against ~3 us of memory latency, so with sequential chunks a workgroup spent its life waiting (240 x 320 frames:
+// 168 us per 512 frames, 0.42 of the copy rate); the vertical pass's bounds / coefficients come out of LDS as well.
+template <int KS, bool ALLIN>
 __global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
                                                                const int* __restrict__ hb, const int* __restrict__ hk,
                                                                const int* __restrict__ vb, const int* __restrict__ vk, int vks,
@@ -1318,30 +1231,43 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned ch
     for (int x = 0; x < KS; ++x) { k[x] = hk[(size_t)xo * KS + x]; px[x] = 3 * min(xmin + x, W - 1); }
   }
   const int roww = W * 3;
-  // the chunk's 16-byte blocks pass through four registers per thread (cr rows <= 12 KB + alignment = at most 770 blocks):
-  // chunk c + 1 is requested BEFORE chunk c is resampled, so a workgroup waits for HBM once per band, not once per chunk
-  uint4 pre[4];
-#define PPF_FETCH(c0_)                                                                             \
-  do {                                                                                             \
-    const int nr_ = min(cr, nrows - (c0_));                                                        \
-    const size_t g0_ = ((size_t)f * H + y0 + (c0_)) * (size_t)roww;                                \
-    const size_t ga_ = g0_ & ~(size_t)15;                                                          \
-    const int nvec_ = ((int)(g0_ - ga_) + nr_ * roww + 15) >> 4;                                   \
-    const uint4* src_ = reinterpret_cast<const uint4*>(in + ga_);                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-      if (t + 256 * j < nvec_) pre[j] = src_[t + 256 * j];                                         \
-  } while (0)
-  PPF_FETCH(0);
-  for (int c0 = 0; c0 < nrows; c0 += cr) {
+  uint4 pre[ALLIN ? 4 : 1][4];
+  if constexpr (ALLIN) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int c0 = c * cr;
+      if (c0 < nrows) {
+        const int nr = min(cr, nrows - c0);
+        const size_t g0 = ((size_t)f * H + y0 + c0) * (size_t)roww;
+        const size_t ga = g0 & ~(size_t)15;
+        const int nvec = ((int)(g0 - ga) + nr * roww + 15) >> 4;
+        const uint4* src = reinterpret_cast<const uint4*>(in + ga);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (t + 256 * j < nvec) pre[c][j] = src[t + 256 * j];
+      }
+    }
+  }
+  __shared__ int svb[2 * 32], svk[32 * 15];      // the band's vertical bounds / coefficients (R <= 32 rows, <= 15 taps)
+  if (t < 2 * (yo1 - yo0)) svb[t] = vb[2 * yo0 + t];
+  for (int i = t; i < (yo1 - yo0) * vks; i += 256) svk[i] = vk[(size_t)yo0 * vks + i];
+#pragma unroll
+  for (int cc = 0; cc < (ALLIN ? 4 : 1); ++cc)
+  for (int c0 = ALLIN ? cc * cr : 0; c0 < (ALLIN ? min(nrows, (cc + 1) * cr) : nrows); c0 += cr) {
     const int nr = min(cr, nrows - c0);
     const size_t g0 = ((size_t)f * H + y0 + c0) * (size_t)roww;
-    const int phase = (int)(g0 & (size_t)15);
+    const size_t ga = g0 & ~(size_t)15;
+    const int phase = (int)(g0 - ga);
     const int nvec = (phase + nr * roww + 15) >> 4;
+    if constexpr (ALLIN) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (t + 256 * j < nvec) reinterpret_cast<uint4*>(raw)[t + 256 * j] = pre[j];
+      for (int j = 0; j < 4; ++j)
+        if (t + 256 * j < nvec) reinterpret_cast<uint4*>(raw)[t + 256 * j] = pre[cc][j];
+    } else {
+      const uint4* src = reinterpret_cast<const uint4*>(in + ga);
+      for (int i = t; i < nvec; i += 256) reinterpret_cast<uint4*>(raw)[i] = src[i];
+    }
     __syncthreads();
-    if (c0 + cr < nrows) PPF_FETCH(c0 + cr);
     if (xo < ocols) {
 #pragma unroll 2
       for (int r = 0; r < nr; ++r) {
@@ -1359,13 +1285,12 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned ch
     }
     __syncthreads();
   }
-#undef PPF_FETCH
   // ---- phase 2: out[f][c][yo][4 g ..] = lut[c][clip8(0.5 + sum_y tmp[ymin - y0 + y][..] * k[yo][y])]
   const int ng = ocols >> 2;
   for (int id = t; id < (yo1 - yo0) * ng; id += 256) {
     const int yl = id / ng, g = id - yl * ng, yo = yo0 + yl;
-    const int ymin = vb[2 * yo] - y0, yn = vb[2 * yo + 1];
-    const int* kv = vk + (size_t)yo * vks;
+    const int ymin = svb[2 * yl] - y0, yn = svb[2 * yl + 1];
+    const int* kv = svk + yl * vks;
     int acc[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 1 << 21;
@@ -1411,17 +1336,24 @@ extern "C" int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, 
     const int maxrows = (int)((R - 1) * ((vksize - 1) / 4.0) + vksize + 2);
     const int cr = std::max(1, std::min(16, 12288 / (W * 3)));              // input rows per LDS chunk (<= 12 KB)
     const size_t lds = (size_t)maxrows * ocols * 3 + (size_t)cr * W * 3 + 32;
-    if (lds <= 96 * 1024 && ocols <= 256 && (maxrows * ocols * 3) % 16 == 0 && (size_t)cr * W * 3 <= 12288) {
+    if (lds <= 96 * 1024 && ocols <= 256 && (maxrows * ocols * 3) % 16 == 0 && R <= 32 && vksize <= 15) {
       const dim3 grid((unsigned)((orows + R - 1) / R), (unsigned)F);
+      // every chunk of a band requested up front: at most four chunks of at most 1024 16-byte blocks
+      const bool allin = (maxrows + cr - 1) / cr <= 4 && (size_t)cr * W * 3 + 32 <= 4 * 256 * 16;
 #define ACX_PPF(KS)                                                                                 \
   do {                                                                                              \
     static bool attr_dev_[64] = {}; int dv_ = 0; (void)hipGetDevice(&dv_); bool& done_ = attr_dev_[dv_ & 63]; \
     if (!done_) {                                                                                   \
-      (void)hipFuncSetAttribute((const void*)preprocess_fused_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)preprocess_fused_kernel<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)preprocess_fused_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
       done_ = true;                                                                                 \
     }                                                                                               \
-    hipLaunchKernelGGL(preprocess_fused_kernel<KS>, grid, dim3(256), lds, s, frames, out, hbounds, hcoef, vbounds, vcoef, vksize, \
-                       H, W, orows, ocols, R, maxrows, cr, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);              \
+    if (allin)                                                                                      \
+      hipLaunchKernelGGL((preprocess_fused_kernel<KS, true>), grid, dim3(256), lds, s, frames, out, hbounds, hcoef, vbounds, vcoef, vksize, \
+                         H, W, orows, ocols, R, maxrows, cr, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);            \
+    else                                                                                            \
+      hipLaunchKernelGGL((preprocess_fused_kernel<KS, false>), grid, dim3(256), lds, s, frames, out, hbounds, hcoef, vbounds, vcoef, vksize, \
+                         H, W, orows, ocols, R, maxrows, cr, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);            \
   } while (0)
       switch (hksize) {
         case 5: ACX_PPF(5); break;   case 7: ACX_PPF(7); break;   case 9: ACX_PPF(9); break;

@@ -143,28 +143,32 @@ __global__ __launch_bounds__(256) void adamw_multi_dev_kernel(const AdamwDevSegs
 // out[c] = sum_r x[r][c] in ONE launch, deterministic: block (slab, column group of 64) writes its partial row, the LAST block
 // of a column group to arrive (device-scope counter) adds the slabs' partials in slab order.  The counter returns to zero,
 // so the launch is replayable from a HIP graph.  Replaces colsum_partials + reduce_rows (two launches per bias gradient).
+// LANES float4 lanes per row slice (column group = 4 * LANES columns), 256 / LANES row slices per block: narrow matrices take
+// narrow groups so that a launch still has >= 256 blocks x 8 rows in flight per lane (D = 512 at 64 slabs was 128 blocks on 128
+// of the 256 CUs: 3.3 TB/s)
+template <int LANES>
 __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
                                                   float* __restrict__ part, float* __restrict__ out,
                                                   unsigned int* __restrict__ counters, const int cg, const int slab, const int nslab,
                                                   const float beta) {
-  // block = 256 columns (64 float4 lanes: one wave-level load covers 1 KB of ONE row) x 4 row slices (the four waves);
-  // slice k adds rows r0 + k, r0 + k + 4, ... in order, the four slices are added in slice order
-  __shared__ float4 red[4][64];
+  // block = 4 LANES columns x NS row slices; slice k adds rows r0 + k, r0 + k + NS, ... in order, the slices are added in slice order
+  constexpr int NS = 256 / LANES;
+  __shared__ float4 red[NS][LANES];
   __shared__ bool last;
-  const int q = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = cg * 256 + 4 * q;
+  const int q = threadIdx.x % LANES, sl = threadIdx.x / LANES;
+  const int c = cg * (4 * LANES) + 4 * q;
   const long long r0 = (long long)slab * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < D) {
     long long r = r0 + sl;
-    for (; r + 28 < r1; r += 32) {                 // eight rows in flight per lane (independent loads, fixed add order)
+    for (; r + 7 * NS < r1; r += 8 * NS) {         // eight rows in flight per lane (independent loads, fixed add order)
       float4 v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(x + (r + 4 * k) * ld + c);
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(x + (r + NS * k) * ld + c);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
     }
-    for (; r < r1; r += 4) {
+    for (; r < r1; r += NS) {
       const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
@@ -179,7 +183,7 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
   if (sl == 0 && c < D) {
     float4 t = red[0][q];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
+    for (int k = 1; k < NS; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
     float* dst = part + (size_t)slab * D + c;
     __hip_atomic_store(dst + 0, t.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dst + 1, t.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -192,23 +196,23 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
     last = __hip_atomic_fetch_add(&counters[cg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nslab - 1;
   __syncthreads();
   if (!last) return;
-  // last block of the column group to arrive: 64 float4 columns x 4 slab lanes; lane l adds slabs l, l + 4, ... in order (four
-  // slabs = sixteen scalar loads in flight), the four lane sums are then added in lane order -- a fixed tree
+  // last block of the column group to arrive: LANES float4 columns x NS slab lanes; lane l adds slabs l, l + NS, ... in order
+  // (four slabs = sixteen scalar loads in flight), the NS lane sums are then added in lane order -- a fixed tree
   {
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < D) {
       int p = sl;
-      for (; p + 12 < nslab; p += 16) {
+      for (; p + 3 * NS < nslab; p += 4 * NS) {
         float v[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            v[4 * k + j] = __hip_atomic_load(part + (size_t)(p + 4 * k) * D + c + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[4 * k + j] = __hip_atomic_load(part + (size_t)(p + NS * k) * D + c + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s0.x += v[4 * k]; s0.y += v[4 * k + 1]; s0.z += v[4 * k + 2]; s0.w += v[4 * k + 3]; }
       }
-      for (; p < nslab; p += 4) {
+      for (; p < nslab; p += NS) {
         s0.x += __hip_atomic_load(part + (size_t)p * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s0.y += __hip_atomic_load(part + (size_t)p * D + c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s0.z += __hip_atomic_load(part + (size_t)p * D + c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -220,7 +224,7 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
     if (sl == 0 && c < D) {
       float4 t = red[0][q];
 #pragma unroll
-      for (int k = 1; k < 4; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
+      for (int k = 1; k < NS; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
       if (beta != 0.f) {
         const float4 o = *reinterpret_cast<const float4*>(out + c);
         t.x += beta * o.x; t.y += beta * o.y; t.z += beta * o.z; t.w += beta * o.w;
@@ -231,10 +235,18 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
   if (threadIdx.x == 0) __hip_atomic_store(&counters[cg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ void colsum_fused_dispatch(int lanes, const float* __restrict__ x, int ld, long long rows, int D, int rpb,
+                                                      float* __restrict__ part, float* __restrict__ out,
+                                                      unsigned int* __restrict__ counters, int cg, int slab, int nslab, float beta) {
+  if (lanes == 64) colsum_fused_body<64>(x, ld, rows, D, rpb, part, out, counters, cg, slab, nslab, beta);
+  else if (lanes == 32) colsum_fused_body<32>(x, ld, rows, D, rpb, part, out, counters, cg, slab, nslab, beta);
+  else colsum_fused_body<16>(x, ld, rows, D, rpb, part, out, counters, cg, slab, nslab, beta);
+}
+
 __global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ x, int ld, long long rows, int D, int rpb,
                                                            float* __restrict__ part, float* __restrict__ out,
-                                                           unsigned int* __restrict__ counters, float beta) {
-  colsum_fused_body(x, ld, rows, D, rpb, part, out, counters, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, beta);
+                                                           unsigned int* __restrict__ counters, float beta, int lanes) {
+  colsum_fused_dispatch(lanes, x, ld, rows, D, rpb, part, out, counters, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, beta);
 }
 
 // several column sums in one launch (the bias gradients of a backward pass): flat block index -> (problem, column group, slab)
@@ -245,6 +257,7 @@ struct ColsumGroup {
   float* out[COLSUM_GROUP_MAX];
   long long rows[COLSUM_GROUP_MAX];
   int ld[COLSUM_GROUP_MAX], D[COLSUM_GROUP_MAX], rpb[COLSUM_GROUP_MAX], cgs[COLSUM_GROUP_MAX], nslab[COLSUM_GROUP_MAX];
+  int lanes[COLSUM_GROUP_MAX];
   int ctr0[COLSUM_GROUP_MAX];                       // first arrival counter of the problem
   int blk0[COLSUM_GROUP_MAX + 1];
   int n;
@@ -258,8 +271,8 @@ __global__ __launch_bounds__(256) void colsum_fused_group_kernel(const ColsumGro
   const int local = b - G.blk0[k];
   const int cgs = G.cgs[k];
   const int slab = local / cgs;
-  colsum_fused_body(G.x[k], G.ld[k], G.rows[k], G.D[k], G.rpb[k], G.part[k], G.out[k], counters + G.ctr0[k], local - slab * cgs, slab,
-                    G.nslab[k], 0.f);
+  colsum_fused_dispatch(G.lanes[k], G.x[k], G.ld[k], G.rows[k], G.D[k], G.rpb[k], G.part[k], G.out[k], counters + G.ctr0[k],
+                        local - slab * cgs, slab, G.nslab[k], 0.f);
 }
 
 // out_k[c] = sum_p part_k[p][c] for several partial tables in one launch (LayerNorm / classifier parameter gradients): fixed
@@ -329,18 +342,18 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long l
 
 }  // namespace
 
-static inline void colsum_geometry(int64_t rows, int32_t D, int* cgs, int* nslab, int* rpb) {
+static inline void colsum_geometry(int64_t rows, int32_t D, int* cgs, int* nslab, int* rpb, int* lanes) {
   // at most 64 slabs of >= 64 rows: the last arriver walks the slabs' partials with memory-latency-bound batches (~1 us per
-  // four slabs per lane), so the slab count, not the block count, sets the kernel's tail (512 slabs: 32 batches = 30 us)
-  const int c = (D + 255) / 256;
+  // four slabs per lane), so the slab count, not the block count, sets the kernel's tail (512 slabs: 32 batches = 30 us);
+  // the column groups narrow (256 -> 128 -> 64 columns) until the launch has 256 blocks
   long long ns = rows / 64;
-  static int probe = -2;
-  if (probe == -2) { const char* e = getenv("ACX_OPT_COLSUM_SLABS"); probe = e ? atoi(e) : -1; }
-  const long long cap = probe > 0 ? probe : 64;
-  if (ns > cap) ns = cap;
+  if (ns > 64) ns = 64;
   if (ns < 1) ns = 1;
   const int r = (int)((rows + ns - 1) / ns);
-  *cgs = c; *rpb = r; *nslab = (int)((rows + r - 1) / r);
+  const int nsl = (int)((rows + r - 1) / r);
+  int ln = 64;
+  while (ln > 16 && (long long)((D + 4 * ln - 1) / (4 * ln)) * nsl < 256) ln >>= 1;
+  *lanes = ln; *cgs = (D + 4 * ln - 1) / (4 * ln); *rpb = r; *nslab = nsl;
 }
 
 extern "C" int acx_prep_multi(acx_ctx* ctx, int32_t nseg, const acx_prep_seg* segs, void* stream) {
@@ -468,13 +481,13 @@ extern "C" int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_
   if (D % 4 || ld % 4 || D > 256 * 256 || (((uintptr_t)x | (uintptr_t)part) & 15))
     return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused: D / ld multiples of 4, D <= 16384, 16-byte aligned x / part%s");
   // slabs: enough blocks to fill the chip a few times over, at least 64 rows each
-  int cgs, nslab_i, rpb;
-  colsum_geometry(rows, D, &cgs, &nslab_i, &rpb);
+  int cgs, nslab_i, rpb, lanes;
+  colsum_geometry(rows, D, &cgs, &nslab_i, &rpb, &lanes);
   long long nslab = nslab_i;
   if ((size_t)nslab * D * sizeof(float) > part_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_colsum_fused: partial buffer too small%s");
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   hipLaunchKernelGGL(colsum_fused_kernel, dim3((unsigned)cgs, (unsigned)nslab), dim3(256), 0, (hipStream_t)stream, x, ld,
-                     (long long)rows, D, rpb, part, out, counters, beta);
+                     (long long)rows, D, rpb, part, out, counters, beta, lanes);
   ACX_CHECK_LAUNCH(ctx, "acx_colsum_fused");
   return ACX_OK;
 }
@@ -494,11 +507,11 @@ extern "C" int acx_colsum_fused_group(acx_ctx* ctx, int32_t nprob, const void* c
       if (rows[i] <= 0 || D[i] <= 0) continue;
       if (!x[i] || !out[i] || !part[i] || D[i] % 4 || ld[i] % 4 || (((uintptr_t)x[i] | (uintptr_t)part[i]) & 15))
         return acx_fail(ctx, ACX_E_BADARG, "acx_colsum_fused_group: D / ld multiples of 4, 16-byte aligned x / part%s");
-      int cgs, nslab, rpb;
-      colsum_geometry(rows[i], D[i], &cgs, &nslab, &rpb);
+      int cgs, nslab, rpb, lanes;
+      colsum_geometry(rows[i], D[i], &cgs, &nslab, &rpb, &lanes);
       if (ctr + cgs > ncounters) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_colsum_fused_group: not enough arrival counters%s");
       G.x[k] = (const float*)x[i]; G.part[k] = (float*)part[i]; G.out[k] = (float*)out[i];
-      G.rows[k] = rows[i]; G.ld[k] = ld[i]; G.D[k] = D[i]; G.rpb[k] = rpb; G.cgs[k] = cgs; G.nslab[k] = nslab;
+      G.rows[k] = rows[i]; G.ld[k] = ld[i]; G.D[k] = D[i]; G.rpb[k] = rpb; G.cgs[k] = cgs; G.nslab[k] = nslab; G.lanes[k] = lanes;
       G.ctr0[k] = ctr; ctr += cgs;
       G.blk0[k] = blocks; blocks += cgs * nslab;
       ++k;
@@ -540,8 +553,8 @@ extern "C" int acx_reduce_rows_group(acx_ctx* ctx, int32_t nprob, const void* co
 
 extern "C" size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D) {
   if (rows <= 0 || D <= 0) return 0;
-  int cgs, nslab, rpb;
-  colsum_geometry(rows, D, &cgs, &nslab, &rpb);
+  int cgs, nslab, rpb, lanes;
+  colsum_geometry(rows, D, &cgs, &nslab, &rpb, &lanes);
   return (size_t)(nslab + 1) * D * sizeof(float);
 }
 

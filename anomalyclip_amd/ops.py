@@ -172,14 +172,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
         if amap == L.AMAP_CONV3X3 and prec == L.PREC_F32:
             # f32 convolutions: the split pieces are reduced INSIDE the kernel (last-arriver, no second launch)
             ctr = _colsum_counters(a.device)
-            d.counters, d.n_counters = ctr.data_ptr(), _CTR_N - 2
+            d.counters, d.n_counters = ctr.data_ptr(), _CTR_N - 1
     if few_rows and K >= 1024 and K % 512 == 0 and ((M + 31) // 32) * ((N + 31) // 32) * (K // 512) <= 512:
         # long K on few tiles (the text tower's K = 2048 GEMMs): K split across workgroups, last-arriver reduction in-kernel
         tiles32 = ((M + 31) // 32) * ((N + 31) // 32)
         ws = _splitk_workspace(a.device, (K // 512) * tiles32 * 4096)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         ctr = _colsum_counters(a.device)
-        d.counters, d.n_counters = ctr.data_ptr(), _CTR_N - 2               # the last entry belongs to the loss kernel
+        d.counters, d.n_counters = ctr.data_ptr(), _CTR_N - 1               # the last entry belongs to the loss kernel
     h = _h(a)
     L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)
     return out
@@ -273,10 +273,9 @@ def selector_project_stats(x: torch.Tensor, ncentroid: torch.Tensor, dirs: torch
     st = torch.empty(3, C1, dtype=torch.float32, device=x.device)
     ws = _bn_workspace(x, rows, C1)
     h = _h(x)
-    ctr = _colsum_counters(x.device)[_CTR_N - 2:]           # its own entry of the stream's arrival-counter table
-    L.check(L.lib().acx_selector_project_stats_one(h, x.data_ptr(), ncentroid.data_ptr(), dirs.data_ptr(), raw.data_ptr(), rows,
-                                                   D, C1, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), ws.data_ptr(),
-                                                   ws.numel() * 8, ctr.data_ptr(), _stream()), h)
+    L.check(L.lib().acx_selector_project_stats(h, x.data_ptr(), ncentroid.data_ptr(), dirs.data_ptr(), raw.data_ptr(), rows, D,
+                                               C1, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), ws.data_ptr(),
+                                               ws.numel() * 8, _stream()), h)
     return raw, st[0], st[1], st[2]
 
 

@@ -225,16 +225,6 @@ int acx_selector_project_stats(acx_ctx* ctx, const float* x, const float* ncentr
                                const float* dirs, float* raw, int64_t rows, int32_t D, int32_t C1,
                                float* mean, float* var_biased, float* var_unbiased,
                                void* workspace, size_t workspace_bytes, void* stream);
-/* acx_selector_project_stats_one: the same in ONE launch where the shape allows it (rows >= 256,
- * C-1 <= 32, D in {128, 256, 512, 768, 1024}; two launches otherwise): the last workgroup to
- * arrive adds the per-workgroup partials in acx_selector_project_stats's order (bit-identical
- * statistics).  `counter`: one uint32 owned by the caller, ZERO when the call is enqueued and
- * zero again when it completes; calls that may run concurrently need distinct counters. */
-int acx_selector_project_stats_one(acx_ctx* ctx, const float* x, const float* ncentroid,
-                                   const float* dirs, float* raw, int64_t rows, int32_t D, int32_t C1,
-                                   float* mean, float* var_biased, float* var_unbiased,
-                                   void* workspace, size_t workspace_bytes, uint32_t* counter,
-                                   void* stream);
 /* acx_selector_bn: logits = (raw - mean) / sqrt(var + eps)  (BatchNorm1d(C-1, affine=False),
  * selector_model.py:30,65).  mean/var [C1] (running stats in eval, batch stats in train). */
 int acx_selector_bn(acx_ctx* ctx, const float* raw, const float* mean, const float* var,
@@ -448,13 +438,13 @@ int acx_bn_running_update(acx_ctx* ctx, const float* mean, const float* var_unbi
 int acx_fill_f32(acx_ctx* ctx, float* p, int64_t n, float value, void* stream);
 /* out[D] = column sums of x[rows, ld] in ONE launch, fixed summation order (bias gradients: the reference's autograd sums
  * dY over rows for every nn.Linear / nn.Conv2d bias).  part: scratch of acx_colsum_fused_part_bytes(rows, D) bytes;
- * counters: >= ceil(D / 256) uint32, ZERO before the first call and left zero by every call (caller-owned, reusable).
+ * counters: >= ceil(D / 64) uint32, ZERO before the first call and left zero by every call (caller-owned, reusable).
  * out = sums + beta * out (beta = 0: overwrite; 1: the ncentroid accumulation of anomaly_clip_module.py:145-171). */
 size_t acx_colsum_fused_part_bytes(int64_t rows, int32_t D);
 int acx_colsum_fused(acx_ctx* ctx, const float* x, int32_t ld, int64_t rows, int32_t D, float* out, float* part,
                      size_t part_bytes, uint32_t* counters, float beta, void* stream);
 /* nprob column sums in ONE launch (part[i]: acx_colsum_fused_part_bytes(rows[i], D[i]) bytes each; `counters`: ncounters
- * zero-at-rest uint32, at least sum_i ceil(D[i] / 256)); and nprob row-partial tables reduced in one launch
+ * zero-at-rest uint32, at least sum_i ceil(D[i] / 64)); and nprob row-partial tables reduced in one launch
  * (out_i[width_i] = sum_p part_i[p][:], the summation tree of acx_reduce_rows). */
 int acx_colsum_fused_group(acx_ctx* ctx, int32_t nprob, const void* const* x, const int32_t* ld, const int64_t* rows,
                            const int32_t* D, void* const* out, void* const* part, uint32_t* counters, int32_t ncounters,

@@ -493,7 +493,12 @@ def test_forward_test_many_crops_and_text_cache(prompts_table):
         t2 = net.get_text_features()
         assert t2 is t1
         net.cache_text_features = False
-        t3 = net.get_text_features()
+        t3 = net.get_text_features()                 # uncached evaluation: the tower replayed from a HIP graph
+        assert net.text_eval_graph and net.__dict__.get("_text_graph") is not None, net.__dict__.get("_text_graph_error")
+        graph0 = net.__dict__["_text_graph"][1]
+        t3b = net.get_text_features()
+        assert net.__dict__["_text_graph"][1] is graph0 and t3b is not t3 and torch.equal(t3b, t3)
+        assert torch.equal(t3, net._text_features_eager())
         net.cache_text_features = True
         assert t3 is not t1 and torch.equal(t3, t1)
         from anomalyclip_amd import ops as OPS
@@ -503,6 +508,10 @@ def test_forward_test_many_crops_and_text_cache(prompts_table):
         net.prompt_learner.ctx.mul_(1.5)             # an in-place edit bumps the tensor version
         t5 = net.get_text_features()
         assert t5 is not t4 and not torch.equal(t5, t4)
+        net.cache_text_features = False
+        t6 = net.get_text_features()                 # the edit re-captured the graph
+        net.cache_text_features = True
+        assert net.__dict__["_text_graph"][1] is not graph0 and torch.equal(t6, t5)
 
 
 def test_vit_bf16_160_frame_window(golden):
