@@ -212,7 +212,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
 
   const int col = n0 + wn * 32 + li;
   const bool cok = col < d.N;
-  if (g.ksplit > 1) {
+  // (only the convolutions are ever split: keeping the branch out of the plain instantiations keeps the ViT's residual GEMMs at
+  // their round-3 register allocation -- with it compiled in, out-proj / proj lost 4-6 %)
+  if (CONV != 0 && g.ksplit > 1) {
     float* P = g.partial + (size_t)blockIdx.y * d.M * d.N;
     if (!g.counters) {                 // partial tiles for splitk_reduce_kernel (second launch)
 #pragma unroll
@@ -226,15 +228,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
     }
     // In-kernel reduction, no second launch: the K pieces publish their raw tiles with agent-scope (write-through) stores --
     // no release fence, which would write back the XCD's whole L2 --, bump the tile's relaxed arrival counter, and the LAST
-    // piece to arrive adds the pieces in piece order (its own from registers: (0 + p0) + p1 + ..., the reduce kernel's
-    // order, bit for bit) and falls through into the normal epilogue.  The counter returns to zero.
+    // piece to arrive adds the pieces in piece order and falls through into the normal epilogue.  The counter returns to zero.
     __shared__ bool last_piece;
+    // lane-constant 32-bit element offset of (row 0 of the lane's tile rows, its column); the 32 tile rows of a lane are
+    // wave-uniform multiples of N further on: one address register for all of them
+    const int rbase = m0 + wm * 64 + 4 * hh;
+    const unsigned loff = (unsigned)rbase * (unsigned)d.N + (unsigned)col;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mi * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
-        if (cok && row < d.M) __hip_atomic_store(P + (size_t)row * d.N + col, acc[mi][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
+        float* rowp = P + (size_t)ro * d.N;                                // wave-uniform
+        if (cok && rbase + ro < d.M) __hip_atomic_store(rowp + loff, acc[mi][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -242,28 +248,32 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
       last_piece = __hip_atomic_fetch_add(g.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.ksplit - 1;
     __syncthreads();
     if (!last_piece) return;
-    float tot[2][16];
+    // every piece -- this block's own included: it was published like the others -- is read back in piece order ((0 + p0) + p1
+    // + ..., the reduce kernel's order, bit for bit), eight values in flight per lane
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tot[mi][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+#pragma unroll 1
     for (int q = 0; q < g.ksplit; ++q) {
       const float* Pq = g.partial + (size_t)q * d.M * d.N;
-      const bool own = q == (int)blockIdx.y;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + mi * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
-          float pv = acc[mi][r];
-          if (!own) pv = (cok && row < d.M) ? __hip_atomic_load(Pq + (size_t)row * d.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-          tot[mi][r] += pv;
+        for (int r8 = 0; r8 < 16; r8 += 8) {
+          float pv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = r8 + u;
+            const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
+            const float* rowp = Pq + (size_t)ro * d.N;                     // wave-uniform
+            pv[u] = (cok && rbase + ro < d.M) ? __hip_atomic_load(rowp + loff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[mi][r8 + u] += pv[u];
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][r] = tot[mi][r];
     if (threadIdx.x == 0) __hip_atomic_store(g.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- vector epilogue.  In the 32x32 C layout a lane holds ONE column and 16 rows, so the natural store is 32 x
