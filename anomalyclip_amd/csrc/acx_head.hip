@@ -1231,42 +1231,15 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned ch
     for (int x = 0; x < KS; ++x) { k[x] = hk[(size_t)xo * KS + x]; px[x] = 3 * min(xmin + x, W - 1); }
   }
   const int roww = W * 3;
-  uint4 pre[ALLIN ? 4 : 1][4];
-  if constexpr (ALLIN) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int c0 = c * cr;
-      if (c0 < nrows) {
-        const int nr = min(cr, nrows - c0);
-        const size_t g0 = ((size_t)f * H + y0 + c0) * (size_t)roww;
-        const size_t ga = g0 & ~(size_t)15;
-        const int nvec = ((int)(g0 - ga) + nr * roww + 15) >> 4;
-        const uint4* src = reinterpret_cast<const uint4*>(in + ga);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (t + 256 * j < nvec) pre[c][j] = src[t + 256 * j];
-      }
-    }
-  }
   __shared__ int svb[2 * 32], svk[32 * 15];      // the band's vertical bounds / coefficients (R <= 32 rows, <= 15 taps)
-  if (t < 2 * (yo1 - yo0)) svb[t] = vb[2 * yo0 + t];
-  for (int i = t; i < (yo1 - yo0) * vks; i += 256) svk[i] = vk[(size_t)yo0 * vks + i];
-#pragma unroll
-  for (int cc = 0; cc < (ALLIN ? 4 : 1); ++cc)
-  for (int c0 = ALLIN ? cc * cr : 0; c0 < (ALLIN ? min(nrows, (cc + 1) * cr) : nrows); c0 += cr) {
+  // one chunk of input rows: `fill` puts its 16-byte blocks into `raw`, then every thread resamples its output column
+  auto chunk = [&](int c0, auto&& fill) {
     const int nr = min(cr, nrows - c0);
     const size_t g0 = ((size_t)f * H + y0 + c0) * (size_t)roww;
     const size_t ga = g0 & ~(size_t)15;
     const int phase = (int)(g0 - ga);
     const int nvec = (phase + nr * roww + 15) >> 4;
-    if constexpr (ALLIN) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (t + 256 * j < nvec) reinterpret_cast<uint4*>(raw)[t + 256 * j] = pre[cc][j];
-    } else {
-      const uint4* src = reinterpret_cast<const uint4*>(in + ga);
-      for (int i = t; i < nvec; i += 256) reinterpret_cast<uint4*>(raw)[i] = src[i];
-    }
+    fill(nvec, ga);
     __syncthreads();
     if (xo < ocols) {
 #pragma unroll 2
@@ -1284,6 +1257,51 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(const unsigned ch
       }
     }
     __syncthreads();
+  };
+  auto stage_v = [&]() {
+    if (t < 2 * (yo1 - yo0)) svb[t] = vb[2 * yo0 + t];
+    for (int i = t; i < (yo1 - yo0) * vks; i += 256) svk[i] = vk[(size_t)yo0 * vks + i];
+  };
+  if constexpr (ALLIN) {
+    // sixteen NAMED registers (arrays handed to lambdas by reference stay in scratch memory: 272 bytes per lane measured)
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 p00 = z4, p01 = z4, p02 = z4, p03 = z4, p10 = z4, p11 = z4, p12 = z4, p13 = z4;
+    uint4 p20 = z4, p21 = z4, p22 = z4, p23 = z4, p30 = z4, p31 = z4, p32 = z4, p33 = z4;
+#define PPF_FETCH(c, a, b, cc_, dd)                                                                \
+    if ((c) * cr < nrows) {                                                                        \
+      const int nr_ = min(cr, nrows - (c) * cr);                                                   \
+      const size_t g0_ = ((size_t)f * H + y0 + (c) * cr) * (size_t)roww;                           \
+      const size_t ga_ = g0_ & ~(size_t)15;                                                        \
+      const int nvec_ = ((int)(g0_ - ga_) + nr_ * roww + 15) >> 4;                                 \
+      const uint4* src_ = reinterpret_cast<const uint4*>(in + ga_);                                \
+      if (t < nvec_) a = src_[t];                                                                  \
+      if (t + 256 < nvec_) b = src_[t + 256];                                                      \
+      if (t + 512 < nvec_) cc_ = src_[t + 512];                                                    \
+      if (t + 768 < nvec_) dd = src_[t + 768];                                                     \
+    }
+    PPF_FETCH(0, p00, p01, p02, p03) PPF_FETCH(1, p10, p11, p12, p13) PPF_FETCH(2, p20, p21, p22, p23) PPF_FETCH(3, p30, p31, p32, p33)
+#undef PPF_FETCH
+    stage_v();
+#define PPF_PUT(a, b, cc_, dd)                                                                     \
+    [&](int nvec, size_t) {                                                                        \
+      uint4* rw = reinterpret_cast<uint4*>(raw);                                                   \
+      if (t < nvec) rw[t] = a;                                                                     \
+      if (t + 256 < nvec) rw[t + 256] = b;                                                         \
+      if (t + 512 < nvec) rw[t + 512] = cc_;                                                       \
+      if (t + 768 < nvec) rw[t + 768] = dd;                                                        \
+    }
+    chunk(0, PPF_PUT(p00, p01, p02, p03));
+    if (cr < nrows) chunk(cr, PPF_PUT(p10, p11, p12, p13));
+    if (2 * cr < nrows) chunk(2 * cr, PPF_PUT(p20, p21, p22, p23));
+    if (3 * cr < nrows) chunk(3 * cr, PPF_PUT(p30, p31, p32, p33));
+#undef PPF_PUT
+  } else {
+    stage_v();
+    for (int c0 = 0; c0 < nrows; c0 += cr)
+      chunk(c0, [&](int nvec, size_t ga) {
+        const uint4* src = reinterpret_cast<const uint4*>(in + ga);
+        for (int i = t; i < nvec; i += 256) reinterpret_cast<uint4*>(raw)[i] = src[i];
+      });
   }
   // ---- phase 2: out[f][c][yo][4 g ..] = lut[c][clip8(0.5 + sum_y tmp[ymin - y0 + y][..] * k[yo][y])]
   const int ng = ocols >> 2;
