@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
     __syncthreads();
     if (!last_piece) return;
     // every piece -- this block's own included: it was published like the others -- is read back in piece order ((0 + p0) + p1
-    // + ..., the reduce kernel's order, bit for bit), eight values in flight per lane
+    // + ..., the reduce kernel's order, bit for bit)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -257,22 +257,20 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
 #pragma unroll 1
     for (int q = 0; q < g.ksplit; ++q) {
       const float* Pq = g.partial + (size_t)q * d.M * d.N;
+      float pv[2][16];                                                     // a whole piece in flight: one memory latency per piece
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r8 = 0; r8 < 16; r8 += 8) {
-          float pv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int r = r8 + u;
-            const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
-            const float* rowp = Pq + (size_t)ro * d.N;                     // wave-uniform
-            pv[u] = (cok && rbase + ro < d.M) ? __hip_atomic_load(rowp + loff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc[mi][r8 + u] += pv[u];
-          __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 16; ++r) {
+          const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
+          const float* rowp = Pq + (size_t)ro * d.N;                       // wave-uniform
+          pv[mi][r] = (cok && rbase + ro < d.M) ? __hip_atomic_load(rowp + loff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
         }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] += pv[mi][r];
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (threadIdx.x == 0) __hip_atomic_store(g.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
