@@ -326,7 +326,11 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
         step, _ = make_train(B_global)
         dt = timer.run(step, steps, warmup)
         ent = {"global_batch_videos": B_global, "videos_per_gpu": B_global // world,
-               "ms_per_step": round(dt / steps * 1e3, 3), "features_per_s": round(B_global * 512 * steps / dt, 1)}
+               "ms_per_step": round(dt / steps * 1e3, 3), "features_per_s": round(B_global * 512 * steps / dt, 1),
+               # whether THIS leg ran on the whole-step graph (one graph set per batch shape) or fell back to the autograd path
+               "whole_step_graph": bool(net.step_graph) and getattr(mod, "step_graph_error", None) is None and
+                                   any(v is not None for v in mod.__dict__.get("_step_graphs", {}).values()),
+               "step_graph_error": getattr(mod, "step_graph_error", None)}
         if t1 is not None:                            # strong: T1 / (N TN); weak: T1 / TN (same per-GPU work as T1)
             ent["efficiency_vs_t1_same_run"] = round(t1 / ((world if mode == "strong" else 1) * dt / steps), 4)
         # per-rank kernel-time breakdown of the same step (separate short pass: the HIP-event pairs around ~700 launches
