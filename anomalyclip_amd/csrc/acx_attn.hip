@@ -596,6 +596,17 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict
       stv[j] = *reinterpret_cast<const uint4*>(p + 2 * W);
     }
   }
+  // ---- Q fragments (B operand) of this wave's (at most two: NT <= 8) query blocks, requested BEHIND the K / V loads so that the
+  // whole workgroup waits for memory once: query row qb*32 + li, d = 8*(2kk + hh) .. +7.  (Loaded at the head of each query
+  // block they cost a second and a third exposed round trip per workgroup: 16.7 us of lifetime for ~3.5 us of arithmetic.)
+  uint4 qpre[2][4];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = min((wave + 4 * it) * 32 + li, L - 1);
+    const u16* qp = base + (int64_t)q * ldqkv + 8 * hh;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qpre[it][kk] = *reinterpret_cast<const uint4*>(qp + 16 * kk);
+  }
 #pragma unroll
   for (int j = 0; j < NSTG; ++j) {
     const int i = t + j * 256;
@@ -611,16 +622,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict
   __syncthreads();
 
   const int nqb = (L + 31) / 32;
-  for (int qb = wave; qb < nqb; qb += 4) {
-    // ---- Q fragments (B operand): query row qb*32 + li, d = 8*(2kk + hh) .. +7
-    const int q = min(qb * 32 + li, L - 1);
-    const u16* qp = base + (int64_t)q * ldqkv + 8 * hh;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int qb = wave + 4 * it;
+    if (qb >= nqb) break;
     bf16x8 qf[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const uint4 v = *reinterpret_cast<const uint4*>(qp + 16 * kk);
-      qf[kk] = *reinterpret_cast<const bf16x8*>(&v);
-    }
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(&qpre[it][kk]);
     // ---- S^T tiles: keys x queries
     f32x16 st[NT];
 #pragma unroll
