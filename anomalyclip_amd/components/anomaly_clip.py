@@ -270,21 +270,31 @@ class AnomalyCLIP(nn.Module):
         ncentroid = ncentroid.to(dev, torch.float32).contiguous()
         N, Lg = self.num_segments, self.seg_length
         x = features.reshape(-1, features.shape[-1]).contiguous().float()
-        # tile table (host ints -> one small H2D copy): video v, crop c, tile s gathers rows row0 + s L + n (S_v L) + l
-        base, stride = [], []
+        # tile table (host ints -> one small H2D copy): video v, crop c, tile s gathers rows row0 + s L + n (S_v L) + l.
+        # Kept per group geometry (a test epoch repeats its groups; pinning a fresh host buffer costs ~0.1 ms per call).
+        tkey = (dev, tuple(int(s_) for s_ in segment_sizes))
+        tables = self.__dict__.setdefault("_tile_tables", {})
+        table = tables.get(tkey)
         r0 = 0
         for rows, S in zip(rows_per_crop, segment_sizes):
-            rows, S = int(rows), int(S)
-            if rows != N * Lg * S:
+            if int(rows) != N * Lg * int(S):
                 raise ValueError("rows_per_crop must equal num_segments * seg_length * segment_size")
-            for c in range(self.ncrops):
-                for s_ in range(S):
-                    base.append(r0 + s_ * Lg)
-                    stride.append(S * Lg)
-                r0 += rows
+            r0 += self.ncrops * int(rows)
         if r0 != x.shape[0]:
             raise ValueError(f"features hold {x.shape[0]} rows, the video list describes {r0}")
-        table = torch.tensor(list(zip(base, stride)), dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        if table is None:
+            base, stride = [], []
+            r0 = 0
+            for rows, S in zip(rows_per_crop, segment_sizes):
+                rows, S = int(rows), int(S)
+                for c in range(self.ncrops):
+                    for s_ in range(S):
+                        base.append(r0 + s_ * Lg)
+                        stride.append(S * Lg)
+                    r0 += rows
+            if len(tables) >= 64:
+                tables.pop(next(iter(tables)))
+            table = tables[tkey] = torch.tensor(list(zip(base, stride)), dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
         text_features = self.get_text_features()
         similarity = self.selector_model(x, text_features, None, ncentroid, True)
         feats, a_sub = self.get_temporal_model_input(x, similarity, ncentroid)
