@@ -11,7 +11,7 @@ from . import _build
 c_void_p, c_int32, c_int64, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 ACX_F32, ACX_BF16 = 0, 1
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F32X6 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1
@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("a_norm_w", c_void_p), ("a_norm_b", c_void_p), ("a_norm_eps", c_float),
         ("counters", c_void_p), ("n_counters", c_int32),
         ("tile_table", c_void_p),
+        ("pairs", c_int32), ("reserved_pairs", c_int32), ("a_plane_stride", c_int64), ("w_plane_stride", c_int64),
     ]
 
 
@@ -92,6 +93,7 @@ _SIGS = {
     "acx_vit_encode": (C.c_int, [c_void_p, C.POINTER(VitDesc), C.POINTER(VitWeights), c_void_p, c_int32, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
     "acx_transformer_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "acx_transformer_workspace_bytes_prec": (c_size_t, [c_int32, c_int32, c_int32]),
     "acx_transformer_forward": (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, C.POINTER(BlockWeights), c_void_p, c_size_t, c_void_p]),
     "acx_text_directions": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
@@ -170,6 +172,7 @@ _SIGS = {
     "acx_preprocess_frames": (C.c_int, [c_void_p] * 6 + [c_int32, c_void_p, c_void_p, c_int32] + [c_int32] * 5 +
                               [C.POINTER(c_float), C.POINTER(c_float), c_void_p]),
     "acx_cast_bf16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "acx_split_bf16x3": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "acx_colsum": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_sort_workspace_bytes": (c_int64, [c_int64]),
     "acx_sort_pairs_batched": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,

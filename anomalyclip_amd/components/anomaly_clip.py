@@ -73,6 +73,11 @@ class AnomalyCLIP(nn.Module):
         self.select_idx_dropout_bottomk = g("select_idx_dropout_bottomk")
         self.ncrops, self.num_topk, self.num_bottomk = g("ncrops", 1), g("num_topk"), g("num_bottomk")
         self.precision = g("precision", "f32")          # "f32": exact-f32 MFMA (parity path); "bf16": bf16 MFMA
+        # "f32x6": the parity path with the ViT's large GEMMs as f32-accurate bf16 x 6 products (clip_vit.PRECISIONS); the text
+        # tower and the head have no problem large enough for that kernel and run exactly as in "f32"
+        vit_precision = self.precision
+        if self.precision == "f32x6":
+            self.precision = "f32"
         geom = g("clip_geometry") or _ARCH[self.arch]
         if isinstance(geom, dict):
             geom = ClipGeometry(**geom)
@@ -116,7 +121,7 @@ class AnomalyCLIP(nn.Module):
                                         geom.transformer_layers, geom.embed_dim, self.precision)
         self.image_encoder = VisionTransformer(geom.image_resolution, geom.vision_patch_size, geom.vision_width,
                                                geom.vision_layers, geom.vision_heads, geom.embed_dim,
-                                               precision=self.precision, chunk=g("vit_chunk", 256))
+                                               precision=vit_precision, chunk=g("vit_chunk", 256))
         self.selector_model = SelectorModel(classnames, self.normal_id, nn.Parameter(torch.tensor(2.6592601)),
                                             self.num_segments, self.seg_length, self.select_idx_dropout_topk,
                                             self.select_idx_dropout_bottomk, self.num_topk, self.num_bottomk)

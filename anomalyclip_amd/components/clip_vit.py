@@ -21,7 +21,10 @@ from torch import nn
 from .. import _lib as L
 from .. import ops
 
-PRECISIONS = {"f32": L.PREC_F32, "bf16": L.PREC_BF16}
+# "f32x6": f32 everywhere, the four large GEMMs of a ViT layer as f32-ACCURATE products on the bf16 matrix cores (three bf16
+# planes per operand, six cross products, f32 accumulation: acx_gemm_desc.pairs) -- lower error than the f32 MFMA kernels at
+# ~0.69 of their time; small problems (the text tower, CLS-only rows) stay on the f32 kernels
+PRECISIONS = {"f32": L.PREC_F32, "bf16": L.PREC_BF16, "f32x6": L.PREC_F32X6}
 
 
 class LayerNorm(nn.Module):
@@ -101,10 +104,11 @@ class Transformer(nn.Module):
             w.out_proj_w, w.out_proj_b = b.attn.out_proj.weight.data_ptr(), b.attn.out_proj.bias.data_ptr()
             w.fc_w, w.fc_b = b.mlp.c_fc.weight.data_ptr(), b.mlp.c_fc.bias.data_ptr()
             w.proj_w, w.proj_b = b.mlp.c_proj.weight.data_ptr(), b.mlp.c_proj.bias.data_ptr()
-            if prec == L.PREC_BF16:
+            if prec in (L.PREC_BF16, L.PREC_F32X6):
                 for name, p in (("in_proj_w_bf16", b.attn.in_proj_weight), ("out_proj_w_bf16", b.attn.out_proj.weight),
                                 ("fc_w_bf16", b.mlp.c_fc.weight), ("proj_w_bf16", b.mlp.c_proj.weight)):
-                    t = ops.cast_bf16(p.detach())
+                    # bf16 mode: one rounded copy; f32x6: the three planes hi | mid | lo of the f32 weight, [3, N, K]
+                    t = ops.cast_bf16(p.detach()) if prec == L.PREC_BF16 else ops.split_bf16x3(p.detach())
                     keep.append(t)
                     setattr(w, name, t.data_ptr())
         self._cache = (key, (arr, keep))
@@ -114,7 +118,7 @@ class Transformer(nn.Module):
         """In-place forward on x [batch*seq, W] (f32, contiguous)."""
         assert x.is_contiguous() and x.dtype == torch.float32 and x.shape == (batch * seq, self.width)
         lib = L.lib()
-        nbytes = lib.acx_transformer_workspace_bytes(self.width, batch * seq)
+        nbytes = lib.acx_transformer_workspace_bytes_prec(self.width, batch * seq, prec)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         arr, _keep = self.block_table(prec)
         h = ops._h(x)

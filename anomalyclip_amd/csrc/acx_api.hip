@@ -128,10 +128,11 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TfWs {   // transformer scratch carved from the caller's workspace
   char *h, *qkv, *att, *mlp, *splitk;
+  char *hp, *mp;  // ACX_PREC_F32X6: three bf16 planes of a [rows, W] / [rows, 4W] GEMM input (nullptr otherwise)
   size_t splitk_bytes, total;
 };
 
-TfWs carve_tf(char* base, int64_t rows, int W) {
+TfWs carve_tf(char* base, int64_t rows, int W, int prec = ACX_PREC_F32) {
   TfWs w;
   size_t off = 0;
   w.h = base + off;   off += al((size_t)rows * W * 4);
@@ -142,8 +143,38 @@ TfWs carve_tf(char* base, int64_t rows, int W) {
   // ... and for the partial last wave of big problems: <= 256 tiles of 128x128 outputs, 4 splits
   w.splitk_bytes = rows <= 4096 ? (size_t)8 * rows * 4 * W * 4 : (size_t)4 * 256 * 128 * 128 * 4;
   w.splitk = base + off; off += al(w.splitk_bytes);
+  w.hp = w.mp = nullptr;
+  if (prec == ACX_PREC_F32X6) {
+    w.hp = base + off; off += al((size_t)3 * rows * W * 2);
+    w.mp = base + off; off += al((size_t)3 * rows * 4 * W * 2);
+  }
   w.total = off;
   return w;
+}
+
+// ACX_PREC_F32X6: the large GEMMs of the ViT as f32-accurate products on the bf16 matrix cores (acx_gemm_desc.pairs = 6): the
+// f32 input is split into three bf16 planes (acx_split_bf16x3), the weights come as three planes from the caller.  A problem
+// the persistent 256x256 kernel does not take (few rows) stays on the f32 MFMA kernels.
+bool x6_takes(acx_ctx* ctx, const TfWs& ws, int64_t M, int N, int K, int lda) {
+  if (!ws.hp || !ACX_DBG_SWITCH("X6", true)) return false;
+  const int64_t rtiles = ((M + 255) / 256) * ((N + 255) / 256);
+  const int ring_min = ctx ? ctx->opt_ring_min_tiles : 512;
+  return rtiles >= ring_min && K % 64 == 0 && N % 4 == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32) &&
+         (size_t)N * K * 2 < ((size_t)1 << 32);
+}
+
+int linear_x6(acx_ctx* ctx, const void* A3, int lda, int64_t a_rows, const void* W3, int64_t w_plane_bytes, int ldw, void* C,
+              int ldc, int M, int N, int K, const float* bias, int act, const float* residual, hipStream_t s, int ldr = 0,
+              int c_dtype = ACX_F32) {
+  if (!W3) return acx_fail(ctx, ACX_E_BADARG, "driver: missing bf16 x 3 weight planes for ACX_PREC_F32X6%s");
+  acx_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.A = A3; d.W = W3; d.C = C;
+  d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc;
+  d.a_dtype = ACX_BF16; d.c_dtype = c_dtype; d.prec = ACX_PREC_BF16;
+  d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
+  d.pairs = 6; d.a_plane_stride = a_rows * (int64_t)lda * 2; d.w_plane_stride = w_plane_bytes;
+  return acx_gemm(ctx, &d, s);
 }
 
 int linear1(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const float* Wf, const void* Wb, int ldw,
@@ -206,9 +237,18 @@ int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const fl
 int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int heads, int layers, int causal, int prec,
                        const acx_block_weights* blk, const TfWs& ws, hipStream_t s, float* cls_ws = nullptr) {
   const int64_t rows = (int64_t)batch * L;
+  const bool x6mode = prec == ACX_PREC_F32X6;
+  if (x6mode) prec = ACX_PREC_F32;               // everything that is not one of the four large GEMMs runs as in f32 mode
   const int hdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   const size_t esz = prec == ACX_PREC_BF16 ? 2 : 4;
   int rc;
+  // the four large GEMMs of a layer in ACX_PREC_F32X6: split the f32 input into planes, multiply on the bf16 matrix cores
+#define X6_LINEAR(Af32, lda_, planes_, Wplanes_, wpb_, Cout_, ldc_, N_, K_, bias_, act_, res_)                          \
+  do {                                                                                                                 \
+    if ((rc = acx_split_bf16x3(ctx, (const float*)(Af32), (lda_), (planes_), (int64_t)rows * (K_) * 2, rows, (K_), s))) return rc;  \
+    if ((rc = linear_x6(ctx, (planes_), (K_), rows, (Wplanes_), (wpb_), (K_), (Cout_), (ldc_), (int)rows, (N_), (K_), (bias_),  \
+                        (act_), (res_), s))) return rc;                                                                \
+  } while (0)
   for (int l = 0; l < layers; ++l) {
     const acx_block_weights& b = blk[l];
     if (cls_ws && l == layers - 1) {
@@ -219,6 +259,11 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
       char* mc = hc + (size_t)batch * W * 4;               // [batch, 4W]  (f32 or bf16)
       if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
       // K | V for every token: rows [W, 3W) of in_proj
+      if (x6mode && x6_takes(ctx, ws, rows, 2 * W, W, W)) {
+        if (!b.in_proj_w_bf16) return acx_fail(ctx, ACX_E_BADARG, "driver: missing bf16 x 3 weight planes for ACX_PREC_F32X6%s");
+        X6_LINEAR(ws.h, W, ws.hp, (const char*)b.in_proj_w_bf16 + (size_t)W * W * 2, (int64_t)3 * W * W * 2, (float*)ws.qkv + W,
+                  3 * W, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr);
+      } else
       if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w + (size_t)W * W,
                        b.in_proj_w_bf16 ? (const char*)b.in_proj_w_bf16 + (size_t)W * W * 2 : nullptr, W,
                        (float*)ws.qkv + W, ACX_F32, 3 * W, (int)rows, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr, s))) return rc;
@@ -237,11 +282,22 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
       continue;
     }
     // x = x + attn(ln_1(x))                                          clip/model.py:215
+    // (ACX_PREC_F32X6: the producers of the four large GEMMs' inputs write the three bf16 planes themselves -- LayerNorm and
+    // the QuickGELU epilogue of c_fc -- only the attention output goes through acx_split_bf16x3)
+    const bool x6_qkv = x6mode && x6_takes(ctx, ws, rows, 3 * W, W, W), x6_out = x6mode && x6_takes(ctx, ws, rows, W, W, W);
+    const bool x6_fc = x6mode && x6_takes(ctx, ws, rows, 4 * W, W, W), x6_proj = x6mode && x6_takes(ctx, ws, rows, W, 4 * W, 4 * W);
+    if (x6_qkv) {
+      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, ACX_BF16X3, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+    } else
     if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     // bf16 mode, non-causal (the ViT): q/k/v, the attention and its output stay bf16 end to end -- half the
     // QKV store traffic, bf16-MFMA attention, and a bf16 A operand (LDS-DMA kernels) for the out-projection
     const bool ab = prec == ACX_PREC_BF16 && !causal && L <= 224 && ACX_DBG_SWITCH("ATTN_BF16", true);
     const int qdt = ab ? ACX_BF16 : ACX_F32;
+    if (x6_qkv) {
+      if ((rc = linear_x6(ctx, ws.hp, W, rows, b.in_proj_w_bf16, (int64_t)3 * W * W * 2, W, ws.qkv, 3 * W, (int)rows, 3 * W, W,
+                          b.in_proj_b, ACX_ACT_NONE, nullptr, s))) return rc;
+    } else
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, qdt, 3 * W, (int)rows, 3 * W, W,
                      b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     if (ab) {
@@ -249,15 +305,32 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     } else {
       if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
     }
+    if (x6_out) {
+      X6_LINEAR(ws.att, W, ws.hp, b.out_proj_w_bf16, (int64_t)W * W * 2, x, W, W, W, b.out_proj_b, ACX_ACT_NONE, x);
+    } else
     if ((rc = linear(ctx, prec, ws.att, qdt, W, b.out_proj_w, b.out_proj_w_bf16, W, x, ACX_F32, W, (int)rows, W, W,
                      b.out_proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     // x = x + mlp(ln_2(x))                                           clip/model.py:216
+    if (x6_fc) {
+      if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.hp, W, ACX_BF16X3, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+    } else
     if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+    if (x6_fc) {
+      // QuickGELU(c_fc) straight into the planes of c_proj's input when c_proj takes the x6 path too
+      if ((rc = linear_x6(ctx, ws.hp, W, rows, b.fc_w_bf16, (int64_t)4 * W * W * 2, W, x6_proj ? (void*)ws.mp : (void*)ws.mlp, 4 * W,
+                          (int)rows, 4 * W, W, b.fc_b, ACX_ACT_QUICKGELU, nullptr, s, 0, x6_proj ? ACX_BF16X3 : ACX_F32))) return rc;
+    } else
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.fc_w, b.fc_w_bf16, W, ws.mlp, hdt, 4 * W, (int)rows, 4 * W, W, b.fc_b,
                      ACX_ACT_QUICKGELU, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
+    if (x6_proj) {
+      if (!x6_fc && (rc = acx_split_bf16x3(ctx, (const float*)ws.mlp, 4 * W, ws.mp, (int64_t)rows * 4 * W * 2, rows, 4 * W, s))) return rc;
+      if ((rc = linear_x6(ctx, ws.mp, 4 * W, rows, b.proj_w_bf16, (int64_t)W * 4 * W * 2, 4 * W, x, W, (int)rows, W, 4 * W, b.proj_b,
+                          ACX_ACT_NONE, x, s))) return rc;
+    } else
     if ((rc = linear(ctx, prec, ws.mlp, hdt, 4 * W, b.proj_w, b.proj_w_bf16, 4 * W, x, ACX_F32, W, (int)rows, W, 4 * W,
                      b.proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
   }
+#undef X6_LINEAR
   return ACX_OK;
 }
 
@@ -266,13 +339,19 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
 extern "C" size_t acx_transformer_workspace_bytes(int32_t width, int32_t rows) {
   return carve_tf(nullptr, rows, width).total;
 }
+extern "C" size_t acx_transformer_workspace_bytes_prec(int32_t width, int32_t rows, int32_t prec) {
+  return carve_tf(nullptr, rows, width, prec).total;
+}
 
 extern "C" int acx_transformer_forward(acx_ctx* ctx, float* x, int32_t batch, int32_t L, int32_t width, int32_t heads,
                                        int32_t layers, int32_t causal, int32_t prec, const acx_block_weights* blocks,
                                        void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !blocks || !workspace) return acx_fail(ctx, ACX_E_BADARG, "acx_transformer_forward: null pointer%s");
   if (width != heads * 64) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_transformer_forward: head dim must be 64%s");
-  const TfWs ws = carve_tf((char*)workspace, (int64_t)batch * L, width);
+  // ACX_PREC_F32X6 with a workspace sized for it (acx_transformer_workspace_bytes_prec); a smaller (f32-sized) workspace runs
+  // the f32 kernels
+  TfWs ws = carve_tf((char*)workspace, (int64_t)batch * L, width, prec);
+  if (ws.total > workspace_bytes && prec == ACX_PREC_F32X6) ws = carve_tf((char*)workspace, (int64_t)batch * L, width);
   if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_transformer_forward: workspace too small%s");
   return transformer_layers(ctx, x, batch, L, width, heads, layers, causal, prec, blocks, ws, (hipStream_t)stream);
 }
@@ -293,7 +372,7 @@ VitWs carve_vit(char* base, const acx_vit_desc* d, int F) {
   w.cls = base + off;       off += al((size_t)F * W * 4);
   w.cls_ws = base + off;    off += al((size_t)F * W * 4 * 8);      // xc, attc, x1, hc, mc(4W)
   w.tf_off = off;
-  off += carve_tf(nullptr, (int64_t)F * (T + 1), W).total;
+  off += carve_tf(nullptr, (int64_t)F * (T + 1), W, d->prec).total;
   w.total = off;
   return w;
 }
@@ -316,7 +395,7 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   const VitWs ws = carve_vit((char*)workspace, d, F);
   if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_vit_encode: workspace too small%s");
   hipStream_t s = (hipStream_t)stream;
-  const int prec = d->prec;
+  const int prec = d->prec == ACX_PREC_F32X6 ? ACX_PREC_F32 : d->prec;   // patch embedding / final projection: small, f32 kernels
   const int pdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   int rc;
   // conv1 as GEMM over im2col'ed patches                               clip/model.py:267-269
@@ -326,9 +405,9 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   // CLS + positional embedding + ln_pre                                :270-279
   if ((rc = acx_vit_embed(ctx, (const float*)ws.patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
                           w->ln_pre_b, (float*)ws.x, F, T, W, s))) return rc;
-  const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W);
+  const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W, d->prec);
   const bool prune = ACX_DBG_SWITCH("VIT_PRUNE", true);
-  if ((rc = transformer_layers(ctx, (float*)ws.x, F, T + 1, W, d->heads, d->layers, 0, prec, w->blocks, tf, s,
+  if ((rc = transformer_layers(ctx, (float*)ws.x, F, T + 1, W, d->heads, d->layers, 0, d->prec, w->blocks, tf, s,
                                prune ? (float*)ws.cls_ws : nullptr))) return rc;
   // ln_post on the CLS rows, then @ proj                                :285-288
   if ((rc = acx_layernorm(ctx, prune ? (const float*)ws.cls_ws : (const float*)ws.x, prune ? (int64_t)W : (int64_t)(T + 1) * W,

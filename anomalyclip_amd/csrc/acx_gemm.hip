@@ -753,16 +753,37 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const bool no_ring = !ACX_DBG_SWITCH("RING", true);
   const int rtiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
   const int ring_min = ctx ? ctx->opt_ring_min_tiles : 512;   // acx_set_option(ACX_OPT_RING_MIN_TILES); tests lower it
-  if (fast && g.ksplit == 1 && prec == ACX_PREC_BF16 && a_bf16 && !no_dma && !no_ring && d->lda % 8 == 0 && d->ldw % 8 == 0 &&
-      d->K % 64 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
-      !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && rtiles >= ring_min && !(d->act == ACX_ACT_QUICKGELU && d->residual)) {
+  const bool ring_ok = fast && g.ksplit == 1 && prec == ACX_PREC_BF16 && a_bf16 && !no_dma && !no_ring && d->lda % 8 == 0 &&
+      d->ldw % 8 == 0 && d->K % 64 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
+      !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && rtiles >= ring_min &&
+      !(d->act == ACX_ACT_QUICKGELU && d->residual);
+  const bool c_x3 = d->c_dtype == ACX_BF16X3;
+  if (c_x3 && (!ring_ok || d->residual || ((d->K / 64) * (d->pairs > 1 ? d->pairs : 1)) % 2 || !ACX_DBG_SWITCH("P8", true)))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: c_dtype ACX_BF16X3 needs the persistent 256x256 bf16 kernel and no residual%s");
+  if (d->pairs > 1 && (d->pairs != 6 || !ring_ok || d->a_plane_stride <= 0 || d->w_plane_stride <= 0 ||
+                       ((d->a_plane_stride | d->w_plane_stride) & 15)))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 needs bf16 planes (16-byte aligned strides) and a problem the persistent 256x256 kernel takes%s");
+  if (ring_ok) {
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     const dim3 rgrid((unsigned)(rtiles < ncu ? rtiles : ncu));
     // even K-tile count and 32-bit operand byte offsets: the phase-interleaved kernel; else the lock-step ring kernel
-    const bool p8 = (d->K / 64) % 2 == 0 && (size_t)d->M * d->lda * 2 < ((size_t)1 << 32) &&
+    const int npairs_ = d->pairs > 1 ? d->pairs : 1;
+    const bool p8 = ((d->K / 64) * npairs_) % 2 == 0 && (size_t)d->M * d->lda * 2 < ((size_t)1 << 32) &&
                     (size_t)d->N * d->ldw * 2 < ((size_t)1 << 32) && ACX_DBG_SWITCH("P8", true);
+    if ((d->pairs > 1 || c_x3) && !p8)
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 / ACX_BF16X3 output need the persistent 256x256 kernel%s");
 #define ACX_RING_L(CB, ACT, RES)                                                                    \
   do {                                                                                              \
+    if (p8 && d->pairs > 1) {                                                                       \
+      static bool attr6_dev_[64] = {}; bool& attr6_done = attr6_dev_[dev_slot];                     \
+      if (!attr6_done) {                                                                            \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<CB, ACT, RES, 1>,                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_B);       \
+        attr6_done = true;                                                                          \
+      }                                                                                             \
+      hipLaunchKernelGGL((gemm_bf16_p8_kernel<CB, ACT, RES, 1>), rgrid, dim3(512), (size_t)P8_LDS_B, s, g); \
+      break;                                                                                        \
+    }                                                                                               \
     if (p8) {                                                                                       \
       static bool attr8_dev_[64] = {}; bool& attr8_done = attr8_dev_[dev_slot];                                                               \
       if (!attr8_done) {                                                                            \
@@ -783,7 +804,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   } while (0)
 #define ACX_RING_SEL()                                                                              \
   do {                                                                                              \
-    if (d->residual) { if (c_bf16) ACX_RING_L(1, 0, 1); else ACX_RING_L(0, 0, 1); }                 \
+    if (c_x3) { if (d->act == ACX_ACT_QUICKGELU) ACX_RING_L(2, 1, 0); else ACX_RING_L(2, 0, 0); }   \
+    else if (d->residual) { if (c_bf16) ACX_RING_L(1, 0, 1); else ACX_RING_L(0, 0, 1); }            \
     else if (d->act == ACX_ACT_QUICKGELU) { if (c_bf16) ACX_RING_L(1, 1, 0); else ACX_RING_L(0, 1, 0); } \
     else { if (c_bf16) ACX_RING_L(1, 0, 0); else ACX_RING_L(0, 0, 0); }                             \
   } while (0)

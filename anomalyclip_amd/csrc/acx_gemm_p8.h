@@ -42,9 +42,17 @@ constexpr int P8_LDS_B = 2 * P8_SLOT_B + 8 * 4096;   // + wave-private epilogue 
 struct P8Src {                                  // DMA source of one K-tile: wave-uniform (the per-lane part is constant)
   int m0, n0;                                   // origin of its output tile
   int kt, j;                                    // K-tile inside the tile, tile ordinal of this workgroup
+  int k1, pr;                                   // pairs mode: K-tile inside the operand plane pair `pr` (plain: k1 == kt, pr == 0)
+  const char *ab, *wb;                          // base of the pair's A / W plane (recomputed when the pair changes, not per DMA)
 };
+// acx_gemm_desc.pairs == 6 (f32-accurate product from three bf16 planes per operand): a tile's K loop walks the six plane
+// pairs one after the other, smallest cross term first -- pair p reads plane (P8_APLANES >> 4 p) & 15 of A and
+// (P8_WPLANES >> 4 p) & 15 of W: (hi,lo) (mid,mid) (lo,hi) (hi,mid) (mid,hi) (hi,hi).  Plain problems have one pair, planes 0.
+constexpr unsigned P8_APLANES = 0x010210u, P8_WPLANES = 0x001012u;
 
-template <int C_BF16, int ACT, int RES>
+// PAIRS: compiled-in support for acx_gemm_desc.pairs = 6 (plane-pair bookkeeping of the K-tile stream); the plain instantiations
+// keep the original cursor (with the bookkeeping compiled into them the f32-C variants lost 4-7 %)
+template <int C_BF16, int ACT, int RES, int PAIRS = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -59,7 +67,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
   const int b0 = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + ((int)blockIdx.x >> 3);
   const int my_tiles = b0 < ntiles ? (ntiles - b0 + G - 1) / G : 0;
   if (my_tiles == 0) return;
-  const int nk = d.K / 64;                      // even (dispatch)
+  const int nk1 = d.K / 64;                     // K-tiles per plane pair
+  const int npairs = PAIRS ? (d.pairs > 1 ? d.pairs : 1) : 1;
+  const int nk = nk1 * npairs;                  // even (dispatch)
 
   // ---- DMA: a half-tile is 16 wave-instructions of 1 KB (8 rows x 128 B); wave w issues instructions 2 w, 2 w + 1
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
@@ -74,8 +84,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
     const int tm_ = L_ / tiles_n, tn_ = L_ - tm_ * tiles_n;                                        \
     S.m0 = tm_ * 256; S.n0 = tn_ * 256;                                                            \
   } while (0)
+#define P8_PLANES(S)                                                                               \
+  do {                                                                                             \
+    S.ab = (const char*)d.A + (size_t)((P8_APLANES >> (4 * S.pr)) & 15u) * (size_t)d.a_plane_stride; \
+    S.wb = (const char*)d.W + (size_t)((P8_WPLANES >> (4 * S.pr)) & 15u) * (size_t)d.w_plane_stride; \
+  } while (0)
 #define P8_ADVANCE(S)                                                                              \
-  do { if (++S.kt == nk) { S.kt = 0; ++S.j; P8_SET_SRC(S, S.j); } } while (0)
+  do {                                                                                             \
+    if constexpr (PAIRS != 0) {                                                                    \
+      ++S.k1;                                                                                      \
+      if (++S.kt == nk) { S.kt = 0; S.k1 = 0; S.pr = 0; ++S.j; P8_SET_SRC(S, S.j); P8_PLANES(S); } \
+      else if (S.k1 == nk1) { S.k1 = 0; ++S.pr; P8_PLANES(S); }                                    \
+    } else {                                                                                       \
+      if (++S.kt == nk) { S.kt = 0; ++S.j; P8_SET_SRC(S, S.j); }                                   \
+    }                                                                                              \
+  } while (0)
 #define P8_GLDS(gptr, ldsaddr)                                                                     \
   do {                                                                                             \
     unsigned keep_;                                                                                \
@@ -88,19 +111,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
     const unsigned l_ = lds0 + (slot) * P8_SLOT_B + (half) * P8_HALF_B + (2 * wave) * 1024;        \
     if constexpr ((half) < 2) {                                                                    \
       const int r0_ = min(S.m0 + ra00 + ((half) & 1) * 64, d.M - 1), r1_ = min(S.m0 + ra01 + ((half) & 1) * 64, d.M - 1); \
-      const char* b_ = (const char*)d.A + (size_t)S.kt * 128;                                      \
+      const char* b_ = PAIRS ? S.ab + (size_t)S.k1 * 128 : (const char*)d.A + (size_t)S.kt * 128;  \
       P8_GLDS(b_ + (size_t)((unsigned)r0_ * (unsigned)d.lda * 2u + (unsigned)ch0), l_);            \
       P8_GLDS(b_ + (size_t)((unsigned)r1_ * (unsigned)d.lda * 2u + (unsigned)ch1), l_ + 1024);     \
     } else {                                                                                       \
       const int r0_ = min(S.n0 + rb00 + ((half) & 1) * 32, d.N - 1), r1_ = min(S.n0 + rb01 + ((half) & 1) * 32, d.N - 1); \
-      const char* b_ = (const char*)d.W + (size_t)S.kt * 128;                                      \
+      const char* b_ = PAIRS ? S.wb + (size_t)S.k1 * 128 : (const char*)d.W + (size_t)S.kt * 128;  \
       P8_GLDS(b_ + (size_t)((unsigned)r0_ * (unsigned)d.ldw * 2u + (unsigned)ch0), l_);            \
       P8_GLDS(b_ + (size_t)((unsigned)r1_ * (unsigned)d.ldw * 2u + (unsigned)ch1), l_ + 1024);     \
     }                                                                                              \
   } while (0)
 
   P8Src c1, c2;                                 // K-tiles s + 1 and s + 2 of the stream
-  c1.kt = 0; c1.j = 0; P8_SET_SRC(c1, 0);
+  c1.kt = 0; c1.j = 0; c1.k1 = 0; c1.pr = 0; c1.ab = c1.wb = nullptr; P8_SET_SRC(c1, 0);
+  if constexpr (PAIRS != 0) P8_PLANES(c1);
   // ---- prologue: K-tile 0 entirely, AH0 / BH0 of K-tile 1
   P8_DMA(c1, 0, 0); P8_DMA(c1, 2, 0); P8_DMA(c1, 3, 0); P8_DMA(c1, 1, 0);
   P8_ADVANCE(c1);                               // c1 = K-tile 1
@@ -250,7 +274,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
               if constexpr (RES != 0) { v.x += res[u][ps].x; v.y += res[u][ps].y; v.z += res[u][ps].z; v.w += res[u][ps].w; }
               const int row = row0 + 8 * ps;
               if (cok && row < d.M && (!(ACX_P8_ABL & 1) || g.ksplit == 12345)) {
-                if constexpr (C_BF16) {
+                if constexpr (C_BF16 == 2) {
+                  // three bf16 planes hi | mid | lo of the f32 value (ACX_BF16X3): the next pairs = 6 product's A operand
+                  const float ov[4] = {v.x, v.y, v.z, v.w};
+                  float r1[4], r2[4];
+                  uint2 ph, pm, pl;
+                  ph.x = f2bf2(ov[0], ov[1]); ph.y = f2bf2(ov[2], ov[3]);
+                  r1[0] = ov[0] - __uint_as_float(ph.x << 16); r1[1] = ov[1] - __uint_as_float(ph.x & 0xffff0000u);
+                  r1[2] = ov[2] - __uint_as_float(ph.y << 16); r1[3] = ov[3] - __uint_as_float(ph.y & 0xffff0000u);
+                  pm.x = f2bf2(r1[0], r1[1]); pm.y = f2bf2(r1[2], r1[3]);
+                  r2[0] = r1[0] - __uint_as_float(pm.x << 16); r2[1] = r1[1] - __uint_as_float(pm.x & 0xffff0000u);
+                  r2[2] = r1[2] - __uint_as_float(pm.y << 16); r2[3] = r1[3] - __uint_as_float(pm.y & 0xffff0000u);
+                  pl.x = f2bf2(r2[0], r2[1]); pl.y = f2bf2(r2[2], r2[3]);
+                  const size_t pe = (size_t)d.M * d.ldc;
+                  u16* dst = (u16*)d.C + (size_t)row * d.ldc + col;
+                  __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&ph), reinterpret_cast<u32x2*>(dst));
+                  __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pm), reinterpret_cast<u32x2*>(dst + pe));
+                  __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pl), reinterpret_cast<u32x2*>(dst + 2 * pe));
+                } else if constexpr (C_BF16 == 1) {
                   uint2 pk;
                   pk.x = f2bf2(v.x, v.y);
                   pk.y = f2bf2(v.z, v.w);
@@ -285,5 +326,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
 #undef P8_DMA
 #undef P8_GLDS
 #undef P8_ADVANCE
+#undef P8_PLANES
 #undef P8_SET_SRC
 }

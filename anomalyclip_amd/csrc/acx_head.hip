@@ -547,6 +547,34 @@ __global__ __launch_bounds__(256) void class_probs_kernel(const float* __restric
   for (int c = 0; c < C1; ++c) probs[r * C1 + c] = expf(sim[r * C1 + c] - mx) * k;
 }
 
+// x = hi + mid + lo with three bf16 (8 significant bits each: 24 in all); x - hi and (x - hi) - mid are exact in f32
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, int64_t ld, u16* __restrict__ dst,
+                                                           int64_t plane, int64_t rows, int cols4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols4) return;
+  const int64_t r = i / cols4;
+  const int c4 = (int)(i - r * cols4);
+  const float4 v = *reinterpret_cast<const float4*>(src + r * ld + 4 * c4);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  u16 h[4], m[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = f2bf(x[k]);
+    const float r1 = x[k] - bf2f(h[k]);
+    m[k] = f2bf(r1);
+    const float r2 = r1 - bf2f(m[k]);
+    l[k] = f2bf(r2);
+  }
+  const int64_t o = r * (int64_t)cols4 * 4 + 4 * c4;
+  uint2 pk;
+  pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+  *reinterpret_cast<uint2*>(dst + o) = pk;
+  pk.x = (uint32_t)m[0] | ((uint32_t)m[1] << 16); pk.y = (uint32_t)m[2] | ((uint32_t)m[3] << 16);
+  *reinterpret_cast<uint2*>(dst + plane + o) = pk;
+  pk.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16); pk.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+  *reinterpret_cast<uint2*>(dst + 2 * plane + o) = pk;
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, int64_t n) {
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -1068,6 +1096,22 @@ extern "C" int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t 
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                      (u16*)dst, n);
   ACX_CHECK_LAUNCH(ctx, "acx_cast_bf16");
+  return ACX_OK;
+}
+
+extern "C" int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
+                                int64_t cols, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  if (!src || !dst) return acx_fail(ctx, ACX_E_BADARG, "acx_split_bf16x3: null pointer%s");
+  if (rows <= 0 || cols <= 0) return ACX_OK;
+  if (cols % 4 || ld % 4 || ld < cols || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7) || (plane_stride_bytes & 7) ||
+      plane_stride_bytes < rows * cols * 2)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_split_bf16x3: cols / ld multiples of 4, aligned pointers, planes of >= rows * cols bf16%s");
+  const int64_t n4 = rows * (cols / 4);
+  if (n4 > ((int64_t)1 << 38)) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_split_bf16x3: too many elements%s");
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, (u16*)dst,
+                     plane_stride_bytes / 2, rows, (int)(cols / 4));
+  ACX_CHECK_LAUNCH(ctx, "acx_split_bf16x3");
   return ACX_OK;
 }
 

@@ -28,9 +28,11 @@ __device__ __forceinline__ void normalize(float (&v)[VPL], float eps, int mode) 
   for (int i = 0; i < VPL; ++i) v[i] *= scale;
 }
 
+// OUT_BF16 == 2: the row as THREE bf16 planes hi | mid | lo (x = hi + mid + lo to 24 bits: the A operand of acx_gemm_desc.pairs =
+// 6), plane p at y + p * plane elements
 template <int VPL, int OUT_BF16>
 __device__ __forceinline__ void store_row_affine(void* y, int lane, const float (&v)[VPL],
-                                                 const float* __restrict__ w, const float* __restrict__ b) {
+                                                 const float* __restrict__ w, const float* __restrict__ b, int64_t plane = 0) {
   if constexpr (VPL % 4 == 0) {
 #pragma unroll
     for (int i = 0; i < VPL / 4; ++i) {
@@ -40,7 +42,24 @@ __device__ __forceinline__ void store_row_affine(void* y, int lane, const float 
       float4 o;
       o.x = v[4 * i] * ww.x + bb.x; o.y = v[4 * i + 1] * ww.y + bb.y;
       o.z = v[4 * i + 2] * ww.z + bb.z; o.w = v[4 * i + 3] * ww.w + bb.w;
-      if constexpr (OUT_BF16) {
+      if constexpr (OUT_BF16 == 2) {
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+        u16 hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hh[k] = f2bf(ov[k]);
+          const float r1 = ov[k] - bf2f(hh[k]);
+          mm[k] = f2bf(r1);
+          ll[k] = f2bf(r1 - bf2f(mm[k]));
+        }
+        uint2 pk;
+        pk.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16); pk.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+        *reinterpret_cast<uint2*>((u16*)y + e) = pk;
+        pk.x = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16); pk.y = (uint32_t)mm[2] | ((uint32_t)mm[3] << 16);
+        *reinterpret_cast<uint2*>((u16*)y + plane + e) = pk;
+        pk.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16); pk.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+        *reinterpret_cast<uint2*>((u16*)y + 2 * plane + e) = pk;
+      } else if constexpr (OUT_BF16 == 1) {
         uint2 pk;
         pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
         pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
@@ -54,7 +73,12 @@ __device__ __forceinline__ void store_row_affine(void* y, int lane, const float 
     for (int i = 0; i < VPL; ++i) {
       const int e = lane + 64 * i;
       const float o = v[i] * w[e] + b[e];
-      if constexpr (OUT_BF16) ((u16*)y)[e] = f2bf(o); else ((float*)y)[e] = o;
+      if constexpr (OUT_BF16 == 2) {
+        const u16 h1 = f2bf(o);
+        const float r1 = o - bf2f(h1);
+        const u16 m1 = f2bf(r1);
+        ((u16*)y)[e] = h1; ((u16*)y)[plane + e] = m1; ((u16*)y)[2 * plane + e] = f2bf(r1 - bf2f(m1));
+      } else if constexpr (OUT_BF16 == 1) ((u16*)y)[e] = f2bf(o); else ((float*)y)[e] = o;
     }
   }
 }
@@ -71,7 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   load_row<VPL>(x + row * ldx, lane, v);
   normalize<VPL>(v, eps, mode);
   void* yr = OUT_BF16 ? (void*)((u16*)y + row * ldy) : (void*)((float*)y + row * ldy);
-  store_row_affine<VPL, OUT_BF16>(yr, lane, v, w, b);
+  store_row_affine<VPL, OUT_BF16>(yr, lane, v, w, b, rows * ldy);
 }
 
 template <int VPL>
@@ -160,7 +184,9 @@ extern "C" int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const fl
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
-  if (y_dtype == ACX_BF16) {
+  if (y_dtype == ACX_BF16X3) {         // three dense planes [rows, ldy] each, y + p * rows * ldy
+    DISPATCH_VPL(D, layernorm_kernel<V COMMA 2><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));
+  } else if (y_dtype == ACX_BF16) {
     DISPATCH_VPL(D, layernorm_kernel<V COMMA 1><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));
   } else {
     DISPATCH_VPL(D, layernorm_kernel<V COMMA 0><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));

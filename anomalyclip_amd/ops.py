@@ -120,6 +120,42 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def split_bf16x3(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f32 [rows, cols] -> bf16 [3, rows, cols]: x = hi + mid + lo to 24 bits (the operands of gemm_x6)."""
+    assert src.dim() == 2 and src.dtype == torch.float32 and src.stride(1) == 1
+    rows, cols = src.shape
+    if out is None:
+        out = torch.empty(3, rows, cols, dtype=_BF16, device=src.device)
+    assert out.shape == (3, rows, cols) and out.dtype == _BF16 and out.is_contiguous()
+    h = _h(src)
+    L.check(L.lib().acx_split_bf16x3(h, src.data_ptr(), src.stride(0), out.data_ptr(), rows * cols * 2, rows, cols, _stream()), h)
+    return out
+
+
+def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, act=L.ACT_NONE,
+            residual=None, out_dtype=torch.float32) -> torch.Tensor:
+    """out[M, N] = epilogue(A W^T) with A = sum of the three bf16 planes a3 [3, M, K] and W = sum of w3 [3, N, K]
+    (split_bf16x3): the six leading cross products on the bf16 matrix cores, f32 accumulation -- the accuracy of an f32
+    product (acx_gemm_desc.pairs = 6).  Large problems only (the persistent 256 x 256 kernel)."""
+    assert a3.dim() == 3 and w3.dim() == 3 and a3.shape[0] == 3 and w3.shape[0] == 3 and a3.dtype == _BF16 and w3.dtype == _BF16
+    assert a3.is_contiguous() and w3.is_contiguous() and a3.shape[2] == w3.shape[2]
+    _, M, K = a3.shape
+    N = w3.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a3.device)
+    d = L.GemmDesc()
+    d.A, d.W, d.C = a3.data_ptr(), w3.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldw, d.ldc = K, K, out.stride(0)
+    d.a_dtype, d.c_dtype, d.prec = _dt(a3), _dt(out), L.PREC_BF16
+    d.bias, d.act = _ptr(bias), act
+    d.residual, d.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
+    d.pairs, d.a_plane_stride, d.w_plane_stride = 6, M * K * 2, N * K * 2
+    h = _h(a3)
+    L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)
+    return out
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None, M: Optional[int] = None,
          bias=None, act=L.ACT_NONE, residual=None, a_sub=None, prec=L.PREC_F32, out_dtype=torch.float32,
          amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, seg=0, pos0=None, pos1=None, a_act=L.ACT_NONE,

@@ -737,6 +737,37 @@ def main():
                                       "ms_per_step": round(dt256 / k * 1e3, 3),
                                       "note": "config[2]'s literal batch: two 256-frame ViT launches per clip"}
         if args.precision == "f32":
+            # the same step with the ViT's four large GEMMs per layer as f32-ACCURATE products on the bf16 matrix cores
+            # (three bf16 planes per operand, six cross products, f32 accumulation: acx_gemm_desc.pairs, precision "f32x6").
+            # NOT the headline: `value` above is the f32 MFMA path.  Reported with its distance to that path's outputs.
+            try:
+                ref_probs, ref_sc = (t.clone() for t in out_holder["o"])
+                net.image_encoder.precision = "f32x6"
+                timer.run(step_keep, 1, 0)
+                p6, s6 = out_holder["o"]
+                den_p, den_s = float(ref_probs.abs().max()), float(ref_sc.abs().max())
+                dt6 = timer.run(step_keep, k, 1)
+                prof.start_gemm_only(); timer.run(step_keep, 1, 0); prof.stop()
+                gf6, c6, t6 = prof.collect()
+                extra["f32_via_bf16x6"] = {
+                    "frames_per_s": round(FRAMES_PER_CLIP * k * world / dt6, 2), "ms_per_step": round(dt6 / k * 1e3, 3),
+                    "max_abs_diff_vs_f32_mfma_path": {"class_probs": float((p6 - ref_probs).abs().max()), "scores": float((s6 - ref_sc).abs().max()),
+                                                      "relative_to_max": [float((p6 - ref_probs).abs().max()) / max(den_p, 1e-30),
+                                                                          float((s6 - ref_sc).abs().max()) / max(den_s, 1e-30)]},
+                    "gemm": {"launches": c6[0], "ms_per_step": round(t6[0], 3),
+                             "f32_equivalent_tflops": round(gf6 / 1e9 / t6[0], 1) if t6[0] else None,
+                             "executed_bf16_tflops": round(6 * gf6 / 1e9 / t6[0], 1) if t6[0] else None,
+                             "frac_of_bf16_mfma_peak": round(6 * gf6 / 1e9 / t6[0] / PEAK_TFLOPS["bf16"], 4) if t6[0] else None,
+                             "note": "per step: 2 M N K of every GEMM launch counted once (f32-equivalent) and six times (the bf16 "
+                                     "products actually executed; the text tower / CLS-row GEMMs of the step run on the f32 kernels "
+                                     "and are counted in both)"},
+                    "note": "precision 'f32x6': x = hi + mid + lo in bf16 (exact 24-bit split), products (hi,lo) (mid,mid) (lo,hi) (hi,mid) "
+                            "(mid,hi) (hi,hi) on v_mfma_f32_32x32x16_bf16, f32 accumulation; tests hold it to the f32 path's bounds "
+                            "against fp64 and against the reference's ViT output"}
+            except Exception as e:  # noqa: BLE001
+                extra["f32_via_bf16x6"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                net.image_encoder.precision = "f32"
             # the secondary legs must not take the headline line with them (an exception raised on every rank alike --
             # out of memory, an unsupported collective -- is reported in place of the leg's numbers)
             try:

@@ -35,8 +35,14 @@ enum {
   ACX_E_WORKSPACE = -4 /* workspace too small */
 };
 
-enum { ACX_F32 = 0, ACX_BF16 = 1 };                 /* storage dtypes */
-enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1 };       /* MFMA arithmetic: exact f32 (v_mfma_f32_32x32x2_f32) or bf16 in / f32 acc */
+enum { ACX_F32 = 0, ACX_BF16 = 1,                    /* storage dtypes */
+       ACX_BF16X3 = 2 };  /* OUTPUT only (acx_layernorm y_dtype, acx_gemm c_dtype with the persistent 256x256 bf16 kernel): the
+                             value as three dense bf16 planes hi | mid | lo [rows, ld] each, plane p at base + p * rows * ld
+                             elements -- the producer writes the A operand of a pairs = 6 product directly */
+enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1,          /* MFMA arithmetic: exact f32 (v_mfma_f32_32x32x2_f32) or bf16 in / f32 acc */
+       ACX_PREC_F32X6 = 2 };  /* acx_vit_encode / acx_transformer_forward only: f32 everywhere, the four large GEMMs of a layer as
+                                 f32-accurate bf16 x 6 products (acx_gemm_desc.pairs); the *_w_bf16 weight fields then hold THREE
+                                 planes each (acx_split_bf16x3 of the f32 weight) */
 enum { ACX_ACT_NONE = 0, ACX_ACT_QUICKGELU = 1, ACX_ACT_LEAKYRELU = 2 };
 enum { ACX_AMAP_IDENTITY = 0, ACX_AMAP_CONV3X3 = 1, ACX_AMAP_TESTTILE = 2, ACX_AMAP_TILETABLE = 3 };
 enum { ACX_NORM_LAYER = 0, ACX_NORM_CHAN = 1 };     /* nn.LayerNorm vs axial_attention ChanLayerNorm (eps added to std) */
@@ -113,6 +119,16 @@ typedef struct acx_gemm_desc {
                                 (tile, n, l) reads source row base + n * stride + l -- the test-mode tiling of
                                 temporal_model.py:46-53 for a batch of videos with DIFFERENT segment sizes (video v, tile s:
                                 base = row0_v + s gl, stride = S_v gl) */
+  int32_t pairs;          /* 0 / 1: plain.  6 (with prec = ACX_PREC_BF16, a_dtype = ACX_BF16): f32-ACCURATE product on the bf16 matrix
+                             cores.  A and W are each THREE bf16 planes (acx_split_bf16x3: x = hi + mid + lo to 24 bits; plane p of
+                             A at A + p * a_plane_stride bytes, of W at W + p * w_plane_stride), and C accumulates, in f32, the six
+                             cross products whose magnitude is >= 2^-16 of the leading one -- (hi,lo) (mid,mid) (lo,hi) (hi,mid)
+                             (mid,hi) (hi,hi), smallest first.  Every bf16 x bf16 product is exact in f32; the three dropped terms
+                             and the split remainders are <= 2^-23 of the product: the error is that of an f32 dot product, at
+                             6/16 of the f32 MFMA's cost (2.5 PFLOP/s bf16 against 157 TFLOP/s f32 on gfx950).  Large
+                             problems only (the persistent 256x256 kernel); K % 128 == 0. */
+  int32_t reserved_pairs;
+  int64_t a_plane_stride, w_plane_stride;   /* bytes */
 } acx_gemm_desc;
 int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
 
@@ -189,6 +205,7 @@ int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit_weights* w
 /* acx_transformer_forward: Transformer.forward (clip/model.py:220-230) in place on x
  * [batch*L, W] f32 -- used by the text encoder (text_encoder.py:16-18). */
 size_t acx_transformer_workspace_bytes(int32_t width, int32_t rows);
+size_t acx_transformer_workspace_bytes_prec(int32_t width, int32_t rows, int32_t prec);   /* ACX_PREC_F32X6 needs room for the planes */
 int acx_transformer_forward(acx_ctx* ctx, float* x, int32_t batch, int32_t L, int32_t width,
                             int32_t heads, int32_t layers, int32_t causal, int32_t prec,
                             const acx_block_weights* blocks, void* workspace,
@@ -283,6 +300,11 @@ int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, float* out,
                           const int32_t* vcoef, int32_t vksize, int32_t F, int32_t H, int32_t W, int32_t orows,
                           int32_t ocols, const float* mean3, const float* std3, void* stream);
 
+/* utility: x[rows, cols] (f32, leading dimension ld) -> three dense bf16 planes dst + p * plane_stride_bytes, [rows, cols] each:
+ * hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (each subtraction exact in f32): the operands of
+ * acx_gemm_desc.pairs = 6.  cols % 4 == 0, 16-byte aligned src rows / 8-byte aligned planes. */
+int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
+                     int64_t cols, void* stream);
 /* utility: f32 -> bf16 (round-to-nearest-even) copy, used to prepare bf16 weight copies. */
 int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* stream);
 /* utility: column sums of x[rows, D] accumulated into acc[D] (ncentroid, anomaly_clip_module.py:145-171). */

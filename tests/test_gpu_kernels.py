@@ -559,3 +559,40 @@ def test_round3_gemm_kernels_random_shapes():
                        gn=N_, gl=Lg, cin=cin)
         ref = torch.nn.functional.leaky_relu(ref, 0.01)
         assert bool(((out.cpu().double() - ref).abs() <= 3e-6 * mag).all()), ("conv", cin, cout, tiles)
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(2048, 768, 768, 0, 1), (1536, 2304, 768, 0, 0), (1024, 3072, 768, 1, 0), (1000, 772, 3072, 0, 1),
+                                           (257, 256, 128, 0, 0)])
+def test_gemm_bf16x6_is_f32_accurate(M, N, K, act, res):
+    """acx_gemm_desc.pairs = 6: A and W as three bf16 planes each (acx_split_bf16x3: exact 24-bit split), the six leading cross
+    products on the bf16 matrix cores with f32 accumulation.  Against fp64: element-wise within 2e-6 * sum_k |a||w| (the bound
+    the f32 MFMA kernels are held to), and no worse than 1.5x the f32 MFMA kernel's own maximum error on the same operands --
+    including a massive-activation column and operands spanning 12 binades."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())
+    a[:, 3] *= 60.0
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    x = torch.randn(M, N, generator=g) if res else None
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    xd = x.to(DEV) if res else None
+    a3, w3 = ops.split_bf16x3(ad), ops.split_bf16x3(wd)
+    assert torch.equal(a3.float().sum(0), ad) and torch.equal(w3.float().sum(0), wd)      # hi + mid + lo == x exactly
+    h = L.ctx(torch.cuda.current_device())
+    L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 1), h)
+    try:
+        y6 = ops.gemm_x6(a3, w3, bias=bd, act=L.ACT_QUICKGELU if act else L.ACT_NONE, residual=xd)
+    finally:
+        L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 512), h)
+    y32 = ops.gemm(ad, wd, bias=bd, act=L.ACT_QUICKGELU if act else L.ACT_NONE, residual=xd)
+    pre = a.double() @ w.double().t() + b.double()
+    ref = pre * torch.sigmoid(1.702 * pre) if act else pre
+    if res:
+        ref = ref + x.double()
+    bound = 2e-6 * (a.double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+    e6, e32 = (y6.cpu().double() - ref).abs(), (y32.cpu().double() - ref).abs()
+    assert bool((e6 <= bound).all()), float((e6 / bound).max())
+    assert float(e6.max()) <= 1.5 * float(e32.max()) + 1e-12
+    with pytest.raises(L.AcxError):                                      # a problem the persistent kernel does not take: refused
+        ops.gemm_x6(a3[:, :64].contiguous(), w3, bias=bd)
+

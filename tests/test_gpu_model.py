@@ -62,7 +62,7 @@ def test_vit_b16_golden(golden):
     assert relerr(out5[:2], out) < 2e-6             # 3-frame vs 2-frame launch: summation order only
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f32x6"])
 def test_vit_b16_full_clip_properties(golden, precision):
     """BASELINE.json's full size (512 frames in ONE launch: 8-wave kernels, the 64x64-tile tail launch, CLS-only last
     layer, 256x256 ring kernels in bf16 mode) through size-independent properties: identical frames give bit-identical
@@ -79,7 +79,7 @@ def test_vit_b16_full_clip_properties(golden, precision):
     assert out.shape == (512, 512) and torch.isfinite(out).all()
     for k in range(8):
         rows = out[idx == k]
-        if precision == "f32":
+        if precision in ("f32", "f32x6"):
             assert torch.equal(rows, rows[:1].expand_as(rows)), k              # bit-identical across ALL slots
         else:
             # bf16 mode: the tail round of tiles runs through another kernel (other f32 summation order), and a
@@ -89,9 +89,11 @@ def test_vit_b16_full_clip_properties(golden, precision):
             assert torch.equal(head, head[:1].expand_as(head)), k
             assert relerr(rows, rows[:1].expand_as(rows)) < 3e-2, k
     small = vit(base.to(DEV))                                                  # 2-frame launch (other kernels)
-    assert relerr(out[:2], small) < (2e-6 if precision == "f32" else 3e-2)
-    if precision == "f32":
-        assert relerr(out[:2], g["out"]) < TOL
+    assert relerr(out[:2], small) < (3e-2 if precision == "bf16" else 2e-6)
+    if precision != "bf16":
+        # "f32x6" (the large GEMMs as f32-accurate bf16 x 6 products; the 2-frame launch above ran the f32 kernels: too few rows
+        # for the persistent kernel) meets the SAME bounds against the reference's output as the f32 MFMA path
+        assert relerr(out[:2], g["out"]) < TOL and elem_ok(out[:2], g["out"])
 
 
 def test_vit_b16_bf16_mode(golden):
