@@ -86,6 +86,7 @@ _SIGS = {
     "acx_attention": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                 c_int32, c_void_p]),
     "acx_attention_bf16": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_attention_x3": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_attention_cls": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_vit_patches": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acx_vit_embed": (C.c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),

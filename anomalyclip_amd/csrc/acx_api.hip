@@ -300,13 +300,18 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     } else
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, qdt, 3 * W, (int)rows, 3 * W, W,
                      b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
+    const bool att_x3 = x6_out && !causal && L > 128 && L <= 224 && ACX_DBG_SWITCH("ATTN16", true);
     if (ab) {
       if ((rc = acx_attention_bf16(ctx, ws.qkv, 3 * W, ws.att, W, batch, L, heads, s))) return rc;
+    } else if (att_x3) {   // the attention writes the out-projection's three planes itself
+      if ((rc = acx_attention_x3(ctx, (const float*)ws.qkv, 3 * W, ws.hp, W, batch, L, heads, s))) return rc;
     } else {
       if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
     }
     if (x6_out) {
-      X6_LINEAR(ws.att, W, ws.hp, b.out_proj_w_bf16, (int64_t)W * W * 2, x, W, W, W, b.out_proj_b, ACX_ACT_NONE, x);
+      if (!att_x3 && (rc = acx_split_bf16x3(ctx, (const float*)ws.att, W, ws.hp, (int64_t)rows * W * 2, rows, W, s))) return rc;
+      if ((rc = linear_x6(ctx, ws.hp, W, rows, b.out_proj_w_bf16, (int64_t)W * W * 2, W, x, W, (int)rows, W, W, b.out_proj_b,
+                          ACX_ACT_NONE, x, s))) return rc;
     } else
     if ((rc = linear(ctx, prec, ws.att, qdt, W, b.out_proj_w, b.out_proj_w_bf16, W, x, ACX_F32, W, (int)rows, W, W,
                      b.out_proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;

@@ -249,9 +249,35 @@ __device__ __forceinline__ float a16_rowsum(float x) {
 }
 
 // One wave's share of a workgroup's items.  HB: the wave owns two query tiles (ta, tb) or one (ta).
+// x3plane > 0: the output is written as three bf16 planes hi | mid | lo (ACX_BF16X3; plane p at (u16*)out + p * x3plane): the A
+// operand of the out-projection in ACX_PREC_F32X6 mode
+__device__ __forceinline__ void a16_store4(float* out, int64_t off, int64_t x3plane, float a, float b, float c, float d) {
+  if (x3plane > 0) {
+    const float ov[4] = {a, b, c, d};
+    u16 hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hh[k] = f2bf(ov[k]);
+      const float r1 = ov[k] - bf2f(hh[k]);
+      mm[k] = f2bf(r1);
+      ll[k] = f2bf(r1 - bf2f(mm[k]));
+    }
+    u16* o3 = reinterpret_cast<u16*>(out) + off;
+    uint2 pk;
+    pk.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16); pk.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+    *reinterpret_cast<uint2*>(o3) = pk;
+    pk.x = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16); pk.y = (uint32_t)mm[2] | ((uint32_t)mm[3] << 16);
+    *reinterpret_cast<uint2*>(o3 + x3plane) = pk;
+    pk.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16); pk.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+    *reinterpret_cast<uint2*>(o3 + 2 * x3plane) = pk;
+  } else {
+    *reinterpret_cast<float4*>(out + off) = make_float4(a, b, c, d);
+  }
+}
+
 template <bool HB, int NW>
 __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out, int64_t ldo,
-                                        int L, int heads, int nitems, char* smem, int ta, int tb) {
+                                        int L, int heads, int nitems, char* smem, int ta, int tb, int64_t x3plane) {
   const int W = heads * 64;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -401,20 +427,18 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
       const float inv = 1.f / a16_rowsum(la);
       const int q = 16 * ta + qi;
       if (q < L) {
-        float* op = out + ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
+        const int64_t o0 = ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<float4*>(op + 4 * r) = make_float4(oa0[r] * inv, oa1[r] * inv, oa2[r] * inv, oa3[r] * inv);
+        for (int r = 0; r < 4; ++r) a16_store4(out, o0 + 4 * r, x3plane, oa0[r] * inv, oa1[r] * inv, oa2[r] * inv, oa3[r] * inv);
       }
     }
     if constexpr (HB) {
       const float inv = 1.f / a16_rowsum(lb);
       const int q = 16 * tb + qi;
       if (q < L) {
-        float* op = out + ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
+        const int64_t o0 = ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<float4*>(op + 4 * r) = make_float4(ob0[r] * inv, ob1[r] * inv, ob2[r] * inv, ob3[r] * inv);
+        for (int r = 0; r < 4; ++r) a16_store4(out, o0 + 4 * r, x3plane, ob0[r] * inv, ob1[r] * inv, ob2[r] * inv, ob3[r] * inv);
       }
     }
   }   // item loop
@@ -435,15 +459,15 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
 // them removed (MFMAs, Q loads and output stores only) the kernel still takes 0.60 ms = 0.73 of the MFMA roof on its
 // padded work: 13 tiles on 8 waves, single-accumulator 16x16x4 chains, item prologue / epilogue.
 __global__ __launch_bounds__(512, 4) void attn16_kernel(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out,
-                                                        int64_t ldo, int L, int heads, int nitems) {
+                                                        int64_t ldo, int L, int heads, int nitems, int64_t x3plane) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nkt = (L + 15) >> 4;
   const int nd = nkt - 8;                                                 // waves with two tiles
   const bool dbl = wave < nd;
   const int ta = dbl ? 2 * wave : nd + wave;
-  if (dbl) a16_run<true, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta + 1);
-  else a16_run<false, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta);
+  if (dbl) a16_run<true, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta + 1, x3plane);
+  else a16_run<false, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta, x3plane);
 }
 
 
@@ -499,8 +523,8 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
-                             int32_t batch, int32_t L, int32_t heads, int32_t causal, void* stream) {
+static int attention_impl(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                          int32_t batch, int32_t L, int32_t heads, int32_t causal, void* stream, int x3) {
   if (!qkv || !out) return acx_fail(ctx, ACX_E_BADARG, "acx_attention: null pointer%s");
   if (batch <= 0) return ACX_OK;
   if (L <= 0 || L > 224 || heads <= 0) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention: need 0 < L <= 224%s");
@@ -516,10 +540,11 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     const int slots = 2 * ncu;                                            // two workgroups per CU
     hipLaunchKernelGGL(attn16_kernel, dim3((unsigned)(nitems < slots ? nitems : slots)), dim3(512), 2 * A16_STAGE_B, s, qkv,
-                       ldqkv, out, ldo, L, heads, nitems);
+                       ldqkv, out, ldo, L, heads, nitems, x3 ? (int64_t)batch * L * ldo : (int64_t)0);
     ACX_CHECK_LAUNCH(ctx, "acx_attention");
     return ACX_OK;
   }
+  if (x3) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention_x3: the ViT kernel only (non-causal, 128 < L <= 224)%s");
 #define ACX_ATTN(NT, NW)                                                                           \
   do {                                                                                             \
     const size_t lds = (size_t)NT * 32 * (KROW + VROW) * 4 + NW * 32 * 4 + 16;                          \
@@ -546,6 +571,16 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
 #undef ACX_ATTN
   ACX_CHECK_LAUNCH(ctx, "acx_attention");
   return ACX_OK;
+}
+
+extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                             int32_t batch, int32_t L, int32_t heads, int32_t causal, void* stream) {
+  return attention_impl(ctx, qkv, ldqkv, out, ldo, batch, L, heads, causal, stream, 0);
+}
+
+extern "C" int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
+                                int32_t batch, int32_t L, int32_t heads, void* stream) {
+  return attention_impl(ctx, qkv, ldqkv, (float*)out_planes, ldo, batch, L, heads, 0, stream, 1);
 }
 
 namespace {

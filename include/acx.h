@@ -147,6 +147,10 @@ int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const float* w, con
  * in_proj output (q | k | v); out: [batch*L, heads*64]. */
 int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
                   int32_t batch, int32_t L, int32_t heads, int32_t causal, void* stream);
+/* the same (non-causal ViT sequences, 128 < L <= 224) with the output as three bf16 planes hi | mid | lo (ACX_BF16X3:
+ * plane p at (uint16_t*)out_planes + p * batch * L * ldo): the out-projection's A operand in ACX_PREC_F32X6 mode */
+int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
+                     int32_t batch, int32_t L, int32_t heads, void* stream);
 
 /* bf16 variant of acx_attention for the bf16 mode of the ViT (NOT a parity path): qkv [batch*L, ldqkv] and out
  * [batch*L, ldo] are bf16, QK^T and PV run on the bf16 MFMA, softmax in f32.  Non-causal only. */
