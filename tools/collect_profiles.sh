@@ -9,6 +9,9 @@ P=$R/profiles
 cd $R
 cp $G/refresh/bench_f32.json $P/${TAG}_bench_f32.json
 cp $G/refresh/bench_bf16.json $P/${TAG}_bench_bf16.json
+cp $G/refresh/bench_f32x6.json $P/${TAG}_bench_f32x6.json
+cp $G/refresh/bench_f32x6_kernel_stats.csv $P/${TAG}_bench_f32x6_kernel_stats.csv
+grep -v amdgpu.ids $G/refresh/x6_probe.txt > $P/${TAG}_gemm_bf16x6_vs_f32.txt
 cp $G/refresh/bench_head.json $P/${TAG}_bench_head.json
 cp $G/refresh/bench_head_eager.json $P/${TAG}_bench_head_eager.json
 for n in 1 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_bench_head_emulated_world$n.json; done

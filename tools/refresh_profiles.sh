@@ -7,6 +7,10 @@ rm -rf $OUT; mkdir -p $OUT
 cd $R
 python bench.py --steps 10 --warmup 3 > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 python bench.py --steps 10 --warmup 3 --precision bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
+# f32 with the ViT's large GEMMs as f32-accurate bf16 x 6 products (a leg of the default run; here as its own line + kernel statistics)
+python bench.py --steps 10 --warmup 3 --precision f32x6 --no-cpu-baseline > $OUT/bench_f32x6.json 2> $OUT/bench_f32x6.err
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/px6 -o x6 -- python $R/bench.py --steps 5 --warmup 1 --precision f32x6 --no-cpu-baseline --no-extra-legs > /dev/null 2>&1; cp $(find /tmp/px6 -name '*kernel_stats.csv' | head -1) $OUT/bench_f32x6_kernel_stats.csv)
+python tools/probes/x6_probe.py > $OUT/x6_probe.txt 2>&1
 # train_batch's default = the whole-step graph; --no-step-graph = its autograd fallback (with / without its own graphs)
 python tools/bench_head.py --steps 40 --warmup 5 > $OUT/bench_head.json 2>/dev/null
 python tools/bench_head.py --steps 20 --no-step-graph > $OUT/bench_head_eager.json 2>/dev/null
