@@ -45,6 +45,28 @@ def test_vit_tiny_golden(golden):
     assert relerr(out, g["out"]) < TOL and elem_ok(out, g["out"])
 
 
+@pytest.mark.parametrize("which", ["vit_tiny", "vit_b16"])
+def test_vit_f32x6_small_launches_vs_reference(golden, which):
+    """precision 'f32x6' with the persistent kernel's minimum size lowered to one tile, so that even the 2-frame golden launches
+    take the bf16 x 6 route: every large-GEMM site of the layer loop (LayerNorm -> planes, the attention writing planes (L = 197)
+    or the split pass (L = 5), c_fc's epilogue writing planes, the K | V product of the CLS-only last layer), ragged row tiles
+    (10 / 394 rows), against the REFERENCE's output under the f32 path's bounds."""
+    from anomalyclip_amd import _lib as L
+    g = golden(which)
+    geom = IW.TINY if which == "vit_tiny" else IW.VIT_B16
+    vit, _ = make_vit(geom, int(g["seed"]), precision="f32x6")
+    frames = torch.from_numpy(g["frames"]) if which == "vit_tiny" else R.vit_frames(int(g["seed"]), 2, 224)
+    h = L.ctx(torch.cuda.current_device())
+    L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 1), h)
+    try:
+        out = vit(frames.to(DEV))
+    finally:
+        L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 512), h)
+    assert relerr(out, g["out"]) < TOL and elem_ok(out, g["out"])
+    vit32, _ = make_vit(geom, int(g["seed"]))
+    assert relerr(out, vit32(frames.to(DEV))) < 5e-6                     # and round-off away from the f32 MFMA path
+
+
 def test_vit_b16_golden(golden):
     g = golden("vit_b16")
     vit, sd = make_vit(IW.VIT_B16, int(g["seed"]))
