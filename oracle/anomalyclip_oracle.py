@@ -438,3 +438,28 @@ def preprocess_frames_ref(frames_u8, size: int = 224):
         t = torch.from_numpy(np.asarray(img).astype(np.float32) / np.float32(255.0)).permute(2, 0, 1)   # :373-381
         out.append((t - torch.from_numpy(mean).view(3, 1, 1)) / torch.from_numpy(std).view(3, 1, 1))    # :479-486
     return torch.stack(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Arithmetic of the library's `f32x6` GEMM mode (acx_gemm_desc.pairs = 6), restated on the CPU.  Not a reference function:
+# the reference computes `x @ w.T` in f32 (clip/model.py:188-217 through torch); this states, in torch-CPU, what the MI355X
+# kernel computes INSTEAD of an f32 FMA chain, so that tests can bound its distance to the exact product without a GPU.
+def split_bf16x3(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x (f32) = hi + mid + lo, each exactly representable in bf16 (round-to-nearest-even), returned as f32 tensors.
+    x - hi and (x - hi) - mid are exact in f32, so the three terms carry x's 24 significant bits."""
+    x = x.float()
+    hi = x.to(torch.bfloat16).float()
+    r1 = x - hi
+    mid = r1.to(torch.bfloat16).float()
+    lo = (r1 - mid).to(torch.bfloat16).float()
+    return hi, mid, lo
+
+
+def matmul_bf16x6(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """a [M, K] @ w [N, K]^T from the six cross products (i + j <= 2) of the bf16 planes, smallest first, as the kernel
+    accumulates them.  Every bf16 x bf16 product is exact in f32; here the products are summed in f64 and rounded once, i.e.
+    the result a perfect f32 accumulator would give -- the kernel's f32 accumulation over K adds its own round-off on top."""
+    ah, am, al = (t.double() for t in split_bf16x3(a))
+    wh, wm, wl = (t.double() for t in split_bf16x3(w))
+    acc = ah @ wl.t() + am @ wm.t() + al @ wh.t() + ah @ wm.t() + am @ wh.t() + ah @ wh.t()
+    return acc.float()

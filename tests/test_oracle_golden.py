@@ -184,3 +184,24 @@ def test_config0_shanghaitech_eval_from_feature_files(golden, prompts_table, tmp
         close(sc, g[f"scores{i}"])
         close(probs[::8], g[f"probs8_{i}"])
         assert abs(float(probs.double().sum()) - float(g[f"probsum{i}"])) < 1e-4 * abs(float(g[f"probsum{i}"]))
+
+
+def test_bf16x6_product_is_f32_accurate():
+    """The arithmetic of the library's f32x6 GEMM mode, on the CPU: the three-plane split is exact (hi + mid + lo == x bit for
+    bit), and the six leading cross products reproduce the exact product to <= 4 * 2^-24 of sum |a||w| -- the three dropped
+    terms are <= 2^-24 of the leading one each, plus one final f32 rounding.  (An f32 FMA chain over K = 768 is allowed
+    K * 2^-24 by the same measure; the GPU tests compare both against fp64.)"""
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(96, 768, generator=g) * torch.exp2(torch.randint(-8, 8, (96, 1), generator=g).float())
+    a[:, 11] *= 80.0
+    w = torch.randn(64, 768, generator=g) * 0.05
+    hi, mid, lo = O.split_bf16x3(a)
+    assert torch.equal(hi + mid + lo, a)
+    assert torch.equal(hi, hi.to(torch.bfloat16).float()) and torch.equal(lo, lo.to(torch.bfloat16).float())
+    y = O.matmul_bf16x6(a, w).double()
+    ref = a.double() @ w.double().t()
+    bound = 4 * 2.0 ** -24 * (a.double().abs() @ w.double().abs().t())
+    assert bool(((y - ref).abs() <= bound + 1e-300).all()), float(((y - ref).abs() / bound).max())
+    plain = (a.to(torch.bfloat16).float().double() @ w.to(torch.bfloat16).float().double().t())
+    assert float((plain - ref).abs().max()) > 1e3 * float((y - ref).abs().max())          # what a single bf16 product loses
+
