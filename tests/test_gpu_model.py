@@ -67,6 +67,20 @@ def test_vit_f32x6_small_launches_vs_reference(golden, which):
     assert relerr(out, vit32(frames.to(DEV))) < 5e-6                     # and round-off away from the f32 MFMA path
 
 
+def test_vit_f32x6_ragged_launch_equals_f32_path(golden):
+    """230 frames in one launch (45 310 rows: not a multiple of the 256-row tile, just above the persistent kernel's minimum for
+    the N = 768 products): the f32x6 mode agrees with the f32 MFMA path to round-off on every frame."""
+    g = golden("vit_b16")
+    frames = torch.randn(230, 3, 224, 224, generator=torch.Generator().manual_seed(9))
+    frames[:2] = R.vit_frames(int(g["seed"]), 2, 224)
+    vit6, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="f32x6")
+    vit32, _ = make_vit(IW.VIT_B16, int(g["seed"]))
+    vit6.chunk = vit32.chunk = 230
+    o6, o32 = vit6(frames.to(DEV)), vit32(frames.to(DEV))
+    assert torch.isfinite(o6).all() and relerr(o6, o32) < 5e-6 and elem_ok(o6, o32)
+    assert relerr(o6[:2], g["out"]) < TOL
+
+
 def test_vit_b16_golden(golden):
     g = golden("vit_b16")
     vit, sd = make_vit(IW.VIT_B16, int(g["seed"]))
