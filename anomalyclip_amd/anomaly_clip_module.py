@@ -509,23 +509,39 @@ class AnomalyCLIPModule(_Base):
         if len(cache) >= 4:
             cache.pop(next(iter(cache)))
         sg = None
+        dist_on = parallel.is_distributed()
+
+        def unavailable(e):
+            import warnings
+            warnings.warn(f"whole-step training graph unavailable ({type(e).__name__}: {e}); using the autograd path")
+            self.step_graph_error = f"{type(e).__name__}: {e}"
+
         try:
             sg = SG.TrainStepGraph(self, optimizer, af.shape[0], nf.shape[0], af.shape[2])
             # dry-run inputs: this batch and an all-ones mask -- NOT generate_mask(): the host RNG stream must advance exactly
             # once per real step, like the reference's (selector_model.py:101-117)
             ones = torch.ones(sg.B, self.net.selector_model.num_segments)
             sg.load_inputs((af, al), (nf, nl), (ones, ones))
-            sg.capture()
         except Exception as e:  # noqa: BLE001
-            import warnings
-            warnings.warn(f"whole-step training graph unavailable ({type(e).__name__}: {e}); using the autograd path")
-            self.step_graph_error = f"{type(e).__name__}: {e}"
+            unavailable(e)
             sg = None
-        if parallel.is_distributed():
-            # all ranks take the same path: the graph path and the autograd path issue different collectives
+        if dist_on:
+            # all ranks take the same path (the graph path and the autograd path issue different collectives), and they agree
+            # BEFORE capture(): its warm-up and capture runs issue real collectives, so a rank that skipped them would leave
+            # the others inside an all_gather it never joins
             flag = torch.tensor([1.0 if sg is not None else 0.0], device=self.device)
             parallel.dist.all_reduce(flag, op=parallel.dist.ReduceOp.MIN)
             if float(flag.item()) < 0.5:
+                sg = None
+        if sg is not None:
+            try:
+                sg.capture()
+            except Exception as e:  # noqa: BLE001
+                if dist_on:
+                    # the ranks' collective sequences no longer match: there is no safe fallback from here
+                    raise RuntimeError(f"whole-step training graph: capture failed on rank {parallel.rank()} inside a "
+                                       f"distributed run ({type(e).__name__}: {e}); set net.step_graph = False") from e
+                unavailable(e)
                 sg = None
         cache[key] = sg
         return sg

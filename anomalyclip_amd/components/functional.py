@@ -80,7 +80,7 @@ def _text_forward_rows(net, ctx_param, text_projection, lo: int, hi: int, tf_out
 def _eot_rows(net, lo, hi, Lc):
     """row index of every local class's EOT token in the [C_loc * Lc, W] activation matrix; built once per (block, length)"""
     cache = net.__dict__.setdefault("_eot_rows_cache", {})
-    key = (lo, hi, Lc, net.eot_index.data_ptr())
+    key = (lo, hi, Lc, net.eot_index.data_ptr(), net.eot_index._version)   # in-place edits (load_state_dict) bump _version
     r = cache.get(key)
     if r is None:
         if torch.cuda.is_current_stream_capturing():
@@ -240,7 +240,8 @@ class _TextGraphs:
         plist = te.__dict__.get("_acx_plist")
         if plist is None:
             plist = te.__dict__["_acx_plist"] = list(te.transformer.parameters())
-        return (lo, hi, int(getattr(net, "text_len", 0))) + tuple((t.data_ptr(), tuple(t.shape)) for t in ts) + tuple(p.data_ptr() for p in plist)
+        return (lo, hi, int(getattr(net, "text_len", 0)), net.eot_index._version) + tuple((t.data_ptr(), tuple(t.shape)) for t in ts) + \
+            tuple(p.data_ptr() for p in plist)
 
 
 class _NoTextRows:
@@ -616,6 +617,7 @@ class _TemporalGraphs:
         params = _temporal_param_list(tm)
         self.x = feats.detach().clone()
         self.a_sub = a_sub
+        self._P = tm._derived(True)                  # the captured launches point into the derived weight buffers: keep them
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():

@@ -226,7 +226,8 @@ class TrainStepGraph:
         nc = module.ncentroid
         return (n_abnormal, n_normal, frames, id(optimizer), par.is_distributed(), par.world_size(), par.rank(),
                 None if nc is None else nc.data_ptr(), bool(net.concat_features), int(getattr(net, "text_len", 0)),
-                bool(getattr(net, "text_class_parallel", True)), torch.cuda.current_stream().cuda_stream) + tuple(
+                bool(getattr(net, "text_class_parallel", True)), torch.cuda.current_stream().cuda_stream,
+                net.eot_index.data_ptr(), net.eot_index._version) + tuple(      # the EOT row table is baked into the capture
             p.data_ptr() for p in module._buckets.params)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -343,6 +344,7 @@ class TrainStepGraph:
         # ---- main: derived weight layouts of the temporal model (the optimizer rewrote the masters), temporal forward
         pg.begin()
         tm.refresh_prepared(True)
+        keep.append(tm._derived(True))                                   # the captured launches point into these buffers
         cT = SimpleNamespace(needs_input_grad=(concat,))
         cT.grad_out = self.gviews
         scores = None
@@ -457,6 +459,11 @@ class TrainStepGraph:
                 text_fwd_items()
         # ---- main tail: the temporal model's gradient exchange and optimizer step
         if dist_on:
+            if not self.in_graph_adamw:
+                # finish(average=True) scales the WHOLE flat buffer, the [text_projection, ctx] bucket included: the text
+                # stream's backward and its reduce_now must have completed first (with the in-graph AdamW nothing on the main
+                # stream touches that bucket: the 1 / world factor is the update's own gscale)
+                pg.main_wait("text_params")
             pg.eager(lambda: (self._ready(list(tparams)), self.buckets.finish(average=not self.in_graph_adamw)))
         else:
             pg.host(lambda: (self._ready(list(tparams) + self.text_params), self.buckets.finish(average=False)))

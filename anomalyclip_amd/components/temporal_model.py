@@ -132,8 +132,11 @@ class TemporalModel(nn.Module):
     def _derived(self, train: bool):
         """Static buffers of every derived layout + the segment list that fills them (ops.prep_multi: ONE launch).  Allocated
         once per (device, parameter addresses); views of the master parameters where no re-layout is needed."""
+        # ONE SLOT PER `train` FLAG: captured graphs (step_graph.TrainStepGraph, functional._TemporalGraphs) hold raw pointers
+        # into the train = True buffers; an evaluation call that builds the train = False layouts must never release them
         key = (bool(train),) + tuple(p.data_ptr() for p in self.parameters())
-        cur = self.__dict__.get("_drv")
+        slots = self.__dict__.setdefault("_drv", {})
+        cur = slots.get(bool(train))
         if cur is not None and cur[0] == key:
             return cur[1], cur[2]
         if torch.cuda.is_current_stream_capturing():
@@ -192,7 +195,7 @@ class TemporalModel(nn.Module):
                         for t in range(9):
                             segs.append((kw.data_ptr() + 4 * t * Cin, o.data_ptr() + 4 * (8 - t) * Cout, Cout, Cin, 9 * Cin,
                                          9 * Cout, 1))
-        self.__dict__["_drv"] = (key, P, segs)
+        slots[bool(train)] = (key, P, segs)
         return P, segs
 
     def refresh_prepared(self, train: bool = True):

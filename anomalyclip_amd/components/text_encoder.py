@@ -30,7 +30,7 @@ class TextEncoder(nn.Module):
         x2 = x.view(Cc * Lc, W)
         self.transformer.forward_(x2, Cc, Lc, prec)                         # text_encoder.py:16-18
         cache = self.__dict__.setdefault("_eot_rows", {})                    # EOT row table: built once per geometry
-        key = (Cc, Lc, eot_index.data_ptr())
+        key = (Cc, Lc, eot_index.data_ptr(), eot_index._version)   # in-place edits (load_state_dict) bump _version
         rows = cache.get(key)
         if rows is None:
             rows = cache[key] = (torch.arange(Cc, device=x.device, dtype=torch.int64) * Lc + eot_index).contiguous()

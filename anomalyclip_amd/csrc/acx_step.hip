@@ -179,7 +179,14 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
   // XCD's L2 -- after a fat GEMM that is megabytes, and it made this kernel take 33-124 us inside a training step.  The
   // partials go out as agent-scope (write-through, sc1) stores, `s_waitcnt vmcnt(0)` waits for their acknowledgement, the
   // arrival counter is a relaxed agent-scope atomic, and the last arriver reads the partials with agent-scope loads
-  // (MI355X_MICROARCH.md, hand-off price list: publish-large / handoff-flag).
+  // (MI355X_MICROARCH.md, hand-off price list: publish-large / handoff-flag).  What orders what: the inline-asm wait carries a
+  // "memory" clobber (a compiler barrier: no store may be moved below it, nothing that follows above it) and makes the wave
+  // wait until every write-through store has been acknowledged by the fabric; __syncthreads() orders the workgroup's waves
+  // around lane 0's counter increment; the last arriver's loads are issued after its fetch_add RETURNED (the `last` flag goes
+  // through LDS and a barrier) and bypass the L1 (sc1).  The guide lists exactly this pairing ("sc1 payload -> asm vmcnt(0)
+  // -> flag", sc1 loads on the reading side) among the valid hand-off forms of gfx950; it is not expressed in C++ memory
+  // orders because a release at agent scope lowers to the L2 write-back above.  tests: the determinism soak
+  // (profiles/r04_determinism_soak.txt, test_colsum_fused_one_launch) runs it under uneven load.
   if (sl == 0 && c < D) {
     float4 t = red[0][q];
 #pragma unroll

@@ -793,6 +793,56 @@ def test_step_graph_full_configs_bit_identical_to_autograd(prompts_table, cfg, B
     assert len(sgs) == 1 and all(v is not None for v in sgs.values()), getattr(mods[0][0], "step_graph_error", None)
 
 
+@pytest.mark.parametrize("path", ["step_graph", "autograd_graphs"])
+def test_train_eval_train_keeps_the_captured_weight_buffers(prompts_table, path):
+    """Captured graphs point into TemporalModel._derived(train=True)'s buffers.  A no-grad evaluation between two training
+    steps builds the train=False layouts (Trainer.fit with per-epoch validation does exactly this): it must not release the
+    buffers the graphs replay into.  Allocations after the evaluation would land in released memory; the third step must
+    still be bit-identical to the graph-free autograd path doing the same train / eval / train sequence."""
+    D, B = IW.TINY.embed_dim, 4
+    mods = [_dp_module(prompts_table, geom="tiny") for _ in range(2)]
+    if path == "step_graph":
+        mods[1][1].step_graph = False
+    else:
+        for m, net in mods:
+            net.step_graph = False
+        mods[0][1].temporal_model.graph = True
+    opts = [m.configure_optimizers()["optimizer"] for m, _ in mods]
+    junk = []
+    for step in range(4):
+        feats, labels, masks = _dp_batch(B, D, 300 + step)
+        f, l = feats.to(DEV), labels.to(DEV)
+        batch = ((f[B // 2:], l[B // 2:]), (f[:B // 2], l[:B // 2]))
+        for (mod, net), opt in zip(mods, opts):
+            if mod.ncentroid is None:
+                mod.ncentroid = torch.zeros(D, device=DEV)
+            net.selector_model.generate_mask = lambda b, m=masks: (m[0], m[1])
+            mod.train_batch(batch, opt)
+        torch.cuda.synchronize()
+        if step in (0, 2):                         # evaluation between training steps (validation_step's forward)
+            outs = []
+            for mod, net in mods:
+                net.eval()
+                with torch.no_grad():
+                    sim, sc = net(f[0].reshape(1, 1, 512, D), None, mod.ncentroid, 1, True)
+                outs.append((sim.clone(), sc.clone()))
+                net.train()
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), step
+            # whatever the evaluation released is up for grabs now: fill the allocator's free blocks with non-zero bytes
+            junk = [torch.full((n,), 7.0, device=DEV) for n in (64, 4096, 16384, 65536, 262144, 1 << 20) for _ in range(4)]
+            torch.cuda.synchronize()
+        pa, pb = dict(mods[0][1].named_parameters()), dict(mods[1][1].named_parameters())
+        for a_, b_ in zip(mods[0][0].last_losses, mods[1][0].last_losses):
+            assert torch.equal(a_, b_), step
+        for n in pa:
+            if pa[n].requires_grad:
+                assert torch.equal(pa[n], pb[n]), (step, n)
+    del junk
+    if path == "step_graph":
+        sgs = mods[0][0].__dict__.get("_step_graphs", {})
+        assert len(sgs) == 1 and all(v is not None for v in sgs.values()), getattr(mods[0][0], "step_graph_error", None)
+
+
 def test_temporal_graph_gradients_survive_the_next_replay(prompts_table):
     """autograd path, temporal_model.graph = True: gradients handed to autograd must not alias the graph's static buffers --
     torch.autograd.grad results of one step stay intact after the graphs are replayed for another input."""
