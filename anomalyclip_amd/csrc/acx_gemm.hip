@@ -432,6 +432,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #include "acx_gemm_sk.h"     // gemm_f32_sk_kernel: few-row problems (text tower of a data-parallel rank), no K-loop barrier
 #include "acx_gemm_bf16.h"   // gemm_bf16_dma_kernel, gemm_bf16_ring_kernel
 #include "acx_gemm_p8.h"     // gemm_bf16_p8_kernel: the ring kernel's tile stream on a phase-interleaved schedule
+#include "acx_gemm_x6.h"     // gemm_x6_p4_kernel: pairs = 6 products, one wave per SIMD, plane-reuse schedule
 #include "acx_gemm_tn.h"     // gemm_tn_kernel, gemm_tn_w8_kernel, tn_reduce_kernel
 
 template <int C_BF16>
@@ -452,7 +453,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     o += d.pos0[(size_t)n * d.N + col] + d.pos1[(size_t)l * d.N + col];
   }
   o += v;
-  if constexpr (C_BF16) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(o);
+  if constexpr (C_BF16 == 2) {               // ACX_BF16X3: three bf16 planes hi | mid | lo of the f32 value
+    const size_t pe = (size_t)d.M * d.ldc, at = (size_t)row * d.ldc + col;
+    const u16 h = f2bf(o);
+    const float r1 = o - bf2f(h);
+    const u16 m = f2bf(r1);
+    ((u16*)d.C)[at] = h; ((u16*)d.C)[at + pe] = m; ((u16*)d.C)[at + 2 * pe] = f2bf(r1 - bf2f(m));
+  } else if constexpr (C_BF16 == 1) ((u16*)d.C)[(size_t)row * d.ldc + col] = f2bf(o);
   else ((float*)d.C)[(size_t)row * d.ldc + col] = o;
 }
 
@@ -630,6 +637,67 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       ACX_CHECK_LAUNCH(ctx, "acx_gemm");
       return ACX_OK;
     }
+  }
+  // ---- pairs = 6 (f32-accurate product from three bf16 planes per operand): the one-wave-per-SIMD plane-reuse kernel
+  // (acx_gemm_x6.h) -- identity rows or the implicit 3x3 convolution; K split across workgroups when the tiles alone
+  // would not fill the chip (caller-provided workspace)
+  if (d->pairs == 6 && ACX_DBG_SWITCH("X6P4", true)) {
+    const bool conv = d->amap == ACX_AMAP_CONV3X3;
+    const bool c_x3_ = d->c_dtype == ACX_BF16X3;
+    const bool shape_ok = prec == ACX_PREC_BF16 && a_bf16 && (d->amap == ACX_AMAP_IDENTITY || conv) && !d->a_sub && !d->pos0 &&
+        d->K % 32 == 0 && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
+        !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && d->a_plane_stride > 0 && d->w_plane_stride > 0 &&
+        !((d->a_plane_stride | d->w_plane_stride) & 15) && (size_t)d->M * d->lda * 2 < ((size_t)1 << 32) &&
+        (size_t)d->N * d->ldw * 2 < ((size_t)1 << 32) && !(d->act == ACX_ACT_QUICKGELU && d->residual) &&
+        !(d->act == ACX_ACT_LEAKYRELU && d->residual) && !(c_x3_ && d->residual) && !(c_bf16 && d->residual) &&
+        (!conv || (d->zero_page && !((uintptr_t)d->zero_page & 15) && d->cin % 32 == 0 && !(d->gl & (d->gl - 1)) &&
+                   !(d->gn & (d->gn - 1)) && d->M % 256 == 0));
+    if (shape_ok) {
+      const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+      const int xt = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+      const int nks = d->K / 32;
+      int split = 1;
+      if (d->workspace && xt < ncu) {            // largest divisor of the K-step count that keeps >= 6 K-steps per piece and <= 2 items per CU
+        for (int s2 = 2; s2 <= 64; ++s2)
+          if (nks % s2 == 0 && nks / s2 >= 6 && xt * s2 <= 2 * ncu && (size_t)s2 * d->M * d->N * sizeof(float) <= d->workspace_bytes) split = s2;
+      }
+      g.ksplit = split; g.kchunk = nks / split; g.partial = split > 1 ? (float*)d->workspace : nullptr;
+      const int items = xt * split;
+      const dim3 xgrid((unsigned)(items < ncu ? items : ncu));
+#define ACX_X6L(CM, ACT, RES, CV)                                                                   \
+  do {                                                                                              \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                          \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<CM, ACT, RES, CV>,                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B);         \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_x6_p4_kernel<CM, ACT, RES, CV>), xgrid, dim3(256), (size_t)X6_LDS_B, s, g); \
+  } while (0)
+#define ACX_X6SEL(CV)                                                                               \
+  do {                                                                                              \
+    if (split > 1) ACX_X6L(0, 0, 0, CV);                                                            \
+    else if (c_x3_) { if (d->act == ACX_ACT_QUICKGELU) ACX_X6L(2, 1, 0, CV); else if (d->act == ACX_ACT_LEAKYRELU) ACX_X6L(2, 2, 0, CV); else ACX_X6L(2, 0, 0, CV); } \
+    else if (c_bf16) { if (d->act == ACX_ACT_QUICKGELU) ACX_X6L(1, 1, 0, CV); else if (d->act == ACX_ACT_LEAKYRELU) ACX_X6L(1, 2, 0, CV); else ACX_X6L(1, 0, 0, CV); } \
+    else if (d->residual) ACX_X6L(0, 0, 1, CV);                                                     \
+    else if (d->act == ACX_ACT_QUICKGELU) ACX_X6L(0, 1, 0, CV);                                     \
+    else if (d->act == ACX_ACT_LEAKYRELU) ACX_X6L(0, 2, 0, CV);                                     \
+    else ACX_X6L(0, 0, 0, CV);                                                                      \
+  } while (0)
+      if (conv) ACX_X6SEL(1); else ACX_X6SEL(0);
+#undef ACX_X6SEL
+#undef ACX_X6L
+      if (split > 1) {
+        const int64_t total = (int64_t)d->M * d->N;
+        const dim3 rgrid((unsigned)((total + 255) / 256));
+        if (c_x3_) hipLaunchKernelGGL((splitk_reduce_kernel<2>), rgrid, dim3(256), 0, s, (const float*)g.partial, split, *d);
+        else if (c_bf16) hipLaunchKernelGGL((splitk_reduce_kernel<1>), rgrid, dim3(256), 0, s, (const float*)g.partial, split, *d);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<0>), rgrid, dim3(256), 0, s, (const float*)g.partial, split, *d);
+      }
+      ACX_CHECK_LAUNCH(ctx, "acx_gemm");
+      return ACX_OK;
+    }
+    if (conv) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 with CONV3X3 needs a power-of-two grid, cin %% 32 == 0, M %% 256 == 0, a zero page and 16-byte aligned planes%s");
   }
   const bool w8_conv = d->amap == ACX_AMAP_CONV3X3 && !d->a_sub && !d->pos0 && d->K % 32 == 0 && d->cin % 32 == 0 &&
                        prec == ACX_PREC_F32 && !c_bf16 && !a_bf16;

@@ -1,0 +1,418 @@
+// acx_gemm -- f32-ACCURATE product from three bf16 planes per operand (acx_gemm_desc.pairs = 6): persistent 256x256 kernel,
+// ONE wave per SIMD, plane-reuse schedule
+// (included by acx_gemm.hip inside its anonymous namespace after acx_gemm_p8.h; shares Args / helpers / typedefs)
+// =====================================================================================================
+// gemm_bf16_p8_kernel runs a pairs = 6 product as six plain bf16 products one after the other: every plane pair streams
+// its A and W K-tiles through LDS again (12 operand tiles per 64 k for 6 products) and every MFMA is fed by 1.5 fragment
+// reads.  Measured there: 1.63 us per K-tile, mfma_pipe_busy 0.58, 3.1 x the algorithmic HBM traffic.  Here the SIX products
+// of one k range are formed while its SIX plane tiles are resident -- each plane tile is staged ONCE and each fragment read
+// feeds three MFMAs:
+//   * 4 waves (2 x 2), 128 x 128 outputs per wave = 4 x 4 accumulators of v_mfma_f32_32x32x16_bf16 (256 registers), one
+//     wave per SIMD with the 512-register budget: two fragment sets of 16 fragments (128 registers), no spills;
+//   * a K-step is 32 k.  LDS holds eight 16 KB "units" (one plane tile: 256 rows x 64 B, source-side bank swizzle
+//     chunk ^ ((row >> 2) & 3)) + 4 KB of epilogue transposer per wave = 144 KB.  A K-step is two HALF-STEPS:
+//         X:  A.hi  x  W.lo, W.mid, W.hi                      (units AH WL WM WH)
+//         Y:  A.lo  x  W.hi ;  A.mid  x  W.mid, W.hi           (units AL AM WM WH)
+//     -- 96 MFMAs per wave per half-step (two k16 substeps x three products x 16 accumulators) behind ONE barrier, fed by
+//     32 ds_read_b128 and 12 LDS-DMA instructions per wave, all of them interleaved one by one between the MFMAs of a
+//     fragment set they do not touch (hand-placed: every group is fenced by sched_barrier(0));
+//   * unit slots: W.hi / W.mid alternate between two slots by K-step parity (they live for a whole K-step and are
+//     restaged a K-step ahead); A.hi, W.lo, A.mid, A.lo own one slot each and are restaged right after the barrier that
+//     ends their half-step, one half-step before they are read again:
+//         after the barrier of X(t):  DMA A.mid(t), A.lo(t), W.hi(t+1)      wait before Y(t):   vmcnt(4)
+//         after the barrier of Y(t):  DMA W.mid(t+1), A.hi(t+1), W.lo(t+1)  wait before X(t+1): vmcnt(0)
+//     (a unit is 4 instructions per wave; loads return in order);
+//   * the K-step stream runs across the workgroup's work items (persistent; XCD-aware item order as in the other
+//     persistent kernels); an item is an output tile, or one K range of a tile when the launch splits K (few tiles: the
+//     head's convolutions at a data-parallel rank's rows) -- split items store raw f32 partial tiles, the epilogue is
+//     splitk_reduce_kernel's;
+//   * CONV: implicit-GEMM 3x3 convolution over the (gn, gl) token grid (power-of-two grid, cin % 32 == 0): the DMA source
+//     of an A row is the row shifted by the K-step's tap, or the caller's zero page outside the grid.
+// Accumulation order differs from the p8 kernel's (all six products of a k range before the next range, smallest cross
+// terms first inside a range); the result is an f32 dot product's either way (tests hold both to the same bounds).
+#ifndef ACX_X6_ABL
+#define ACX_X6_ABL 0     // timing ablations (wrong results), bit mask: 1 no DMA in the K loop, 2 no vmcnt waits, 4 no epilogue stores, 8 no ds_reads
+#endif
+constexpr int X6_UNIT_B = 256 * 64;              // one plane tile: 256 rows x 32 bf16
+constexpr int X6_LDS_B = 8 * X6_UNIT_B + 4 * 4096;
+enum { X6_WH0 = 0, X6_WM0 = 1, X6_AH = 2, X6_WL = 3, X6_AM = 4, X6_AL = 5, X6_WH1 = 6, X6_WM1 = 7 };
+
+struct X6Src {                                   // one K-step of the stream (wave-uniform)
+  int m0, n0;                                    // origin of its output tile
+  int kk;                                        // K-step (32 k) inside the operand rows
+  int tk, j;                                     // step inside the item, item ordinal of this workgroup
+};
+
+template <int C_MODE, int ACT, int RES, int CONV>
+__global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const acx_gemm_desc& d = g.d;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+  const int tiles_n = (d.N + 255) / 256, tiles_m = (d.M + 255) / 256;
+  const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
+  const int nitems = tiles_m * tiles_n * ksplit;
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
+  const int b0 = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + ((int)blockIdx.x >> 3);
+  const int my_items = b0 < nitems ? (nitems - b0 + G - 1) / G : 0;
+  if (my_items == 0) return;
+  const int spi = (d.K / 32) / ksplit;           // K-steps per item (dispatch: divisible)
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  // ---- DMA: a unit is 16 wave-instructions of 1 KB (16 rows x 64 B); wave w issues instructions 4 w .. 4 w + 3.
+  // lane -> row (lane >> 2) of the instruction's 16, LDS chunk position lane & 3 = global chunk ^ ((row >> 2) & 3)
+  const int dr = 64 * wave + (lane >> 2);                        // + 16 i: this lane's unit row of instruction i
+  const int dc = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;          // byte offset of its 16-byte piece inside the row's 64 B
+  const char* zsrc = CONV ? (const char*)g.zeros + (lane & 3) * 16 : nullptr;
+  const int sh_gl = CONV ? __builtin_ctz((unsigned)d.gl) : 0;
+  const int steps_per_tap = CONV ? d.cin / 32 : 1;
+#define X6_SET_ITEM(S, jj)                                                                         \
+  do {                                                                                             \
+    const int L_ = b0 + min((jj), my_items - 1) * G;   /* past the end: re-read the last item (never consumed) */ \
+    const int tile_ = L_ / ksplit, ks_ = L_ - tile_ * ksplit;                                      \
+    const int tm_ = tile_ / tiles_n, tn_ = tile_ - tm_ * tiles_n;                                  \
+    S.m0 = tm_ * 256; S.n0 = tn_ * 256; S.kk = ks_ * spi;                                          \
+  } while (0)
+  // per-lane byte offsets of this lane's four A rows / W rows of item S (the same for every plane and K-step), and -- CONV --
+  // the taps that stay inside the token grid for each of the A rows (bit tap of VM[i])
+#define X6_ROWS(S, RA, RW, VM)                                                                     \
+  do {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+      const int m_ = S.m0 + dr + 16 * i;                                                           \
+      RA[i] = (unsigned)(CONV ? m_ : min(m_, d.M - 1)) * ((ACX_X6_ABL & 16) ? 64u : (unsigned)d.lda * 2u) + (unsigned)dc; \
+      RW[i] = (unsigned)min(S.n0 + dr + 16 * i, d.N - 1) * ((ACX_X6_ABL & 16) ? 64u : (unsigned)d.ldw * 2u) + (unsigned)dc; \
+      if constexpr (CONV != 0) {                                                                   \
+        const int n_ = (m_ >> sh_gl) & (d.gn - 1), l_c = m_ & (d.gl - 1);                          \
+        const unsigned rn_ = (n_ > 0 ? 1u : 0u) | 2u | (n_ < d.gn - 1 ? 4u : 0u);   /* dn = -1, 0, +1 */ \
+        const unsigned rl_ = (l_c > 0 ? 1u : 0u) | 2u | (l_c < d.gl - 1 ? 4u : 0u); /* dl = -1, 0, +1 */ \
+        VM[i] = ((rn_ & 1u) ? rl_ : 0u) | ((rn_ & 2u) ? rl_ << 3 : 0u) | ((rn_ & 4u) ? rl_ << 6 : 0u); \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+#define X6_ADVANCE(S, RA, RW, VM)                                                                  \
+  do {                                                                                             \
+    ++S.kk;                                                                                        \
+    if (++S.tk == spi) { S.tk = 0; ++S.j; X6_SET_ITEM(S, S.j); X6_ROWS(S, RA, RW, VM); }           \
+  } while (0)
+  // One LDS-DMA instruction: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS [m0 ..+1 KB).  M0 is not
+  // restored: nothing else in this kernel reads it (ds_read / ds_write do not use M0 on gfx9+).
+#define X6_GLDS_S(base, voff, ldsaddr)                                                             \
+  do {                                                                                             \
+    if ((ACX_X6_ABL & 1) && g.ksplit != 12345) break;                                              \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"                   \
+                 : : "v"(voff), "s"(ldsaddr), "s"(base) : "memory");                               \
+  } while (0)
+#define X6_GLDS_V(gptr, ldsaddr)                                                                   \
+  do {                                                                                             \
+    if ((ACX_X6_ABL & 1) && g.ksplit != 12345) break;                                              \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                  \
+                 : : "v"(gptr), "s"(ldsaddr) : "memory");                                          \
+  } while (0)
+  // instruction i (0..3) of this wave's share of a unit: plane `pl` of A at K-step S (row offsets RA, tap masks VM) -> slot
+#define X6_DMA_A(S, RA, VM, pl, slot, i)                                                           \
+  do {                                                                                             \
+    const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (4 * wave + (i)) * 1024;                       \
+    const char* b_ = (const char*)d.A + (size_t)(pl) * (size_t)d.a_plane_stride;                   \
+    if constexpr (CONV != 0) {                                                                     \
+      const int tap_ = S.kk / steps_per_tap, kc_ = S.kk - tap_ * steps_per_tap;                    \
+      const int t3_ = tap_ / 3;                                                                    \
+      const int dn_ = t3_ - 1, dl_ = tap_ - 3 * t3_ - 1;                                           \
+      const char* bt_ = b_ + ((ptrdiff_t)(dn_ * d.gl + dl_) * d.lda * 2 + kc_ * 64);   /* uniform: tap shift + channel block */ \
+      const bool ok_ = (VM[i] >> tap_) & 1u;                                                       \
+      X6_GLDS_V(ok_ ? bt_ + RA[i] : zsrc, l_);                                                     \
+    } else {                                                                                       \
+      X6_GLDS_S(b_ + (size_t)S.kk * ((ACX_X6_ABL & 16) ? (size_t)d.M * 64 : (size_t)64), RA[i], l_); \
+    }                                                                                              \
+  } while (0)
+#define X6_DMA_W(S, RW, pl, slot, i)                                                               \
+  do {                                                                                             \
+    const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (4 * wave + (i)) * 1024;                       \
+    const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride + (size_t)S.kk * ((ACX_X6_ABL & 16) ? (size_t)d.N * 64 : (size_t)64); \
+    X6_GLDS_S(b_, RW[i], l_);                                                                      \
+  } while (0)
+
+  X6Src c0, c1;                                  // K-steps gs and gs + 1 of the stream
+  unsigned ra0[4], rw0[4], vm0[4] = {0u, 0u, 0u, 0u}, ra1[4], rw1[4], vm1[4] = {0u, 0u, 0u, 0u};
+  c0.tk = 0; c0.j = 0; X6_SET_ITEM(c0, 0); X6_ROWS(c0, ra0, rw0, vm0);
+  // ---- prologue: W.hi, W.mid, A.hi, W.lo of K-step 0 (parity 0 slots)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) X6_DMA_W(c0, rw0, 0, X6_WH0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) X6_DMA_W(c0, rw0, 1, X6_WM0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) X6_DMA_A(c0, ra0, vm0, 0, X6_AH, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) X6_DMA_W(c0, rw0, 2, X6_WL, i);
+  c1 = c0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ra1[i] = ra0[i]; rw1[i] = rw0[i]; vm1[i] = vm0[i]; }
+  X6_ADVANCE(c1, ra1, rw1, vm1);
+
+  // ---- fragment addresses inside a unit: row, chunk 2 s + hh at position chunk ^ ((li >> 2) & 3); + 2048 per 32-row block
+  const int sw = (li >> 2) & 3;
+  const int fa0 = (wm * 128 + li) * 64 + ((0 + hh) ^ sw) * 16, fa1 = (wm * 128 + li) * 64 + ((2 + hh) ^ sw) * 16;
+  const int fw0 = (wn * 128 + li) * 64 + ((0 + hh) ^ sw) * 16, fw1 = (wn * 128 + li) * 64 + ((2 + hh) ^ sw) * 16;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+  // fragment sets: [0..3] A.hi (X) / A.mid (Y) row blocks, [4..7] W.hi, [8..11] W.mid column blocks, [12..15] W.lo column
+  // blocks (X) / A.lo row blocks (Y)
+  bf16x8 F0[16], F1[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) F1[q][e] = (__bf16)0.f;
+
+#define X6_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (((ACX_X6_ABL & 8) && g.ksplit != 12345) ? 0 : (off))))
+  // fragment q (0..15) of substep s of an X / Y half-step; wpar = byte offset of this K-step's W.hi / W.mid slots
+#define X6_RD_X(F, s, q)                                                                           \
+  do {                                                                                             \
+    if ((q) < 4) F[q] = X6_FRAG(X6_AH * X6_UNIT_B + ((s) ? fa1 : fa0) + (q) * 2048);               \
+    else if ((q) < 8) F[q] = X6_FRAG(wpar + X6_WH0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 4) * 2048); \
+    else if ((q) < 12) F[q] = X6_FRAG(wpar + X6_WM0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 8) * 2048); \
+    else F[q] = X6_FRAG(X6_WL * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 12) * 2048);                \
+  } while (0)
+#define X6_RD_Y(F, s, q)                                                                           \
+  do {                                                                                             \
+    if ((q) < 4) F[q] = X6_FRAG(X6_AM * X6_UNIT_B + ((s) ? fa1 : fa0) + (q) * 2048);               \
+    else if ((q) < 8) F[q] = X6_FRAG(wpar + X6_WH0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 4) * 2048); \
+    else if ((q) < 12) F[q] = X6_FRAG(wpar + X6_WM0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 8) * 2048); \
+    else F[q] = X6_FRAG(X6_AL * X6_UNIT_B + ((s) ? fa1 : fa0) + ((q) - 12) * 2048);                \
+  } while (0)
+  // MFMA q (0..47) of a fragment set: product q / 16, row block (q % 16) / 4, column block q % 4.  Operands swapped: the
+  // accumulator holds C^T (lane = output row, registers = 4-column groups), as in the p8 kernel.
+  //   X: (A.hi, W.lo) (A.hi, W.mid) (A.hi, W.hi)        Y: (A.lo, W.hi) (A.mid, W.mid) (A.mid, W.hi)
+#define X6_MM_X(F, q)                                                                              \
+  do {                                                                                             \
+    constexpr int p_ = (q) / 16, mi_ = ((q) % 16) / 4, ni_ = (q) % 4;                              \
+    acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[(p_ == 0 ? 12 : p_ == 1 ? 8 : 4) + ni_], F[mi_], acc[mi_][ni_], 0, 0, 0); \
+  } while (0)
+#define X6_MM_Y(F, q)                                                                              \
+  do {                                                                                             \
+    constexpr int p_ = (q) / 16, mi_ = ((q) % 16) / 4, ni_ = (q) % 4;                              \
+    acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[(p_ == 1 ? 8 : 4) + ni_], F[(p_ == 0 ? 12 : 0) + mi_], acc[mi_][ni_], 0, 0, 0); \
+  } while (0)
+#define X6_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define X6_REP48(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32) M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40) M(41) M(42) M(43) M(44) M(45) M(46) M(47)
+
+  int wpar = 0;                                  // 0 / 6 units: the W.hi / W.mid slots of the current K-step
+  for (int j = 0; j < my_items; ++j) {
+    for (int tk = 0; tk < spi; ++tk) {
+      const int wnext = wpar ? 0 : 6 * X6_UNIT_B;
+      const int slot_wh_next = wpar ? X6_WH0 : X6_WH1, slot_wm_next = wpar ? X6_WM0 : X6_WM1;
+      // =========================================================================== half-step X
+      if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      X6_FENCE();
+      __builtin_amdgcn_s_barrier();
+      X6_FENCE();
+      // block 1: the previous half-step's second substep (set F1, Y products; F1 is ZERO at an item's first K-step: no branch
+      // around the accumulators, whose register assignment hipcc only keeps in place in straight-line code) with this
+      // half-step's first-substep reads (-> F0) and its 12 DMA instructions between the MFMAs
+#define X6_B1_X(q)                                                                                 \
+  do {                                                                                             \
+    if constexpr ((q) < 16) X6_RD_X(F0, 0, (q) & 15);                                                             \
+    if constexpr ((q) >= 16 && (q) < 40 && (((q) - 16) % 2) == 0) {                                          \
+      constexpr int u_ = (((q) - 16) / 8) & 3, i_ = (((q) - 16) / 2) & 3;                                \
+      if (u_ == 0) X6_DMA_A(c0, ra0, vm0, 1, X6_AM, i_);                                                     \
+      else if (u_ == 1) X6_DMA_A(c0, ra0, vm0, 2, X6_AL, i_);                                                \
+      else X6_DMA_W(c1, rw1, 0, slot_wh_next, i_);                                                      \
+    }                                                                                              \
+    X6_MM_Y(F1, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+      X6_REP48(X6_B1_X)
+#undef X6_B1_X
+      // block 2: this half-step's first substep (F0, X products) with its second-substep reads (-> F1)
+#define X6_B2_X(q)                                                                                 \
+  do {                                                                                             \
+    if constexpr ((q) < 16) X6_RD_X(F1, 1, (q) & 15);                                                             \
+    X6_MM_X(F0, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+      X6_REP48(X6_B2_X)
+#undef X6_B2_X
+      // =========================================================================== half-step Y
+      if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");     // A.mid, A.lo landed (W.hi of the next K-step may be in flight)
+      X6_FENCE();
+      __builtin_amdgcn_s_barrier();
+      X6_FENCE();
+#define X6_B1_Y(q)                                                                                 \
+  do {                                                                                             \
+    if constexpr ((q) < 16) X6_RD_Y(F0, 0, (q) & 15);                                                             \
+    if constexpr ((q) >= 16 && (q) < 40 && (((q) - 16) % 2) == 0) {                                          \
+      constexpr int u_ = (((q) - 16) / 8) & 3, i_ = (((q) - 16) / 2) & 3;                                \
+      if (u_ == 0) X6_DMA_W(c1, rw1, 1, slot_wm_next, i_);                                              \
+      else if (u_ == 1) X6_DMA_A(c1, ra1, vm1, 0, X6_AH, i_);                                                \
+      else X6_DMA_W(c1, rw1, 2, X6_WL, i_);                                                             \
+    }                                                                                              \
+    X6_MM_X(F1, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+      X6_REP48(X6_B1_Y)
+#undef X6_B1_Y
+#define X6_B2_Y(q)                                                                                 \
+  do {                                                                                             \
+    if constexpr ((q) < 16) X6_RD_Y(F1, 1, (q) & 15);                                                             \
+    X6_MM_Y(F0, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+      X6_REP48(X6_B2_Y)
+#undef X6_B2_Y
+      wpar = wnext;
+      c0 = c1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ra0[i] = ra1[i]; rw0[i] = rw1[i]; vm0[i] = vm1[i]; }
+      X6_ADVANCE(c1, ra1, rw1, vm1);
+    }
+    // ---- item end: the last substep (F1, Y products), then the epilogue.  The DMA queue is drained first: the epilogue's
+    // stores must not sit in front of a counted wait (one in-order vmcnt for loads and stores)
+#define X6_DRAIN(q) X6_MM_Y(F1, (q));
+    X6_REP48(X6_DRAIN)
+#undef X6_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+      const int L = b0 + j * G;
+      const int tile = L / ksplit, ks = L - tile * ksplit;
+      const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+      const int m0 = tm * 256, n0 = tn * 256;
+      const bool raw = ksplit > 1;               // split items: raw f32 partial tile [ks][M][N], epilogue in the reduce launch
+      float* Cf = raw ? g.partial + (size_t)ks * d.M * d.N : (float*)d.C;
+      const int ldc = raw ? d.N : d.ldc;
+      // each 32x32 accumulator tile goes through this wave's private 4 KB of LDS (XOR-swizzled 128-B rows) and comes back
+      // row-major: lane l owns 4 consecutive columns (l & 7) of row (l >> 3) + 8 pass: 4 stores of 8 rows x 128 B per tile.
+      char* scr = smem + 8 * X6_UNIT_B + wave * 4096;
+      const int rl = lane >> 3, cj = lane & 7;
+      const int colw = n0 + wn * 128 + 4 * cj;   // + 32 ni
+      const int roww = m0 + wm * 128 + rl;       // + 32 mi + 8 ps
+      // bias of the four column blocks: consumed HERE, outside every store -- a load still pending when stores are issued
+      // makes hipcc's counted waits cover the stores as well (one in-order vmcnt)
+      float4 bia[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        bia[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias && !raw) bia[ni] = *reinterpret_cast<const float4*>(d.bias + min(colw + 32 * ni, d.N - 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(bia[ni].x), "+v"(bia[ni].y), "+v"(bia[ni].z), "+v"(bia[ni].w));
+      // residual of accumulator tile bi = 4 ni + mi into R (rows / columns clamped: an edge tile masks at the store)
+#define X6_RES_LOAD(R, bi)                                                                         \
+  do {                                                                                             \
+    if constexpr (RES != 0) {                                                                      \
+      _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                             \
+        R[ps] = *reinterpret_cast<const float4*>(                                                  \
+            d.residual + (size_t)min(roww + ((bi) & 3) * 32 + 8 * ps, d.M - 1) * d.ldr + min(colw + 32 * ((bi) >> 2), d.N - 4)); \
+    }                                                                                              \
+  } while (0)
+      // transposer + epilogue arithmetic + stores of accumulator tile bi; PRED: mask rows / columns outside the problem
+#define X6_EPI_BLOCK(R, bi, PRED)                                                                  \
+  do {                                                                                             \
+    constexpr int ni = (bi) >> 2, mi = (bi) & 3;                                                   \
+    const int col = colw + 32 * ni;                                                                \
+    const float4 b4 = bia[ni];                                                                     \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)   /* accumulator (C^T layout): row li, columns 8k + 4hh .. +3 = chunk 2k + hh */ \
+      *reinterpret_cast<float4*>(scr + li * 128 + (((2 * k + hh) ^ (li & 7)) * 16)) =             \
+          make_float4(acc[mi][ni][4 * k], acc[mi][ni][4 * k + 1], acc[mi][ni][4 * k + 2], acc[mi][ni][4 * k + 3]); \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                             \
+      const int rr_ = rl + 8 * ps;                                                                 \
+      float4 v = *reinterpret_cast<const float4*>(scr + rr_ * 128 + ((cj ^ (rr_ & 7)) * 16));     \
+      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;                                          \
+      if constexpr (ACT == ACX_ACT_QUICKGELU) {                                                    \
+        v.x = acx_quickgelu(v.x); v.y = acx_quickgelu(v.y);                                        \
+        v.z = acx_quickgelu(v.z); v.w = acx_quickgelu(v.w);                                        \
+      } else if constexpr (ACT == ACX_ACT_LEAKYRELU) {                                             \
+        v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;                  \
+        v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;                  \
+      }                                                                                            \
+      if constexpr (RES != 0) { v.x += R[ps].x; v.y += R[ps].y; v.z += R[ps].z; v.w += R[ps].w; }  \
+      const int row = roww + mi * 32 + 8 * ps;                                                     \
+      if ((!(PRED) || (col < d.N && row < d.M)) && (!(ACX_X6_ABL & 4) || g.ksplit == 12345)) {     \
+        if constexpr (C_MODE == 2) {                                                               \
+          /* three bf16 planes hi | mid | lo of the f32 value (ACX_BF16X3): the next pairs = 6 product's A operand */ \
+          const float ov[4] = {v.x, v.y, v.z, v.w};                                                \
+          float r1[4], r2[4];                                                                      \
+          uint2 ph, pm, pl;                                                                        \
+          ph.x = f2bf2(ov[0], ov[1]); ph.y = f2bf2(ov[2], ov[3]);                                  \
+          r1[0] = ov[0] - __uint_as_float(ph.x << 16); r1[1] = ov[1] - __uint_as_float(ph.x & 0xffff0000u); \
+          r1[2] = ov[2] - __uint_as_float(ph.y << 16); r1[3] = ov[3] - __uint_as_float(ph.y & 0xffff0000u); \
+          pm.x = f2bf2(r1[0], r1[1]); pm.y = f2bf2(r1[2], r1[3]);                                  \
+          r2[0] = r1[0] - __uint_as_float(pm.x << 16); r2[1] = r1[1] - __uint_as_float(pm.x & 0xffff0000u); \
+          r2[2] = r1[2] - __uint_as_float(pm.y << 16); r2[3] = r1[3] - __uint_as_float(pm.y & 0xffff0000u); \
+          pl.x = f2bf2(r2[0], r2[1]); pl.y = f2bf2(r2[2], r2[3]);                                  \
+          const size_t pe = (size_t)d.M * d.ldc;                                                   \
+          u16* dst = (u16*)d.C + (size_t)row * d.ldc + col;                                        \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&ph), reinterpret_cast<u32x2*>(dst)); \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pm), reinterpret_cast<u32x2*>(dst + pe)); \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pl), reinterpret_cast<u32x2*>(dst + 2 * pe)); \
+        } else if constexpr (C_MODE == 1) {                                                        \
+          uint2 pk;                                                                                \
+          pk.x = f2bf2(v.x, v.y);                                                                  \
+          pk.y = f2bf2(v.z, v.w);                                                                  \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pk),                        \
+                                      reinterpret_cast<u32x2*>((u16*)d.C + (size_t)row * d.ldc + col)); \
+        } else {                                                                                   \
+          f32x4* dst = reinterpret_cast<f32x4*>(Cf + (size_t)row * ldc + col);                     \
+          if constexpr (RES != 0) *dst = *reinterpret_cast<const f32x4*>(&v);                      \
+          else __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&v), dst);              \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;                          \
+  } while (0)
+      float4 R0[4], R1[4];
+      if (m0 + 256 <= d.M && n0 + 256 <= d.N) {
+        // full tile: unpredicated stores (straight-line code: hipcc's counted waits then leave the stores in flight), the
+        // residual loaded TWO accumulator tiles ahead of its use -- a wait for it never covers the stores of the last two
+#define X6_FULL2(bi) X6_EPI_BLOCK(R0, bi, false); X6_RES_LOAD(R0, (bi) + 2); X6_EPI_BLOCK(R1, (bi) + 1, false); X6_RES_LOAD(R1, (bi) + 3);
+        X6_RES_LOAD(R0, 0); X6_RES_LOAD(R1, 1);
+        X6_FULL2(0) X6_FULL2(2) X6_FULL2(4) X6_FULL2(6) X6_FULL2(8) X6_FULL2(10) X6_FULL2(12)
+        X6_EPI_BLOCK(R0, 14, false); X6_EPI_BLOCK(R1, 15, false);
+#undef X6_FULL2
+      } else {
+        // edge tile: rows / columns masked at the store (a pending residual load then makes every store block wait: one
+        // accumulator tile at a time, edge tiles only)
+#define X6_EDGE(bi)                                                                                \
+  do {                                                                                             \
+    X6_RES_LOAD(R0, bi);                                                                           \
+    if constexpr (RES != 0) {                                                                      \
+      _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                             \
+        asm volatile("" : "+v"(R0[ps].x), "+v"(R0[ps].y), "+v"(R0[ps].z), "+v"(R0[ps].w));         \
+    }                                                                                              \
+    X6_EPI_BLOCK(R0, bi, true);                                                                    \
+  } while (0);
+        X6_EDGE(0) X6_EDGE(1) X6_EDGE(2) X6_EDGE(3) X6_EDGE(4) X6_EDGE(5) X6_EDGE(6) X6_EDGE(7)
+        X6_EDGE(8) X6_EDGE(9) X6_EDGE(10) X6_EDGE(11) X6_EDGE(12) X6_EDGE(13) X6_EDGE(14) X6_EDGE(15)
+#undef X6_EDGE
+      }
+#undef X6_EPI_BLOCK
+#undef X6_RES_LOAD
+    }
+    // the next item's first block 1 multiplies F1: zero (after the epilogue: the registers are free for the residual until here)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) F1[q][e] = (__bf16)0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no DMA may still be writing this workgroup's LDS at exit
+#undef X6_REP48
+#undef X6_FENCE
+#undef X6_MM_Y
+#undef X6_MM_X
+#undef X6_RD_Y
+#undef X6_RD_X
+#undef X6_FRAG
+#undef X6_DMA_W
+#undef X6_DMA_A
+#undef X6_GLDS_V
+#undef X6_GLDS_S
+#undef X6_ROWS
+#undef X6_ADVANCE
+#undef X6_SET_ITEM
+}

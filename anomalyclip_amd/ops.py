@@ -133,24 +133,41 @@ def split_bf16x3(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
 
 
 def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, act=L.ACT_NONE,
-            residual=None, out_dtype=torch.float32) -> torch.Tensor:
-    """out[M, N] = epilogue(A W^T) with A = sum of the three bf16 planes a3 [3, M, K] and W = sum of w3 [3, N, K]
+            residual=None, out_dtype=torch.float32, amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, M: Optional[int] = None,
+            planes_out: bool = False, split_k: bool = True) -> torch.Tensor:
+    """out[M, N] = epilogue(amap(A) W^T) with A = sum of the three bf16 planes a3 [3, rows, Ka] and W = sum of w3 [3, N, K]
     (split_bf16x3): the six leading cross products on the bf16 matrix cores, f32 accumulation -- the accuracy of an f32
-    product (acx_gemm_desc.pairs = 6).  Large problems only (the persistent 256 x 256 kernel)."""
+    product (acx_gemm_desc.pairs = 6; acx_gemm_x6.h).  amap = AMAP_CONV3X3: implicit 3x3 convolution over the (gn, gl) token
+    grid (K = 9 cin, a3 [3, rows, cin]).  planes_out: the result as three bf16 planes [3, M, N] (the next product's A operand).
+    Few output tiles: K is split across workgroups (split_k, workspace owned by this module)."""
     assert a3.dim() == 3 and w3.dim() == 3 and a3.shape[0] == 3 and w3.shape[0] == 3 and a3.dtype == _BF16 and w3.dtype == _BF16
-    assert a3.is_contiguous() and w3.is_contiguous() and a3.shape[2] == w3.shape[2]
-    _, M, K = a3.shape
-    N = w3.shape[1]
+    assert a3.is_contiguous() and w3.is_contiguous()
+    _, rows, Ka = a3.shape
+    N, K = w3.shape[1], w3.shape[2]
+    if amap == L.AMAP_CONV3X3:
+        assert K == 9 * cin and Ka == cin
+    else:
+        assert Ka == K
+    if M is None:
+        M = rows
     if out is None:
-        out = torch.empty(M, N, dtype=out_dtype, device=a3.device)
+        out = torch.empty((3, M, N) if planes_out else (M, N), dtype=_BF16 if planes_out else out_dtype, device=a3.device)
     d = L.GemmDesc()
     d.A, d.W, d.C = a3.data_ptr(), w3.data_ptr(), out.data_ptr()
     d.M, d.N, d.K = M, N, K
-    d.lda, d.ldw, d.ldc = K, K, out.stride(0)
-    d.a_dtype, d.c_dtype, d.prec = _dt(a3), _dt(out), L.PREC_BF16
+    d.lda, d.ldw, d.ldc = Ka, K, out.stride(-2)
+    d.a_dtype, d.c_dtype, d.prec = _dt(a3), (L.BF16X3 if planes_out else _dt(out)), L.PREC_BF16
     d.bias, d.act = _ptr(bias), act
     d.residual, d.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
-    d.pairs, d.a_plane_stride, d.w_plane_stride = 6, M * K * 2, N * K * 2
+    d.pairs, d.a_plane_stride, d.w_plane_stride = 6, rows * Ka * 2, N * K * 2
+    d.amap, d.gn, d.gl, d.cin = amap, gn, gl, cin
+    if amap == L.AMAP_CONV3X3:
+        d.zero_page = _zero_page(a3.device).data_ptr()
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    ws = None
+    if split_k and tiles < 256 and K >= 384:
+        ws = _splitk_workspace(a3.device, min(16, max(2, 512 // tiles)) * M * N * 4)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a3)
     L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)
     return out

@@ -593,6 +593,62 @@ def test_gemm_bf16x6_is_f32_accurate(M, N, K, act, res):
     e6, e32 = (y6.cpu().double() - ref).abs(), (y32.cpu().double() - ref).abs()
     assert bool((e6 <= bound).all()), float((e6 / bound).max())
     assert float(e6.max()) <= 1.5 * float(e32.max()) + 1e-12
-    with pytest.raises(L.AcxError):                                      # a problem the persistent kernel does not take: refused
-        ops.gemm_x6(a3[:, :64].contiguous(), w3, bias=bd)
+    # a single row tile (the plane-reuse kernel takes any size; K split across workgroups through the module's workspace)
+    ys = ops.gemm_x6(a3[:, :64].contiguous(), w3, bias=bd)
+    es = (ys.cpu().double() - (a[:64].double() @ w.double().t() + b.double())).abs()
+    assert bool((es <= 2e-6 * (a[:64].double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-30).all())
+    with pytest.raises(L.AcxError):                                      # K not a multiple of the 32-wide K-step: refused
+        ops.gemm_x6(a3[:, :, :40].contiguous(), w3[:, :, :40].contiguous(), bias=bd)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(512, 256, 2304, True), (1024, 512, 9216, True), (4096, 1024, 2304, True), (300, 260, 96, False),
+                                         (2048, 1024, 768, False), (70000, 768, 768, False)])
+def test_gemm_x6_split_k_and_planes_output(M, N, K, split):
+    """The plane-reuse kernel (acx_gemm_x6.h): few output tiles -> K split across workgroups + reduce launch, equal to the
+    unsplit launch up to summation order; planes output (ACX_BF16X3) of both routes sums back to the f32 output to <= 1 ulp
+    of its lo plane; ragged edge tiles; more tiles than CUs (persistent stream across tiles)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    a3, w3 = ops.split_bf16x3(a), ops.split_bf16x3(w)
+    y = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=split)
+    y0 = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=False)
+    pre = a.double() @ w.double().t() + b.double()
+    ref = torch.where(pre > 0, pre, 0.01 * pre)
+    bound = 2e-6 * (a.double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+    assert bool(((y.double() - ref).abs() <= bound).all()) and bool(((y0.double() - ref).abs() <= bound).all())
+    yp = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=split, planes_out=True)
+    assert yp.shape == (3, M, N) and torch.equal(yp.float().sum(0), y)            # hi + mid + lo == the f32 result exactly
+    yb = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=split, out_dtype=torch.bfloat16)
+    assert torch.equal(yb, y.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("cin,cout,tiles,act,res", [(64, 256, 1, 2, 0), (256, 1024, 2, 2, 0), (1024, 256, 8, 0, 1), (128, 512, 40, 0, 0),
+                                                     (256, 1024, 64, 2, 0)])
+def test_conv3x3_x6_vs_f32_conv(cin, cout, tiles, act, res):
+    """pairs = 6 with AMAP_CONV3X3 (per-tap source rows, zero page outside the 32 x 16 token grid) against the f32 MFMA
+    convolution and fp64: the head's convolutions at 1 .. 64 tiles (K split across workgroups below 256 output tiles)."""
+    gn, gl = 32, 16
+    rows = tiles * gn * gl
+    g = torch.Generator().manual_seed(cin + cout + tiles)
+    x = (torch.randn(rows, cin, generator=g) * 0.7).to(DEV)
+    w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    r = torch.randn(rows, cout, generator=g).to(DEV) if res else None
+    y32 = ops.gemm(x, w, bias=b, act=act, residual=r, amap=L.AMAP_CONV3X3, gn=gn, gl=gl, cin=cin)
+    y6 = ops.gemm_x6(ops.split_bf16x3(x), ops.split_bf16x3(w), bias=b, act=act, residual=r, amap=L.AMAP_CONV3X3, gn=gn, gl=gl, cin=cin)
+    # fp64 reference by explicit im2col
+    xg = x.double().view(tiles, gn, gl, cin)
+    xp = torch.zeros(tiles, gn + 2, gl + 2, cin, dtype=torch.float64, device=DEV)
+    xp[:, 1:-1, 1:-1] = xg
+    cols = torch.cat([xp[:, kh:kh + gn, kw:kw + gl] for kh in range(3) for kw in range(3)], dim=-1).reshape(rows, 9 * cin)
+    pre = cols @ w.double().t() + b.double()
+    ref = torch.where(pre > 0, pre, 0.01 * pre) if act == 2 else pre
+    if res:
+        ref = ref + r.double()
+    bound = 2e-6 * (cols.abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+    e6, e32 = (y6.double() - ref).abs(), (y32.double() - ref).abs()
+    assert bool((e6 <= bound).all()), float((e6 / bound).max())
+    assert float(e6.max()) <= 1.5 * float(e32.max()) + 1e-12
 
