@@ -72,12 +72,14 @@ class AnomalyCLIP(nn.Module):
         self.select_idx_dropout_topk = g("select_idx_dropout_topk")
         self.select_idx_dropout_bottomk = g("select_idx_dropout_bottomk")
         self.ncrops, self.num_topk, self.num_bottomk = g("ncrops", 1), g("num_topk"), g("num_bottomk")
-        self.precision = g("precision", "f32")          # "f32": exact-f32 MFMA (parity path); "bf16": bf16 MFMA
-        # "f32x6": the parity path with the ViT's large GEMMs as f32-accurate bf16 x 6 products (clip_vit.PRECISIONS); the text
-        # tower and the head have no problem large enough for that kernel and run exactly as in "f32"
-        vit_precision = self.precision
+        # "auto" (default): f32 results; every product large enough for the plane-reuse kernel runs as an f32-accurate bf16 x 6
+        # product on the bf16 matrix cores (clip_vit.PRECISIONS), everything else on the f32 MFMA kernels.  "f32": the f32 MFMA
+        # kernels everywhere.  "bf16": bf16 MFMA (BASELINE configs[4]; not a parity path).  "f32x6" = "auto" (older name).
+        self.precision = g("precision", "auto")
         if self.precision == "f32x6":
-            self.precision = "f32"
+            self.precision = "auto"
+        vit_precision = self.precision
+        head_precision = "f32" if self.precision == "auto" else self.precision      # text tower / selector / temporal head
         geom = g("clip_geometry") or _ARCH[self.arch]
         if isinstance(geom, dict):
             geom = ClipGeometry(**geom)
@@ -118,7 +120,7 @@ class AnomalyCLIP(nn.Module):
         full = int(tokenized.shape[-1])
         self.text_len = min(full, (int(tokenized.argmax(dim=-1).max()) + 1 + 3) // 4 * 4) if bool(g("text_truncate", True)) else full
         self.text_encoder = TextEncoder(geom.context_length, geom.transformer_width, geom.transformer_heads,
-                                        geom.transformer_layers, geom.embed_dim, self.precision)
+                                        geom.transformer_layers, geom.embed_dim, head_precision)
         self.image_encoder = VisionTransformer(geom.image_resolution, geom.vision_patch_size, geom.vision_width,
                                                geom.vision_layers, geom.vision_heads, geom.embed_dim,
                                                precision=vit_precision, chunk=g("vit_chunk", 256))
@@ -129,7 +131,7 @@ class AnomalyCLIP(nn.Module):
         input_size = self.embedding_dim + additional * int(self.concat_features)     # anomaly_clip.py:92-93
         self.temporal_model = TemporalModel(input_size, self.emb_size, 1, self.heads, self.dim_heads, self.depth,
                                             self.num_segments, self.seg_length)
-        self.temporal_model.precision = self.precision
+        self.temporal_model.precision = head_precision
         # evaluation: the prompt parameters are frozen under no_grad, so the per-video text tower of the reference
         # (anomaly_clip.py:136: recomputed for every test video) returns the same tensor every time -- it is computed once and
         # kept, keyed by the optimizer epoch and the version / address of every input of the text path (any edit of those

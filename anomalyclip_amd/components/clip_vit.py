@@ -21,10 +21,12 @@ from torch import nn
 from .. import _lib as L
 from .. import ops
 
-# "f32x6": f32 everywhere, the four large GEMMs of a ViT layer as f32-ACCURATE products on the bf16 matrix cores (three bf16
-# planes per operand, six cross products, f32 accumulation: acx_gemm_desc.pairs) -- lower error than the f32 MFMA kernels at
-# ~0.69 of their time; small problems (the text tower, CLS-only rows) stay on the f32 kernels
-PRECISIONS = {"f32": L.PREC_F32, "bf16": L.PREC_BF16, "f32x6": L.PREC_F32X6}
+# "auto" (the default) = "f32x6": f32 everywhere, the four large GEMMs of a ViT layer as f32-ACCURATE products on the bf16 matrix
+# cores (three bf16 planes per operand, six cross products, f32 accumulation: acx_gemm_desc.pairs, acx_gemm_x6.h) -- lower
+# error against fp64 than the f32 MFMA kernels at ~0.6 of their time (gfx950's f32 MFMA peak is 1/16 of its bf16 peak); problems
+# too small for that kernel (few-frame launches, the text tower, CLS-only rows) run on the f32 MFMA kernels.  "f32": the f32 MFMA
+# kernels everywhere (v_mfma_f32_32x32x2_f32: an fmaf chain).  "bf16": bf16 operands, not a parity path.
+PRECISIONS = {"auto": L.PREC_F32X6, "f32": L.PREC_F32, "bf16": L.PREC_BF16, "f32x6": L.PREC_F32X6}
 
 
 class LayerNorm(nn.Module):
@@ -139,7 +141,7 @@ class VisionTransformer(nn.Module):
     chunks of `chunk` frames (workspace is allocated once per chunk size and reused)."""
 
     def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int,
-                 output_dim: int, precision: str = "f32", chunk: int = 256):
+                 output_dim: int, precision: str = "auto", chunk: int = 256):
         super().__init__()
         self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
         self.width, self.layers, self.heads = width, layers, heads

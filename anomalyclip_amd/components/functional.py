@@ -427,6 +427,7 @@ class TemporalFn(torch.autograd.Function):
                       pos0=P["pos0"], pos1=P["pos1"])
         blks = tm.axial_attn.layers.blocks
         saved = []
+        tap = tm.__dict__.get("_act_tap")            # tests only: a dict that receives the conv hidden activations
 
         def attn(x_in, resid, d, fg, axis):
             pn = getattr(blks[2 * d], fg).net.fn
@@ -443,6 +444,8 @@ class TemporalFn(torch.autograd.Function):
             u = ops.gemm(h, P[f"c1_w{d}{fg}"], bias=f[1].bias.detach(), act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
             out = ops.gemm(u, P[f"c2_w{d}{fg}"], bias=f[3].bias.detach(), residual=resid, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
             saved.append(("ff", d, fg, 0, x_in, h, u, None))
+            if tap is not None:                                  # tests: the hidden activation (its sign = the LeakyReLU side taken)
+                tap[(d, fg)] = u
             return out
 
         x1 = x2 = x0

@@ -174,7 +174,7 @@ class TrainStepGraph:
         self.mod, self.net, self.opt = module, net, optimizer
         self.dev = module.device
         par = _par()
-        if not net.load_from_features or net.ncrops != 1 or net.precision != "f32":
+        if not net.load_from_features or net.ncrops != 1 or net.precision not in ("f32", "auto"):
             raise L.AcxError("the step graph covers training from pre-extracted features, one crop, f32")
         if not (net.prompt_learner.ctx.requires_grad and net.text_encoder.text_projection.requires_grad):
             raise L.AcxError("the step graph expects trainable prompt context and text projection")

@@ -649,7 +649,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
         !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && d->a_plane_stride > 0 && d->w_plane_stride > 0 &&
         !((d->a_plane_stride | d->w_plane_stride) & 15) && (size_t)d->M * d->lda * 2 < ((size_t)1 << 32) &&
         (size_t)d->N * d->ldw * 2 < ((size_t)1 << 32) && !(d->act == ACX_ACT_QUICKGELU && d->residual) &&
-        !(d->act == ACX_ACT_LEAKYRELU && d->residual) && !(c_x3_ && d->residual) && !(c_bf16 && d->residual) &&
+        !(d->act == ACX_ACT_LEAKYRELU && d->residual) && !(c_x3_ && (d->residual || d->N % 8 || d->ldc % 8)) && !(c_bf16 && d->residual) &&
         (!conv || (d->zero_page && !((uintptr_t)d->zero_page & 15) && d->cin % 32 == 0 && !(d->gl & (d->gl - 1)) &&
                    !(d->gn & (d->gn - 1)) && d->M % 256 == 0));
     if (shape_ok) {

@@ -294,14 +294,28 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       const int roww = m0 + wm * 128 + rl;       // + 32 mi + 8 ps
       // bias of the four column blocks: consumed HERE, outside every store -- a load still pending when stores are issued
       // makes hipcc's counted waits cover the stores as well (one in-order vmcnt)
-      float4 bia[4];
+      // (plane outputs, C_MODE 2: lane l owns EIGHT consecutive columns (l & 3) of row (l >> 2) + 16 pass -- 16-byte bf16 stores,
+      // 6 instead of 12 store instructions per tile: the store path takes ~64 cycles per wave-instruction whatever its width)
+      const int colp = n0 + wn * 128 + 8 * (lane & 3);   // + 32 ni
+      const int rowp = m0 + wm * 128 + (lane >> 2);      // + 32 mi + 16 pass
+      float4 bia[4], bib[4];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        bia[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias && !raw) bia[ni] = *reinterpret_cast<const float4*>(d.bias + min(colw + 32 * ni, d.N - 4));
+        bia[ni] = bib[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias && !raw) {
+          if constexpr (C_MODE == 2) {
+            bia[ni] = *reinterpret_cast<const float4*>(d.bias + min(colp + 32 * ni, d.N - 8));
+            bib[ni] = *reinterpret_cast<const float4*>(d.bias + min(colp + 32 * ni, d.N - 8) + 4);
+          } else {
+            bia[ni] = *reinterpret_cast<const float4*>(d.bias + min(colw + 32 * ni, d.N - 4));
+          }
+        }
       }
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(bia[ni].x), "+v"(bia[ni].y), "+v"(bia[ni].z), "+v"(bia[ni].w));
+      for (int ni = 0; ni < 4; ++ni) {
+        asm volatile("" : "+v"(bia[ni].x), "+v"(bia[ni].y), "+v"(bia[ni].z), "+v"(bia[ni].w));
+        if constexpr (C_MODE == 2) asm volatile("" : "+v"(bib[ni].x), "+v"(bib[ni].y), "+v"(bib[ni].z), "+v"(bib[ni].w));
+      }
       // residual of accumulator tile bi = 4 ni + mi into R (rows / columns clamped: an edge tile masks at the store)
 #define X6_RES_LOAD(R, bi)                                                                         \
   do {                                                                                             \
@@ -320,6 +334,42 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     _Pragma("unroll") for (int k = 0; k < 4; ++k)   /* accumulator (C^T layout): row li, columns 8k + 4hh .. +3 = chunk 2k + hh */ \
       *reinterpret_cast<float4*>(scr + li * 128 + (((2 * k + hh) ^ (li & 7)) * 16)) =             \
           make_float4(acc[mi][ni][4 * k], acc[mi][ni][4 * k + 1], acc[mi][ni][4 * k + 2], acc[mi][ni][4 * k + 3]); \
+    if constexpr (C_MODE == 2) {                                                                   \
+      _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                           \
+        const int rr_ = (lane >> 2) + 16 * ps;                                                     \
+        const float4 va_ = *reinterpret_cast<const float4*>(scr + rr_ * 128 + (((2 * (lane & 3)) ^ (rr_ & 7)) * 16));     \
+        const float4 vb_ = *reinterpret_cast<const float4*>(scr + rr_ * 128 + (((2 * (lane & 3) + 1) ^ (rr_ & 7)) * 16)); \
+        float ov[8] = {va_.x + bia[ni].x, va_.y + bia[ni].y, va_.z + bia[ni].z, va_.w + bia[ni].w,                          \
+                       vb_.x + bib[ni].x, vb_.y + bib[ni].y, vb_.z + bib[ni].z, vb_.w + bib[ni].w};                          \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                            \
+          if constexpr (ACT == ACX_ACT_QUICKGELU) ov[e] = acx_quickgelu(ov[e]);                    \
+          else if constexpr (ACT == ACX_ACT_LEAKYRELU) ov[e] = ov[e] > 0.f ? ov[e] : 0.01f * ov[e]; \
+        }                                                                                          \
+        /* three bf16 planes hi | mid | lo of the f32 value (ACX_BF16X3): the next pairs = 6 product's A operand */ \
+        uint4 ph, pm, pl;                                                                          \
+        float r1[8], r2[8];                                                                        \
+        ph.x = f2bf2(ov[0], ov[1]); ph.y = f2bf2(ov[2], ov[3]); ph.z = f2bf2(ov[4], ov[5]); ph.w = f2bf2(ov[6], ov[7]); \
+        const unsigned hw_[4] = {ph.x, ph.y, ph.z, ph.w};                                          \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+          r1[2 * e] = ov[2 * e] - __uint_as_float(hw_[e] << 16); r1[2 * e + 1] = ov[2 * e + 1] - __uint_as_float(hw_[e] & 0xffff0000u); \
+        }                                                                                          \
+        pm.x = f2bf2(r1[0], r1[1]); pm.y = f2bf2(r1[2], r1[3]); pm.z = f2bf2(r1[4], r1[5]); pm.w = f2bf2(r1[6], r1[7]); \
+        const unsigned mw_[4] = {pm.x, pm.y, pm.z, pm.w};                                          \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+          r2[2 * e] = r1[2 * e] - __uint_as_float(mw_[e] << 16); r2[2 * e + 1] = r1[2 * e + 1] - __uint_as_float(mw_[e] & 0xffff0000u); \
+        }                                                                                          \
+        pl.x = f2bf2(r2[0], r2[1]); pl.y = f2bf2(r2[2], r2[3]); pl.z = f2bf2(r2[4], r2[5]); pl.w = f2bf2(r2[6], r2[7]); \
+        const int row = rowp + mi * 32 + 16 * ps, colq = colp + 32 * ni;                           \
+        if ((!(PRED) || (colq < d.N && row < d.M)) && (!(ACX_X6_ABL & 4) || g.ksplit == 12345)) {  \
+          typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));                         \
+          const size_t pe = (size_t)d.M * d.ldc;                                                   \
+          u16* dst = (u16*)d.C + (size_t)row * d.ldc + colq;                                       \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&ph), reinterpret_cast<u32x4_*>(dst)); \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pm), reinterpret_cast<u32x4_*>(dst + pe)); \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pl), reinterpret_cast<u32x4_*>(dst + 2 * pe)); \
+        }                                                                                          \
+      }                                                                                            \
+    } else                                                                                         \
     _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                             \
       const int rr_ = rl + 8 * ps;                                                                 \
       float4 v = *reinterpret_cast<const float4*>(scr + rr_ * 128 + ((cj ^ (rr_ & 7)) * 16));     \
@@ -334,24 +384,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       if constexpr (RES != 0) { v.x += R[ps].x; v.y += R[ps].y; v.z += R[ps].z; v.w += R[ps].w; }  \
       const int row = roww + mi * 32 + 8 * ps;                                                     \
       if ((!(PRED) || (col < d.N && row < d.M)) && (!(ACX_X6_ABL & 4) || g.ksplit == 12345)) {     \
-        if constexpr (C_MODE == 2) {                                                               \
-          /* three bf16 planes hi | mid | lo of the f32 value (ACX_BF16X3): the next pairs = 6 product's A operand */ \
-          const float ov[4] = {v.x, v.y, v.z, v.w};                                                \
-          float r1[4], r2[4];                                                                      \
-          uint2 ph, pm, pl;                                                                        \
-          ph.x = f2bf2(ov[0], ov[1]); ph.y = f2bf2(ov[2], ov[3]);                                  \
-          r1[0] = ov[0] - __uint_as_float(ph.x << 16); r1[1] = ov[1] - __uint_as_float(ph.x & 0xffff0000u); \
-          r1[2] = ov[2] - __uint_as_float(ph.y << 16); r1[3] = ov[3] - __uint_as_float(ph.y & 0xffff0000u); \
-          pm.x = f2bf2(r1[0], r1[1]); pm.y = f2bf2(r1[2], r1[3]);                                  \
-          r2[0] = r1[0] - __uint_as_float(pm.x << 16); r2[1] = r1[1] - __uint_as_float(pm.x & 0xffff0000u); \
-          r2[2] = r1[2] - __uint_as_float(pm.y << 16); r2[3] = r1[3] - __uint_as_float(pm.y & 0xffff0000u); \
-          pl.x = f2bf2(r2[0], r2[1]); pl.y = f2bf2(r2[2], r2[3]);                                  \
-          const size_t pe = (size_t)d.M * d.ldc;                                                   \
-          u16* dst = (u16*)d.C + (size_t)row * d.ldc + col;                                        \
-          __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&ph), reinterpret_cast<u32x2*>(dst)); \
-          __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pm), reinterpret_cast<u32x2*>(dst + pe)); \
-          __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pl), reinterpret_cast<u32x2*>(dst + 2 * pe)); \
-        } else if constexpr (C_MODE == 1) {                                                        \
+        if constexpr (C_MODE == 1) {                                                        \
           uint2 pk;                                                                                \
           pk.x = f2bf2(v.x, v.y);                                                                  \
           pk.y = f2bf2(v.z, v.w);                                                                  \

@@ -560,6 +560,9 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     h[k] = f2bf(x[k]);
+    // |x| above bf16's largest finite value (3.3895e38) rounds to bf16 infinity although x is finite: truncate instead (the
+    // remainder then has <= 16 significant bits: mid + lo still hold it exactly)
+    if ((h[k] & 0x7fffu) == 0x7f80u && (__float_as_uint(x[k]) & 0x7fffffffu) < 0x7f800000u) h[k] = (u16)(__float_as_uint(x[k]) >> 16);
     const float r1 = x[k] - bf2f(h[k]);
     m[k] = f2bf(r1);
     const float r2 = r1 - bf2f(m[k]);

@@ -231,13 +231,29 @@ def axial_self_attention(x, sd: SD, p: str, heads: int, e: int, axis: int):
     return o @ sd[p + "fn.to_out.weight"].t() + sd[p + "fn.to_out.bias"]
 
 
+LEAKY_SIDE = None     # optional {conv_ff prefix p: bool tensor (T, 4D, N, L)}: see conv_ff
+LEAKY_REPORT = {}
+
+
 def conv_ff(x, sd: SD, p: str):
     """get_ff(): ChanLayerNorm -> Conv2d(D,4D,3,pad1) -> LeakyReLU(0.01) -> Conv2d(4D,D,3,pad1),
     evaluated on channels-last x (T,N,L,D) (conv done channels-first through F.conv2d)."""
     h = chan_layer_norm_last(x, sd[p + "0.g"], sd[p + "0.b"])
     h = h.permute(0, 3, 1, 2)
     h = F.conv2d(h, sd[p + "1.weight"], sd[p + "1.bias"], padding=1)
-    h = F.leaky_relu(h, 0.01)
+    side = None if LEAKY_SIDE is None else LEAKY_SIDE.get(p)
+    if side is None:
+        h = F.leaky_relu(h, 0.01)
+    else:
+        # gradient checks against a LOWER-precision path (tests/test_gpu_train.py): LeakyReLU has a kink at 0, and a
+        # pre-activation within round-off of 0 lands on either side depending on the arithmetic -- a discrete change of that
+        # element's derivative (1 <-> 0.01).  With LEAKY_SIDE[p] (bool, the other path's choice per element) the activation is
+        # evaluated on THAT side; LEAKY_REPORT[p] records how many elements disagreed with this path's own sign and how far
+        # from 0 the farthest of them was (relative to max |pre-activation|): the caller asserts "round-off of 0".
+        own = h.detach() > 0
+        dis = own != side
+        LEAKY_REPORT[p] = (int(dis.sum()), float((h.detach().abs() * dis).max() / h.detach().abs().max()), dis.numel())
+        h = torch.where(side, h, 0.01 * h)
     h = F.conv2d(h, sd[p + "3.weight"], sd[p + "3.bias"], padding=1)
     return h.permute(0, 2, 3, 1)
 

@@ -601,7 +601,53 @@ def test_gemm_bf16x6_is_f32_accurate(M, N, K, act, res):
         ops.gemm_x6(a3[:, :, :40].contiguous(), w3[:, :, :40].contiguous(), bias=bd)
 
 
-@pytest.mark.parametrize("M,N,K,split", [(512, 256, 2304, True), (1024, 512, 9216, True), (4096, 1024, 2304, True), (300, 260, 96, False),
+def test_split_bf16x3_edge_values():
+    """acx_split_bf16x3 at the edges of f32: the split is EXACT (hi + mid + lo == x bit for bit) for every finite x whose lo
+    plane stays a normal bf16 number; below that (|x| < 2^-110: the third plane falls under 2^-126) the reconstruction error is
+    bounded by bf16's smallest normal, 2^-126, in absolute terms -- f32's own denormal range; values above bf16's largest finite
+    number (3.3895e38 .. FLT_MAX) stay finite (hi truncated instead of rounded to infinity); signed zeros keep their sign
+    in the hi plane; +-inf and NaN stay non-finite in the hi plane (the products then propagate non-finite values exactly
+    where the f32 kernels do: checked through a GEMM row)."""
+    tiny = float(2.0 ** -126)
+    vals = [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, float(np.float32(3.4028235e38)), -float(np.float32(3.4028235e38)), 3.39e38, 1.17549435e-38, -1.17549435e-38,
+            2.0 ** -100, -(2.0 ** -100) * 1.2345678, 2.0 ** -111 * 1.7654321, -(2.0 ** -120) * 1.3333333, 2.0 ** -127, 2.0 ** -140 * 1.5,
+            1.401298464e-45, -1.401298464e-45, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 65504.0, 1e-30, -7.7e-20]
+    g = torch.Generator().manual_seed(0)
+    rnd = (torch.randn(4096, generator=g) * torch.exp2(torch.randint(-126, 121, (4096,), generator=g).float())).tolist()
+    x = torch.tensor(vals + rnd + [0.0] * (64 - (len(vals) + len(rnd)) % 64), dtype=torch.float32).view(-1, 64)
+    p = ops.split_bf16x3(x.to(DEV)).cpu()
+    rec = p[0].double() + p[1].double() + p[2].double()
+    xd = x.double()
+    big = xd.abs() >= 2.0 ** -100
+    assert torch.equal(rec[big].float(), x[big]) and bool((rec[big] == xd[big]).all())          # exact
+    assert float((rec - xd).abs().max()) <= tiny                                                 # denormal range: absolute bound
+    assert torch.equal(torch.signbit(p[0].float().view(-1)[:2]), torch.tensor([False, True]))    # +0 / -0
+    # non-finite values: inf / NaN in A rows 1 and 2, finite row 0 -- outputs are non-finite exactly where the f32 kernel's are
+    M, N, K = 256, 256, 256
+    a = torch.randn(M, K, generator=g)
+    a[1, 7] = float("inf"); a[2, 9] = float("nan"); a[3, 11] = float("-inf")
+    w = torch.randn(N, K, generator=g) * 0.1
+    ad, wd = a.to(DEV), w.to(DEV)
+    a3 = ops.split_bf16x3(ad)
+    assert not torch.isfinite(a3[0, 1, 7].float()) and not torch.isfinite(a3[0, 2, 9].float()) and not torch.isfinite(a3[0, 3, 11].float())
+    y6 = ops.gemm_x6(a3, ops.split_bf16x3(wd), split_k=False)
+    y32 = ops.gemm(ad, wd)
+    assert torch.equal(torch.isfinite(y6), torch.isfinite(y32))
+    assert bool(torch.isfinite(y6[0]).all()) and bool(torch.isfinite(y6[4:]).all()) and not bool(torch.isfinite(y6[1:4]).any())
+    # a product that overflows f32: both paths give +-inf there, equal signs
+    a2 = torch.full((M, K), 3.0e19); w2 = torch.full((N, K), 3.0e19); w2[5] = -3.0e19
+    z6 = ops.gemm_x6(ops.split_bf16x3(a2.to(DEV)), ops.split_bf16x3(w2.to(DEV)), split_k=False)
+    z32 = ops.gemm(a2.to(DEV), w2.to(DEV))
+    assert torch.equal(z6, z32) and bool(torch.isinf(z6).all())
+    # products of tiny operands against fp64 (absolute bound from the planes' 2^-126 floor)
+    a4 = (torch.randn(M, K, generator=g) * 2.0 ** -70)
+    w4 = (torch.randn(N, K, generator=g) * 2.0 ** -50)
+    y4 = ops.gemm_x6(ops.split_bf16x3(a4.to(DEV)), ops.split_bf16x3(w4.to(DEV)), split_k=False).cpu().double()
+    ref4 = a4.double() @ w4.double().t()
+    assert float((y4 - ref4).abs().max()) <= 2e-6 * float((a4.double().abs() @ w4.double().abs().t()).max()) + 1e-45
+
+
+@pytest.mark.parametrize("M,N,K,split", [(512, 256, 2304, True), (1024, 512, 9216, True), (4096, 1024, 2304, True), (300, 260, 96, False), (300, 264, 96, False),
                                          (2048, 1024, 768, False), (70000, 768, 768, False)])
 def test_gemm_x6_split_k_and_planes_output(M, N, K, split):
     """The plane-reuse kernel (acx_gemm_x6.h): few output tiles -> K split across workgroups + reduce launch, equal to the
@@ -618,8 +664,9 @@ def test_gemm_x6_split_k_and_planes_output(M, N, K, split):
     ref = torch.where(pre > 0, pre, 0.01 * pre)
     bound = 2e-6 * (a.double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
     assert bool(((y.double() - ref).abs() <= bound).all()) and bool(((y0.double() - ref).abs() <= bound).all())
-    yp = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=split, planes_out=True)
-    assert yp.shape == (3, M, N) and torch.equal(yp.float().sum(0), y)            # hi + mid + lo == the f32 result exactly
+    if N % 8 == 0:                                # plane outputs go out as 16-byte pieces of eight bf16 columns
+        yp = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=split, planes_out=True)
+        assert yp.shape == (3, M, N) and torch.equal(yp.float().sum(0), y)        # hi + mid + lo == the f32 result exactly
     yb = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=split, out_dtype=torch.bfloat16)
     assert torch.equal(yb, y.to(torch.bfloat16))
 

@@ -98,7 +98,7 @@ def test_vit_b16_golden(golden):
     assert relerr(out5[:2], out) < 2e-6             # 3-frame vs 2-frame launch: summation order only
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16", "f32x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "auto"])
 def test_vit_b16_full_clip_properties(golden, precision):
     """BASELINE.json's full size (512 frames in ONE launch: 8-wave kernels, the 64x64-tile tail launch, CLS-only last
     layer, 256x256 ring kernels in bf16 mode) through size-independent properties: identical frames give bit-identical
@@ -115,7 +115,7 @@ def test_vit_b16_full_clip_properties(golden, precision):
     assert out.shape == (512, 512) and torch.isfinite(out).all()
     for k in range(8):
         rows = out[idx == k]
-        if precision in ("f32", "f32x6"):
+        if precision in ("f32", "auto"):
             assert torch.equal(rows, rows[:1].expand_as(rows)), k              # bit-identical across ALL slots
         else:
             # bf16 mode: the tail round of tiles runs through another kernel (other f32 summation order), and a
@@ -127,7 +127,7 @@ def test_vit_b16_full_clip_properties(golden, precision):
     small = vit(base.to(DEV))                                                  # 2-frame launch (other kernels)
     assert relerr(out[:2], small) < (3e-2 if precision == "bf16" else 2e-6)
     if precision != "bf16":
-        # "f32x6" (the large GEMMs as f32-accurate bf16 x 6 products; the 2-frame launch above ran the f32 kernels: too few rows
+        # "auto" (the default: the large GEMMs as f32-accurate bf16 x 6 products; the 2-frame launch above ran the f32 kernels: too few rows
         # for the persistent kernel) meets the SAME bounds against the reference's output as the f32 MFMA path
         assert relerr(out[:2], g["out"]) < TOL and elem_ok(out[:2], g["out"])
 

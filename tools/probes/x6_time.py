@@ -25,6 +25,10 @@ if which in ("vit", "all"):
         t6 = _event_time(lambda: ops.gemm_x6(a3, w3, **kw), 8)
         fl = 2.0 * M * N * K
         print(f"{name:5s} x6 {t6 * 1e3:7.3f} ms {fl / t6 / 1e12:6.1f} TF-equiv ({6 * fl / t6 / 1e12:6.0f} bf16 TF)", flush=True)
+        if name == "fc":
+            op = torch.empty(3, M, N, dtype=torch.bfloat16, device=dev)
+            t6 = _event_time(lambda: ops.gemm_x6(a3, w3, bias=bias, act=L.ACT_QUICKGELU, out=op, planes_out=True), 8)
+            print(f"fc->planes x6 {t6 * 1e3:7.3f} ms {fl / t6 / 1e12:6.1f} TF-equiv ({6 * fl / t6 / 1e12:6.0f} bf16 TF)", flush=True)
 if which in ("conv", "all"):
     for tiles in (8, 64):
         rows = tiles * 512
