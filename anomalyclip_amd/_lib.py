@@ -129,6 +129,7 @@ _SIGS = {
     "acx_layernorm_bwd": (C.c_int, [c_void_p] * 6 + [c_int64, c_int32, c_float, c_int32, c_float, c_void_p, c_void_p]),
     "acx_cls_head_bwd": (C.c_int, [c_void_p] * 10 + [c_int64, c_int32, c_void_p]),
     "acx_act": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "acx_leaky_grad_planes": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "acx_add": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_transpose": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "acx_conv_weight_dx": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
@@ -168,6 +169,9 @@ _SIGS = {
                                         C.POINTER(c_int32), c_void_p]),
     "acx_gemm_tn_zp": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                  c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "acx_gemm_tn_x6_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "acx_gemm_tn_x6": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                 c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "acx_ctx_grad": (C.c_int, [c_void_p] * 3 + [c_int32] * 5 + [c_void_p]),
     "acx_scatter_rows": (C.c_int, [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
     "acx_preprocess_frames": (C.c_int, [c_void_p] * 6 + [c_int32, c_void_p, c_void_p, c_int32] + [c_int32] * 5 +

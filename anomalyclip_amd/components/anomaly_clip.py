@@ -79,7 +79,7 @@ class AnomalyCLIP(nn.Module):
         if self.precision == "f32x6":
             self.precision = "auto"
         vit_precision = self.precision
-        head_precision = "f32" if self.precision == "auto" else self.precision      # text tower / selector / temporal head
+        head_precision = "f32" if self.precision == "auto" else self.precision      # text tower (too small for the bf16 x 6 kernel)
         geom = g("clip_geometry") or _ARCH[self.arch]
         if isinstance(geom, dict):
             geom = ClipGeometry(**geom)
@@ -131,7 +131,7 @@ class AnomalyCLIP(nn.Module):
         input_size = self.embedding_dim + additional * int(self.concat_features)     # anomaly_clip.py:92-93
         self.temporal_model = TemporalModel(input_size, self.emb_size, 1, self.heads, self.dim_heads, self.depth,
                                             self.num_segments, self.seg_length)
-        self.temporal_model.precision = head_precision
+        self.temporal_model.precision = self.precision        # "auto": the feed-forward convolutions as bf16 x 6 products
         # evaluation: the prompt parameters are frozen under no_grad, so the per-video text tower of the reference
         # (anomaly_clip.py:136: recomputed for every test video) returns the same tensor every time -- it is computed once and
         # kept, keyed by the optimizer epoch and the version / address of every input of the text path (any edit of those

@@ -438,8 +438,20 @@ class TemporalFn(torch.autograd.Function):
             saved.append(("attn", d, fg, axis, x_in, h, qkv, o))
             return out
 
+        x6 = f"c1_w0f_3" in P                          # the convolutions as bf16 x 6 products (TemporalModel.x6_convs)
+
         def ff(x_in, resid, d, fg):
             f = getattr(blks[2 * d + 1], fg).net
+            if x6:                                       # activations as three bf16 planes: [3, rows, C]
+                h = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN, planes_out=True)
+                u = ops.gemm_x6(h, P[f"c1_w{d}{fg}_3"], bias=f[1].bias.detach(), act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg,
+                                cin=E, planes_out=True)
+                out = ops.gemm_x6(u, P[f"c2_w{d}{fg}_3"], bias=f[3].bias.detach(), residual=resid, amap=L.AMAP_CONV3X3, gn=N, gl=Lg,
+                                  cin=4 * E)
+                saved.append(("ff", d, fg, 0, x_in, h, u, None))
+                if tap is not None:
+                    tap[(d, fg)] = u[0]                  # the hi plane carries the sign
+                return out
             h = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN)
             u = ops.gemm(h, P[f"c1_w{d}{fg}"], bias=f[1].bias.detach(), act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
             out = ops.gemm(u, P[f"c2_w{d}{fg}"], bias=f[3].bias.detach(), residual=resid, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
@@ -536,14 +548,25 @@ class TemporalFn(torch.autograd.Function):
             f = getattr(blks[2 * d + 1], fg).net
             w2_dst, w1_dst = dest(f[3].weight, (E, 36 * E)), dest(f[1].weight, (4 * E, 9 * E))
             cs_jobs.append((d_out, lambda g, b=f[3].bias: grads.__setitem__(b, g)))
-            gw2 = ops.gemm_tn(d_out, u, conv=True, gn=N, gl=Lg, cin=4 * E, out=w2_dst)        # [E, 9*4E]  ([Cout][tap][Cin])
-            put(f[3].weight, gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2), w2_dst)
-            d_u = ops.gemm(d_out, P[f"c2_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
-            d_pre = ops.act(u, d_u, 0)                                                 # LeakyReLU'
-            cs_jobs.append((d_pre, lambda g, b=f[1].bias: grads.__setitem__(b, g)))
-            gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E, out=w1_dst)            # [4E, 9E]
-            put(f[1].weight, gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2), w1_dst)
-            d_h = ops.gemm(d_pre, P[f"c1_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
+            if u.dim() == 3:                             # bf16 x 6 path: h, u are planes; dY goes to planes for its two products
+                d_out3 = ops.split_bf16x3(d_out)
+                gw2 = ops.gemm_tn_x6(d_out3, u, conv=True, gn=N, gl=Lg, cin=4 * E, out=w2_dst)
+                put(f[3].weight, gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2), w2_dst)
+                d_u = ops.gemm_x6(d_out3, P[f"c2_dx{d}{fg}_3"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
+                d_pre, d_pre3 = ops.leaky_grad_planes(u, d_u)                          # LeakyReLU': f32 (bias gradient) + planes
+                cs_jobs.append((d_pre, lambda g, b=f[1].bias: grads.__setitem__(b, g)))
+                gw1 = ops.gemm_tn_x6(d_pre3, h, conv=True, gn=N, gl=Lg, cin=E, out=w1_dst)
+                put(f[1].weight, gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2), w1_dst)
+                d_h = ops.gemm_x6(d_pre3, P[f"c1_dx{d}{fg}_3"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
+            else:
+                gw2 = ops.gemm_tn(d_out, u, conv=True, gn=N, gl=Lg, cin=4 * E, out=w2_dst)        # [E, 9*4E]  ([Cout][tap][Cin])
+                put(f[3].weight, gw2.view(E, 3, 3, 4 * E).permute(0, 3, 1, 2), w2_dst)
+                d_u = ops.gemm(d_out, P[f"c2_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E)
+                d_pre = ops.act(u, d_u, 0)                                                 # LeakyReLU'
+                cs_jobs.append((d_pre, lambda g, b=f[1].bias: grads.__setitem__(b, g)))
+                gw1 = ops.gemm_tn(d_pre, h, conv=True, gn=N, gl=Lg, cin=E, out=w1_dst)            # [4E, 9E]
+                put(f[1].weight, gw1.view(4 * E, 3, 3, E).permute(0, 3, 1, 2), w1_dst)
+                d_h = ops.gemm(d_pre, P[f"c1_dx{d}{fg}"], amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
             d_in, lpart = ops.layernorm_bwd_parts(x_in, P[f"g{d}{fg}"], d_h, mode=L.NORM_CHAN, add=add)
 
             def ln_params(sred, f=f):

@@ -124,9 +124,18 @@ class TemporalModel(nn.Module):
         # "f32": exact-f32 MFMA (parity path).  "bf16" (inference only, BASELINE configs[4]): every GEMM / implicit-GEMM
         # convolution runs on the bf16 MFMA with f32 accumulation -- bf16 weights, bf16 LayerNorm outputs and conv
         # hidden activations; the residual streams, attention, norms and the classifier stay f32.
+        # "auto": f32 results; the convolutions of the feed-forward blocks (93 % of the head's flops) and their input / weight
+        # gradients run as f32-ACCURATE bf16 x 6 products on the bf16 matrix cores (three bf16 planes per operand, acx_gemm_x6.h)
+        # when the geometry allows (x6_convs), everything else on the f32 MFMA kernels.
         self.precision = "f32"
         self.graph = False                 # training: replay forward / backward as HIP graphs (functional._TemporalGraphs)
         self._prep = None
+
+    def x6_convs(self) -> bool:
+        """the feed-forward convolutions as bf16 x 6 products: precision "auto", a power-of-two token grid, and channel counts
+        the weight-gradient kernel's 256-wide tiles divide (E % 256 == 0: the UCF-Crime / ShanghaiTech heads)"""
+        N, Lg = self.num_segments, self.seg_length
+        return (self.precision == "auto" and self.emb_size % 256 == 0 and N & (N - 1) == 0 and Lg & (Lg - 1) == 0)
 
     # ---- derived weight layouts for the kernels
     def _derived(self, train: bool):
@@ -134,7 +143,7 @@ class TemporalModel(nn.Module):
         once per (device, parameter addresses); views of the master parameters where no re-layout is needed."""
         # ONE SLOT PER `train` FLAG: captured graphs (step_graph.TrainStepGraph, functional._TemporalGraphs) hold raw pointers
         # into the train = True buffers; an evaluation call that builds the train = False layouts must never release them
-        key = (bool(train),) + tuple(p.data_ptr() for p in self.parameters())
+        key = (bool(train), self.precision) + tuple(p.data_ptr() for p in self.parameters())
         slots = self.__dict__.setdefault("_drv", {})
         cur = slots.get(bool(train))
         if cur is not None and cur[0] == key:
@@ -195,6 +204,12 @@ class TemporalModel(nn.Module):
                         for t in range(9):
                             segs.append((kw.data_ptr() + 4 * t * Cin, o.data_ptr() + 4 * (8 - t) * Cout, Cout, Cin, 9 * Cin,
                                          9 * Cout, 1))
+        # bf16 x 6 convolutions: three bf16 planes of every conv operand (split after the layouts above are current)
+        P["_x6"] = []
+        if self.x6_convs():
+            for k in [k for k in P if isinstance(k, str) and k.startswith(("c1_w", "c2_w", "c1_dx", "c2_dx"))]:
+                P[k + "_3"] = torch.empty((3,) + tuple(P[k].shape), dtype=torch.bfloat16, device=dev)
+                P["_x6"].append((P[k], P[k + "_3"]))
         slots[bool(train)] = (key, P, segs)
         return P, segs
 
@@ -203,6 +218,8 @@ class TemporalModel(nn.Module):
         (capturable -- the step graphs replay it after each optimizer update)."""
         P, segs = self._derived(train)
         ops.prep_multi(segs, device=self.projection.weight.device)
+        for src, dst in P["_x6"]:
+            ops.split_bf16x3(src, out=dst)
         self._prep = (self._prep_key(train), P)
         return P
 
@@ -245,6 +262,11 @@ class TemporalModel(nn.Module):
         ff = getattr(self.axial_attn.layers.blocks[2 * d + 1], fg).net
         bf = self.precision == "bf16"
         prec, adt = (L.PREC_BF16, torch.bfloat16) if bf else (L.PREC_F32, torch.float32)
+        if f"c1_w{d}{fg}_3" in P:          # bf16 x 6: ChanLayerNorm and the first convolution write their results as planes
+            h3 = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN, planes_out=True)
+            u3 = ops.gemm_x6(h3, P[f"c1_w{d}{fg}_3"], bias=ff[1].bias, act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E,
+                             planes_out=True)
+            return ops.gemm_x6(u3, P[f"c2_w{d}{fg}_3"], bias=ff[3].bias, residual=resid, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=4 * E)
         h = ops.layernorm(x_in, P[f"g{d}{fg}"], P[f"b{d}{fg}"], mode=L.NORM_CHAN, out_dtype=adt)
         u = ops.gemm(h, P[f"c1_w{d}{fg}"], bias=ff[1].bias, act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=N, gl=Lg, cin=E,
                      prec=prec, out_dtype=adt)
@@ -264,8 +286,8 @@ class TemporalModel(nn.Module):
                 # no_grad (validation_step / test_step), so a differentiable test-mode pass is not part of the path.
                 raise RuntimeError("TemporalModel(test_mode=True) must run under torch.no_grad(): the differentiable "
                                    "path implements the training tiling only (temporal_model.py:55-60)")
-            if self.precision != "f32":
-                raise RuntimeError("the bf16 head is an inference path; training runs on the exact-f32 kernels")
+            if self.precision not in ("f32", "auto"):
+                raise RuntimeError("the bf16 head is an inference path; training runs on the f32 / f32-accurate kernels")
             return Fn.temporal_train(self, features, a_sub)
         P = self.prepared()
         N, Lg, E = self.num_segments, self.seg_length, self.emb_size

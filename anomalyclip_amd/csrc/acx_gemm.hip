@@ -485,6 +485,22 @@ bool acx_gemm_takes_strip_stream(const acx_gemm_desc* d) {
   return tiles >= 1024 && (size_t)d->M * d->lda < ((size_t)1 << 31) && (size_t)d->N * d->ldw < ((size_t)1 << 31);
 }
 
+// K split of the plane-reuse kernel: `tiles` output tiles of `nks` K-steps on ncu persistent workgroups.  Cost of s pieces =
+// rounds(tiles s) x ceil(nks / s) K-steps (+ a term for the s partial images the reduce launch reads); every non-empty split
+// is allowed (the last K range of a tile takes what is left).  A pure function of the shape: fixed summation order.
+static int x6_choose_split(int tiles, int nks, int ncu, size_t image_bytes, size_t workspace_bytes, int min_steps) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s2 = 1; s2 <= 64; ++s2) {
+    const int spi = (nks + s2 - 1) / s2;
+    if (s2 > 1 && (spi < min_steps || spi * (s2 - 1) >= nks || (size_t)s2 * image_bytes > workspace_bytes)) continue;
+    const int rounds = (tiles * s2 + ncu - 1) / ncu;
+    const double cost = (double)rounds * (spi + 4.0) * 3.0 + (s2 > 1 ? (s2 + 1.0) * (double)image_bytes / 4.0e6 + 4.0 : 0.0);   // us
+    if (cost < best_cost * 0.995) { best_cost = cost; best = s2; }
+  }
+  return best;
+}
+
 extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->C) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: null pointer%s");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: empty shape%s");
@@ -657,11 +673,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       const int xt = ((d->M + 255) / 256) * ((d->N + 255) / 256);
       const int nks = d->K / 32;
       int split = 1;
-      if (d->workspace && xt < ncu) {            // largest divisor of the K-step count that keeps >= 6 K-steps per piece and <= 2 items per CU
-        for (int s2 = 2; s2 <= 64; ++s2)
-          if (nks % s2 == 0 && nks / s2 >= 6 && xt * s2 <= 2 * ncu && (size_t)s2 * d->M * d->N * sizeof(float) <= d->workspace_bytes) split = s2;
-      }
-      g.ksplit = split; g.kchunk = nks / split; g.partial = split > 1 ? (float*)d->workspace : nullptr;
+      if (d->workspace && xt < ncu) split = x6_choose_split(xt, nks, ncu, (size_t)d->M * d->N * sizeof(float), d->workspace_bytes, 6);
+      g.ksplit = split; g.kchunk = (nks + split - 1) / split; g.partial = split > 1 ? (float*)d->workspace : nullptr;
       const int items = xt * split;
       const dim3 xgrid((unsigned)(items < ncu ? items : ncu));
 #define ACX_X6L(CM, ACT, RES, CV)                                                                   \
@@ -1061,6 +1074,63 @@ extern "C" int acx_gemm_tn_group(acx_ctx* ctx, int32_t nprob, const acx_tn_probl
     if (nr > 0) hipLaunchKernelGGL(tn_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, R);
   }
   ACX_CHECK_LAUNCH(ctx, "acx_gemm_tn_group");
+  return ACX_OK;
+}
+
+// ---- weight gradient as an f32-accurate product of bf16 planes: C[N1, N2] = sum_m A[m, n1] B[m, n2], A and B as three bf16 planes
+// each (acx_split_bf16x3 of dY and of the layer input), the TN instantiation of the plane-reuse kernel (acx_gemm_x6.h)
+static int tn_x6_splits(int64_t M, int64_t N1, int64_t N2, int ncu, size_t workspace_bytes) {
+  return x6_choose_split((int)((N1 / 256) * (N2 / 256)), (int)((M + 31) / 32), ncu, (size_t)N1 * N2 * sizeof(float), workspace_bytes, 8);
+}
+extern "C" size_t acx_gemm_tn_x6_workspace_bytes(int32_t M, int32_t N1, int32_t N2) {
+  const int tiles = (N1 / 256) * (N2 / 256);
+  if (tiles <= 0) return 0;
+  int s = 512 / tiles;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (size_t)s * N1 * N2 * sizeof(float);
+}
+extern "C" int acx_gemm_tn_x6(acx_ctx* ctx, const void* A3, int64_t a_plane_stride, int32_t lda, const void* B3, int64_t b_plane_stride,
+                              int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N1, int32_t N2, int32_t conv, int32_t gn, int32_t gl,
+                              int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream) {
+  if (!A3 || !B3 || !C || !zero_page) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_x6: null pointer (the zero page is required)%s");
+  if (M <= 0 || N1 <= 0 || N2 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_x6: empty shape%s");
+  if (N1 % 256 || N2 % 256 || lda % 8 || ldb % 8 || ldc != N2 || ((a_plane_stride | b_plane_stride) & 15) ||
+      (((uintptr_t)A3 | (uintptr_t)B3 | (uintptr_t)C | (uintptr_t)zero_page) & 15))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: N1 / N2 multiples of 256, lda / ldb of 8, dense C, 16-byte aligned planes%s");
+  if (conv && (cin <= 0 || cin % 256 || N2 != 9 * cin || gn <= 0 || gl <= 0 || (gl & (gl - 1)) || (gn & (gn - 1)) || M % (gn * gl)))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: conv needs cin %% 256 == 0, N2 == 9 cin, a power-of-two grid, whole tiles%s");
+  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  const int split = workspace ? tn_x6_splits(M, N1, N2, ncu, workspace_bytes) : 1;
+  Args g;
+  memset(&g, 0, sizeof(g));
+  g.d.A = A3; g.d.W = B3; g.d.C = C;
+  g.d.M = N1; g.d.N = N2; g.d.K = M; g.d.lda = lda; g.d.ldw = ldb; g.d.ldc = ldc;
+  g.d.a_dtype = ACX_BF16; g.d.c_dtype = ACX_F32; g.d.prec = ACX_PREC_BF16; g.d.pairs = 6;
+  g.d.a_plane_stride = a_plane_stride; g.d.w_plane_stride = b_plane_stride;
+  g.d.amap = conv ? ACX_AMAP_CONV3X3 : ACX_AMAP_IDENTITY; g.d.gn = gn; g.d.gl = gl; g.d.cin = cin;
+  g.ksplit = split; g.kchunk = ((int)((M + 31) / 32) + split - 1) / split; g.partial = split > 1 ? (float*)workspace : nullptr;
+  g.zeros = (const float*)zero_page;
+  const int items = (N1 / 256) * (N2 / 256) * split;
+  const dim3 xgrid((unsigned)(items < ncu ? items : ncu));
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_GEMM_TN, s);
+  if (ctx && ctx->prof_on) { ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2; ctx->prof_tn_flops += 2.0 * M * (double)N1 * N2; }
+  const int dev_slot = (ctx ? ctx->device : 0) & 63;
+  if (conv) {
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<0, 0, 0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B); attr_done = true; }
+    hipLaunchKernelGGL((gemm_x6_p4_kernel<0, 0, 0, 1, 1>), xgrid, dim3(256), (size_t)X6_LDS_B, s, g);
+  } else {
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<0, 0, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B); attr_done = true; }
+    hipLaunchKernelGGL((gemm_x6_p4_kernel<0, 0, 0, 0, 1>), xgrid, dim3(256), (size_t)X6_LDS_B, s, g);
+  }
+  if (split > 1) {
+    const int64_t n4 = (int64_t)N1 * N2 / 4;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, n4, split);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_gemm_tn_x6");
   return ACX_OK;
 }
 

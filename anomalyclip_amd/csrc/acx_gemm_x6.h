@@ -41,9 +41,30 @@ struct X6Src {                                   // one K-step of the stream (wa
   int m0, n0;                                    // origin of its output tile
   int kk;                                        // K-step (32 k) inside the operand rows
   int tk, j;                                     // step inside the item, item ordinal of this workgroup
+  int steps;                                     // K-steps of the item (the last K range of a tile may be shorter)
+  int dn, dl, c0;                                // TN: tap shift of the tile's B rows (conv) and its first input channel
 };
 
-template <int C_MODE, int ACT, int RES, int CONV>
+typedef short x6_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) x6_s16x4 x6_lds_s16x4;
+// TN fragment: the LDS image is [32 k][256 channels] (k-major), the MFMA wants 8 consecutive k of ONE channel per lane:
+// two hardware transpose reads (ds_read_b64_tr_b16: every 16 lanes read a [4 k][16 channel] block, lane c of the 16 gets
+// its channel's 4 k values) -- k = 8 hh .. + 3 and + 4 .. + 7.  tools/probes/tr16_probe.hip checks this address map.
+__device__ __forceinline__ bf16x8 x6_tr_frag(const char* smem, int off_lo, int off_hi) {
+  const x6_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x6_lds_s16x4*)(smem + off_lo));
+  const x6_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x6_lds_s16x4*)(smem + off_hi));
+  typedef short s16x8_ __attribute__((ext_vector_type(8)));
+  const s16x8_ v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// TN != 0: C[n1, n2] = sum_m A[m, n1] B[m, n2] (a weight gradient: the reduction runs over ROWS).  d.M / d.N = channel counts
+// N1 / N2 (output rows / columns, multiples of 256), d.K = rows, d.lda / d.ldw = row strides of the A / B planes; CONV: B's row
+// for reduction index m is the token row shifted by the tap of the tile's column block (d.cin % 256 == 0: a 256-column tile
+// lies inside one tap), zero page outside the grid and behind the last row.  A unit is then 32 rows x 256 channels (k-major,
+// 512 B per row, its eight 64-byte chunks XOR-swizzled by row & 7); the product structure, the slots and the waits are those
+// of the NT kernel.  Output: raw f32 (ksplit > 1: partial tiles for tn_reduce_kernel).
+template <int C_MODE, int ACT, int RES, int CONV, int TN = 0>
 __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -59,27 +80,36 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   const int b0 = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + ((int)blockIdx.x >> 3);
   const int my_items = b0 < nitems ? (nitems - b0 + G - 1) / G : 0;
   if (my_items == 0) return;
-  const int spi = (d.K / 32) / ksplit;           // K-steps per item (dispatch: divisible)
+  const int nks = (d.K + 31) / 32;               // K-steps of a tile (TN: the last one may be ragged: zero page)
+  const int spi = (nks + ksplit - 1) / ksplit;   // K-steps per item; the last K range of a tile takes what is left (dispatch: > 0)
 
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
   // ---- DMA: a unit is 16 wave-instructions of 1 KB (16 rows x 64 B); wave w issues instructions 4 w .. 4 w + 3.
   // lane -> row (lane >> 2) of the instruction's 16, LDS chunk position lane & 3 = global chunk ^ ((row >> 2) & 3)
   const int dr = 64 * wave + (lane >> 2);                        // + 16 i: this lane's unit row of instruction i
   const int dc = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;          // byte offset of its 16-byte piece inside the row's 64 B
-  const char* zsrc = CONV ? (const char*)g.zeros + (lane & 3) * 16 : nullptr;
+  const char* zsrc = (CONV || TN) ? (const char*)g.zeros + (lane & 3) * 16 : nullptr;
   const int sh_gl = CONV ? __builtin_ctz((unsigned)d.gl) : 0;
-  const int steps_per_tap = CONV ? d.cin / 32 : 1;
+  const int steps_per_tap = (CONV && !TN) ? d.cin / 32 : 1;
+  // TN: byte offset of this lane's 16-byte piece of instruction i inside the row's 512-byte tile slice (source-side swizzle)
+#define X6_TCH(i) ((((((lane & 31) >> 2) ^ ((2 * (i) + (lane >> 5)) & 7)) << 2) | (lane & 3)) * 16)
 #define X6_SET_ITEM(S, jj)                                                                         \
   do {                                                                                             \
     const int L_ = b0 + min((jj), my_items - 1) * G;   /* past the end: re-read the last item (never consumed) */ \
     const int tile_ = L_ / ksplit, ks_ = L_ - tile_ * ksplit;                                      \
     const int tm_ = tile_ / tiles_n, tn_ = tile_ - tm_ * tiles_n;                                  \
-    S.m0 = tm_ * 256; S.n0 = tn_ * 256; S.kk = ks_ * spi;                                          \
+    S.m0 = tm_ * 256; S.n0 = tn_ * 256; S.kk = ks_ * spi; S.steps = min(spi, nks - ks_ * spi);     \
+    S.dn = S.dl = 0; S.c0 = S.n0;                                                                  \
+    if constexpr (TN != 0 && CONV != 0) {                                                          \
+      const int tap_ = S.n0 / d.cin, t3_ = tap_ / 3;                                               \
+      S.c0 = S.n0 - tap_ * d.cin; S.dn = t3_ - 1; S.dl = tap_ - 3 * t3_ - 1;                       \
+    }                                                                                              \
   } while (0)
   // per-lane byte offsets of this lane's four A rows / W rows of item S (the same for every plane and K-step), and -- CONV --
   // the taps that stay inside the token grid for each of the A rows (bit tap of VM[i])
 #define X6_ROWS(S, RA, RW, VM)                                                                     \
   do {                                                                                             \
+    if constexpr (TN == 0)                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
       const int m_ = S.m0 + dr + 16 * i;                                                           \
       RA[i] = (unsigned)(CONV ? m_ : min(m_, d.M - 1)) * ((ACX_X6_ABL & 16) ? 64u : (unsigned)d.lda * 2u) + (unsigned)dc; \
@@ -95,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 #define X6_ADVANCE(S, RA, RW, VM)                                                                  \
   do {                                                                                             \
     ++S.kk;                                                                                        \
-    if (++S.tk == spi) { S.tk = 0; ++S.j; X6_SET_ITEM(S, S.j); X6_ROWS(S, RA, RW, VM); }           \
+    if (++S.tk == S.steps) { S.tk = 0; ++S.j; X6_SET_ITEM(S, S.j); X6_ROWS(S, RA, RW, VM); }       \
   } while (0)
   // One LDS-DMA instruction: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS [m0 ..+1 KB).  M0 is not
   // restored: nothing else in this kernel reads it (ds_read / ds_write do not use M0 on gfx9+).
@@ -116,7 +146,11 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   do {                                                                                             \
     const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (4 * wave + (i)) * 1024;                       \
     const char* b_ = (const char*)d.A + (size_t)(pl) * (size_t)d.a_plane_stride;                   \
-    if constexpr (CONV != 0) {                                                                     \
+    if constexpr (TN != 0) {                                                                       \
+      const int m_ = S.kk * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
+      const char* p_ = b_ + ((size_t)(unsigned)m_ * (size_t)(d.lda * 2) + (size_t)(S.m0 * 2 + X6_TCH(i))); \
+      X6_GLDS_V(m_ < d.K ? p_ : zsrc, l_);                                                         \
+    } else if constexpr (CONV != 0) {                                                              \
       const int tap_ = S.kk / steps_per_tap, kc_ = S.kk - tap_ * steps_per_tap;                    \
       const int t3_ = tap_ / 3;                                                                    \
       const int dn_ = t3_ - 1, dl_ = tap_ - 3 * t3_ - 1;                                           \
@@ -130,8 +164,22 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 #define X6_DMA_W(S, RW, pl, slot, i)                                                               \
   do {                                                                                             \
     const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (4 * wave + (i)) * 1024;                       \
-    const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride + (size_t)S.kk * ((ACX_X6_ABL & 16) ? (size_t)d.N * 64 : (size_t)64); \
-    X6_GLDS_S(b_, RW[i], l_);                                                                      \
+    if constexpr (TN != 0) {                                                                       \
+      const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride;                 \
+      const int m_ = S.kk * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
+      bool ok_ = m_ < d.K;                                                                         \
+      int row_ = m_;                                                                               \
+      if constexpr (CONV != 0) {                                                                   \
+        const int n_ = (m_ >> sh_gl) & (d.gn - 1), l_c = m_ & (d.gl - 1);                          \
+        ok_ = ok_ && (unsigned)(n_ + S.dn) < (unsigned)d.gn && (unsigned)(l_c + S.dl) < (unsigned)d.gl; \
+        row_ = m_ + S.dn * d.gl + S.dl;                                                            \
+      }                                                                                            \
+      const char* p_ = b_ + ((size_t)(unsigned)(ok_ ? row_ : 0) * (size_t)(d.ldw * 2) + (size_t)(S.c0 * 2 + X6_TCH(i))); \
+      X6_GLDS_V(ok_ ? p_ : zsrc, l_);                                                              \
+    } else {                                                                                       \
+      const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride + (size_t)S.kk * ((ACX_X6_ABL & 16) ? (size_t)d.N * 64 : (size_t)64); \
+      X6_GLDS_S(b_, RW[i], l_);                                                                    \
+    }                                                                                              \
   } while (0)
 
   X6Src c0, c1;                                  // K-steps gs and gs + 1 of the stream
@@ -156,6 +204,18 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   const int fa0 = (wm * 128 + li) * 64 + ((0 + hh) ^ sw) * 16, fa1 = (wm * 128 + li) * 64 + ((2 + hh) ^ sw) * 16;
   const int fw0 = (wn * 128 + li) * 64 + ((0 + hh) ^ sw) * 16, fw1 = (wn * 128 + li) * 64 + ((2 + hh) ^ sw) * 16;
 
+  // TN: transpose-read addresses of row block / column block blk, k half r (see x6_tr_frag); + 8192 for substep 1
+  int trA[4][2], trW[4][2];
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i16 = lane & 15, x_ = 4 * r + (i16 >> 2);
+      const int base_ = (8 * hh + x_) * 512 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+      trA[blk][r] = TN ? base_ + (((wm * 4 + blk) ^ x_) * 64) : 0;
+      trW[blk][r] = TN ? base_ + (((wn * 4 + blk) ^ x_) * 64) : 0;
+    }
+
   f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -173,19 +233,24 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 
 #define X6_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (((ACX_X6_ABL & 8) && g.ksplit != 12345) ? 0 : (off))))
   // fragment q (0..15) of substep s of an X / Y half-step; wpar = byte offset of this K-step's W.hi / W.mid slots
+#define X6_LOADF(dst, slotoff, TRX, fx0, fx1, blk, s)                                              \
+  do {                                                                                             \
+    if constexpr (TN != 0) dst = x6_tr_frag(smem, (slotoff) + (s) * 8192 + TRX[blk][0], (slotoff) + (s) * 8192 + TRX[blk][1]); \
+    else dst = X6_FRAG((slotoff) + ((s) ? fx1 : fx0) + (blk) * 2048);                              \
+  } while (0)
 #define X6_RD_X(F, s, q)                                                                           \
   do {                                                                                             \
-    if ((q) < 4) F[q] = X6_FRAG(X6_AH * X6_UNIT_B + ((s) ? fa1 : fa0) + (q) * 2048);               \
-    else if ((q) < 8) F[q] = X6_FRAG(wpar + X6_WH0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 4) * 2048); \
-    else if ((q) < 12) F[q] = X6_FRAG(wpar + X6_WM0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 8) * 2048); \
-    else F[q] = X6_FRAG(X6_WL * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 12) * 2048);                \
+    if ((q) < 4) X6_LOADF(F[q], X6_AH * X6_UNIT_B, trA, fa0, fa1, (q) & 3, s);                     \
+    else if ((q) < 8) X6_LOADF(F[q], wpar + X6_WH0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);        \
+    else if ((q) < 12) X6_LOADF(F[q], wpar + X6_WM0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);       \
+    else X6_LOADF(F[q], X6_WL * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);                             \
   } while (0)
 #define X6_RD_Y(F, s, q)                                                                           \
   do {                                                                                             \
-    if ((q) < 4) F[q] = X6_FRAG(X6_AM * X6_UNIT_B + ((s) ? fa1 : fa0) + (q) * 2048);               \
-    else if ((q) < 8) F[q] = X6_FRAG(wpar + X6_WH0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 4) * 2048); \
-    else if ((q) < 12) F[q] = X6_FRAG(wpar + X6_WM0 * X6_UNIT_B + ((s) ? fw1 : fw0) + ((q) - 8) * 2048); \
-    else F[q] = X6_FRAG(X6_AL * X6_UNIT_B + ((s) ? fa1 : fa0) + ((q) - 12) * 2048);                \
+    if ((q) < 4) X6_LOADF(F[q], X6_AM * X6_UNIT_B, trA, fa0, fa1, (q) & 3, s);                     \
+    else if ((q) < 8) X6_LOADF(F[q], wpar + X6_WH0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);        \
+    else if ((q) < 12) X6_LOADF(F[q], wpar + X6_WM0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);       \
+    else X6_LOADF(F[q], X6_AL * X6_UNIT_B, trA, fa0, fa1, (q) & 3, s);                             \
   } while (0)
   // MFMA q (0..47) of a fragment set: product q / 16, row block (q % 16) / 4, column block q % 4.  Operands swapped: the
   // accumulator holds C^T (lane = output row, registers = 4-column groups), as in the p8 kernel.
@@ -205,7 +270,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 
   int wpar = 0;                                  // 0 / 6 units: the W.hi / W.mid slots of the current K-step
   for (int j = 0; j < my_items; ++j) {
-    for (int tk = 0; tk < spi; ++tk) {
+    const int steps_j = c0.steps;                // (c0 is at the item's first K-step here)
+    for (int tk = 0; tk < steps_j; ++tk) {
       const int wnext = wpar ? 0 : 6 * X6_UNIT_B;
       const int slot_wh_next = wpar ? X6_WH0 : X6_WH1, slot_wm_next = wpar ? X6_WM0 : X6_WM1;
       // =========================================================================== half-step X
@@ -440,6 +506,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 #undef X6_MM_X
 #undef X6_RD_Y
 #undef X6_RD_X
+#undef X6_LOADF
+#undef X6_TCH
 #undef X6_FRAG
 #undef X6_DMA_W
 #undef X6_DMA_A

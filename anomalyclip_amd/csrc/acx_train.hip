@@ -227,6 +227,37 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ save
   reinterpret_cast<float4*>(out)[i] = make_float4(gv[0], gv[1], gv[2], gv[3]);
 }
 
+// LeakyReLU backward with the saved activation as the HI bf16 plane of its three-plane form (sign(hi) = sign(u)); the result
+// goes out as f32 (bias-gradient column sums) AND as three bf16 planes (the operand of the next bf16 x 6 products)
+__global__ __launch_bounds__(256) void leaky_grad_planes_kernel(const u16* __restrict__ u_hi, const float* __restrict__ d,
+                                                                float* __restrict__ out, u16* __restrict__ planes, int64_t plane,
+                                                                int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const uint2 uh = reinterpret_cast<const uint2*>(u_hi)[i];
+  const float4 g = reinterpret_cast<const float4*>(d)[i];
+  const float sv[4] = {__uint_as_float(uh.x << 16), __uint_as_float(uh.x & 0xffff0000u), __uint_as_float(uh.y << 16),
+                       __uint_as_float(uh.y & 0xffff0000u)};
+  float gv[4] = {g.x, g.y, g.z, g.w};
+  u16 h[4], m[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    gv[k] *= sv[k] > 0.f ? 1.f : 0.01f;
+    h[k] = f2bf(gv[k]);
+    const float r1 = gv[k] - bf2f(h[k]);
+    m[k] = f2bf(r1);
+    l[k] = f2bf(r1 - bf2f(m[k]));
+  }
+  reinterpret_cast<float4*>(out)[i] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+  uint2 pk;
+  pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+  reinterpret_cast<uint2*>(planes)[i] = pk;
+  pk.x = (uint32_t)m[0] | ((uint32_t)m[1] << 16); pk.y = (uint32_t)m[2] | ((uint32_t)m[3] << 16);
+  reinterpret_cast<uint2*>(planes + plane)[i] = pk;
+  pk.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16); pk.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+  reinterpret_cast<uint2*>(planes + 2 * plane)[i] = pk;
+}
+
 // out = a + b
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ out, int64_t n4) {
@@ -1604,6 +1635,18 @@ extern "C" int acx_act(acx_ctx* ctx, const float* saved, const float* d, float* 
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   hipLaunchKernelGGL(act_kernel, GRID1(n / 4), dim3(256), 0, (hipStream_t)stream, saved, d, out, n / 4, mode);
   ACX_CHECK_LAUNCH(ctx, "acx_act");
+  return ACX_OK;
+}
+
+extern "C" int acx_leaky_grad_planes(acx_ctx* ctx, const void* u_hi, const float* d, float* out, void* planes, int64_t plane_elems,
+                                     int64_t n, void* stream) {
+  if (!u_hi || !d || !out || !planes) return acx_fail(ctx, ACX_E_BADARG, "acx_leaky_grad_planes: null pointer%s");
+  if (n <= 0) return ACX_OK;
+  if (n % 4 || plane_elems % 4 || plane_elems < n) return acx_fail(ctx, ACX_E_BADARG, "acx_leaky_grad_planes: n %% 4, plane_elems >= n%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(leaky_grad_planes_kernel, GRID1(n / 4), dim3(256), 0, (hipStream_t)stream, (const u16*)u_hi, d, out, (u16*)planes,
+                     plane_elems, n / 4);
+  ACX_CHECK_LAUNCH(ctx, "acx_leaky_grad_planes");
   return ACX_OK;
 }
 

@@ -239,15 +239,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *, eps=1e-5, mode=L.NORM_LAYER,
-              out_dtype=torch.float32, rows: Optional[int] = None, ldx: Optional[int] = None) -> torch.Tensor:
+              out_dtype=torch.float32, rows: Optional[int] = None, ldx: Optional[int] = None, planes_out: bool = False) -> torch.Tensor:
+    """planes_out: the result as three bf16 planes [3, rows, D] (hi | mid | lo of the f32 value: a bf16 x 6 product's operand)"""
     D = w.numel()
     if rows is None:
         rows = x.numel() // D
         ldx = D
-    y = torch.empty(rows, D, dtype=out_dtype, device=x.device)
+    y = torch.empty((3, rows, D) if planes_out else (rows, D), dtype=_BF16 if planes_out else out_dtype, device=x.device)
     h = _h(x)
-    L.check(L.lib().acx_layernorm(h, x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), y.data_ptr(), D, _dt(y), rows, D,
-                                  eps, mode, _stream()), h)
+    L.check(L.lib().acx_layernorm(h, x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), y.data_ptr(), D, L.BF16X3 if planes_out else _dt(y),
+                                  rows, D, eps, mode, _stream()), h)
     return y
 
 
@@ -445,6 +446,27 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, b_sub=None, conv=False, gn=0, g
     return out
 
 
+def gemm_tn_x6(a3: torch.Tensor, b3: torch.Tensor, *, conv=False, gn=0, gl=0, cin=0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C[N1, N2] = sum_m A[m, n1] * bmap(B)[m, n2] with A = sum of the planes a3 [3, M, N1], B = sum of b3 [3, M, cin or N2]
+    (split_bf16x3): the weight gradient as an f32-accurate product on the bf16 matrix cores (acx_gemm_tn_x6).  N1, N2
+    multiples of 256 (conv: cin % 256 == 0)."""
+    assert a3.dim() == 3 and b3.dim() == 3 and a3.shape[0] == 3 and b3.shape[0] == 3 and a3.dtype == _BF16 and b3.dtype == _BF16
+    assert a3.is_contiguous() and b3.is_contiguous() and a3.shape[1] == b3.shape[1]
+    _, M, N1 = a3.shape
+    N2 = 9 * cin if conv else b3.shape[2]
+    if out is None:
+        out = torch.empty(N1, N2, dtype=torch.float32, device=a3.device)
+    else:
+        assert out.shape == (N1, N2) and out.is_contiguous() and out.dtype == torch.float32
+    lib = L.lib()
+    ws = _splitk_workspace(a3.device, int(lib.acx_gemm_tn_x6_workspace_bytes(M, N1, N2)))
+    h = _h(a3)
+    L.check(lib.acx_gemm_tn_x6(h, a3.data_ptr(), M * N1 * 2, N1, b3.data_ptr(), M * b3.shape[2] * 2, b3.shape[2], out.data_ptr(), N2,
+                               M, N1, N2, int(conv), gn, gl, cin, ws.data_ptr(), ws.numel(), _zero_page(a3.device).data_ptr(),
+                               _stream()), h)
+    return out
+
+
 def gemm_tn_group(problems):
     """problems: list of (a [M, N1], b [M, N2], out or None, b_sub or None) -> list of C_k = a_k^T (b_k - b_sub_k); ONE launch
     (+ one reduce) for all of them, bit-identical to separate gemm_tn calls (acx_gemm_tn_group)."""
@@ -585,6 +607,17 @@ def act(saved: torch.Tensor, d: Optional[torch.Tensor], mode: int) -> torch.Tens
     h = _h(saved)
     L.check(L.lib().acx_act(h, saved.data_ptr(), _ptr(d), out.data_ptr(), saved.numel(), mode, _stream()), h)
     return out
+
+
+def leaky_grad_planes(u3: torch.Tensor, d: torch.Tensor):
+    """LeakyReLU backward from the three-plane activation u3 [3, rows, C] (only its hi plane is read): returns
+    (d_pre [rows, C] f32, d_pre3 [3, rows, C] bf16 planes)."""
+    assert u3.dim() == 3 and u3.shape[0] == 3 and u3.dtype == _BF16 and u3.is_contiguous() and d.is_contiguous() and d.shape == u3.shape[1:]
+    out = torch.empty_like(d)
+    planes = torch.empty_like(u3)
+    h = _h(d)
+    L.check(L.lib().acx_leaky_grad_planes(h, u3.data_ptr(), d.data_ptr(), out.data_ptr(), planes.data_ptr(), d.numel(), d.numel(), _stream()), h)
+    return out, planes
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -341,6 +341,17 @@ int acx_gemm_tn_group(acx_ctx* ctx, int32_t nprob, const acx_tn_problem* probs, 
 int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                 int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
                 int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream);
+/* The same weight gradient as an f32-ACCURATE product on the bf16 matrix cores: A (dY, [M, lda]) and B (the layer input,
+ * [M, ldb]) as three bf16 planes each (acx_split_bf16x3: plane p at base + p * plane_stride bytes), the six leading cross
+ * products with f32 accumulation -- the TN instantiation of the plane-reuse kernel (acx_gemm_desc.pairs = 6).  N1, N2 multiples
+ * of 256; conv: cin % 256 == 0, N2 == 9 cin, power-of-two grid, M % (gn gl) == 0.  zero_page: >= 256 bytes of zeros, 16-byte
+ * aligned (rows behind M and taps outside the grid are DMA'd from it).  workspace: acx_gemm_tn_x6_workspace_bytes (the rows are
+ * split across workgroups; fixed summation order for a given shape).  Replaces the weight-gradient products of
+ * temporal_model.py:32-39's convolutions under autograd (loss.backward() in src/models/anomaly_clip_module.py:173-293). */
+size_t acx_gemm_tn_x6_workspace_bytes(int32_t M, int32_t N1, int32_t N2);
+int acx_gemm_tn_x6(acx_ctx* ctx, const void* A3, int64_t a_plane_stride, int32_t lda, const void* B3, int64_t b_plane_stride,
+                   int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N1, int32_t N2, int32_t conv, int32_t gn, int32_t gl,
+                   int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream);
 int acx_reduce_rows(acx_ctx* ctx, const float* part, float* out, int32_t nparts, int32_t width, void* stream);
 /* LayerNorm / ChanLayerNorm backward.  dx (may be NULL) = [add +] dx_scale * dL/dx (add [rows, D] may be NULL: the
  * residual branch of a pre-norm block, clip/model.py:214-216, folded into the same pass); part (may be NULL)
@@ -355,6 +366,11 @@ int acx_cls_head_bwd(acx_ctx* ctx, const float* x1, const float* x2, const float
 /* elementwise: mode 0 LeakyReLU' from saved output, 1 QuickGELU' from saved pre-activation (out = d * f'),
  * 2 QuickGELU forward (d ignored). */
 int acx_act(acx_ctx* ctx, const float* saved, const float* d, float* out, int64_t n, int32_t mode, void* stream);
+/* LeakyReLU(0.01) backward for the bf16 x 6 path of the temporal model's feed-forward (temporal_model.py:32-39 under autograd):
+ * u_hi = the hi bf16 plane of the saved activation (its sign is the activation's), d [n] the upstream gradient; out [n] f32 and
+ * planes (three bf16 planes, plane p at (uint16_t*)planes + p * plane_elems) both receive d * (u > 0 ? 1 : 0.01). */
+int acx_leaky_grad_planes(acx_ctx* ctx, const void* u_hi, const float* d, float* out, void* planes, int64_t plane_elems, int64_t n,
+                          void* stream);
 int acx_add(acx_ctx* ctx, const float* a, const float* b, float* out, int64_t n, void* stream);
 int acx_transpose(acx_ctx* ctx, const float* in, float* out, int32_t R, int32_t Cn, void* stream);
 /* conv weight [Cout,Cin,3,3] -> [Cin][tap'][Cout] with flipped taps: the W operand of the dX implicit GEMM */

@@ -70,6 +70,43 @@ def test_conv_grads_256_tiles(cin, cout, tiles):
     assert R.elem_excess(got, wt.grad, rtol=1e-4, afrac=2e-6) <= 1
 
 
+@pytest.mark.parametrize("M,N1,N2", [(4096, 256, 512), (2048 + 32, 512, 256), (1000, 256, 256), (32768, 256, 768)])
+def test_gemm_tn_x6_plain(M, N1, N2):
+    """acx_gemm_tn_x6 (the TN instantiation of the plane-reuse kernel: LDS transpose reads, rows split across workgroups,
+    ragged last K-step from the zero page) against fp64 and the f32 MFMA weight-gradient kernel."""
+    g = torch.Generator().manual_seed(M + N1)
+    a = (torch.randn(M, N1, generator=g) * torch.exp2(torch.randint(-3, 3, (M, 1), generator=g).float())).to(DEV)
+    b = torch.randn(M, N2, generator=g).to(DEV)
+    y6 = ops.gemm_tn_x6(ops.split_bf16x3(a), ops.split_bf16x3(b))
+    y32 = ops.gemm_tn(a, b)
+    ref = a.double().t() @ b.double()
+    bound = 2e-6 * (a.double().abs().t() @ b.double().abs()) + 1e-30
+    e6, e32 = (y6.double() - ref).abs(), (y32.double() - ref).abs()
+    assert bool((e6 <= bound).all()), float((e6 / bound).max())
+    assert float(e6.max()) <= 1.5 * float(e32.max()) + 1e-12
+
+
+@pytest.mark.parametrize("cin,cout,tiles", [(256, 1024, 8), (1024, 256, 16), (256, 256, 1), (256, 1024, 64)])
+def test_conv_weight_grad_x6(cin, cout, tiles):
+    """the 3x3 convolution's weight gradient [cout, 9 cin] from planes (per-tap shifted rows of the layer input, zero page
+    outside the 32 x 16 token grid) against fp64 by explicit im2col and against the f32 kernel."""
+    gn, gl = 32, 16
+    rows = tiles * gn * gl
+    g = torch.Generator().manual_seed(cin + cout + tiles)
+    dy = (torch.randn(rows, cout, generator=g) * 0.3).to(DEV)
+    x = torch.randn(rows, cin, generator=g).to(DEV)
+    y6 = ops.gemm_tn_x6(ops.split_bf16x3(dy), ops.split_bf16x3(x), conv=True, gn=gn, gl=gl, cin=cin)
+    y32 = ops.gemm_tn(dy, x, conv=True, gn=gn, gl=gl, cin=cin)
+    xp = torch.zeros(tiles, gn + 2, gl + 2, cin, dtype=torch.float64, device=DEV)
+    xp[:, 1:-1, 1:-1] = x.double().view(tiles, gn, gl, cin)
+    cols = torch.cat([xp[:, kh:kh + gn, kw:kw + gl] for kh in range(3) for kw in range(3)], dim=-1).reshape(rows, 9 * cin)
+    ref = dy.double().t() @ cols
+    bound = 2e-6 * (dy.double().abs().t() @ cols.abs()) + 1e-30
+    e6, e32 = (y6.double() - ref).abs(), (y32.double() - ref).abs()
+    assert bool((e6 <= bound).all()), float((e6 / bound).max())
+    assert float(e6.max()) <= 1.5 * float(e32.max()) + 1e-12
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 256), (256, 64)])
 def test_conv_grads(cin, cout):
     """dW (TN implicit GEMM) and dX (NT implicit GEMM with flipped weights) of the 3x3 conv vs autograd."""
@@ -566,14 +603,18 @@ def test_ncentroid_from_frames_tiny(prompts_table):
     assert nc.shape == (IW.TINY.embed_dim,) and relerr(nc, ref) < 1e-5 and R.elem_excess(nc, ref) <= 1
 
 
-@pytest.mark.parametrize("cfg,B", [("ucf", 4), ("sht", 4), ("ucf", 64), ("sht", 16)])
-def test_full_config_train_step_vs_oracle(prompts_table, cfg, B):
-    """UCF (E=256, depth 1) and ShanghaiTech (concat on, depth 2) head configs: loss and every trainable gradient
-    against the oracle's autograd on the same seeded inputs.  B = 4 runs the single-video-sized GEMMs (split-K convs,
+@pytest.mark.parametrize("cfg,B,precision", [("ucf", 4, "auto"), ("sht", 4, "auto"), ("ucf", 64, "auto"), ("sht", 16, "auto"),
+                                              ("ucf", 4, "f32"), ("ucf", 64, "f32")])
+def test_full_config_train_step_vs_oracle(prompts_table, cfg, B, precision):
+    """UCF (E=256, depth 1) and ShanghaiTech (concat on, depth 2) head configs, in both f32-result modes: loss and every trainable
+    gradient against the oracle's autograd on the same seeded inputs.  B = 4 runs the single-video-sized GEMMs (split-K convs,
     64x64 tiles); B = 64 is BASELINE.json configs[1] itself (32 768 features per step: the 8-wave conv / GEMM kernels
     and the cost-model split counts of the weight-gradient GEMMs that the features/s numbers are measured on)."""
     hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD}[cfg]
-    net, sd, eot = build_net("ViT-B/16", hc, cfg, 11, prompts_table)
+    net, sd, eot = build_net("ViT-B/16", hc, cfg, 11, prompts_table, precision=precision)
+    # "auto" (the default): the feed-forward convolutions and their input / weight gradients as bf16 x 6 products; "f32": the
+    # f32 MFMA kernels everywhere -- the same bounds for both
+    assert net.temporal_model.x6_convs() == (precision == "auto")
     g = torch.Generator().manual_seed(5)
     abn = [c for c in range(hc.num_classes) if c != hc.normal_id]
     labels = torch.tensor(([1, hc.num_classes - 1] + abn * 3)[:B // 2] + [hc.normal_id] * (B // 2))

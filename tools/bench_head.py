@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--text-graph", action="store_true", help="text tower as two replayed HIP graphs on a side stream")
     ap.add_argument("--temporal-graph", action="store_true", help="temporal model forward / backward as two replayed HIP graphs")
     ap.add_argument("--no-step-graph", action="store_true", help="autograd path instead of train_batch's whole-step graph")
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32"], help="auto: the convolutions as bf16 x 6 products (default)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local_rank)
@@ -118,7 +119,7 @@ def main():
     from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
     from anomalyclip_amd.components.loss import ComputeLoss
 
-    net, sd, eot, hc = B.build_net("f32", dev)
+    net, sd, eot, hc = B.build_net(args.precision, dev)
     net.load_from_features = True
     net.text_class_parallel = not args.no_text_shard
     net.text_graph = bool(args.text_graph)

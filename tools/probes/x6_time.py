@@ -40,4 +40,14 @@ if which in ("conv", "all"):
             t32 = _event_time(lambda: ops.gemm(x, w, bias=b, amap=L.AMAP_CONV3X3, gn=32, gl=16, cin=cin), 8)
             t6 = _event_time(lambda: ops.gemm_x6(x3, w3, bias=b, amap=L.AMAP_CONV3X3, gn=32, gl=16, cin=cin), 8)
             fl = 2.0 * rows * cout * 9 * cin
+            xi = torch.randn(3, rows, 9 * cin, generator=g, device=dev).to(torch.bfloat16)
+            ti = _event_time(lambda: ops.gemm_x6(xi, w3, bias=b), 8)
+            print(f"{name} rows {rows:6d}: identity-map product of the same shape: x6 {ti * 1e6:7.1f} us {fl / ti / 1e12:6.1f} TF-equiv", flush=True)
+            del xi
             print(f"{name} rows {rows:6d}: f32 {t32 * 1e6:7.1f} us {fl / t32 / 1e12:6.1f} TF | x6 {t6 * 1e6:7.1f} us {fl / t6 / 1e12:6.1f} TF-equiv", flush=True)
+            dy = torch.randn(rows, cout, generator=g, device=dev)
+            dy3 = ops.split_bf16x3(dy)
+            t32 = _event_time(lambda: ops.gemm_tn(dy, x, conv=True, gn=32, gl=16, cin=cin), 8)
+            t6 = _event_time(lambda: ops.gemm_tn_x6(dy3, x3, conv=True, gn=32, gl=16, cin=cin), 8)
+            ts = _event_time(lambda: ops.split_bf16x3(dy, out=dy3), 8)
+            print(f"{name} dW rows {rows:6d}: f32 {t32 * 1e6:7.1f} us {fl / t32 / 1e12:6.1f} TF | x6 {t6 * 1e6:7.1f} us {fl / t6 / 1e12:6.1f} TF-equiv | split of dY {ts * 1e6:6.1f} us", flush=True)
