@@ -10,7 +10,7 @@ from . import _build
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
-ACX_F32, ACX_BF16, BF16X3 = 0, 1, 2      # BF16X3: output only (three bf16 planes hi | mid | lo)
+ACX_F32, ACX_BF16, BF16X3, BF16X3P = 0, 1, 2, 3      # BF16X3 / BF16X3P: output only (three bf16 planes hi | mid | lo; P: K-panel layout)
 PREC_F32, PREC_BF16, PREC_F32X6 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("a_norm_w", c_void_p), ("a_norm_b", c_void_p), ("a_norm_eps", c_float),
         ("counters", c_void_p), ("n_counters", c_int32),
         ("tile_table", c_void_p),
-        ("pairs", c_int32), ("reserved_pairs", c_int32), ("a_plane_stride", c_int64), ("w_plane_stride", c_int64),
+        ("pairs", c_int32), ("panels", c_int32), ("a_plane_stride", c_int64), ("w_plane_stride", c_int64),
     ]
 
 
@@ -87,6 +87,7 @@ _SIGS = {
                                 c_int32, c_void_p]),
     "acx_attention_bf16": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_attention_x3": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "acx_attention_x3_panel": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_attention_cls": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "acx_vit_patches": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acx_vit_embed": (C.c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
@@ -178,6 +179,7 @@ _SIGS = {
                               [C.POINTER(c_float), C.POINTER(c_float), c_void_p]),
     "acx_cast_bf16": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_split_bf16x3": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "acx_split_bf16x3_panel": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "acx_colsum": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_sort_workspace_bytes": (c_int64, [c_int64]),
     "acx_sort_pairs_batched": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,

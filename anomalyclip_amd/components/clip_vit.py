@@ -109,8 +109,9 @@ class Transformer(nn.Module):
             if prec in (L.PREC_BF16, L.PREC_F32X6):
                 for name, p in (("in_proj_w_bf16", b.attn.in_proj_weight), ("out_proj_w_bf16", b.attn.out_proj.weight),
                                 ("fc_w_bf16", b.mlp.c_fc.weight), ("proj_w_bf16", b.mlp.c_proj.weight)):
-                    # bf16 mode: one rounded copy; f32x6: the three planes hi | mid | lo of the f32 weight, [3, N, K]
-                    t = ops.cast_bf16(p.detach()) if prec == L.PREC_BF16 else ops.split_bf16x3(p.detach())
+                    # bf16 mode: one rounded copy; f32x6: the three planes hi | mid | lo of the f32 weight, each in K-panel
+                    # layout [K / 32][N][32] (ACX_BF16X3P: what acx_transformer_forward's bf16 x 6 products read)
+                    t = ops.cast_bf16(p.detach()) if prec == L.PREC_BF16 else ops.split_bf16x3(p.detach(), panel=True)
                     keep.append(t)
                     setattr(w, name, t.data_ptr())
         self._cache = (key, (arr, keep))

@@ -159,10 +159,13 @@ bool x6_takes(acx_ctx* ctx, const TfWs& ws, int64_t M, int N, int K, int lda) {
   if (!ws.hp || !ACX_DBG_SWITCH("X6", true)) return false;
   const int64_t rtiles = ((M + 255) / 256) * ((N + 255) / 256);
   const int ring_min = ctx ? ctx->opt_ring_min_tiles : 512;
-  return rtiles >= ring_min && K % 64 == 0 && N % 4 == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32) &&
+  return rtiles >= ring_min && K % 256 == 0 && N % 8 == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32) &&
          (size_t)N * K * 2 < ((size_t)1 << 32);
 }
 
+// Both operands' planes are in K-PANEL layout (ACX_BF16X3P: the driver's producers -- LayerNorm, the attention, c_fc's epilogue,
+// acx_split_bf16x3_panel -- write it, the caller's weight planes come in it): a 256-row x 32-column unit of the plane-reuse
+// kernel is then ONE contiguous 16 KB block (+5-6 % on the ViT products against row-major planes, profiles/r05_gemm_x6_notes.txt).
 int linear_x6(acx_ctx* ctx, const void* A3, int lda, int64_t a_rows, const void* W3, int64_t w_plane_bytes, int ldw, void* C,
               int ldc, int M, int N, int K, const float* bias, int act, const float* residual, hipStream_t s, int ldr = 0,
               int c_dtype = ACX_F32) {
@@ -174,6 +177,7 @@ int linear_x6(acx_ctx* ctx, const void* A3, int lda, int64_t a_rows, const void*
   d.a_dtype = ACX_BF16; d.c_dtype = c_dtype; d.prec = ACX_PREC_BF16;
   d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
   d.pairs = 6; d.a_plane_stride = a_rows * (int64_t)lda * 2; d.w_plane_stride = w_plane_bytes;
+  d.panels = 3;
   return acx_gemm(ctx, &d, s);
 }
 
@@ -245,7 +249,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
   // the four large GEMMs of a layer in ACX_PREC_F32X6: split the f32 input into planes, multiply on the bf16 matrix cores
 #define X6_LINEAR(Af32, lda_, planes_, Wplanes_, wpb_, Cout_, ldc_, N_, K_, bias_, act_, res_)                          \
   do {                                                                                                                 \
-    if ((rc = acx_split_bf16x3(ctx, (const float*)(Af32), (lda_), (planes_), (int64_t)rows * (K_) * 2, rows, (K_), s))) return rc;  \
+    if ((rc = acx_split_bf16x3_panel(ctx, (const float*)(Af32), (lda_), (planes_), (int64_t)rows * (K_) * 2, rows, (K_), s))) return rc;  \
     if ((rc = linear_x6(ctx, (planes_), (K_), rows, (Wplanes_), (wpb_), (K_), (Cout_), (ldc_), (int)rows, (N_), (K_), (bias_),  \
                         (act_), (res_), s))) return rc;                                                                \
   } while (0)
@@ -261,7 +265,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
       // K | V for every token: rows [W, 3W) of in_proj
       if (x6mode && x6_takes(ctx, ws, rows, 2 * W, W, W)) {
         if (!b.in_proj_w_bf16) return acx_fail(ctx, ACX_E_BADARG, "driver: missing bf16 x 3 weight planes for ACX_PREC_F32X6%s");
-        X6_LINEAR(ws.h, W, ws.hp, (const char*)b.in_proj_w_bf16 + (size_t)W * W * 2, (int64_t)3 * W * W * 2, (float*)ws.qkv + W,
+        X6_LINEAR(ws.h, W, ws.hp, (const char*)b.in_proj_w_bf16 + (size_t)W * 64 /* row W of every K-panel */, (int64_t)3 * W * W * 2, (float*)ws.qkv + W,
                   3 * W, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr);
       } else
       if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w + (size_t)W * W,
@@ -287,7 +291,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     const bool x6_qkv = x6mode && x6_takes(ctx, ws, rows, 3 * W, W, W), x6_out = x6mode && x6_takes(ctx, ws, rows, W, W, W);
     const bool x6_fc = x6mode && x6_takes(ctx, ws, rows, 4 * W, W, W), x6_proj = x6mode && x6_takes(ctx, ws, rows, W, 4 * W, 4 * W);
     if (x6_qkv) {
-      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, ACX_BF16X3, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, ACX_BF16X3P, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     } else
     if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     // bf16 mode, non-causal (the ViT): q/k/v, the attention and its output stay bf16 end to end -- half the
@@ -304,12 +308,12 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     if (ab) {
       if ((rc = acx_attention_bf16(ctx, ws.qkv, 3 * W, ws.att, W, batch, L, heads, s))) return rc;
     } else if (att_x3) {   // the attention writes the out-projection's three planes itself
-      if ((rc = acx_attention_x3(ctx, (const float*)ws.qkv, 3 * W, ws.hp, W, batch, L, heads, s))) return rc;
+      if ((rc = acx_attention_x3_panel(ctx, (const float*)ws.qkv, 3 * W, ws.hp, W, batch, L, heads, s))) return rc;
     } else {
       if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
     }
     if (x6_out) {
-      if (!att_x3 && (rc = acx_split_bf16x3(ctx, (const float*)ws.att, W, ws.hp, (int64_t)rows * W * 2, rows, W, s))) return rc;
+      if (!att_x3 && (rc = acx_split_bf16x3_panel(ctx, (const float*)ws.att, W, ws.hp, (int64_t)rows * W * 2, rows, W, s))) return rc;
       if ((rc = linear_x6(ctx, ws.hp, W, rows, b.out_proj_w_bf16, (int64_t)W * W * 2, W, x, W, (int)rows, W, W, b.out_proj_b,
                           ACX_ACT_NONE, x, s))) return rc;
     } else
@@ -317,18 +321,18 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
                      b.out_proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     // x = x + mlp(ln_2(x))                                           clip/model.py:216
     if (x6_fc) {
-      if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.hp, W, ACX_BF16X3, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+      if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.hp, W, ACX_BF16X3P, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     } else
     if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     if (x6_fc) {
       // QuickGELU(c_fc) straight into the planes of c_proj's input when c_proj takes the x6 path too
       if ((rc = linear_x6(ctx, ws.hp, W, rows, b.fc_w_bf16, (int64_t)4 * W * W * 2, W, x6_proj ? (void*)ws.mp : (void*)ws.mlp, 4 * W,
-                          (int)rows, 4 * W, W, b.fc_b, ACX_ACT_QUICKGELU, nullptr, s, 0, x6_proj ? ACX_BF16X3 : ACX_F32))) return rc;
+                          (int)rows, 4 * W, W, b.fc_b, ACX_ACT_QUICKGELU, nullptr, s, 0, x6_proj ? ACX_BF16X3P : ACX_F32))) return rc;
     } else
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.fc_w, b.fc_w_bf16, W, ws.mlp, hdt, 4 * W, (int)rows, 4 * W, W, b.fc_b,
                      ACX_ACT_QUICKGELU, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     if (x6_proj) {
-      if (!x6_fc && (rc = acx_split_bf16x3(ctx, (const float*)ws.mlp, 4 * W, ws.mp, (int64_t)rows * 4 * W * 2, rows, 4 * W, s))) return rc;
+      if (!x6_fc && (rc = acx_split_bf16x3_panel(ctx, (const float*)ws.mlp, 4 * W, ws.mp, (int64_t)rows * 4 * W * 2, rows, 4 * W, s))) return rc;
       if ((rc = linear_x6(ctx, ws.mp, 4 * W, rows, b.proj_w_bf16, (int64_t)W * 4 * W * 2, 4 * W, x, W, (int)rows, W, 4 * W, b.proj_b,
                           ACX_ACT_NONE, x, s))) return rc;
     } else

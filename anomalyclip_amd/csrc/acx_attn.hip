@@ -251,7 +251,10 @@ __device__ __forceinline__ float a16_rowsum(float x) {
 // One wave's share of a workgroup's items.  HB: the wave owns two query tiles (ta, tb) or one (ta).
 // x3plane > 0: the output is written as three bf16 planes hi | mid | lo (ACX_BF16X3; plane p at (u16*)out + p * x3plane): the A
 // operand of the out-projection in ACX_PREC_F32X6 mode
-__device__ __forceinline__ void a16_store4(float* out, int64_t off, int64_t x3plane, float a, float b, float c, float d) {
+// prows > 0: the planes are in K-panel layout (ACX_BF16X3P: [ldo / 32][prows][32])
+__device__ __forceinline__ void a16_store4(float* out, int64_t row, int col, int64_t ldo, int64_t x3plane, int64_t prows, float a, float b,
+                                           float c, float d) {
+  const int64_t off = prows > 0 ? ((int64_t)(col >> 5) * prows + row) * 32 + (col & 31) : row * ldo + col;
   if (x3plane > 0) {
     const float ov[4] = {a, b, c, d};
     u16 hh[4], mm[4], ll[4];
@@ -277,7 +280,7 @@ __device__ __forceinline__ void a16_store4(float* out, int64_t off, int64_t x3pl
 
 template <bool HB, int NW>
 __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out, int64_t ldo,
-                                        int L, int heads, int nitems, char* smem, int ta, int tb, int64_t x3plane) {
+                                        int L, int heads, int nitems, char* smem, int ta, int tb, int64_t x3plane, int64_t prows) {
   const int W = heads * 64;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -427,18 +430,18 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
       const float inv = 1.f / a16_rowsum(la);
       const int q = 16 * ta + qi;
       if (q < L) {
-        const int64_t o0 = ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a16_store4(out, o0 + 4 * r, x3plane, oa0[r] * inv, oa1[r] * inv, oa2[r] * inv, oa3[r] * inv);
+        for (int r = 0; r < 4; ++r)
+          a16_store4(out, (int64_t)b * L + q, h * 64 + 16 * g + 4 * r, ldo, x3plane, prows, oa0[r] * inv, oa1[r] * inv, oa2[r] * inv, oa3[r] * inv);
       }
     }
     if constexpr (HB) {
       const float inv = 1.f / a16_rowsum(lb);
       const int q = 16 * tb + qi;
       if (q < L) {
-        const int64_t o0 = ((int64_t)b * L + q) * ldo + h * 64 + 16 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a16_store4(out, o0 + 4 * r, x3plane, ob0[r] * inv, ob1[r] * inv, ob2[r] * inv, ob3[r] * inv);
+        for (int r = 0; r < 4; ++r)
+          a16_store4(out, (int64_t)b * L + q, h * 64 + 16 * g + 4 * r, ldo, x3plane, prows, ob0[r] * inv, ob1[r] * inv, ob2[r] * inv, ob3[r] * inv);
       }
     }
   }   // item loop
@@ -459,15 +462,15 @@ __device__ __forceinline__ void a16_run(const float* __restrict__ qkv, int64_t l
 // them removed (MFMAs, Q loads and output stores only) the kernel still takes 0.60 ms = 0.73 of the MFMA roof on its
 // padded work: 13 tiles on 8 waves, single-accumulator 16x16x4 chains, item prologue / epilogue.
 __global__ __launch_bounds__(512, 4) void attn16_kernel(const float* __restrict__ qkv, int64_t ldqkv, float* __restrict__ out,
-                                                        int64_t ldo, int L, int heads, int nitems, int64_t x3plane) {
+                                                        int64_t ldo, int L, int heads, int nitems, int64_t x3plane, int64_t prows) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nkt = (L + 15) >> 4;
   const int nd = nkt - 8;                                                 // waves with two tiles
   const bool dbl = wave < nd;
   const int ta = dbl ? 2 * wave : nd + wave;
-  if (dbl) a16_run<true, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta + 1, x3plane);
-  else a16_run<false, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta, x3plane);
+  if (dbl) a16_run<true, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta + 1, x3plane, prows);
+  else a16_run<false, 8>(qkv, ldqkv, out, ldo, L, heads, nitems, smem, ta, ta, x3plane, prows);
 }
 
 
@@ -540,7 +543,8 @@ static int attention_impl(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* 
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     const int slots = 2 * ncu;                                            // two workgroups per CU
     hipLaunchKernelGGL(attn16_kernel, dim3((unsigned)(nitems < slots ? nitems : slots)), dim3(512), 2 * A16_STAGE_B, s, qkv,
-                       ldqkv, out, ldo, L, heads, nitems, x3 ? (int64_t)batch * L * ldo : (int64_t)0);
+                       ldqkv, out, ldo, L, heads, nitems, x3 ? (int64_t)batch * L * ldo : (int64_t)0,
+                       x3 == 2 ? (int64_t)batch * L : (int64_t)0);
     ACX_CHECK_LAUNCH(ctx, "acx_attention");
     return ACX_OK;
   }
@@ -581,6 +585,11 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
 extern "C" int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
                                 int32_t batch, int32_t L, int32_t heads, void* stream) {
   return attention_impl(ctx, qkv, ldqkv, (float*)out_planes, ldo, batch, L, heads, 0, stream, 1);
+}
+extern "C" int acx_attention_x3_panel(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
+                                      int32_t batch, int32_t L, int32_t heads, void* stream) {
+  if (ldo != (int64_t)heads * 64) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_x3_panel: dense planes (ldo == heads * 64)%s");
+  return attention_impl(ctx, qkv, ldqkv, (float*)out_planes, ldo, batch, L, heads, 0, stream, 2);
 }
 
 namespace {

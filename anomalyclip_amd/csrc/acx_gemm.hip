@@ -659,13 +659,14 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   // would not fill the chip (caller-provided workspace)
   if (d->pairs == 6 && ACX_DBG_SWITCH("X6P4", true)) {
     const bool conv = d->amap == ACX_AMAP_CONV3X3;
-    const bool c_x3_ = d->c_dtype == ACX_BF16X3;
+    const bool c_x3_ = d->c_dtype == ACX_BF16X3 || d->c_dtype == ACX_BF16X3P;
     const bool shape_ok = prec == ACX_PREC_BF16 && a_bf16 && (d->amap == ACX_AMAP_IDENTITY || conv) && !d->a_sub && !d->pos0 &&
         d->K % 32 == 0 && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
         !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && d->a_plane_stride > 0 && d->w_plane_stride > 0 &&
         !((d->a_plane_stride | d->w_plane_stride) & 15) && (size_t)d->M * d->lda * 2 < ((size_t)1 << 32) &&
         (size_t)d->N * d->ldw * 2 < ((size_t)1 << 32) && !(d->act == ACX_ACT_QUICKGELU && d->residual) &&
         !(d->act == ACX_ACT_LEAKYRELU && d->residual) && !(c_x3_ && (d->residual || d->N % 8 || d->ldc % 8)) && !(c_bf16 && d->residual) &&
+        (!d->panels || (!conv && d->K % 32 == 0 && d->lda == d->K && d->ldw == d->K)) && (d->c_dtype != ACX_BF16X3P || d->ldc == d->N) &&
         (!conv || (d->zero_page && !((uintptr_t)d->zero_page & 15) && d->cin % 32 == 0 && !(d->gl & (d->gl - 1)) &&
                    !(d->gn & (d->gn - 1)) && d->M % 256 == 0));
     if (shape_ok) {

@@ -31,7 +31,7 @@
 // Accumulation order differs from the p8 kernel's (all six products of a k range before the next range, smallest cross
 // terms first inside a range); the result is an f32 dot product's either way (tests hold both to the same bounds).
 #ifndef ACX_X6_ABL
-#define ACX_X6_ABL 0     // timing ablations (wrong results), bit mask: 1 no DMA in the K loop, 2 no vmcnt waits, 4 no epilogue stores, 8 no ds_reads
+#define ACX_X6_ABL 0     // timing ablations (wrong results), bit mask: 1 no DMA in the K loop, 2 no vmcnt waits, 4 no epilogue stores, 8 every ds_read from one address
 #endif
 constexpr int X6_UNIT_B = 256 * 64;              // one plane tile: 256 rows x 32 bf16
 constexpr int X6_LDS_B = 8 * X6_UNIT_B + 4 * 4096;
@@ -91,6 +91,12 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   const char* zsrc = (CONV || TN) ? (const char*)g.zeros + (lane & 3) * 16 : nullptr;
   const int sh_gl = CONV ? __builtin_ctz((unsigned)d.gl) : 0;
   const int steps_per_tap = (CONV && !TN) ? d.cin / 32 : 1;
+  // K-panel layout of the planes (acx_gemm_desc.panels; identity rows): plane = [K / 32][rows][32], a unit is one contiguous
+  // 16 KB block -- the byte distance between K-steps is a whole panel (plane bytes / panels), rows are 64 B apart
+  const bool apanel = !CONV && !TN && (d.panels & 1), wpanel = !TN && (d.panels & 2);
+  const size_t a_kstride = apanel ? (size_t)d.a_plane_stride / (size_t)(d.K / 32) : (size_t)64;
+  const size_t w_kstride = wpanel ? (size_t)d.w_plane_stride / (size_t)(d.K / 32) : (size_t)64;
+  const bool cpanel = C_MODE == 2 && d.c_dtype == ACX_BF16X3P;
   // TN: byte offset of this lane's 16-byte piece of instruction i inside the row's 512-byte tile slice (source-side swizzle)
 #define X6_TCH(i) ((((((lane & 31) >> 2) ^ ((2 * (i) + (lane >> 5)) & 7)) << 2) | (lane & 3)) * 16)
 #define X6_SET_ITEM(S, jj)                                                                         \
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     if constexpr (TN == 0)                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
       const int m_ = S.m0 + dr + 16 * i;                                                           \
-      RA[i] = (unsigned)(CONV ? m_ : min(m_, d.M - 1)) * ((ACX_X6_ABL & 16) ? 64u : (unsigned)d.lda * 2u) + (unsigned)dc; \
-      RW[i] = (unsigned)min(S.n0 + dr + 16 * i, d.N - 1) * ((ACX_X6_ABL & 16) ? 64u : (unsigned)d.ldw * 2u) + (unsigned)dc; \
+      RA[i] = (unsigned)(CONV ? m_ : min(m_, d.M - 1)) * (apanel ? 64u : (unsigned)d.lda * 2u) + (unsigned)dc; \
+      RW[i] = (unsigned)min(S.n0 + dr + 16 * i, d.N - 1) * (wpanel ? 64u : (unsigned)d.ldw * 2u) + (unsigned)dc; \
       if constexpr (CONV != 0) {                                                                   \
         const int n_ = (m_ >> sh_gl) & (d.gn - 1), l_c = m_ & (d.gl - 1);                          \
         const unsigned rn_ = (n_ > 0 ? 1u : 0u) | 2u | (n_ < d.gn - 1 ? 4u : 0u);   /* dn = -1, 0, +1 */ \
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       const bool ok_ = (VM[i] >> tap_) & 1u;                                                       \
       X6_GLDS_V(ok_ ? bt_ + RA[i] : zsrc, l_);                                                     \
     } else {                                                                                       \
-      X6_GLDS_S(b_ + (size_t)S.kk * ((ACX_X6_ABL & 16) ? (size_t)d.M * 64 : (size_t)64), RA[i], l_); \
+      X6_GLDS_S(b_ + (size_t)S.kk * a_kstride, RA[i], l_);                                         \
     }                                                                                              \
   } while (0)
 #define X6_DMA_W(S, RW, pl, slot, i)                                                               \
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       const char* p_ = b_ + ((size_t)(unsigned)(ok_ ? row_ : 0) * (size_t)(d.ldw * 2) + (size_t)(S.c0 * 2 + X6_TCH(i))); \
       X6_GLDS_V(ok_ ? p_ : zsrc, l_);                                                              \
     } else {                                                                                       \
-      const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride + (size_t)S.kk * ((ACX_X6_ABL & 16) ? (size_t)d.N * 64 : (size_t)64); \
+      const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride + (size_t)S.kk * w_kstride; \
       X6_GLDS_S(b_, RW[i], l_);                                                                    \
     }                                                                                              \
   } while (0)
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
         if ((!(PRED) || (colq < d.N && row < d.M)) && (!(ACX_X6_ABL & 4) || g.ksplit == 12345)) {  \
           typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));                         \
           const size_t pe = (size_t)d.M * d.ldc;                                                   \
-          u16* dst = (u16*)d.C + (size_t)row * d.ldc + colq;                                       \
+          u16* dst = (u16*)d.C + (cpanel ? ((size_t)(colq >> 5) * d.M + row) * 32 + (colq & 31) : (size_t)row * d.ldc + colq); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&ph), reinterpret_cast<u32x4_*>(dst)); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pm), reinterpret_cast<u32x4_*>(dst + pe)); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pl), reinterpret_cast<u32x4_*>(dst + 2 * pe)); \

@@ -548,6 +548,7 @@ __global__ __launch_bounds__(256) void class_probs_kernel(const float* __restric
 }
 
 // x = hi + mid + lo with three bf16 (8 significant bits each: 24 in all); x - hi and (x - hi) - mid are exact in f32
+template <int PANEL>
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, int64_t ld, u16* __restrict__ dst,
                                                            int64_t plane, int64_t rows, int cols4) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -568,7 +569,8 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     const float r2 = r1 - bf2f(m[k]);
     l[k] = f2bf(r2);
   }
-  const int64_t o = r * (int64_t)cols4 * 4 + 4 * c4;
+  // PANEL: K-panel layout [cols / 32][rows][32] (ACX_BF16X3P)
+  const int64_t o = PANEL ? ((int64_t)(c4 >> 3) * rows + r) * 32 + 4 * (c4 & 7) : r * (int64_t)cols4 * 4 + 4 * c4;
   uint2 pk;
   pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
   *reinterpret_cast<uint2*>(dst + o) = pk;
@@ -1102,20 +1104,32 @@ extern "C" int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t 
   return ACX_OK;
 }
 
-extern "C" int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
-                                int64_t cols, void* stream) {
+static int split_bf16x3_impl(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
+                             int64_t cols, void* stream, int panel) {
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
   if (!src || !dst) return acx_fail(ctx, ACX_E_BADARG, "acx_split_bf16x3: null pointer%s");
   if (rows <= 0 || cols <= 0) return ACX_OK;
   if (cols % 4 || ld % 4 || ld < cols || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7) || (plane_stride_bytes & 7) ||
-      plane_stride_bytes < rows * cols * 2)
-    return acx_fail(ctx, ACX_E_BADARG, "acx_split_bf16x3: cols / ld multiples of 4, aligned pointers, planes of >= rows * cols bf16%s");
+      plane_stride_bytes < rows * cols * 2 || (panel && cols % 32))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_split_bf16x3: cols / ld multiples of 4 (panel layout: cols of 32), aligned pointers, planes of >= rows * cols bf16%s");
   const int64_t n4 = rows * (cols / 4);
   if (n4 > ((int64_t)1 << 38)) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_split_bf16x3: too many elements%s");
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, (u16*)dst,
-                     plane_stride_bytes / 2, rows, (int)(cols / 4));
+  if (panel)
+    hipLaunchKernelGGL(split_bf16x3_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, (u16*)dst,
+                       plane_stride_bytes / 2, rows, (int)(cols / 4));
+  else
+    hipLaunchKernelGGL(split_bf16x3_kernel<0>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, (u16*)dst,
+                       plane_stride_bytes / 2, rows, (int)(cols / 4));
   ACX_CHECK_LAUNCH(ctx, "acx_split_bf16x3");
   return ACX_OK;
+}
+extern "C" int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
+                                int64_t cols, void* stream) {
+  return split_bf16x3_impl(ctx, src, ld, dst, plane_stride_bytes, rows, cols, stream, 0);
+}
+extern "C" int acx_split_bf16x3_panel(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
+                                      int64_t cols, void* stream) {
+  return split_bf16x3_impl(ctx, src, ld, dst, plane_stride_bytes, rows, cols, stream, 1);
 }
 
 extern "C" int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows, int32_t D, void* stream) {

@@ -30,9 +30,12 @@ __device__ __forceinline__ void normalize(float (&v)[VPL], float eps, int mode) 
 
 // OUT_BF16 == 2: the row as THREE bf16 planes hi | mid | lo (x = hi + mid + lo to 24 bits: the A operand of acx_gemm_desc.pairs =
 // 6), plane p at y + p * plane elements
+// OUT_BF16 == 3: the same planes in K-panel layout (ACX_BF16X3P): y = plane base, element e of row `prow` of `prows` rows at
+// ((e / 32) * prows + prow) * 32 + e % 32
 template <int VPL, int OUT_BF16>
 __device__ __forceinline__ void store_row_affine(void* y, int lane, const float (&v)[VPL],
-                                                 const float* __restrict__ w, const float* __restrict__ b, int64_t plane = 0) {
+                                                 const float* __restrict__ w, const float* __restrict__ b, int64_t plane = 0,
+                                                 int64_t prow = 0, int64_t prows = 0) {
   if constexpr (VPL % 4 == 0) {
 #pragma unroll
     for (int i = 0; i < VPL / 4; ++i) {
@@ -42,7 +45,7 @@ __device__ __forceinline__ void store_row_affine(void* y, int lane, const float 
       float4 o;
       o.x = v[4 * i] * ww.x + bb.x; o.y = v[4 * i + 1] * ww.y + bb.y;
       o.z = v[4 * i + 2] * ww.z + bb.z; o.w = v[4 * i + 3] * ww.w + bb.w;
-      if constexpr (OUT_BF16 == 2) {
+      if constexpr (OUT_BF16 == 2 || OUT_BF16 == 3) {
         const float ov[4] = {o.x, o.y, o.z, o.w};
         u16 hh[4], mm[4], ll[4];
 #pragma unroll
@@ -52,13 +55,14 @@ __device__ __forceinline__ void store_row_affine(void* y, int lane, const float 
           mm[k] = f2bf(r1);
           ll[k] = f2bf(r1 - bf2f(mm[k]));
         }
+        const int64_t eo = OUT_BF16 == 3 ? ((int64_t)(e >> 5) * prows + prow) * 32 + (e & 31) : (int64_t)e;
         uint2 pk;
         pk.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16); pk.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
-        *reinterpret_cast<uint2*>((u16*)y + e) = pk;
+        *reinterpret_cast<uint2*>((u16*)y + eo) = pk;
         pk.x = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16); pk.y = (uint32_t)mm[2] | ((uint32_t)mm[3] << 16);
-        *reinterpret_cast<uint2*>((u16*)y + plane + e) = pk;
+        *reinterpret_cast<uint2*>((u16*)y + plane + eo) = pk;
         pk.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16); pk.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
-        *reinterpret_cast<uint2*>((u16*)y + 2 * plane + e) = pk;
+        *reinterpret_cast<uint2*>((u16*)y + 2 * plane + eo) = pk;
       } else if constexpr (OUT_BF16 == 1) {
         uint2 pk;
         pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
@@ -73,11 +77,12 @@ __device__ __forceinline__ void store_row_affine(void* y, int lane, const float 
     for (int i = 0; i < VPL; ++i) {
       const int e = lane + 64 * i;
       const float o = v[i] * w[e] + b[e];
-      if constexpr (OUT_BF16 == 2) {
+      if constexpr (OUT_BF16 == 2 || OUT_BF16 == 3) {
         const u16 h1 = f2bf(o);
         const float r1 = o - bf2f(h1);
         const u16 m1 = f2bf(r1);
-        ((u16*)y)[e] = h1; ((u16*)y)[plane + e] = m1; ((u16*)y)[2 * plane + e] = f2bf(r1 - bf2f(m1));
+        const int64_t eo = OUT_BF16 == 3 ? ((int64_t)(e >> 5) * prows + prow) * 32 + (e & 31) : (int64_t)e;
+        ((u16*)y)[eo] = h1; ((u16*)y)[plane + eo] = m1; ((u16*)y)[2 * plane + eo] = f2bf(r1 - bf2f(m1));
       } else if constexpr (OUT_BF16 == 1) ((u16*)y)[e] = f2bf(o); else ((float*)y)[e] = o;
     }
   }
@@ -94,8 +99,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   float v[VPL];
   load_row<VPL>(x + row * ldx, lane, v);
   normalize<VPL>(v, eps, mode);
-  void* yr = OUT_BF16 ? (void*)((u16*)y + row * ldy) : (void*)((float*)y + row * ldy);
-  store_row_affine<VPL, OUT_BF16>(yr, lane, v, w, b, rows * ldy);
+  void* yr = OUT_BF16 == 3 ? y : OUT_BF16 ? (void*)((u16*)y + row * ldy) : (void*)((float*)y + row * ldy);
+  store_row_affine<VPL, OUT_BF16>(yr, lane, v, w, b, rows * ldy, row, rows);
 }
 
 template <int VPL>
@@ -184,7 +189,10 @@ extern "C" int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const fl
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
-  if (y_dtype == ACX_BF16X3) {         // three dense planes [rows, ldy] each, y + p * rows * ldy
+  if (y_dtype == ACX_BF16X3P) {        // three planes in K-panel layout [D / 32][rows][32] each (ldy == D), y + p * rows * ldy
+    if (ldy != D || D % 256) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm: ACX_BF16X3P needs ldy == D, D %% 256 == 0%s");
+    DISPATCH_VPL(D, layernorm_kernel<V COMMA 3><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));
+  } else if (y_dtype == ACX_BF16X3) {  // three dense planes [rows, ldy] each, y + p * rows * ldy
     DISPATCH_VPL(D, layernorm_kernel<V COMMA 2><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));
   } else if (y_dtype == ACX_BF16) {
     DISPATCH_VPL(D, layernorm_kernel<V COMMA 1><<<grid COMMA block COMMA 0 COMMA s>>>(x, ldx, w, b, y, ldy, rows, eps, mode));

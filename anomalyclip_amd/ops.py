@@ -120,21 +120,29 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def split_bf16x3(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """f32 [rows, cols] -> bf16 [3, rows, cols]: x = hi + mid + lo to 24 bits (the operands of gemm_x6)."""
+def split_bf16x3(src: torch.Tensor, out: Optional[torch.Tensor] = None, panel: bool = False) -> torch.Tensor:
+    """f32 [rows, cols] -> bf16 [3, rows, cols]: x = hi + mid + lo to 24 bits (the operands of gemm_x6).  panel: each plane in
+    K-panel layout [cols / 32][rows][32] (ACX_BF16X3P; the tensor keeps the shape [3, rows, cols], its memory is panel-ordered)."""
     assert src.dim() == 2 and src.dtype == torch.float32 and src.stride(1) == 1
     rows, cols = src.shape
     if out is None:
         out = torch.empty(3, rows, cols, dtype=_BF16, device=src.device)
     assert out.shape == (3, rows, cols) and out.dtype == _BF16 and out.is_contiguous()
     h = _h(src)
-    L.check(L.lib().acx_split_bf16x3(h, src.data_ptr(), src.stride(0), out.data_ptr(), rows * cols * 2, rows, cols, _stream()), h)
+    fn = L.lib().acx_split_bf16x3_panel if panel else L.lib().acx_split_bf16x3
+    L.check(fn(h, src.data_ptr(), src.stride(0), out.data_ptr(), rows * cols * 2, rows, cols, _stream()), h)
     return out
+
+
+def unpanel(planes: torch.Tensor) -> torch.Tensor:
+    """[3, rows, cols] planes in K-panel memory order -> the same values in row-major order (tests / debugging)"""
+    _, rows, cols = planes.shape
+    return planes.reshape(3, cols // 32, rows, 32).permute(0, 2, 1, 3).reshape(3, rows, cols).contiguous()
 
 
 def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, act=L.ACT_NONE,
             residual=None, out_dtype=torch.float32, amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, M: Optional[int] = None,
-            planes_out: bool = False, split_k: bool = True) -> torch.Tensor:
+            planes_out: bool = False, split_k: bool = True, panels: int = 0, panel_out: bool = False) -> torch.Tensor:
     """out[M, N] = epilogue(amap(A) W^T) with A = sum of the three bf16 planes a3 [3, rows, Ka] and W = sum of w3 [3, N, K]
     (split_bf16x3): the six leading cross products on the bf16 matrix cores, f32 accumulation -- the accuracy of an f32
     product (acx_gemm_desc.pairs = 6; acx_gemm_x6.h).  amap = AMAP_CONV3X3: implicit 3x3 convolution over the (gn, gl) token
@@ -156,10 +164,11 @@ def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] =
     d.A, d.W, d.C = a3.data_ptr(), w3.data_ptr(), out.data_ptr()
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldw, d.ldc = Ka, K, out.stride(-2)
-    d.a_dtype, d.c_dtype, d.prec = _dt(a3), (L.BF16X3 if planes_out else _dt(out)), L.PREC_BF16
+    d.a_dtype, d.c_dtype, d.prec = _dt(a3), ((L.BF16X3P if panel_out else L.BF16X3) if planes_out else _dt(out)), L.PREC_BF16
     d.bias, d.act = _ptr(bias), act
     d.residual, d.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
     d.pairs, d.a_plane_stride, d.w_plane_stride = 6, rows * Ka * 2, N * K * 2
+    d.panels = panels                      # bit 0: a3 in K-panel memory order (split_bf16x3(panel=True)), bit 1: w3
     d.amap, d.gn, d.gl, d.cin = amap, gn, gl, cin
     if amap == L.AMAP_CONV3X3:
         d.zero_page = _zero_page(a3.device).data_ptr()

@@ -36,9 +36,13 @@ enum {
 };
 
 enum { ACX_F32 = 0, ACX_BF16 = 1,                    /* storage dtypes */
-       ACX_BF16X3 = 2 };  /* OUTPUT only (acx_layernorm y_dtype, acx_gemm c_dtype with the persistent 256x256 bf16 kernel): the
-                             value as three dense bf16 planes hi | mid | lo [rows, ld] each, plane p at base + p * rows * ld
-                             elements -- the producer writes the A operand of a pairs = 6 product directly */
+       ACX_BF16X3 = 2,    /* OUTPUT only (acx_layernorm y_dtype, acx_gemm c_dtype of a pairs = 6 product): the value as three dense
+                             bf16 planes hi | mid | lo [rows, ld] each, plane p at base + p * rows * ld elements -- the producer
+                             writes the A operand of a pairs = 6 product directly */
+       ACX_BF16X3P = 3 }; /* the same three planes in K-PANEL layout: a plane is [ld / 32][rows][32] -- the 32 columns of K-step kp
+                             of all rows are contiguous (element (r, c) at ((c / 32) * rows + r) * 32 + c % 32; ld % 32 == 0,
+                             dense).  The plane-reuse kernel then stages a 256-row x 32-column unit from ONE contiguous 16 KB block
+                             instead of 256 half cache lines (acx_gemm_desc.panels) */
 enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1,          /* MFMA arithmetic: exact f32 (v_mfma_f32_32x32x2_f32) or bf16 in / f32 acc */
        ACX_PREC_F32X6 = 2 };  /* acx_vit_encode / acx_transformer_forward only: f32 everywhere, the four large GEMMs of a layer as
                                  f32-accurate bf16 x 6 products (acx_gemm_desc.pairs); the *_w_bf16 weight fields then hold THREE
@@ -127,7 +131,8 @@ typedef struct acx_gemm_desc {
                              and the split remainders are <= 2^-23 of the product: the error is that of an f32 dot product, at
                              6/16 of the f32 MFMA's cost (2.5 PFLOP/s bf16 against 157 TFLOP/s f32 on gfx950).  Large
                              problems only (the persistent 256x256 kernel); K % 128 == 0. */
-  int32_t reserved_pairs;
+  int32_t panels;         /* pairs = 6: bit 0 -- the A planes are in K-panel layout (ACX_BF16X3P, rows = a_plane_stride / (2 K));
+                             bit 1 -- the W planes are (rows = N).  Identity row map only. */
   int64_t a_plane_stride, w_plane_stride;   /* bytes */
 } acx_gemm_desc;
 int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
@@ -151,6 +156,9 @@ int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int
  * plane p at (uint16_t*)out_planes + p * batch * L * ldo): the out-projection's A operand in ACX_PREC_F32X6 mode */
 int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
                      int32_t batch, int32_t L, int32_t heads, void* stream);
+/* ... with the planes in K-panel layout (ACX_BF16X3P: [ldo / 32][batch * L][32] each; ldo == heads * 64) */
+int acx_attention_x3_panel(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
+                           int32_t batch, int32_t L, int32_t heads, void* stream);
 
 /* bf16 variant of acx_attention for the bf16 mode of the ViT (NOT a parity path): qkv [batch*L, ldqkv] and out
  * [batch*L, ldo] are bf16, QK^T and PV run on the bf16 MFMA, softmax in f32.  Non-causal only. */
@@ -309,6 +317,8 @@ int acx_preprocess_frames(acx_ctx* ctx, const unsigned char* frames, float* out,
  * acx_gemm_desc.pairs = 6.  cols % 4 == 0, 16-byte aligned src rows / 8-byte aligned planes. */
 int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
                      int64_t cols, void* stream);
+/* the same into K-panel layout (ACX_BF16X3P: plane = [cols / 32][rows][32]; cols % 32 == 0) */
+int acx_split_bf16x3_panel(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_bytes, int64_t rows, int64_t cols, void* stream);
 /* utility: f32 -> bf16 (round-to-nearest-even) copy, used to prepare bf16 weight copies. */
 int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* stream);
 /* utility: column sums of x[rows, D] accumulated into acc[D] (ncentroid, anomaly_clip_module.py:145-171). */

@@ -647,7 +647,7 @@ def test_split_bf16x3_edge_values():
     assert float((y4 - ref4).abs().max()) <= 2e-6 * float((a4.double().abs() @ w4.double().abs().t()).max()) + 1e-45
 
 
-@pytest.mark.parametrize("M,N,K,split", [(512, 256, 2304, True), (1024, 512, 9216, True), (4096, 1024, 2304, True), (300, 260, 96, False), (300, 264, 96, False),
+@pytest.mark.parametrize("M,N,K,split", [(512, 256, 2304, True), (1024, 512, 9216, True), (4096, 1024, 2304, True), (300, 260, 96, False), (300, 264, 96, False), (300, 288, 96, False),
                                          (2048, 1024, 768, False), (70000, 768, 768, False)])
 def test_gemm_x6_split_k_and_planes_output(M, N, K, split):
     """The plane-reuse kernel (acx_gemm_x6.h): few output tiles -> K split across workgroups + reduce launch, equal to the
@@ -669,6 +669,14 @@ def test_gemm_x6_split_k_and_planes_output(M, N, K, split):
         assert yp.shape == (3, M, N) and torch.equal(yp.float().sum(0), y)        # hi + mid + lo == the f32 result exactly
     yb = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_LEAKYRELU, split_k=split, out_dtype=torch.bfloat16)
     assert torch.equal(yb, y.to(torch.bfloat16))
+    if K % 32 == 0 and N % 32 == 0:
+        # K-panel layout of the planes (ACX_BF16X3P: what the ViT driver's producers write): the same arithmetic in the same order
+        a3p, w3p = ops.split_bf16x3(a, panel=True), ops.split_bf16x3(w, panel=True)
+        assert torch.equal(ops.unpanel(a3p), a3) and torch.equal(ops.unpanel(w3p), w3)
+        assert torch.equal(ops.gemm_x6(a3p, w3p, bias=b, act=L.ACT_LEAKYRELU, split_k=False, panels=3), y0)
+        assert torch.equal(ops.gemm_x6(a3, w3p, bias=b, act=L.ACT_LEAKYRELU, split_k=False, panels=2), y0)
+        ypp = ops.gemm_x6(a3p, w3p, bias=b, act=L.ACT_LEAKYRELU, split_k=False, panels=3, planes_out=True, panel_out=True)
+        assert torch.equal(ops.unpanel(ypp).float().sum(0), y0)
 
 
 @pytest.mark.parametrize("cin,cout,tiles,act,res", [(64, 256, 1, 2, 0), (256, 1024, 2, 2, 0), (1024, 256, 8, 0, 1), (128, 512, 40, 0, 0),
