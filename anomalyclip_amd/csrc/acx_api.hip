@@ -129,6 +129,7 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct TfWs {   // transformer scratch carved from the caller's workspace
   char *h, *qkv, *att, *mlp, *splitk;
   char *hp, *mp;  // ACX_PREC_F32X6: three bf16 planes of a [rows, W] / [rows, 4W] GEMM input (nullptr otherwise)
+  char* qkv3;     // ACX_PREC_F32X6: three bf16 planes of q | k | v [rows, 3W] (the plane attention's operands)
   size_t splitk_bytes, total;
 };
 
@@ -143,10 +144,11 @@ TfWs carve_tf(char* base, int64_t rows, int W, int prec = ACX_PREC_F32) {
   // ... and for the partial last wave of big problems: <= 256 tiles of 128x128 outputs, 4 splits
   w.splitk_bytes = rows <= 4096 ? (size_t)8 * rows * 4 * W * 4 : (size_t)4 * 256 * 128 * 128 * 4;
   w.splitk = base + off; off += al(w.splitk_bytes);
-  w.hp = w.mp = nullptr;
+  w.hp = w.mp = w.qkv3 = nullptr;
   if (prec == ACX_PREC_F32X6) {
     w.hp = base + off; off += al((size_t)3 * rows * W * 2);
     w.mp = base + off; off += al((size_t)3 * rows * 4 * W * 2);
+    w.qkv3 = base + off; off += al((size_t)3 * rows * 3 * W * 2);
   }
   w.total = off;
   return w;
@@ -298,22 +300,26 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     // QKV store traffic, bf16-MFMA attention, and a bf16 A operand (LDS-DMA kernels) for the out-projection
     const bool ab = prec == ACX_PREC_BF16 && !causal && L <= 224 && ACX_DBG_SWITCH("ATTN_BF16", true);
     const int qdt = ab ? ACX_BF16 : ACX_F32;
+    // the attention on the bf16 matrix cores (acx_attention_p3): q | k | v leave the in-projection as three bf16 planes
+    const bool att_p3 = x6_qkv && x6_out && ws.qkv3 && !causal && L > 192 && L <= 208 && ACX_DBG_SWITCH("ATTN_P3", true);
     if (x6_qkv) {
-      if ((rc = linear_x6(ctx, ws.hp, W, rows, b.in_proj_w_bf16, (int64_t)3 * W * W * 2, W, ws.qkv, 3 * W, (int)rows, 3 * W, W,
-                          b.in_proj_b, ACX_ACT_NONE, nullptr, s))) return rc;
+      if ((rc = linear_x6(ctx, ws.hp, W, rows, b.in_proj_w_bf16, (int64_t)3 * W * W * 2, W, att_p3 ? (void*)ws.qkv3 : (void*)ws.qkv, 3 * W,
+                          (int)rows, 3 * W, W, b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, att_p3 ? ACX_BF16X3P : ACX_F32))) return rc;
     } else
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, qdt, 3 * W, (int)rows, 3 * W, W,
                      b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     const bool att_x3 = x6_out && !causal && L > 128 && L <= 224 && ACX_DBG_SWITCH("ATTN16", true);
     if (ab) {
       if ((rc = acx_attention_bf16(ctx, ws.qkv, 3 * W, ws.att, W, batch, L, heads, s))) return rc;
+    } else if (att_p3) {   // planes in, planes out
+      if ((rc = acx_attention_p3(ctx, ws.qkv3, ws.hp, batch, L, heads, s))) return rc;
     } else if (att_x3) {   // the attention writes the out-projection's three planes itself
       if ((rc = acx_attention_x3_panel(ctx, (const float*)ws.qkv, 3 * W, ws.hp, W, batch, L, heads, s))) return rc;
     } else {
       if ((rc = acx_attention(ctx, (const float*)ws.qkv, 3 * W, (float*)ws.att, W, batch, L, heads, causal, s))) return rc;
     }
     if (x6_out) {
-      if (!att_x3 && (rc = acx_split_bf16x3_panel(ctx, (const float*)ws.att, W, ws.hp, (int64_t)rows * W * 2, rows, W, s))) return rc;
+      if (!att_x3 && !att_p3 && (rc = acx_split_bf16x3_panel(ctx, (const float*)ws.att, W, ws.hp, (int64_t)rows * W * 2, rows, W, s))) return rc;
       if ((rc = linear_x6(ctx, ws.hp, W, rows, b.out_proj_w_bf16, (int64_t)W * W * 2, W, x, W, (int)rows, W, W, b.out_proj_b,
                           ACX_ACT_NONE, x, s))) return rc;
     } else

@@ -582,6 +582,293 @@ extern "C" int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, floa
   return attention_impl(ctx, qkv, ldqkv, out, ldo, batch, L, heads, causal, stream, 0);
 }
 
+namespace {
+// =====================================================================================================
+// attn_p3_kernel -- the ViT's attention on the bf16 matrix cores at f32 accuracy (the ACX_PREC_F32X6 mode of the layer loop).
+// q, k, v arrive as THREE bf16 planes each (hi | mid | lo: exact 24-bit split of the f32 values, written by the in-projection's
+// epilogue in K-panel layout ACX_BF16X3P: plane = [3 W / 32][rows][32]); S = Q K^T and O = P V are six-product bf16 x 6
+// products with f32 accumulation (acx_gemm_desc.pairs), the softmax runs in f32 in registers, P is split into three planes as
+// it is consumed.  The f32 MFMA kernel above is bounded by the f32 pipe (1/16 of the bf16 rate): 61 GFLOP per layer at 157
+// TFLOP/s = 0.39 ms at best (0.73-0.88 measured); here the same layer is 2 x 6 x 30.5 GFLOP of bf16 work = 0.15 ms of pipe time.
+//   * one workgroup (8 waves, one per CU: 156 KB of LDS) per (frame, head), persistent; waves 0..6 own the seven 32-query
+//     tiles of L = 197, wave 7 stages the operands: K and V of the head are copied by LDS-DMA from the panel-layout planes -- a
+//     (plane, panel) block is 197 contiguous rows of 64 B, so the LDS image IS the global image (13 instructions of 1 KB per
+//     block; K with the source-side bank swizzle chunk ^ ((row >> 2) & 3) of the GEMM units);
+//   * phase A: S^T = K Q^T per 32-key tile (A operand = K rows from LDS by ds_read_b128, B operand = this wave's Q fragments,
+//     loaded once per item from global): a lane then holds ONE query's scores (col = lane & 31), half of the keys each for the
+//     two lane halves -- row max / sum are in-register plus one cross-half exchange;
+//   * phase B: O^T = V^T P^T per 16-key step: the B operand is the lane's own probabilities, converted to bf16 planes in the
+//     order the accumulator holds them (k-slot j of lane half hh <-> key 4 hh + (j & 3) + 8 (j >> 2) of the step: no lane
+//     exchange), the A operand V^T by LDS transpose reads (ds_read_b64_tr_b16) in the SAME key order;
+//   * K of item i + 1 is staged while item i is in phase B, V of item i + 1 while it is in phase A (two barriers per item).
+// Output: three bf16 planes of O in K-panel layout (the out-projection's A operand), 8 bytes per lane and plane.
+#ifndef AP3_NOFENCE
+#define AP3_NOFENCE 0
+#endif
+#ifndef AP3_ABL
+#define AP3_ABL 0   // timing ablations (wrong results): 1 no exp, 2 no output stores, 4 no P V MFMAs, 8 no Q K^T MFMAs, 16 no staging, 32 no plane split of P, 64 no V fragment reads
+#endif
+constexpr int AP3_ROWS = 208;                         // key rows staged per (plane, panel) block: 13 DMA instructions of 16 rows
+constexpr int AP3_BLK_B = AP3_ROWS * 64;              // 13312
+constexpr int AP3_LDS_B = 12 * AP3_BLK_B;             // K: 6 blocks (plane, panel), V: 6 blocks = 159744
+
+typedef short ap3_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ap3_s16x4 ap3_lds_s16x4;
+typedef __attribute__((address_space(3))) void ap3_lds_void;
+
+__device__ __forceinline__ void ap3_split8(const float (&p)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = f2bf2(p[2 * e], p[2 * e + 1]);
+    const float r0 = p[2 * e] - __uint_as_float(h[e] << 16), r1 = p[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+    m[e] = f2bf2(r0, r1);
+    l[e] = f2bf2(r0 - __uint_as_float(m[e] << 16), r1 - __uint_as_float(m[e] & 0xffff0000u));
+  }
+  typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ hv = {h[0], h[1], h[2], h[3]}, mv = {m[0], m[1], m[2], m[3]}, lv = {l[0], l[1], l[2], l[3]};
+  hi = __builtin_bit_cast(bf16x8, hv); mid = __builtin_bit_cast(bf16x8, mv); lo = __builtin_bit_cast(bf16x8, lv);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__ qkv3, int64_t plane_elems, int64_t rows_total,
+                                                         u16* __restrict__ out3, int64_t out_plane_elems, int L, int heads, int nitems) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, hh = lane >> 5;
+  const int W = heads * 64;
+  const int np = W / 32;                                // panels of q (k: + np, v: + 2 np)
+  const unsigned lds0 = (unsigned)(uintptr_t)(ap3_lds_void*)smem;
+  // one LDS-DMA instruction: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS [m0 .. + 1 KB)
+#define AP3_GLDS(base, voff, ldsaddr)                                                              \
+  do {                                                                                             \
+    if ((AP3_ABL & 16) && nitems != 12345) break;                                                  \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(ldsaddr), "s"(base) : "memory"); \
+  } while (0)
+  // the stager (wave 7: the seven query tiles belong to waves 0..6): the 6 blocks (plane p, panel c) of K (which = 1) or V
+  // (which = 2) of item `it` -> LDS blocks `blk0 + 2 p + c`.  Rolled loops: this code shares the kernel's register budget.
+#define AP3_STAGE(it, which, blk0, SWZ)                                                            \
+  do {                                                                                             \
+    const int b_ = (it) / heads, h_ = (it) - b_ * heads;                                           \
+    const unsigned vc_ = (unsigned)(((SWZ) ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)) * 16); \
+    _Pragma("unroll 1") for (int pc = 0; pc < 6; ++pc) {                                           \
+      const u16* src_ = qkv3 + (int64_t)(pc >> 1) * plane_elems + ((int64_t)((which) * np + 2 * h_ + (pc & 1)) * rows_total + (int64_t)b_ * L) * 32; \
+      _Pragma("unroll 1") for (int j = 0; j < 13; ++j) {                                           \
+        const unsigned r_ = min(16u * (unsigned)j + (unsigned)(lane >> 2), (unsigned)(L - 1));   /* behind the sequence: a finite duplicate */ \
+        AP3_GLDS(src_, r_ * 64u + vc_, lds0 + (unsigned)(((blk0) + pc) * AP3_BLK_B + j * 1024));   \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
+  // the same 78 instructions dealt over all eight waves (V: phase A is short -- 168 MFMAs per wave -- and one wave needs longer
+  // than that just to ISSUE 78 LDS-DMA instructions; every wave waits for its own share before the barrier that ends the phase)
+#define AP3_STAGE_SHARED(it, which, blk0, SWZ)                                                     \
+  do {                                                                                             \
+    const int b_ = (it) / heads, h_ = (it) - b_ * heads;                                           \
+    const unsigned vc_ = (unsigned)(((SWZ) ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)) * 16); \
+    _Pragma("unroll 1") for (int idx = wave; idx < 78; idx += 8) {                                 \
+      const int pc = idx / 13, j = idx - 13 * pc;                                                  \
+      const u16* src_ = qkv3 + (int64_t)(pc >> 1) * plane_elems + ((int64_t)((which) * np + 2 * h_ + (pc & 1)) * rows_total + (int64_t)b_ * L) * 32; \
+      const unsigned r_ = min(16u * (unsigned)j + (unsigned)(lane >> 2), (unsigned)(L - 1));       \
+      AP3_GLDS(src_, r_ * 64u + vc_, lds0 + (unsigned)(((blk0) + pc) * AP3_BLK_B + j * 1024));     \
+    }                                                                                              \
+  } while (0)
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  const float sc = 0.125f * 1.44269504088896340736f;    // 1 / sqrt(64) and log2(e): p = exp2((s - max) sc)
+  if (wave == 7) {
+    // ================================================================ the stager
+    AP3_STAGE(item, 1, 0, 1);                           // K of the first item
+    for (; item < nitems; item += (int)gridDim.x) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K(item) landed
+      __builtin_amdgcn_s_barrier();                     // B1: ... and everybody is done with V(previous item)
+      AP3_STAGE_SHARED(item, 2, 6, 0);                  // this wave's share of V(item): needed after phase A
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // B2: V(item) landed, everybody is done with K(item)
+      const int nxt = item + (int)gridDim.x;
+      if (nxt < nitems) AP3_STAGE(nxt, 1, 0, 1);        // K(next item) during this item's phase B
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may still be writing this workgroup's LDS at exit
+    return;
+  }
+  // ================================================================== the seven query tiles
+  // V^T fragment addresses (ds_read_b64_tr_b16: every 16 lanes read a [4 keys][16 d] block): lane i of the group supplies
+  // key (4 hh + 8 r + (i >> 2)) of the 16-key step, d = 16 ((lane >> 4) & 1) + 4 (i & 3) of the 32-d panel
+  const int i16 = lane & 15;
+  // every LDS address below = one of six per-lane base registers + an immediate < 64 KB (LDS offsets beyond the 16-bit
+  // immediate would each cost a hoisted address register: the blocks of the lo planes get bases of their own)
+  int va = 6 * AP3_BLK_B + (4 * hh + (i16 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;     // V hi / mid planes
+  int va2 = va + 4 * AP3_BLK_B;                                                                         // V lo plane
+  const int swk = (li >> 2) & 3;
+  int ka0 = li * 64 + ((0 + hh) ^ swk) * 16, ka1 = li * 64 + ((2 + hh) ^ swk) * 16;                     // K hi / mid planes, d step parity
+  int ka0l = ka0 + 4 * AP3_BLK_B, ka1l = ka1 + 4 * AP3_BLK_B;                                           // K lo plane
+  asm volatile("" : "+v"(va), "+v"(va2), "+v"(ka0), "+v"(ka1), "+v"(ka0l), "+v"(ka1l));
+  const int qrow = min(32 * wave + li, L - 1);
+  for (; item < nitems; item += (int)gridDim.x) {
+    const int b = item / heads, h = item - b * heads;
+    // ---------------------------------------------------------------- phase A: S^T = K Q^T
+    bf16x8 qf[3][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        qf[p][ks] = *reinterpret_cast<const bf16x8*>(qkv3 + (int64_t)p * plane_elems +
+                                                     ((int64_t)(2 * h + (ks >> 1)) * rows_total + (int64_t)b * L + qrow) * 32 + ((ks & 1) * 2 + hh) * 8);
+    __builtin_amdgcn_s_barrier();                       // B1
+    AP3_STAGE_SHARED(item, 2, 6, 0);                    // this wave's share of V(item)
+    f32x16 sacc[7];
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cst = (ks >> 1) * AP3_BLK_B + 32 * kt * 64;        // panel of the d step, key tile (swizzle: row bits 2..3 = li's)
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + cst);
+        const bf16x8 km = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + 2 * AP3_BLK_B + cst);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1l : ka0l) + cst);
+        // smallest cross terms first: (hi,lo) (mid,mid) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
+        if ((AP3_ABL & 8) && nitems != 12345) { sacc[kt][0] += (float)kh[0] + (float)km[0] + (float)kl[0]; continue; }
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[2][ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[1][ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ks], sacc[kt], 0, 0, 0);
+      }
+#if !AP3_NOFENCE
+      __builtin_amdgcn_sched_barrier(0);                // keep the tiles' fragment loads from piling up (register budget)
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of V(item) landed
+    __builtin_amdgcn_s_barrier();                       // B2
+    // ---------------------------------------------------------------- phase B: softmax, O^T = V^T P^T
+    // lane (query li, half hh) holds the scores of keys 32 kt + (e & 3) + 8 (e >> 2) + 4 hh
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (kt == 6) {                                  // 192 < L <= 208: only the last tile is cut
+          const int key = 192 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          sacc[kt][e] = key < L ? sacc[kt][e] : -INFINITY;
+        }
+        mx = fmaxf(mx, sacc[kt][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * sc;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (!(AP3_ABL & 1) || nitems == 12345) sacc[kt][e] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], sc, -mxs));      // v_exp_f32: 2^x, exp2(-inf) = 0
+        sum += sacc[kt][e];
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    f32x16 oacc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 13; ++st) {                   // 16-key steps; keys >= 208 are all masked
+      const int kt = st >> 1, u = st & 1;
+      const float pv[8] = {sacc[kt][8 * u], sacc[kt][8 * u + 1], sacc[kt][8 * u + 2], sacc[kt][8 * u + 3],
+                           sacc[kt][8 * u + 4], sacc[kt][8 * u + 5], sacc[kt][8 * u + 6], sacc[kt][8 * u + 7]};
+      bf16x8 ph, pm, pl;
+      if ((AP3_ABL & 32) && nitems != 12345) { ph = pm = pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&pv[0])); } else
+      ap3_split8(pv, ph, pm, pl);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16x8 vf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const char* vb = smem + (p == 2 ? va2 : va) + ((p == 2 ? 0 : 2 * p) + dt) * AP3_BLK_B + (16 * st) * 64;
+          const ap3_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ap3_lds_s16x4*)(vb));
+          const ap3_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ap3_lds_s16x4*)(vb + 8 * 64));
+          typedef short s16x8_ __attribute__((ext_vector_type(8)));
+          const s16x8_ v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          vf[p] = __builtin_bit_cast(bf16x8, v8);
+        }
+        if ((AP3_ABL & 4) && nitems != 12345) { oacc[dt][0] += (float)vf[0][0] + (float)vf[1][0] + (float)vf[2][0] + (float)ph[0] + (float)pm[0] + (float)pl[0]; continue; }
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], ph, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pm, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pl, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], ph, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pm, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, oacc[dt], 0, 0, 0);
+      }
+#if !AP3_NOFENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    // normalise, split into planes, store: lane (query li, hh) holds d = 32 dt + (e & 3) + 8 (e >> 2) + 4 hh, i.e. for every
+    // group g4 of four registers an 8-byte piece of its row; v_permlane32_swap pairs the pieces of the two lane halves -- half
+    // 0 ends up with d = 16 gp .. + 7, half 1 with d = 16 gp + 8 .. + 15 of the row: 16-byte stores, 12 per wave and item
+    const float inv = 1.f / sum;
+    const int q = 32 * wave + li;
+    const bool st_ok = q < L && (!(AP3_ABL & 2) || nitems == 12345);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        uint2 pl_[2][3];                                  // [g4 = 2 gp + {0, 1}][plane]
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+          const int g4 = 2 * gp + z;
+          const float ov[4] = {oacc[dt][4 * g4] * inv, oacc[dt][4 * g4 + 1] * inv, oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv};
+          uint2 ph2, pm2, pl2;
+          ph2.x = f2bf2(ov[0], ov[1]); ph2.y = f2bf2(ov[2], ov[3]);
+          const float r0 = ov[0] - __uint_as_float(ph2.x << 16), r1 = ov[1] - __uint_as_float(ph2.x & 0xffff0000u);
+          const float r2 = ov[2] - __uint_as_float(ph2.y << 16), r3 = ov[3] - __uint_as_float(ph2.y & 0xffff0000u);
+          pm2.x = f2bf2(r0, r1); pm2.y = f2bf2(r2, r3);
+          pl2.x = f2bf2(r0 - __uint_as_float(pm2.x << 16), r1 - __uint_as_float(pm2.x & 0xffff0000u));
+          pl2.y = f2bf2(r2 - __uint_as_float(pm2.y << 16), r3 - __uint_as_float(pm2.y & 0xffff0000u));
+          pl_[z][0] = ph2; pl_[z][1] = pm2; pl_[z][2] = pl2;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          // swap(X = piece of g4 = 2 gp, Y = piece of g4 = 2 gp + 1): half 0 gets (own X, partner's X), half 1 (partner's Y, own Y)
+          typedef unsigned ap3_u2 __attribute__((ext_vector_type(2)));
+          const ap3_u2 w0 = __builtin_amdgcn_permlane32_swap(pl_[0][p].x, pl_[1][p].x, false, false);
+          const ap3_u2 w1 = __builtin_amdgcn_permlane32_swap(pl_[0][p].y, pl_[1][p].y, false, false);
+          // half 0: w0[0], w1[0] = own X (d 0..3), w0[1], w1[1] = partner's X (d 4..7); half 1: [0] = partner's Y (d 0..3), [1] = own Y
+          const uint4 v16 = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+          if (st_ok) {
+            u16* dst = out3 + (int64_t)p * out_plane_elems + ((int64_t)(2 * h + dt) * rows_total + (int64_t)b * L + q) * 32 + 8 * (2 * gp + hh);
+            *reinterpret_cast<uint4*>(dst) = v16;
+          }
+        }
+      }
+  }
+#undef AP3_STAGE_SHARED
+#undef AP3_STAGE
+#undef AP3_GLDS
+}
+}  // namespace
+
+// q | k | v as three bf16 planes in K-panel layout (ACX_BF16X3P of the [batch * L, 3 heads * 64] in-projection output) ->
+// attention output as three bf16 planes in K-panel layout ([heads * 64 / 32][batch * L][32]); 128 < L <= 208, non-causal
+extern "C" int acx_attention_p3(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads,
+                                void* stream) {
+  if (!qkv_planes || !out_planes) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_p3: null pointer%s");
+  if (batch <= 0) return ACX_OK;
+  if (L <= 192 || L > AP3_ROWS || heads <= 0 || (((uintptr_t)qkv_planes | (uintptr_t)out_planes) & 15))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention_p3: 192 < L <= 208, 16-byte aligned planes%s");
+  const int64_t rows = (int64_t)batch * L;
+  const int nitems = batch * heads;
+  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_ATTN, s);
+  const int dev_slot = (ctx ? ctx->device : 0) & 63;
+  static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_p3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B); attr_done = true; }
+  hipLaunchKernelGGL(attn_p3_kernel, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
+                     rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems);
+  ACX_CHECK_LAUNCH(ctx, "acx_attention_p3");
+  return ACX_OK;
+}
+
 extern "C" int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
                                 int32_t batch, int32_t L, int32_t heads, void* stream) {
   return attention_impl(ctx, qkv, ldqkv, (float*)out_planes, ldo, batch, L, heads, 0, stream, 1);

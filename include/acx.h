@@ -156,6 +156,12 @@ int acx_attention(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out, int
  * plane p at (uint16_t*)out_planes + p * batch * L * ldo): the out-projection's A operand in ACX_PREC_F32X6 mode */
 int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
                      int32_t batch, int32_t L, int32_t heads, void* stream);
+/* The ViT attention on the bf16 matrix cores at f32 accuracy (clip/model.py:206-212 in the ACX_PREC_F32X6 mode): q | k | v as
+ * three bf16 planes in K-panel layout (ACX_BF16X3P of the in-projection output [batch * L, 3 heads * 64]: plane p at
+ * (uint16_t*)qkv_planes + p * batch * L * 3 * heads * 64), S = Q K^T and O = P V as six-product bf16 x 6 products with f32
+ * accumulation, softmax in f32; output = three bf16 planes of [batch * L, heads * 64] in K-panel layout (the out-projection's
+ * A operand).  Non-causal, 192 < L <= 208 (seven 32-query tiles: the ViT-B/16 sequence of 197). */
+int acx_attention_p3(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads, void* stream);
 /* ... with the planes in K-panel layout (ACX_BF16X3P: [ldo / 32][batch * L][32] each; ldo == heads * 64) */
 int acx_attention_x3_panel(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
                            int32_t batch, int32_t L, int32_t heads, void* stream);

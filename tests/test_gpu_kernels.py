@@ -601,6 +601,32 @@ def test_gemm_bf16x6_is_f32_accurate(M, N, K, act, res):
         ops.gemm_x6(a3[:, :, :40].contiguous(), w3[:, :, :40].contiguous(), bias=bd)
 
 
+@pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (1, 193, 1), (40, 197, 12)])
+def test_attention_p3_vs_fp64(batch, L_, heads):
+    """acx_attention_p3 (q, k, v as three bf16 planes in K-panel layout; QK^T and PV as bf16 x 6 products, softmax in f32) against
+    fp64 softmax attention and against the f32 MFMA kernel on the same inputs: no worse than 1.5 x the f32 kernel's maximum
+    error, identical sequences give bit-identical outputs wherever they sit in the batch."""
+    W = heads * 64
+    g = torch.Generator().manual_seed(batch * 1000 + L_)
+    qkv = torch.randn(batch * L_, 3 * W, generator=g) * 1.7
+    qkv[:, :W] *= 1.5                                  # logits of a few units: a peaked softmax
+    if batch > 2:
+        qkv[(batch - 1) * L_:] = qkv[:L_]              # the last sequence repeats the first
+    qd = qkv.to(DEV)
+    q3 = ops.split_bf16x3(qd, panel=True)
+    o3 = ops.attention_p3(q3, batch, L_, heads)
+    out = ops.unpanel(o3).float().sum(0)
+    ref32 = ops.attention(qd, batch, L_, heads, False)
+    x = qd.double().view(batch, L_, 3, heads, 64)
+    q_, k_, v_ = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q_ @ k_.transpose(-1, -2) / 8.0, dim=-1) @ v_).transpose(1, 2).reshape(batch * L_, W)
+    e3, e32 = (out.double() - ref).abs().max().item(), (ref32.double() - ref).abs().max().item()
+    print("max |err| vs fp64: planes", e3, " f32 MFMA", e32)
+    assert torch.isfinite(out).all() and e3 <= 1.5 * e32 + 1e-9 and e3 <= 2e-6 * ref.abs().max().item()
+    if batch > 2:
+        assert torch.equal(out[(batch - 1) * L_:], out[:L_])
+
+
 def test_split_bf16x3_edge_values():
     """acx_split_bf16x3 at the edges of f32: the split is EXACT (hi + mid + lo == x bit for bit) for every finite x whose lo
     plane stays a normal bf16 number; below that (|x| < 2^-110: the third plane falls under 2^-126) the reconstruction error is
