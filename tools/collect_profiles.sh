@@ -1,17 +1,20 @@
 #!/bin/bash
 # Copies what tools/refresh_profiles.sh left under gpurun_out/ into profiles/<tag>_* (run in the development container after
-# the gpurun call merged its outputs back).  usage: tools/collect_profiles.sh [tag]   (default r04)
+# the gpurun call merged its outputs back).  usage: tools/collect_profiles.sh [tag]   (default r05)
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(cd "$(dirname "$0")/.." && pwd)
 G=$R/gpurun_out
 P=$R/profiles
 cd $R
+cp $G/refresh/bench_auto.json $P/${TAG}_bench_auto.json
 cp $G/refresh/bench_f32.json $P/${TAG}_bench_f32.json
 cp $G/refresh/bench_bf16.json $P/${TAG}_bench_bf16.json
-cp $G/refresh/bench_f32x6.json $P/${TAG}_bench_f32x6.json
-cp $G/refresh/bench_f32x6_kernel_stats.csv $P/${TAG}_bench_f32x6_kernel_stats.csv
 grep -v amdgpu.ids $G/refresh/x6_probe.txt > $P/${TAG}_gemm_bf16x6_vs_f32.txt
+{ echo "# tools/probes/x6_time.py all (the plane-reuse kernel: ViT shapes at 512 frames, the head's convolutions and weight gradients)"; grep -v amdgpu.ids $G/refresh/x6_time.txt;
+  echo "# tools/probes/attn_p3_time.py"; grep -v amdgpu.ids $G/refresh/attn_p3_time.txt; } > $P/${TAG}_x6_kernels.txt
+cp $G/refresh/bench_head_f32.json $P/${TAG}_bench_head_f32.json
+cp $G/refresh/bench_head_f32_emulated_world8.json $P/${TAG}_bench_head_f32_emulated_world8.json
 cp $G/refresh/bench_head.json $P/${TAG}_bench_head.json
 cp $G/refresh/bench_head_eager.json $P/${TAG}_bench_head_eager.json
 for n in 1 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_bench_head_emulated_world$n.json; done
@@ -30,7 +33,8 @@ cp $G/refresh/feature_stream.json $P/${TAG}_feature_stream.json
   echo "# tools/attn_bench.py, tools/attn_bf16_bench.py"; grep -v amdgpu.ids $G/refresh/attn.txt;
   echo "# tools/probes/selector_bench.py"; grep -v amdgpu.ids $G/refresh/selector_bench.txt; } > $P/${TAG}_kernel_microbench.txt
 grep -v amdgpu.ids $G/refresh/text_gemm.txt > $P/${TAG}_text_gemm.txt
-python tools/summarize_pmc.py gpurun_out/prof_bench $TAG f32 > /dev/null
+python tools/summarize_pmc.py gpurun_out/prof_bench_auto $TAG auto > /dev/null
+python tools/summarize_pmc.py gpurun_out/prof_bench_f32 $TAG f32 > /dev/null
 python tools/summarize_pmc.py gpurun_out/prof_bench_bf16 $TAG bf16 > /dev/null
 cp $G/prof_extra/train/t_kernel_stats.csv $P/${TAG}_train_step_kernel_stats.csv
 cp $G/prof_extra/dp8/dp8_kernel_stats.csv $P/${TAG}_dp8_rank_share_kernel_stats.csv

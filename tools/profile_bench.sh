@@ -1,11 +1,10 @@
 #!/bin/bash
 # rocprofv3 captures of bench.py (run on the GPU box through gpurun).  Counter passes are separate runs with
 # --kernel-trace only (gpurun refuses --pmc together with sys/hip traces).  Outputs under gpurun_out/prof_bench/.
-# usage: profile_bench.sh [f32|bf16|f32x6]   (other than f32: that mode of the headline step -> gpurun_out/prof_bench_<mode>/)
-PREC=${1:-f32}
+# usage: profile_bench.sh [auto|f32|bf16]   (auto = the default / headline; -> gpurun_out/prof_bench_<mode>/)
+PREC=${1:-auto}
 cd /tmp && export TMPDIR=/tmp
-OUT=/root/repo/gpurun_out/prof_bench
-[ "$PREC" != "f32" ] && OUT=/root/repo/gpurun_out/prof_bench_$PREC
+OUT=/root/repo/gpurun_out/prof_bench_$PREC
 rm -rf $OUT; mkdir -p $OUT
 CMD="python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-live-pmc --precision $PREC"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1

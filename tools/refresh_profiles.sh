@@ -1,16 +1,18 @@
 #!/bin/bash
-# One pass over everything profiles/r04_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
+# One pass over everything profiles/r05_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
 set -x
 R=/root/repo
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-python bench.py --steps 10 --warmup 3 > $OUT/bench_f32.json 2> $OUT/bench_f32.err
+# the default (precision auto: f32 results, the large products as bf16 x 6 on the bf16 matrix cores) = the driver's command
+python bench.py --steps 10 --warmup 3 > $OUT/bench_auto.json 2> $OUT/bench_auto.err
 python bench.py --steps 10 --warmup 3 --precision bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
-# f32 with the ViT's large GEMMs as f32-accurate bf16 x 6 products (a leg of the default run; here as its own line + kernel statistics)
-python bench.py --steps 10 --warmup 3 --precision f32x6 --no-cpu-baseline > $OUT/bench_f32x6.json 2> $OUT/bench_f32x6.err
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/px6 -o x6 -- python $R/bench.py --steps 5 --warmup 1 --precision f32x6 --no-cpu-baseline --no-extra-legs > /dev/null 2>&1; cp $(find /tmp/px6 -name '*kernel_stats.csv' | head -1) $OUT/bench_f32x6_kernel_stats.csv)
+# the f32 MFMA kernels everywhere (a leg of the default run; here as its own line)
+python bench.py --steps 10 --warmup 3 --precision f32 --no-cpu-baseline > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 python tools/probes/x6_probe.py > $OUT/x6_probe.txt 2>&1
+python tools/probes/x6_time.py all > $OUT/x6_time.txt 2>&1
+python tools/probes/attn_p3_time.py > $OUT/attn_p3_time.txt 2>&1
 # train_batch's default = the whole-step graph; --no-step-graph = its autograd fallback (with / without its own graphs)
 python tools/bench_head.py --steps 40 --warmup 5 > $OUT/bench_head.json 2>/dev/null
 python tools/bench_head.py --steps 20 --no-step-graph > $OUT/bench_head_eager.json 2>/dev/null
@@ -39,7 +41,10 @@ python tools/bench_preprocess.py 2>/dev/null | tail -1 > $OUT/preprocess.json
 python tools/bench_preprocess.py --hw 720x1280 --frames 64 --cpu-frames 8 2>/dev/null | tail -1 >> $OUT/preprocess.json
 python tools/bench_feature_stream.py 2>/dev/null | tail -1 > $OUT/feature_stream.json
 ACX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_gloo2_smoke.json 2> $OUT/bench_gloo2_smoke.err
+bash tools/profile_bench.sh auto > $OUT/profile_bench_auto.log 2>&1
 bash tools/profile_bench.sh f32 > $OUT/profile_bench.log 2>&1
 bash tools/profile_bench.sh bf16 > $OUT/profile_bench_bf16.log 2>&1
+python tools/bench_head.py --steps 40 --warmup 5 --precision f32 > $OUT/bench_head_f32.json 2>/dev/null
+python tools/bench_head.py --steps 40 --warmup 5 --emulate-world 8 --precision f32 > $OUT/bench_head_f32_emulated_world8.json 2>/dev/null
 bash tools/profile_extra.sh > $OUT/profile_extra.log 2>&1
 ls -la $OUT

@@ -14,7 +14,7 @@ for d in ("fetch", "write", "sq", "grbm", "l2"):
     for r in rows(d):
         name = r["Kernel_Name"]
         kind = "gemm" if ("gemm_" in name and "reduce" not in name) else (
-            "attn" if ("attn_kernel" in name or "attn16_kernel" in name or "attn_bf16_kernel" in name) else None)
+            "attn" if ("attn_kernel" in name or "attn16_kernel" in name or "attn_bf16_kernel" in name or "attn_p3_kernel" in name) else None)
         if kind is None:
             continue
         agg[kind][r["Counter_Name"]] += float(r["Counter_Value"])
