@@ -842,9 +842,10 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const bool c_x3 = d->c_dtype == ACX_BF16X3;
   if (c_x3 && (!ring_ok || d->residual || ((d->K / 64) * (d->pairs > 1 ? d->pairs : 1)) % 2 || !ACX_DBG_SWITCH("P8", true)))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: c_dtype ACX_BF16X3 needs the persistent 256x256 bf16 kernel and no residual%s");
-  if (d->pairs > 1 && (d->pairs != 6 || !ring_ok || d->a_plane_stride <= 0 || d->w_plane_stride <= 0 ||
-                       ((d->a_plane_stride | d->w_plane_stride) & 15)))
-    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 needs bf16 planes (16-byte aligned strides) and a problem the persistent 256x256 kernel takes%s");
+  // (pairs = 6 problems were taken by the plane-reuse kernel above; the PAIRS instantiation of the kernel below -- round 4's route,
+  // six plain products one after the other -- is no longer built)
+  if (d->pairs > 1)
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 needs bf16 planes (16-byte aligned strides), K %% 32 == 0, N %% 4 == 0 (plane output: N %% 8 == 0), identity rows or CONV3X3 on a power-of-two grid%s");
   if (ring_ok) {
     const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     const dim3 rgrid((unsigned)(rtiles < ncu ? rtiles : ncu));
@@ -856,16 +857,6 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 / ACX_BF16X3 output need the persistent 256x256 kernel%s");
 #define ACX_RING_L(CB, ACT, RES)                                                                    \
   do {                                                                                              \
-    if (p8 && d->pairs > 1) {                                                                       \
-      static bool attr6_dev_[64] = {}; bool& attr6_done = attr6_dev_[dev_slot];                     \
-      if (!attr6_done) {                                                                            \
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<CB, ACT, RES, 1>,                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_B);       \
-        attr6_done = true;                                                                          \
-      }                                                                                             \
-      hipLaunchKernelGGL((gemm_bf16_p8_kernel<CB, ACT, RES, 1>), rgrid, dim3(512), (size_t)P8_LDS_B, s, g); \
-      break;                                                                                        \
-    }                                                                                               \
     if (p8) {                                                                                       \
       static bool attr8_dev_[64] = {}; bool& attr8_done = attr8_dev_[dev_slot];                                                               \
       if (!attr8_done) {                                                                            \

@@ -127,10 +127,14 @@ typedef struct acx_gemm_desc {
                              cores.  A and W are each THREE bf16 planes (acx_split_bf16x3: x = hi + mid + lo to 24 bits; plane p of
                              A at A + p * a_plane_stride bytes, of W at W + p * w_plane_stride), and C accumulates, in f32, the six
                              cross products whose magnitude is >= 2^-16 of the leading one -- (hi,lo) (mid,mid) (lo,hi) (hi,mid)
-                             (mid,hi) (hi,hi), smallest first.  Every bf16 x bf16 product is exact in f32; the three dropped terms
-                             and the split remainders are <= 2^-23 of the product: the error is that of an f32 dot product, at
-                             6/16 of the f32 MFMA's cost (2.5 PFLOP/s bf16 against 157 TFLOP/s f32 on gfx950).  Large
-                             problems only (the persistent 256x256 kernel); K % 128 == 0. */
+                             (mid,hi) (hi,hi): per 32-wide k range, smallest first.  Every bf16 x bf16 product is exact in f32; the
+                             three dropped terms and the split remainders are <= 2^-23 of the product: the error is that of an
+                             f32 dot product, at 6/16 of the f32 MFMA's cost (2.5 PFLOP/s bf16 against 157 TFLOP/s f32 on gfx950).
+                             Kernel: gemm_x6_p4_kernel (csrc/acx_gemm_x6.h).  K % 32 == 0, N % 4 == 0, 16-byte aligned planes; row
+                             maps IDENTITY and CONV3X3 (power-of-two grid, cin % 32 == 0, M % 256 == 0, zero_page); epilogues bias,
+                             QuickGELU / LeakyReLU, residual (f32 C), c_dtype ACX_F32 / ACX_BF16 / ACX_BF16X3[P] (plane output:
+                             N % 8 == 0, no residual).  With `workspace`, launches of fewer output tiles than CUs split K across
+                             workgroups (fixed split per shape; partial tiles + the generic reduce launch). */
   int32_t panels;         /* pairs = 6: bit 0 -- the A planes are in K-panel layout (ACX_BF16X3P, rows = a_plane_stride / (2 K));
                              bit 1 -- the W planes are (rows = N).  Identity row map only. */
   int64_t a_plane_stride, w_plane_stride;   /* bytes */
@@ -187,7 +191,8 @@ int acx_vit_embed(acx_ctx* ctx, const float* patch_out, const float* cls, const 
                   void* stream);
 
 /* Transformer block weights (clip/model.py:188-217).  All f32 masters; the *_bf16 pointers are
- * the bf16 copies used when prec == ACX_PREC_BF16 (may be NULL otherwise). */
+ * the bf16 copies used when prec == ACX_PREC_BF16, or -- prec == ACX_PREC_F32X6 -- the THREE bf16 planes of the f32 weight in
+ * K-panel layout (acx_split_bf16x3_panel: plane p at base + p * rows * cols * 2 bytes); may be NULL otherwise. */
 typedef struct acx_block_weights {
   const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
   const float *in_proj_w, *in_proj_b;     /* [3W, W], [3W] */
