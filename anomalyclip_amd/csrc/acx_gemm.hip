@@ -855,6 +855,30 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
                     (size_t)d->N * d->ldw * 2 < ((size_t)1 << 32) && ACX_DBG_SWITCH("P8", true);
     if ((d->pairs > 1 || c_x3) && !p8)
       return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 / ACX_BF16X3 output need the persistent 256x256 kernel%s");
+#ifdef ACX_DEBUG_SWITCHES
+    // A/B only (tools build, ACX_P4=1): the one-wave-per-SIMD frame's PLAIN schedule (acx_gemm_x6.h: 64-k super-steps, 64 MFMAs per
+    // wave and barrier).  Measured equal to or 3-15 % behind the p8 kernel on the ViT shapes, its K loop alone (no DMA, no stores)
+    // at 0.46 of the bf16 roof (profiles/r05_gemm_plain_bf16_notes.txt): not a product route.
+    if (p8 && !c_x3 && !(c_bf16 && d->residual) && d->act != ACX_ACT_LEAKYRELU && ACX_DBG_SWITCH("P4", false)) {
+      g.d.panels = 0; g.ksplit = 1; g.partial = nullptr;
+#define ACX_P4L(CM, ACT, RES)                                                                       \
+  do {                                                                                              \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                          \
+    if (!attr_done) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<CM, ACT, RES, 0, 0, 1>,              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B);         \
+      attr_done = true;                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_x6_p4_kernel<CM, ACT, RES, 0, 0, 1>), rgrid, dim3(256), (size_t)X6_LDS_B, s, g); \
+  } while (0)
+      if (d->residual) ACX_P4L(0, 0, 1);
+      else if (d->act == ACX_ACT_QUICKGELU) { if (c_bf16) ACX_P4L(1, 1, 0); else ACX_P4L(0, 1, 0); }
+      else { if (c_bf16) ACX_P4L(1, 0, 0); else ACX_P4L(0, 0, 0); }
+#undef ACX_P4L
+      ACX_CHECK_LAUNCH(ctx, "acx_gemm");
+      return ACX_OK;
+    }
+#endif
 #define ACX_RING_L(CB, ACT, RES)                                                                    \
   do {                                                                                              \
     if (p8) {                                                                                       \

@@ -64,7 +64,12 @@ __device__ __forceinline__ bf16x8 x6_tr_frag(const char* smem, int off_lo, int o
 // lies inside one tap), zero page outside the grid and behind the last row.  A unit is then 32 rows x 256 channels (k-major,
 // 512 B per row, its eight 64-byte chunks XOR-swizzled by row & 7); the product structure, the slots and the waits are those
 // of the NT kernel.  Output: raw f32 (ksplit > 1: partial tiles for tn_reduce_kernel).
-template <int C_MODE, int ACT, int RES, int CONV, int TN = 0>
+// PLAIN != 0: an ordinary bf16 product (one plane per operand: acx_gemm with prec = ACX_PREC_BF16, bf16 A, pairs <= 1) on the same
+// one-wave-per-SIMD frame -- work items, LDS-DMA units, fragments and the epilogue are shared; the K loop walks SUPER-STEPS of 64 k:
+// four units (A and W of two 32-wide K-steps) per super-step, 64 MFMAs per wave behind one barrier in four blocks of 16, the
+// fragments of block b + 1 read between the MFMAs of block b, the next super-step's four units requested between the MFMAs of the
+// first block (two unit parities in the eight LDS slots).  K % 64 == 0.
+template <int C_MODE, int ACT, int RES, int CONV, int TN = 0, int PLAIN = 0>
 __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   const int b0 = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + ((int)blockIdx.x >> 3);
   const int my_items = b0 < nitems ? (nitems - b0 + G - 1) / G : 0;
   if (my_items == 0) return;
-  const int nks = (d.K + 31) / 32;               // K-steps of a tile (TN: the last one may be ragged: zero page)
+  const int nks = PLAIN ? d.K / 64 : (d.K + 31) / 32;   // K-steps of a tile (TN: the last one may be ragged: zero page; PLAIN: super-steps)
   const int spi = (nks + ksplit - 1) / ksplit;   // K-steps per item; the last K range of a tile takes what is left (dispatch: > 0)
 
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
@@ -148,31 +153,31 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
                  : : "v"(gptr), "s"(ldsaddr) : "memory");                                          \
   } while (0)
   // instruction i (0..3) of this wave's share of a unit: plane `pl` of A at K-step S (row offsets RA, tap masks VM) -> slot
-#define X6_DMA_A(S, RA, VM, pl, slot, i)                                                           \
+#define X6_DMA_A_K(S, KK, RA, VM, pl, slot, i)                                                           \
   do {                                                                                             \
     const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (4 * wave + (i)) * 1024;                       \
     const char* b_ = (const char*)d.A + (size_t)(pl) * (size_t)d.a_plane_stride;                   \
     if constexpr (TN != 0) {                                                                       \
-      const int m_ = S.kk * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
+      const int m_ = (KK) * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
       const char* p_ = b_ + ((size_t)(unsigned)m_ * (size_t)(d.lda * 2) + (size_t)(S.m0 * 2 + X6_TCH(i))); \
       X6_GLDS_V(m_ < d.K ? p_ : zsrc, l_);                                                         \
     } else if constexpr (CONV != 0) {                                                              \
-      const int tap_ = S.kk / steps_per_tap, kc_ = S.kk - tap_ * steps_per_tap;                    \
+      const int tap_ = (KK) / steps_per_tap, kc_ = (KK) - tap_ * steps_per_tap;                    \
       const int t3_ = tap_ / 3;                                                                    \
       const int dn_ = t3_ - 1, dl_ = tap_ - 3 * t3_ - 1;                                           \
       const char* bt_ = b_ + ((ptrdiff_t)(dn_ * d.gl + dl_) * d.lda * 2 + kc_ * 64);   /* uniform: tap shift + channel block */ \
       const bool ok_ = (VM[i] >> tap_) & 1u;                                                       \
       X6_GLDS_V(ok_ ? bt_ + RA[i] : zsrc, l_);                                                     \
     } else {                                                                                       \
-      X6_GLDS_S(b_ + (size_t)S.kk * a_kstride, RA[i], l_);                                         \
+      X6_GLDS_S(b_ + (size_t)(KK) * a_kstride, RA[i], l_);                                         \
     }                                                                                              \
   } while (0)
-#define X6_DMA_W(S, RW, pl, slot, i)                                                               \
+#define X6_DMA_W_K(S, KK, RW, pl, slot, i)                                                               \
   do {                                                                                             \
     const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (4 * wave + (i)) * 1024;                       \
     if constexpr (TN != 0) {                                                                       \
       const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride;                 \
-      const int m_ = S.kk * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
+      const int m_ = (KK) * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
       bool ok_ = m_ < d.K;                                                                         \
       int row_ = m_;                                                                               \
       if constexpr (CONV != 0) {                                                                   \
@@ -183,14 +188,28 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       const char* p_ = b_ + ((size_t)(unsigned)(ok_ ? row_ : 0) * (size_t)(d.ldw * 2) + (size_t)(S.c0 * 2 + X6_TCH(i))); \
       X6_GLDS_V(ok_ ? p_ : zsrc, l_);                                                              \
     } else {                                                                                       \
-      const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride + (size_t)S.kk * w_kstride; \
+      const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride + (size_t)(KK) * w_kstride; \
       X6_GLDS_S(b_, RW[i], l_);                                                                    \
     }                                                                                              \
   } while (0)
 
+#define X6_DMA_A(S, RA, VM, pl, slot, i) X6_DMA_A_K(S, S.kk, RA, VM, pl, slot, i)
+#define X6_DMA_W(S, RW, pl, slot, i) X6_DMA_W_K(S, S.kk, RW, pl, slot, i)
+
   X6Src c0, c1;                                  // K-steps gs and gs + 1 of the stream
   unsigned ra0[4], rw0[4], vm0[4] = {0u, 0u, 0u, 0u}, ra1[4], rw1[4], vm1[4] = {0u, 0u, 0u, 0u};
   c0.tk = 0; c0.j = 0; X6_SET_ITEM(c0, 0); X6_ROWS(c0, ra0, rw0, vm0);
+  if constexpr (PLAIN != 0) {
+    // ---- prologue (PLAIN): the four units of super-step 0 -> slots 0..3 (A of k-step 0, A of k-step 1, W, W)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_A_K(c0, 2 * c0.kk, ra0, vm0, 0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_A_K(c0, 2 * c0.kk + 1, ra0, vm0, 0, 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_W_K(c0, 2 * c0.kk, rw0, 0, 2, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_W_K(c0, 2 * c0.kk + 1, rw0, 0, 3, i);
+  } else {
   // ---- prologue: W.hi, W.mid, A.hi, W.lo of K-step 0 (parity 0 slots)
 #pragma unroll
   for (int i = 0; i < 4; ++i) X6_DMA_W(c0, rw0, 0, X6_WH0, i);
@@ -200,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   for (int i = 0; i < 4; ++i) X6_DMA_A(c0, ra0, vm0, 0, X6_AH, i);
 #pragma unroll
   for (int i = 0; i < 4; ++i) X6_DMA_W(c0, rw0, 2, X6_WL, i);
+  }
   c1 = c0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { ra1[i] = ra0[i]; rw1[i] = rw0[i]; vm1[i] = vm0[i]; }
@@ -278,6 +298,59 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   for (int j = 0; j < my_items; ++j) {
     const int steps_j = c0.steps;                // (c0 is at the item's first K-step here)
     for (int tk = 0; tk < steps_j; ++tk) {
+      if constexpr (PLAIN != 0) {
+        // ======================================================================= one super-step (64 k) of a plain product
+        const int par = wpar ? 4 * X6_UNIT_B : 0, nxt = wpar ? 0 : 4;       // this super-step's slots (byte offset), the next one's (slot)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        X6_FENCE();
+        __builtin_amdgcn_s_barrier();
+        X6_FENCE();
+        // fragment q (0..3: row blocks of A, 4..7: column blocks of W) of substep s (0..3: 16 k each; 0, 1 in the first K-step's units)
+#define X6_RD_P(F, s, q)                                                                           \
+  do {                                                                                             \
+    if ((q) < 4) F[q] = X6_FRAG(par + ((s) >> 1) * X6_UNIT_B + (((s) & 1) ? fa1 : fa0) + (q) * 2048); \
+    else F[q] = X6_FRAG(par + (2 + ((s) >> 1)) * X6_UNIT_B + (((s) & 1) ? fw1 : fw0) + ((q) - 4) * 2048); \
+  } while (0)
+#define X6_MM_P(F, q) acc[(q) >> 2][(q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[4 + ((q) & 3)], F[(q) >> 2], acc[(q) >> 2][(q) & 3], 0, 0, 0)
+        // block A: the previous super-step's last substep (F1; zero at an item's first super-step) + reads of substep 0 -> F0 + the
+        // 16 DMA instructions of the NEXT super-step's units (their slots were read last before the barrier above)
+#define X6_BA(q)                                                                                   \
+  do {                                                                                             \
+    if constexpr ((q) < 8) X6_RD_P(F0, 0, (q) & 7);                                                \
+    { constexpr int u_ = ((q) >> 2) & 3, i_ = (q) & 3;                                             \
+      if (u_ == 0) X6_DMA_A_K(c1, 2 * c1.kk, ra1, vm1, 0, nxt + 0, i_);                            \
+      else if (u_ == 1) X6_DMA_A_K(c1, 2 * c1.kk + 1, ra1, vm1, 0, nxt + 1, i_);                   \
+      else if (u_ == 2) X6_DMA_W_K(c1, 2 * c1.kk, rw1, 0, nxt + 2, i_);                            \
+      else X6_DMA_W_K(c1, 2 * c1.kk + 1, rw1, 0, nxt + 3, i_); }                                   \
+    X6_MM_P(F1, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+#define X6_BX(q, FC, FN, sn)                                                                       \
+  do {                                                                                             \
+    if constexpr ((q) < 8) X6_RD_P(FN, sn, (q) & 7);                                               \
+    X6_MM_P(FC, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+#define X6_REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+        X6_REP16(X6_BA)
+#define X6_BB(q) X6_BX(q, F0, F1, 1)
+#define X6_BC(q) X6_BX(q, F1, F0, 2)
+#define X6_BD(q) X6_BX(q, F0, F1, 3)
+        X6_REP16(X6_BB)
+        X6_REP16(X6_BC)
+        X6_REP16(X6_BD)
+#undef X6_BD
+#undef X6_BC
+#undef X6_BB
+#undef X6_BX
+#undef X6_BA
+        wpar = wpar ? 0 : 1;
+        c0 = c1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra0[i] = ra1[i]; rw0[i] = rw1[i]; vm0[i] = vm1[i]; }
+        X6_ADVANCE(c1, ra1, rw1, vm1);
+        continue;
+      }
       const int wnext = wpar ? 0 : 6 * X6_UNIT_B;
       const int slot_wh_next = wpar ? X6_WH0 : X6_WH1, slot_wm_next = wpar ? X6_WM0 : X6_WM1;
       // =========================================================================== half-step X
@@ -346,9 +419,15 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     }
     // ---- item end: the last substep (F1, Y products), then the epilogue.  The DMA queue is drained first: the epilogue's
     // stores must not sit in front of a counted wait (one in-order vmcnt for loads and stores)
+    if constexpr (PLAIN != 0) {
+#define X6_DRAINP(q) X6_MM_P(F1, (q));
+      X6_REP16(X6_DRAINP)
+#undef X6_DRAINP
+    } else {
 #define X6_DRAIN(q) X6_MM_Y(F1, (q));
     X6_REP48(X6_DRAIN)
 #undef X6_DRAIN
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const int L = b0 + j * G;
@@ -507,6 +586,11 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no DMA may still be writing this workgroup's LDS at exit
 #undef X6_REP48
+#undef X6_REP16
+#undef X6_MM_P
+#undef X6_RD_P
+#undef X6_DMA_W_K
+#undef X6_DMA_A_K
 #undef X6_FENCE
 #undef X6_MM_Y
 #undef X6_MM_X
