@@ -15,7 +15,7 @@ PREC_F32, PREC_BF16, PREC_F32X6 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1
-OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS = 1, 2, 3
+OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS, OPT_X6_CUS = 1, 2, 3, 4
 
 
 class GemmDesc(C.Structure):
@@ -104,6 +104,7 @@ _SIGS = {
                                        c_void_p]),
     "acx_probe_mfma": (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, C.POINTER(C.c_double), c_void_p]),
     "acx_probe_copy": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "acx_probe_read": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "acx_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "acx_bn_combine": (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acx_bn_stats": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -26,6 +26,7 @@ The reference hard-codes /usr/src/app/logs/{train,eval}/runs/<run> (:409,:596); 
 `hparams.logs_root` (default "/usr/src/app/logs")."""
 from __future__ import annotations
 
+import contextlib
 import json
 import os
 from pathlib import Path
@@ -35,6 +36,9 @@ import torch
 
 from . import ops, parallel
 from .optim import AcxAdamW
+
+X6_RESERVE_ROWS = 8192     # rank shares of at most this many feature rows ...
+X6_RESERVE_CUS = 32        # ... keep this many CUs out of the persistent bf16 x 6 kernels' grids (train_batch)
 
 try:  # pragma: no cover - not installed in the build image
     from pytorch_lightning import LightningModule as _Base
@@ -552,6 +556,32 @@ class AnomalyCLIPModule(_Base):
         from HIP graphs (step_graph.TrainStepGraph); automatic fallback: the autograd path below, itself with the text tower /
         temporal model as replayed graphs where they capture, eager otherwise."""
         buckets = self._make_buckets()
+        with self._x6_cu_reservation(batch):
+            return self._train_batch(batch, optimizer, batch_idx, buckets)
+
+    @contextlib.contextmanager
+    def _x6_cu_reservation(self, batch):
+        """A small rank share (<= X6_RESERVE_ROWS feature rows: 4 or more ranks at the UCF batch) leaves X6_RESERVE_CUS CUs to the
+        text stream for the duration of the step (eager launches and graph capture alike -- the grid and the K split are part
+        of a captured launch): the head's bf16 x 6 convolutions are persistent one-workgroup-per-CU kernels that hold a CU's
+        whole register file for ~90 us at a time, and the text tower's ~160 few-row launches (5-10 us each) otherwise queue
+        behind every one of them (emulated world 8: 2.74 -> 2.33 ms per step, world 4: 3.89 -> 3.74; at 16 384 rows and more
+        the convolutions need the whole chip: 6.04 -> 6.47, so nothing is reserved there).  The choice depends on the batch
+        geometry only: every rank makes the same one, the step graph and the autograd path stay bit-identical."""
+        (nf, _), (af, _) = batch
+        dev = af.device
+        rows = (nf.numel() + af.numel()) // max(1, int(af.shape[-1]))            # feature rows of this rank's share
+        reserve = dev.type == "cuda" and getattr(self.net, "precision", "auto") == "auto" and rows <= X6_RESERVE_ROWS
+        if reserve:
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            ops.set_x6_cus(dev.index or 0, max(1, ncu - X6_RESERVE_CUS))
+        try:
+            yield
+        finally:
+            if reserve:
+                ops.set_x6_cus(dev.index or 0, 0)
+
+    def _train_batch(self, batch, optimizer, batch_idx, buckets) -> torch.Tensor:
         sg = self._step_graph_for(batch, optimizer)
         if sg is not None:
             (nf, nl), (af, al) = batch

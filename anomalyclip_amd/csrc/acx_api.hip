@@ -39,6 +39,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->opt_ring_min_tiles = 512;
   c->opt_sk_max_m = 320;
   c->opt_tn_p256_min_rows = 4096;
+  c->opt_x6_cus = 0;
   c->err[0] = 0;
   c->prof_on = false;
   c->prof_gemm_only = false;
@@ -110,6 +111,10 @@ extern "C" int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value) {
     case ACX_OPT_TN_P256_MIN_ROWS:
       if (value < 1) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: tn_p256_min_rows must be >= 1%s");
       ctx->opt_tn_p256_min_rows = (int)(value > 0x7fffffff ? 0x7fffffff : value);
+      return ACX_OK;
+    case ACX_OPT_X6_CUS:
+      if (value < 0) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: x6_cus must be >= 0%s");
+      ctx->opt_x6_cus = (int)(value > 4096 ? 4096 : value);
       return ACX_OK;
     case ACX_OPT_SK_MAX_M:
       if (value < 0) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: sk_max_m must be >= 0%s");

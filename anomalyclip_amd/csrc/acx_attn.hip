@@ -884,17 +884,21 @@ namespace {
 // acx_attention_bf16 -- the same attention with bf16 operands (bf16 mode of the ViT, not a parity path):
 // qkv and the output are bf16 in global memory, QK^T and PV run on v_mfma_f32_32x32x16_bf16, softmax in f32.
 //   * K of the head in LDS as bf16 rows of 128 B padded to 144 B (conflict-free ds_read_b128 A fragments);
-//     V TRANSPOSED, Vt[e][key] with 520-B rows, because the bf16 MFMA packs 8 contraction indices (keys) per
-//     lane -- the transposition happens while staging (16-byte global loads, 2-byte LDS writes).
-//     K + Vt = 64 KB -> two workgroups per CU (the f32 kernel needs 112 KB and runs one).
+//     V as two 32-column panels of 64-byte rows (16-byte LDS writes, like K); the bf16 MFMA packs 8 contraction indices
+//     (keys) per lane, so the V^T fragments come out of LDS by transpose reads (ds_read_b64_tr_b16: every 16 lanes read a
+//     [4 keys][16 d] block) -- round 4 transposed while staging with 2-byte LDS writes: eight ds_write_b16 per 16 bytes and
+//     the kernel's only LDS bank conflicts (6.8 M cycles per launch).
+//     K + V = 61 KB -> two workgroups per CU (the f32 kernel needs 112 KB and runs one).
 //   * S^T = K Q^T exactly as in the f32 kernel (lane = query column, registers = keys), so softmax is
 //     in-register + one cross-half exchange, and register group 8c..8c+7 of a key tile, packed to bf16, IS the
 //     B operand of O^T = V^T P^T for key chunk c.  The keys a lane half holds there are
-//     {16c + 4h + (0..3)} u {16c + 8 + 4h + (0..3)}: the Vt fragment is two ds_read_b64 at those offsets.
+//     {16c + 4h + (0..3)} u {16c + 8 + 4h + (0..3)}: the V^T fragment is two transpose reads, eight rows apart.
 //   * O^T's C layout has lane = query again: 1/rowsum is a per-lane scalar and a lane stores 4 x 8 bytes per
 //     32-wide slice of its row.
 constexpr int BK_ROWB = 144;       // bytes per K row in LDS
-constexpr int BV_ROWB = 520;       // bytes per Vt row (224 keys * 2 B = 448, +72: stride/4 = 130 = 2 mod 64)
+constexpr int BV_PANEL_B = 224 * 64 + 64;   // one 32-column panel of V: 224 rows of 64 B (+ 64: the two panels' rows on different banks)
+typedef short ab_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ab_s16x4 ab_lds_s16x4;
 
 __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) { return f2bf2(a, b); }
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict
                                                           int64_t ldo, int L, int heads) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;                                  // [NT*32][144 B]
-  char* sV = smem + NT * 32 * BK_ROWB;              // [64][520 B]
+  char* sV = smem + NT * 32 * BK_ROWB;              // [2 panels][224 rows][64 B]
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int W = heads * 64;
   const u16* base = qkv + (int64_t)b * L * ldqkv + h * 64;
@@ -944,15 +948,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict
     const int row = i >> 3, pc = i & 7;
     if (i < NP) {
       *reinterpret_cast<uint4*>(sK + row * BK_ROWB + pc * 16) = stk[j];
-      const uint32_t w4[4] = {stv[j].x, stv[j].y, stv[j].z, stv[j].w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        *reinterpret_cast<u16*>(sV + (8 * pc + e) * BV_ROWB + row * 2) = (u16)(w4[e >> 1] >> (16 * (e & 1)));
+      *reinterpret_cast<uint4*>(sV + (pc >> 2) * BV_PANEL_B + row * 64 + (pc & 3) * 16) = stv[j];
     }
   }
   __syncthreads();
 
   const int nqb = (L + 31) / 32;
+  const int vtr = (4 * hh + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;   // transpose-read offset inside a 16-key step
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int qb = wave + 4 * it;
@@ -1020,17 +1022,19 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const u16* __restrict
         pk.z = pack2_bf16(st[kt][8 * c + 4], st[kt][8 * c + 5]);
         pk.w = pack2_bf16(st[kt][8 * c + 6], st[kt][8 * c + 7]);
         const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pk);
-        const int kb = (kt * 32 + 16 * c + 4 * hh) * 2;
-        const char* v0 = sV + li * BV_ROWB + kb;
-        uint4 va, vb;
-        {
-          const uint2 x0 = *reinterpret_cast<const uint2*>(v0), x1 = *reinterpret_cast<const uint2*>(v0 + 16);
-          va = make_uint4(x0.x, x0.y, x1.x, x1.y);
-          const uint2 y0 = *reinterpret_cast<const uint2*>(v0 + 32 * BV_ROWB), y1 = *reinterpret_cast<const uint2*>(v0 + 32 * BV_ROWB + 16);
-          vb = make_uint4(y0.x, y0.y, y1.x, y1.y);
+        // lane i of a 16-lane group supplies key 4 hh + (i >> 2) (+ 8: second read) of the 16-key step, d = 16 ((lane >> 4) & 1) + 4 (i & 3)
+        const char* v0 = sV + vtr + (kt * 32 + 16 * c) * 64;
+        typedef short s16x8_ __attribute__((ext_vector_type(8)));
+        bf16x8 vf[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const ab_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ab_lds_s16x4*)(v0 + dt * BV_PANEL_B));
+          const ab_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ab_lds_s16x4*)(v0 + dt * BV_PANEL_B + 8 * 64));
+          const s16x8_ v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          vf[dt] = __builtin_bit_cast(bf16x8, v8);
         }
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&va), pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&vb), pf, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf, o1, 0, 0, 0);
       }
     // ---- store: lane = query, register r of tile et is column e = et*32 + (r&3) + 8(r>>2) + 4hh
     const int qrow = qb * 32 + li;
@@ -1063,7 +1067,7 @@ extern "C" int acx_attention_bf16(acx_ctx* ctx, const void* qkv, int64_t ldqkv, 
   AcxProfScope prof__(ctx, ACX_K_ATTN, s);
 #define ACX_ATTNB(NT)                                                                              \
   do {                                                                                             \
-    const size_t lds = (size_t)NT * 32 * BK_ROWB + 64 * BV_ROWB;                                   \
+    const size_t lds = (size_t)NT * 32 * BK_ROWB + 2 * BV_PANEL_B;                                 \
     static bool done = false;                                                                      \
     if (!done) {                                                                                   \
       (void)hipFuncSetAttribute((const void*)attn_bf16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

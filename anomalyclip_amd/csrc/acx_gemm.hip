@@ -670,7 +670,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
         (!conv || (d->zero_page && !((uintptr_t)d->zero_page & 15) && d->cin % 32 == 0 && !(d->gl & (d->gl - 1)) &&
                    !(d->gn & (d->gn - 1)) && d->M % 256 == 0));
     if (shape_ok) {
-      const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+      int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+      if (ctx && ctx->opt_x6_cus > 0 && ctx->opt_x6_cus < ncu) ncu = ctx->opt_x6_cus;   // ACX_OPT_X6_CUS
       const int xt = ((d->M + 255) / 256) * ((d->N + 255) / 256);
       const int nks = d->K / 32;
       int split = 1;
@@ -1116,7 +1117,8 @@ extern "C" int acx_gemm_tn_x6(acx_ctx* ctx, const void* A3, int64_t a_plane_stri
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: N1 / N2 multiples of 256, lda / ldb of 8, dense C, 16-byte aligned planes%s");
   if (conv && (cin <= 0 || cin % 256 || N2 != 9 * cin || gn <= 0 || gl <= 0 || (gl & (gl - 1)) || (gn & (gn - 1)) || M % (gn * gl)))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: conv needs cin %% 256 == 0, N2 == 9 cin, a power-of-two grid, whole tiles%s");
-  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  if (ctx && ctx->opt_x6_cus > 0 && ctx->opt_x6_cus < ncu) ncu = ctx->opt_x6_cus;   // ACX_OPT_X6_CUS
   const int split = workspace ? tn_x6_splits(M, N1, N2, ncu, workspace_bytes) : 1;
   Args g;
   memset(&g, 0, sizeof(g));

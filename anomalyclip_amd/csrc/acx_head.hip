@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256, 2) void selector_project_mfma_kernel(const flo
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, b4.z, acc[t], 0, 0, 0);                      \
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, b4.w, acc[t], 0, 0, 0);                      \
       }                                                                                                  \
+      /* keep the direction fragments of later K-steps out of this one: with the chunk loop fully unrolled (D = 256) the */ \
+      /* scheduler hoisted every ds_read_b128 of a chunk above its first MFMA (NT = 3, 4: 108-176 spilled VGPRs)        */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
     }                                                                                                    \
   }
     if (grp != grp0) { SELM_LOAD(a0, 0) }

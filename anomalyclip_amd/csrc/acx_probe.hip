@@ -7,6 +7,7 @@
 //   acx_probe_copy  -- 16-byte-per-lane grid-stride copy (global_load_dwordx4 / global_store_dwordx4): the HBM stream
 //                      ceiling (read + write) the row kernels are measured against.
 #include "acx_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -53,7 +54,35 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const f32x4* __restrict
   }
 }
 
+// read-only stream: every lane folds its 16-byte pieces into one value, nothing is written (the sink store never happens) --
+// the floor of a ONE-SHOT launch that reads `bytes` once (ramp-up and tail included): what the skinny reductions of the head
+// (selector projection, column sums: 67 MB in, a few KB out) are measured against
+__global__ __launch_bounds__(256) void probe_read_kernel(const f32x4* __restrict__ src, int64_t n16, float* __restrict__ sink) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 2048 + threadIdx.x; i < n16; i += stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = i + 256 * k < n16 ? src[i + 256 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += v[k];
+  }
+  if (a[0] + a[1] + a[2] + a[3] == 12345.678f) sink[0] = a[0];   // never true for the probe's inputs
+}
+
 }  // namespace
+
+extern "C" int acx_probe_read(acx_ctx* ctx, const void* src, int64_t bytes, float* sink, void* stream) {
+  if (!src || !sink || bytes <= 0 || (bytes & 15) || ((uintptr_t)src & 15))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_probe_read: need a 16-byte aligned buffer and size%s");
+  const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+  const int64_t n16 = bytes / 16;
+  const int64_t want = (n16 + 2047) / 2048;
+  hipLaunchKernelGGL(probe_read_kernel, dim3((unsigned)std::min<int64_t>(want, (int64_t)ncu * 16)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)src, n16, sink);
+  ACX_CHECK_LAUNCH(ctx, "acx_probe_read");
+  return ACX_OK;
+}
 
 extern "C" int acx_probe_mfma(acx_ctx* ctx, int32_t bf16, int32_t iters, int32_t waves_per_simd, float* sink, double* flops_out,
                               void* stream) {

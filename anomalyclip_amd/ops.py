@@ -51,6 +51,14 @@ def set_few_row_limit(device_index: int, rows: int) -> None:
     L.check(L.lib().acx_set_option(h, L.OPT_SK_MAX_M, int(rows)), h)
     SK_MAX_ROWS = int(rows)
 
+def set_x6_cus(device_index: int, cus: int) -> None:
+    """ACX_OPT_X6_CUS: cap the persistent bf16 x 6 kernels' grid (0: every CU) so that other streams' kernels find free CUs while
+    one of them runs -- they hold a CU's whole register file and 144 KB of its LDS.  Changes the K split (a pure function of
+    the shape and of this value): set it BEFORE capturing graphs, and identically on every rank."""
+    h = L.ctx(device_index)
+    L.check(L.lib().acx_set_option(h, L.OPT_X6_CUS, int(cus)), h)
+
+
 _SPLITK_WS: dict = {}
 _SPLITK_RETIRED: list = []
 

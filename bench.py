@@ -446,6 +446,13 @@ def hbm_kernel_legs(dev, copy_TBps, fill_TBps=None):
           "x (32768, 512) -> raw (32768, 13): f32-MFMA skinny GEMM")
     entry("selector_project_stats", rows * D * 4 + rows * C1 * 4,
           _event_time(lambda: ops.selector_project_stats(nxt(xs), nc, dirs), 24), "the same + BatchNorm batch statistics (2 launches; finishing them in the last workgroup to arrive measured slower: 23.5 vs 21.2 us)")
+    # the floor of these one-shot launches: a kernel that only READS the same 67 MB (ramp-up and tail included)
+    lib, h, st = L.lib(), L.ctx(torch.device(dev).index or 0), torch.cuda.current_stream().cuda_stream
+    sink = torch.zeros(4, device=dev)
+    read_s = _event_time(lambda: L.check(lib.acx_probe_read(h, nxt(xs).data_ptr(), rows * D * 4, sink.data_ptr(), st), h), 24)
+    for k_ in ("selector_project", "selector_project_stats"):
+        out[k_]["read_floor_us"] = round(read_s * 1e6, 2)
+        out[k_]["frac_of_read_floor"] = round(read_s * 1e6 / out[k_]["us"], 4)
     acc = torch.zeros(D, device=dev)
     entry("colsum_ncentroid", rows * D * 4, _event_time(lambda: ops.colsum_(acc, nxt(xs)), 24))
     del xs

@@ -66,7 +66,12 @@ const char* acx_last_error(acx_ctx* ctx);
  *                           for the a_act / gelu_grad_of fusions, which always need it). */
 /*   ACX_OPT_TN_P256_MIN_ROWS acx_gemm_tn problems with at least this many rows (and >= 8 output tiles of 256 x 256, no
  *                           b_sub) take the 256 x 256 LDS-DMA kernel (default 4096). */
-enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2, ACX_OPT_TN_P256_MIN_ROWS = 3 };
+/*   ACX_OPT_X6_CUS          the pairs = 6 kernels (acx_gemm, acx_gemm_tn_x6) are persistent, ONE workgroup per CU with the whole
+ *                           register file and 144 KB of LDS: nothing else runs on a CU they hold.  value > 0 caps their grid
+ *                           (and the K split is chosen for that many workgroups) so that the remaining CUs stay free for
+ *                           kernels of OTHER streams -- the data-parallel step runs the text tower's ~160 few-row launches
+ *                           beside the head's convolutions; 0 (default): all CUs. */
+enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2, ACX_OPT_TN_P256_MIN_ROWS = 3, ACX_OPT_X6_CUS = 4 };
 int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value);
 
 /* ------------------------------------------------------------------------------------------
@@ -593,6 +598,9 @@ int acx_prof_gemm_tn(acx_ctx* ctx, double* flops, double* total_ms, int32_t* lau
 int acx_probe_mfma(acx_ctx* ctx, int32_t bf16, int32_t iters, int32_t waves_per_simd, float* sink, double* flops_out,
                    void* stream);
 int acx_probe_copy(acx_ctx* ctx, const void* src, void* dst, int64_t bytes, void* stream);
+/* acx_probe_read: reads `bytes` once (16 bytes per lane, grid-stride), writes nothing: the floor of a one-shot launch over an
+ * input of that size -- the denominator for the head's skinny reductions (selector projection, column sums). */
+int acx_probe_read(acx_ctx* ctx, const void* src, int64_t bytes, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -423,7 +423,7 @@ def test_selector_kernels():
 
 
 @pytest.mark.parametrize("rows,D,C1", [(32768, 512, 13), (16 * 511 + 5, 512, 17), (1000, 512, 6), (40960, 512, 6), (777, 128, 13),
-                                      (100, 64, 33), (3, 256, 64), (513, 1024, 13), (600, 768, 13), (64, 512, 64), (200, 1024, 33)])
+                                      (100, 64, 33), (3, 256, 64), (4099, 256, 40), (2050, 256, 64), (513, 1024, 13), (600, 768, 13), (64, 512, 64), (200, 1024, 33)])
 def test_selector_project_mfma_and_fused_stats(rows, D, C1):
     """selector_model.py:54,62,65: the projection as a skinny f32-MFMA GEMM (16-row groups, 1..4 column tiles of 16
     directions, ragged last group, every supported width; (1024, 33) overflows the MFMA kernel's LDS layout and takes the

@@ -730,7 +730,8 @@ def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom, path
                 mod.train_batch(batch, opt)
             else:
                 opt.zero_grad(set_to_none=True)
-                with torch.enable_grad():
+                # (train_batch's CU reservation for small rank shares changes the convolutions' K split: same option here)
+                with torch.enable_grad(), mod._x6_cu_reservation(batch):
                     mod.training_step(batch)["loss"].backward()
                 opt.step()
         gb = mods[0][0]._buckets
