@@ -104,6 +104,7 @@ _SIGS = {
                                        c_void_p]),
     "acx_probe_mfma": (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, C.POINTER(C.c_double), c_void_p]),
     "acx_probe_copy": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "acx_split_bf16x3_multi": (C.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acx_probe_read": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "acx_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "acx_bn_combine": (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -218,8 +218,7 @@ class TemporalModel(nn.Module):
         (capturable -- the step graphs replay it after each optimizer update)."""
         P, segs = self._derived(train)
         ops.prep_multi(segs, device=self.projection.weight.device)
-        for src, dst in P["_x6"]:
-            ops.split_bf16x3(src, out=dst)
+        ops.split_bf16x3_multi(P["_x6"])                     # the convolution weights' bf16 planes: one launch
         self._prep = (self._prep_key(train), P)
         return P
 

@@ -1126,6 +1126,54 @@ static int split_bf16x3_impl(acx_ctx* ctx, const float* src, int64_t ld, void* d
   ACX_CHECK_LAUNCH(ctx, "acx_split_bf16x3");
   return ACX_OK;
 }
+// up to 16 dense matrices (ld == cols) in ONE launch: the head's convolution weights (forward and dX layouts of two layers =
+// eight tensors) are re-split after every optimizer step -- eight 6-us launches at the head of a data-parallel rank's 2.3 ms step
+struct SplitSegs { const float* src[16]; u16* dst[16]; long long n4[16]; long long blk0[17]; int n; };
+__global__ __launch_bounds__(256) void split_bf16x3_multi_kernel(const SplitSegs S) {
+  int k = 0;
+  while (k + 1 < S.n && (long long)blockIdx.x >= S.blk0[k + 1]) ++k;
+  const long long i = ((long long)blockIdx.x - S.blk0[k]) * 256 + threadIdx.x;
+  if (i >= S.n4[k]) return;
+  const float4 v = reinterpret_cast<const float4*>(S.src[k])[i];
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  u16 h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = f2bf(x[e]);
+    if ((h[e] & 0x7fffu) == 0x7f80u && (__float_as_uint(x[e]) & 0x7fffffffu) < 0x7f800000u) h[e] = (u16)(__float_as_uint(x[e]) >> 16);
+    const float r1 = x[e] - bf2f(h[e]);
+    m[e] = f2bf(r1);
+    l[e] = f2bf(r1 - bf2f(m[e]));
+  }
+  u16* d0 = S.dst[k] + 4 * i;
+  const long long plane = 4 * S.n4[k];
+  *reinterpret_cast<uint2*>(d0) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  *reinterpret_cast<uint2*>(d0 + plane) = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
+  *reinterpret_cast<uint2*>(d0 + 2 * plane) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+extern "C" int acx_split_bf16x3_multi(acx_ctx* ctx, int32_t n, const float* const* src, void* const* dst, const int64_t* numel, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  if (n < 0 || (n > 0 && (!src || !dst || !numel))) return acx_fail(ctx, ACX_E_BADARG, "acx_split_bf16x3_multi: null pointer%s");
+  for (int base = 0; base < n; base += 16) {
+    SplitSegs S;
+    memset(&S, 0, sizeof(S));
+    long long blocks = 0;
+    int k = 0;
+    for (; k < 16 && base + k < n; ++k) {
+      const int64_t ne = numel[base + k];
+      if (!src[base + k] || !dst[base + k] || ne <= 0 || ne % 4 || (((uintptr_t)src[base + k] | (uintptr_t)dst[base + k]) & 15) || ((ne * 2) & 15))
+        return acx_fail(ctx, ACX_E_BADARG, "acx_split_bf16x3_multi: dense 16-byte aligned tensors with numel %% 8 == 0%s");
+      S.src[k] = src[base + k]; S.dst[k] = (u16*)dst[base + k]; S.n4[k] = ne / 4; S.blk0[k] = blocks;
+      blocks += (ne / 4 + 255) / 256;
+    }
+    S.blk0[k] = blocks; S.n = k;
+    if (blocks > 0x7fffffffLL) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_split_bf16x3_multi: too many elements%s");
+    hipLaunchKernelGGL(split_bf16x3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, S);
+  }
+  ACX_CHECK_LAUNCH(ctx, "acx_split_bf16x3_multi");
+  return ACX_OK;
+}
+
 extern "C" int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
                                 int64_t cols, void* stream) {
   return split_bf16x3_impl(ctx, src, ld, dst, plane_stride_bytes, rows, cols, stream, 0);

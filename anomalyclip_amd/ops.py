@@ -142,6 +142,28 @@ def split_bf16x3(src: torch.Tensor, out: Optional[torch.Tensor] = None, panel: b
     return out
 
 
+_SPLIT_MULTI_ARGS: dict = {}
+
+
+def split_bf16x3_multi(pairs) -> None:
+    """[(src f32 dense, dst bf16 [3, *src.shape]), ...] -> every dst = the three planes of its src, ONE launch (the head's
+    convolution weights after an optimizer step).  The pointer tables are host arrays kept alive per pair list."""
+    if not pairs:
+        return
+    key = tuple((s.data_ptr(), d.data_ptr(), s.numel()) for s, d in pairs)
+    args = _SPLIT_MULTI_ARGS.get(key)
+    if args is None:
+        n = len(pairs)
+        for s, d in pairs:
+            assert s.dtype == torch.float32 and s.is_contiguous() and d.dtype == _BF16 and d.is_contiguous() and d.numel() == 3 * s.numel()
+        if len(_SPLIT_MULTI_ARGS) > 64:
+            _SPLIT_MULTI_ARGS.clear()
+        args = _SPLIT_MULTI_ARGS[key] = (n, (C.c_void_p * n)(*[s.data_ptr() for s, _ in pairs]), (C.c_void_p * n)(*[d.data_ptr() for _, d in pairs]),
+                                         (C.c_int64 * n)(*[s.numel() for s, _ in pairs]))
+    h = _h(pairs[0][0])
+    L.check(L.lib().acx_split_bf16x3_multi(h, args[0], args[1], args[2], args[3], _stream()), h)
+
+
 def unpanel(planes: torch.Tensor) -> torch.Tensor:
     """[3, rows, cols] planes in K-panel memory order -> the same values in row-major order (tests / debugging)"""
     _, rows, cols = planes.shape

@@ -335,6 +335,10 @@ int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int6
                      int64_t cols, void* stream);
 /* the same into K-panel layout (ACX_BF16X3P: plane = [cols / 32][rows][32]; cols % 32 == 0) */
 int acx_split_bf16x3_panel(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_bytes, int64_t rows, int64_t cols, void* stream);
+/* n dense f32 tensors (numel[i] elements each, multiples of 8, 16-byte aligned) -> three row-major bf16 planes each
+ * (dst[i]: 3 * numel[i] bf16, plane stride numel[i]) in ONE launch: a training step re-splits every convolution weight of the
+ * temporal model after the optimizer has stepped. */
+int acx_split_bf16x3_multi(acx_ctx* ctx, int32_t n, const float* const* src, void* const* dst, const int64_t* numel, void* stream);
 /* utility: f32 -> bf16 (round-to-nearest-even) copy, used to prepare bf16 weight copies. */
 int acx_cast_bf16(acx_ctx* ctx, const float* src, void* dst, int64_t n, void* stream);
 /* utility: column sums of x[rows, D] accumulated into acc[D] (ncentroid, anomaly_clip_module.py:145-171). */

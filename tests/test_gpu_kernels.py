@@ -703,6 +703,13 @@ def test_gemm_x6_split_k_and_planes_output(M, N, K, split):
         assert torch.equal(ops.gemm_x6(a3, w3p, bias=b, act=L.ACT_LEAKYRELU, split_k=False, panels=2), y0)
         ypp = ops.gemm_x6(a3p, w3p, bias=b, act=L.ACT_LEAKYRELU, split_k=False, panels=3, planes_out=True, panel_out=True)
         assert torch.equal(ops.unpanel(ypp).float().sum(0), y0)
+        # ... and the reduce launch of a K split writes the panel layout as well
+        yps = ops.gemm_x6(a3p, w3p, bias=b, act=L.ACT_LEAKYRELU, split_k=split, panels=3, planes_out=True, panel_out=True)
+        assert torch.equal(ops.unpanel(yps).float().sum(0), y)
+    # the multi-tensor split (one launch for a list of dense tensors) writes what the single-tensor launches write
+    w3m, a3m = torch.empty_like(w3), torch.empty_like(a3)
+    ops.split_bf16x3_multi([(w, w3m), (a, a3m)])
+    assert torch.equal(w3m, w3) and torch.equal(a3m, a3)
 
 
 @pytest.mark.parametrize("cin,cout,tiles,act,res", [(64, 256, 1, 2, 0), (256, 1024, 2, 2, 0), (1024, 256, 8, 0, 1), (128, 512, 40, 0, 0),
