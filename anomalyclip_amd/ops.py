@@ -278,16 +278,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *, eps=1e-5, mode=L.NORM_LAYER,
-              out_dtype=torch.float32, rows: Optional[int] = None, ldx: Optional[int] = None, planes_out: bool = False) -> torch.Tensor:
-    """planes_out: the result as three bf16 planes [3, rows, D] (hi | mid | lo of the f32 value: a bf16 x 6 product's operand)"""
+              out_dtype=torch.float32, rows: Optional[int] = None, ldx: Optional[int] = None, planes_out: bool = False,
+              panel_out: bool = False) -> torch.Tensor:
+    """planes_out: the result as three bf16 planes [3, rows, D] (hi | mid | lo of the f32 value: a bf16 x 6 product's operand);
+    panel_out: each plane in K-panel memory order (ACX_BF16X3P; unpanel() for row-major)"""
     D = w.numel()
     if rows is None:
         rows = x.numel() // D
         ldx = D
     y = torch.empty((3, rows, D) if planes_out else (rows, D), dtype=_BF16 if planes_out else out_dtype, device=x.device)
     h = _h(x)
-    L.check(L.lib().acx_layernorm(h, x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), y.data_ptr(), D, L.BF16X3 if planes_out else _dt(y),
-                                  rows, D, eps, mode, _stream()), h)
+    L.check(L.lib().acx_layernorm(h, x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), y.data_ptr(), D,
+                                  (L.BF16X3P if panel_out else L.BF16X3) if planes_out else _dt(y), rows, D, eps, mode, _stream()), h)
     return y
 
 

@@ -712,6 +712,55 @@ def test_gemm_x6_split_k_and_planes_output(M, N, K, split):
     assert torch.equal(w3m, w3) and torch.equal(a3m, a3)
 
 
+@pytest.mark.parametrize("rows,D", [(197 * 3, 768), (64, 256), (1001, 512), (7, 1024), (100864, 768)])
+def test_layernorm_plane_outputs(rows, D):
+    """acx_layernorm with three-plane outputs (the A operand of the ViT's bf16 x 6 in-projection / c_fc): hi + mid + lo is the f32
+    LayerNorm bit for bit, and the K-panel layout (two rows per wave, 16-byte stores; odd row counts) holds the row-major planes."""
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 3 + 0.5).to(DEV)
+    w, b = (torch.rand(D, generator=g) + 0.5).to(DEV), torch.randn(D, generator=g).to(DEV)
+    y = ops.layernorm(x, w, b)
+    y3 = ops.layernorm(x, w, b, planes_out=True)
+    y3p = ops.layernorm(x, w, b, planes_out=True, panel_out=True)
+    assert torch.equal(y3.float().sum(0), y)
+    assert torch.equal(ops.unpanel(y3p), y3)
+
+
+def test_x6_cus_option_caps_the_grid_same_product():
+    """ACX_OPT_X6_CUS (ops.set_x6_cus): the persistent pairs = 6 kernels on fewer workgroups, K split chosen for that many -- a
+    data-parallel rank leaves CUs to the text stream this way.  Same product up to the summation order of the K pieces (both
+    within the f32 bound of fp64), deterministic for a given value, and back to the default's bits when the cap is lifted."""
+    gn, gl, cin, cout, tiles = 32, 16, 256, 1024, 8
+    rows = tiles * gn * gl
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(rows, cin, generator=g) * 0.7).to(DEV)
+    w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    x3, w3 = ops.split_bf16x3(x), ops.split_bf16x3(w)
+    run = lambda: ops.gemm_x6(x3, w3, bias=b, act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=gn, gl=gl, cin=cin)
+    y0 = run()
+    dev = torch.device(DEV).index or 0
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    try:
+        ops.set_x6_cus(dev, ncu - 32)
+        y1, y1b = run(), run()
+        ops.set_x6_cus(dev, 7)                                             # fewer workgroups than tiles x pieces: several items each
+        y2 = run()
+    finally:
+        ops.set_x6_cus(dev, 0)
+    y3 = run()
+    assert torch.equal(y1, y1b) and torch.equal(y3, y0)
+    xg = x.double().view(tiles, gn, gl, cin)
+    xp = torch.zeros(tiles, gn + 2, gl + 2, cin, dtype=torch.float64, device=DEV)
+    xp[:, 1:-1, 1:-1] = xg
+    cols = torch.cat([xp[:, kh:kh + gn, kw:kw + gl] for kh in range(3) for kw in range(3)], dim=-1).reshape(rows, 9 * cin)
+    pre = cols @ w.double().t() + b.double()
+    ref = torch.where(pre > 0, pre, 0.01 * pre)
+    bound = 2e-6 * (cols.abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+    for y in (y0, y1, y2):
+        assert bool(((y.double() - ref).abs() <= bound).all())
+
+
 @pytest.mark.parametrize("cin,cout,tiles,act,res", [(64, 256, 1, 2, 0), (256, 1024, 2, 2, 0), (1024, 256, 8, 0, 1), (128, 512, 40, 0, 0),
                                                      (256, 1024, 64, 2, 0)])
 def test_conv3x3_x6_vs_f32_conv(cin, cout, tiles, act, res):
