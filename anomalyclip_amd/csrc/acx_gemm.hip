@@ -53,7 +53,13 @@ namespace {
 // QuickGELU of every epilogue: v * sigmoid(1.702 v) with v_exp_f32 + v_rcp_f32 (1 ulp).  "1.f / x" would be the IEEE division
 // sequence (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup): ten VALU instructions per element of a
 // 256 x 256 tile, with the MFMA pipe idle behind them.
-__device__ __forceinline__ float acx_quickgelu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v)); }
+// (the empty asm pins the product as an f32 value HERE -- a plane epilogue that splits the result into hi | mid | lo would otherwise get
+// the multiply contracted into its first residual, fma(v, s, -hi), and its planes would hold a value that is not the f32 result)
+__device__ __forceinline__ float acx_quickgelu(float v) {
+  float r = v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+  asm volatile("" : "+v"(r));
+  return r;
+}
 
 constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 144;                // LDS row stride in bytes (128 data + 16 pad)
@@ -576,7 +582,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   if (d->a_sub && (a_bf16 || ((uintptr_t)d->a_sub & 15)))
     return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: a_sub needs f32 A and 16-byte alignment%s");
   if (d->amap == ACX_AMAP_CONV3X3) {
-    const int ke = prec == ACX_PREC_F32 ? 32 : 64;
+    const int ke = (prec == ACX_PREC_F32 || d->pairs == 6) ? 32 : 64;   // (the plane-reuse kernel's K-steps are 32 wide)
     if (d->cin <= 0 || d->K != 9 * d->cin || d->cin % ke || d->gn <= 0 || d->gl <= 0 || d->M % (d->gn * d->gl))
       return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: bad conv3x3 geometry%s");
     if (d->a_sub) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_sub with conv3x3%s");

@@ -726,6 +726,67 @@ def test_layernorm_plane_outputs(rows, D):
     assert torch.equal(ops.unpanel(y3p), y3)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_gemm_x6_random_shapes_vs_fp64(seed):
+    """Seeded sweep over what acx_gemm takes with pairs = 6: ragged M / N (edge tiles), K = 32 .. 2304 in steps of 32, every
+    epilogue (bias, QuickGELU / LeakyReLU, residual; f32, bf16 and plane outputs), K split on or off, the workgroup cap of
+    ACX_OPT_X6_CUS, identity rows and the 3x3 convolution on power-of-two grids -- every element against fp64 within the f32
+    bound 2e-6 sum_k |a||w|, and the variants of one problem against each other."""
+    rng = np.random.RandomState(1000 + seed)
+    g = torch.Generator().manual_seed(2000 + seed)
+    conv = seed % 3 == 2
+    if conv:
+        gn, gl = int(rng.choice([4, 8, 32])), int(rng.choice([4, 16]))
+        tiles = max(1, 256 // (gn * gl)) * int(rng.randint(1, 4))
+        M, cin = tiles * gn * gl, 32 * int(rng.randint(1, 9))
+        if M % 256:
+            M = (M // 256 + 1) * 256
+            tiles = M // (gn * gl)
+        K, N = 9 * cin, 4 * int(rng.randint(8, 160))
+    else:
+        M, N, K = int(rng.randint(1, 1400)), 4 * int(rng.randint(1, 200)), 32 * int(rng.randint(1, 73))
+    act = int(rng.choice([L.ACT_NONE, L.ACT_QUICKGELU, L.ACT_LEAKYRELU]))
+    res = bool(rng.randint(0, 2)) and act == L.ACT_NONE
+    a = (torch.randn(M, K // 9 if conv else K, generator=g) * torch.exp2(torch.randint(-3, 3, (M, 1), generator=g).float())).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV) if res else None
+    a3, w3 = ops.split_bf16x3(a), ops.split_bf16x3(w)
+    kw = dict(bias=b, act=act, residual=r)
+    if conv:
+        kw.update(amap=L.AMAP_CONV3X3, gn=gn, gl=gl, cin=K // 9)
+        xg = a.double().view(-1, gn, gl, K // 9)
+        xp = torch.zeros(xg.shape[0], gn + 2, gl + 2, K // 9, dtype=torch.float64, device=DEV)
+        xp[:, 1:-1, 1:-1] = xg
+        A = torch.cat([xp[:, kh:kh + gn, kw_:kw_ + gl] for kh in range(3) for kw_ in range(3)], dim=-1).reshape(M, K)
+    else:
+        A = a.double()
+    pre = A @ w.double().t() + b.double()
+    ref = pre * torch.sigmoid(1.702 * pre) if act == L.ACT_QUICKGELU else torch.where(pre > 0, pre, 0.01 * pre) if act == L.ACT_LEAKYRELU else pre
+    if res:
+        ref = ref + r.double()
+    bound = 2.5e-6 * (A.abs() @ w.double().abs().t() + b.double().abs() + (r.double().abs() if res else 0)) + 1e-30
+    dev = torch.device(DEV).index or 0
+    outs = {}
+    for split in (True, False):
+        for cus in (0, 5):
+            try:
+                ops.set_x6_cus(dev, cus)
+                y = ops.gemm_x6(a3, w3, split_k=split, **kw)
+            finally:
+                ops.set_x6_cus(dev, 0)
+            e = (y.double() - ref).abs()
+            assert bool((e <= bound).all()), (seed, M, N, K, conv, act, res, split, cus, float((e / bound).max()))
+            outs[(split, cus)] = y
+    assert torch.equal(outs[(False, 0)], outs[(False, 5)])                  # without a K split the workgroup count changes nothing
+    if not res:
+        yb = ops.gemm_x6(a3, w3, out_dtype=torch.bfloat16, **kw)
+        assert torch.equal(yb, outs[(True, 0)].to(torch.bfloat16))
+        if N % 8 == 0:
+            yp = ops.gemm_x6(a3, w3, planes_out=True, **kw)
+            assert torch.equal(yp.float().sum(0), outs[(True, 0)])
+
+
 def test_x6_cus_option_caps_the_grid_same_product():
     """ACX_OPT_X6_CUS (ops.set_x6_cus): the persistent pairs = 6 kernels on fewer workgroups, K split chosen for that many -- a
     data-parallel rank leaves CUs to the text stream this way.  Same product up to the summation order of the K pieces (both
