@@ -601,7 +601,7 @@ def test_gemm_bf16x6_is_f32_accurate(M, N, K, act, res):
         ops.gemm_x6(a3[:, :, :40].contiguous(), w3[:, :, :40].contiguous(), bias=bd)
 
 
-@pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (1, 193, 1), (40, 197, 12)])
+@pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (1, 193, 1), (40, 197, 12)] + [(3, l_, 3) for l_ in range(194, 208) if l_ != 197])
 def test_attention_p3_vs_fp64(batch, L_, heads):
     """acx_attention_p3 (q, k, v as three bf16 planes in K-panel layout; QK^T and PV as bf16 x 6 products, softmax in f32) against
     fp64 softmax attention and against the f32 MFMA kernel on the same inputs: no worse than 1.5 x the f32 kernel's maximum

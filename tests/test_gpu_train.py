@@ -86,6 +86,46 @@ def test_gemm_tn_x6_plain(M, N1, N2):
     assert float(e6.max()) <= 1.5 * float(e32.max()) + 1e-12
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_gemm_tn_x6_random_shapes_vs_fp64(seed):
+    """Seeded sweep of acx_gemm_tn_x6: ragged row counts (last K-step padded from the zero page), 1 .. 3 x 1 .. 3 output tiles,
+    plain and convolution (taps outside power-of-two token grids of several shapes), with and without the workgroup cap of
+    ACX_OPT_X6_CUS (another row split): every element within the f32 bound of fp64."""
+    import numpy as np
+    rng = np.random.RandomState(300 + seed)
+    g = torch.Generator().manual_seed(400 + seed)
+    conv = seed % 2 == 1
+    N1 = 256 * int(rng.randint(1, 4))
+    if conv:
+        gn, gl = int(rng.choice([4, 8, 32])), int(rng.choice([4, 16]))
+        M = gn * gl * int(rng.randint(1, 40))
+        cin = 256 * int(rng.randint(1, 3))
+        ncol = cin
+    else:
+        M, ncol = int(rng.randint(1, 9000)), 256 * int(rng.randint(1, 4))
+        gn = gl = cin = 0
+    a = (torch.randn(M, N1, generator=g) * torch.exp2(torch.randint(-3, 3, (M, 1), generator=g).float())).to(DEV)
+    b = torch.randn(M, ncol, generator=g).to(DEV)
+    a3, b3 = ops.split_bf16x3(a), ops.split_bf16x3(b)
+    if conv:
+        xp = torch.zeros(M // (gn * gl), gn + 2, gl + 2, cin, dtype=torch.float64, device=DEV)
+        xp[:, 1:-1, 1:-1] = b.double().view(-1, gn, gl, cin)
+        B = torch.cat([xp[:, kh:kh + gn, kw:kw + gl] for kh in range(3) for kw in range(3)], dim=-1).reshape(M, 9 * cin)
+    else:
+        B = b.double()
+    ref = a.double().t() @ B
+    bound = 2.5e-6 * (a.double().abs().t() @ B.abs()) + 1e-30
+    dev = torch.device(DEV).index or 0
+    for cus in (0, 37):
+        try:
+            ops.set_x6_cus(dev, cus)
+            y = ops.gemm_tn_x6(a3, b3, conv=conv, gn=gn, gl=gl, cin=cin)
+        finally:
+            ops.set_x6_cus(dev, 0)
+        e = (y.double() - ref).abs()
+        assert bool((e <= bound).all()), (seed, M, N1, ncol, conv, gn, gl, cus, float((e / bound).max()))
+
+
 @pytest.mark.parametrize("cin,cout,tiles", [(256, 1024, 8), (1024, 256, 16), (256, 256, 1), (256, 1024, 64)])
 def test_conv_weight_grad_x6(cin, cout, tiles):
     """the 3x3 convolution's weight gradient [cout, 9 cin] from planes (per-tap shifted rows of the layer input, zero page
