@@ -15,7 +15,7 @@ PREC_F32, PREC_BF16, PREC_F32X6 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1
-OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS, OPT_X6_CUS = 1, 2, 3, 4
+OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS, OPT_X6_CUS, OPT_X6_TAIL_SPLIT = 1, 2, 3, 4, 5
 
 
 class GemmDesc(C.Structure):
@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("counters", c_void_p), ("n_counters", c_int32),
         ("tile_table", c_void_p),
         ("pairs", c_int32), ("panels", c_int32), ("a_plane_stride", c_int64), ("w_plane_stride", c_int64),
+        ("c_plane_rows", c_int64),
     ]
 
 

@@ -40,6 +40,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->opt_sk_max_m = 320;
   c->opt_tn_p256_min_rows = 4096;
   c->opt_x6_cus = 0;
+  c->opt_x6_tail = 0;
   c->err[0] = 0;
   c->prof_on = false;
   c->prof_gemm_only = false;
@@ -112,6 +113,9 @@ extern "C" int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value) {
       if (value < 1) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: tn_p256_min_rows must be >= 1%s");
       ctx->opt_tn_p256_min_rows = (int)(value > 0x7fffffff ? 0x7fffffff : value);
       return ACX_OK;
+    case ACX_OPT_X6_TAIL_SPLIT:
+      ctx->opt_x6_tail = value != 0;
+      return ACX_OK;
     case ACX_OPT_X6_CUS:
       if (value < 0) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: x6_cus must be >= 0%s");
       ctx->opt_x6_cus = (int)(value > 4096 ? 4096 : value);
@@ -175,7 +179,7 @@ bool x6_takes(acx_ctx* ctx, const TfWs& ws, int64_t M, int N, int K, int lda) {
 // kernel is then ONE contiguous 16 KB block (+5-6 % on the ViT products against row-major planes, profiles/r05_gemm_x6_notes.txt).
 int linear_x6(acx_ctx* ctx, const void* A3, int lda, int64_t a_rows, const void* W3, int64_t w_plane_bytes, int ldw, void* C,
               int ldc, int M, int N, int K, const float* bias, int act, const float* residual, hipStream_t s, int ldr = 0,
-              int c_dtype = ACX_F32) {
+              int c_dtype = ACX_F32, void* tail_ws = nullptr, size_t tail_bytes = 0) {
   if (!W3) return acx_fail(ctx, ACX_E_BADARG, "driver: missing bf16 x 3 weight planes for ACX_PREC_F32X6%s");
   acx_gemm_desc d;
   memset(&d, 0, sizeof(d));
@@ -185,6 +189,8 @@ int linear_x6(acx_ctx* ctx, const void* A3, int lda, int64_t a_rows, const void*
   d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
   d.pairs = 6; d.a_plane_stride = a_rows * (int64_t)lda * 2; d.w_plane_stride = w_plane_bytes;
   d.panels = 3;
+  // scratch for the K split of a partly filled last round of tiles (acx_gemm: row-major outputs only)
+  d.workspace = tail_ws; d.workspace_bytes = tail_ws ? tail_bytes : 0;
   return acx_gemm(ctx, &d, s);
 }
 
@@ -309,7 +315,8 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     const bool att_p3 = x6_qkv && x6_out && ws.qkv3 && !causal && L > 192 && L <= 208 && ACX_DBG_SWITCH("ATTN_P3", true);
     if (x6_qkv) {
       if ((rc = linear_x6(ctx, ws.hp, W, rows, b.in_proj_w_bf16, (int64_t)3 * W * W * 2, W, att_p3 ? (void*)ws.qkv3 : (void*)ws.qkv, 3 * W,
-                          (int)rows, 3 * W, W, b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, att_p3 ? ACX_BF16X3P : ACX_F32))) return rc;
+                          (int)rows, 3 * W, W, b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, att_p3 ? ACX_BF16X3P : ACX_F32,
+                          att_p3 ? ws.qkv : ws.h, att_p3 ? (size_t)rows * 3 * W * 4 : (size_t)rows * W * 4))) return rc;   // (free f32 buffers: tail scratch)
     } else
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, qdt, 3 * W, (int)rows, 3 * W, W,
                      b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
@@ -325,8 +332,9 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     }
     if (x6_out) {
       if (!att_x3 && !att_p3 && (rc = acx_split_bf16x3_panel(ctx, (const float*)ws.att, W, ws.hp, (int64_t)rows * W * 2, rows, W, s))) return rc;
+      // (ws.h is free here and at c_proj: LayerNorm's output has been consumed, or went to the planes)
       if ((rc = linear_x6(ctx, ws.hp, W, rows, b.out_proj_w_bf16, (int64_t)W * W * 2, W, x, W, (int)rows, W, W, b.out_proj_b,
-                          ACX_ACT_NONE, x, s))) return rc;
+                          ACX_ACT_NONE, x, s, 0, ACX_F32, ws.h, (size_t)rows * W * 4))) return rc;
     } else
     if ((rc = linear(ctx, prec, ws.att, qdt, W, b.out_proj_w, b.out_proj_w_bf16, W, x, ACX_F32, W, (int)rows, W, W,
                      b.out_proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
@@ -338,14 +346,15 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     if (x6_fc) {
       // QuickGELU(c_fc) straight into the planes of c_proj's input when c_proj takes the x6 path too
       if ((rc = linear_x6(ctx, ws.hp, W, rows, b.fc_w_bf16, (int64_t)4 * W * W * 2, W, x6_proj ? (void*)ws.mp : (void*)ws.mlp, 4 * W,
-                          (int)rows, 4 * W, W, b.fc_b, ACX_ACT_QUICKGELU, nullptr, s, 0, x6_proj ? ACX_BF16X3P : ACX_F32))) return rc;
+                          (int)rows, 4 * W, W, b.fc_b, ACX_ACT_QUICKGELU, nullptr, s, 0, x6_proj ? ACX_BF16X3P : ACX_F32,
+                          x6_proj ? ws.mlp : ws.h, x6_proj ? (size_t)rows * 4 * W * 4 : (size_t)rows * W * 4))) return rc;
     } else
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.fc_w, b.fc_w_bf16, W, ws.mlp, hdt, 4 * W, (int)rows, 4 * W, W, b.fc_b,
                      ACX_ACT_QUICKGELU, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     if (x6_proj) {
       if (!x6_fc && (rc = acx_split_bf16x3_panel(ctx, (const float*)ws.mlp, 4 * W, ws.mp, (int64_t)rows * 4 * W * 2, rows, 4 * W, s))) return rc;
       if ((rc = linear_x6(ctx, ws.mp, 4 * W, rows, b.proj_w_bf16, (int64_t)W * 4 * W * 2, 4 * W, x, W, (int)rows, W, 4 * W, b.proj_b,
-                          ACX_ACT_NONE, x, s))) return rc;
+                          ACX_ACT_NONE, x, s, 0, ACX_F32, ws.h, (size_t)rows * W * 4))) return rc;
     } else
     if ((rc = linear(ctx, prec, ws.mlp, hdt, 4 * W, b.proj_w, b.proj_w_bf16, 4 * W, x, ACX_F32, W, (int)rows, W, 4 * W,
                      b.proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
   o += v;
   if constexpr (C_BF16 == 2) {               // ACX_BF16X3: three bf16 planes hi | mid | lo of the f32 value
-    const size_t pe = (size_t)d.M * d.ldc, at = (size_t)row * d.ldc + col;
+    const size_t pe = (d.c_plane_rows ? (size_t)d.c_plane_rows : (size_t)d.M) * d.ldc, at = (size_t)row * d.ldc + col;
     const u16 h = f2bf(o);
     const float r1 = o - bf2f(h);
     const u16 m = f2bf(r1);
@@ -506,8 +506,9 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __rest
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] += v[e];
   if constexpr (OUT == 2) {
-    const size_t pe = (size_t)d.M * d.ldc;
-    u16* dst = (u16*)d.C + (d.c_dtype == ACX_BF16X3P ? ((size_t)(col >> 5) * d.M + row) * 32 + (col & 31) : (size_t)row * d.ldc + col);
+    const size_t crows = d.c_plane_rows ? (size_t)d.c_plane_rows : (size_t)d.M;
+    const size_t pe = crows * d.ldc;
+    u16* dst = (u16*)d.C + (d.c_dtype == ACX_BF16X3P ? ((size_t)(col >> 5) * crows + row) * 32 + (col & 31) : (size_t)row * d.ldc + col);
     u16 h[4], m[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -552,7 +553,7 @@ bool acx_gemm_takes_strip_stream(const acx_gemm_desc* d) {
 // K split of the plane-reuse kernel: `tiles` output tiles of `nks` K-steps on ncu persistent workgroups.  Cost of s pieces =
 // rounds(tiles s) x ceil(nks / s) K-steps (+ a term for the s partial images the reduce launch reads); every non-empty split
 // is allowed (the last K range of a tile takes what is left).  A pure function of the shape: fixed summation order.
-static int x6_choose_split(int tiles, int nks, int ncu, size_t image_bytes, size_t workspace_bytes, int min_steps) {
+static int x6_choose_split(int tiles, int nks, int ncu, size_t image_bytes, size_t workspace_bytes, int min_steps, double* cost_us = nullptr) {
   int best = 1;
   double best_cost = 1e30;
   for (int s2 = 1; s2 <= 64; ++s2) {
@@ -562,6 +563,7 @@ static int x6_choose_split(int tiles, int nks, int ncu, size_t image_bytes, size
     const double cost = (double)rounds * (spi + 4.0) * 3.0 + (s2 > 1 ? (s2 + 1.0) * (double)image_bytes / 4.0e6 + 4.0 : 0.0);   // us
     if (cost < best_cost * 0.995) { best_cost = cost; best = s2; }
   }
+  if (cost_us) *cost_us = best_cost;
   return best;
 }
 
@@ -597,6 +599,47 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   }
   if ((d->pos0 != nullptr) != (d->pos1 != nullptr) || (d->pos0 && (d->gn <= 0 || d->gl <= 0)))
     return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: pos0/pos1 need both pointers and a grid%s");
+
+  // ---- pairs = 6, more 256 x 256 tiles than CUs, a last round that fills only part of the chip (the ViT's N = 768 products: 1182
+  // tiles = 4.6 rounds at 512 frames, 591 = 2.3 at 256): the whole tile rows of the full rounds go out as one launch, the rest
+  // as a second problem on its row range -- fewer tiles than CUs, so its K is split across workgroups and reduced by a launch
+  // that also applies the epilogue (below; plane outputs: acx_gemm_desc.c_plane_rows).  Identity rows, caller-provided workspace; taken when
+  // the split model says >= 1 % (x6_choose_split's units).  Opt-in (ACX_OPT_X6_TAIL_SPLIT): the tail rows sum K in another order than
+  // the rows before them, and the default keeps identical rows of one launch bit-identical.  Decided before the profiling scope:
+  // the two calls are two launches.
+  if (d->pairs == 6 && d->amap == ACX_AMAP_IDENTITY && d->workspace && prec == ACX_PREC_BF16 && a_bf16 && !d->a_sub && !d->pos0 &&
+      d->K % 32 == 0 && ctx && ctx->opt_x6_tail) {
+    int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
+    if (ctx && ctx->opt_x6_cus > 0 && ctx->opt_x6_cus < ncu) ncu = ctx->opt_x6_cus;
+    const int tm = (d->M + 255) / 256, tn = (d->N + 255) / 256, xt = tm * tn, nks = d->K / 32;
+    const int rounds = xt / ncu, rem = xt - rounds * ncu;
+    if (rounds >= 1 && rem > 0) {
+      const int tm_main = (rounds * ncu) / tn, xtail = (tm - tm_main) * tn;
+      const int64_t row0 = (int64_t)tm_main * 256, m_tail = d->M - row0;
+      if (tm_main >= 1 && xtail < ncu && m_tail > 0) {
+        double tail_us = 0.0;
+        const int s_tail = x6_choose_split(xtail, nks, ncu, (size_t)m_tail * d->N * sizeof(float), d->workspace_bytes, 6, &tail_us);
+        const double now_us = (rounds + 1) * (nks + 7.0) * 3.0, new_us = rounds * (nks + 7.0) * 3.0 + tail_us + 6.0;
+#ifndef ACX_X6TAIL_THRESH
+#define ACX_X6TAIL_THRESH 0.99
+#endif
+        if (s_tail > 1 && new_us < ACX_X6TAIL_THRESH * now_us) {
+          acx_gemm_desc dm = *d, dt = *d;
+          dm.M = (int)row0; dm.workspace = nullptr; dm.workspace_bytes = 0;
+          const bool apanel = (d->panels & 1) != 0;
+          dt.M = (int)m_tail;
+          dt.A = (const char*)d->A + (apanel ? (size_t)row0 * 64 : (size_t)row0 * d->lda * 2);
+          const bool c_planes = d->c_dtype == ACX_BF16X3 || d->c_dtype == ACX_BF16X3P;
+          if (c_planes) dm.c_plane_rows = dt.c_plane_rows = d->c_plane_rows ? d->c_plane_rows : (int64_t)d->M;
+          dt.C = (char*)d->C + (d->c_dtype == ACX_BF16X3P ? (size_t)row0 * 32 * 2
+                                                          : (size_t)row0 * d->ldc * (d->c_dtype == ACX_F32 ? 4 : 2));
+          if (d->residual) dt.residual = d->residual + (size_t)row0 * d->ldr;
+          const int rc = acx_gemm(ctx, &dm, stream);
+          return rc ? rc : acx_gemm(ctx, &dt, stream);
+        }
+      }
+    }
+  }
 
   Args g;
   g.d = *d;

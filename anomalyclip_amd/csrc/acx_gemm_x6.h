@@ -513,8 +513,9 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
         const int row = rowp + mi * 32 + 16 * ps, colq = colp + 32 * ni;                           \
         if ((!(PRED) || (colq < d.N && row < d.M)) && (!(ACX_X6_ABL & 4) || g.ksplit == 12345)) {  \
           typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));                         \
-          const size_t pe = (size_t)d.M * d.ldc;                                                   \
-          u16* dst = (u16*)d.C + (cpanel ? ((size_t)(colq >> 5) * d.M + row) * 32 + (colq & 31) : (size_t)row * d.ldc + colq); \
+          const size_t crows_ = d.c_plane_rows ? (size_t)d.c_plane_rows : (size_t)d.M;             \
+          const size_t pe = crows_ * d.ldc;                                                        \
+          u16* dst = (u16*)d.C + (cpanel ? ((size_t)(colq >> 5) * crows_ + row) * 32 + (colq & 31) : (size_t)row * d.ldc + colq); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&ph), reinterpret_cast<u32x4_*>(dst)); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pm), reinterpret_cast<u32x4_*>(dst + pe)); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pl), reinterpret_cast<u32x4_*>(dst + 2 * pe)); \

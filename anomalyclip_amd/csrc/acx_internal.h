@@ -39,6 +39,7 @@ struct acx_ctx {
   int opt_sk_max_m;         // ACX_OPT_SK_MAX_M
   int opt_tn_p256_min_rows; // ACX_OPT_TN_P256_MIN_ROWS
   int opt_x6_cus;           // ACX_OPT_X6_CUS (0: all)
+  int opt_x6_tail;          // ACX_OPT_X6_TAIL_SPLIT (0: off)
   char err[512];
   bool prof_on;
   bool prof_gemm_only;   // acx_prof_enable(ctx, 2): event pairs around the GEMM launches only

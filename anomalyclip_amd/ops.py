@@ -59,6 +59,13 @@ def set_x6_cus(device_index: int, cus: int) -> None:
     L.check(L.lib().acx_set_option(h, L.OPT_X6_CUS, int(cus)), h)
 
 
+def set_x6_tail_split(device_index: int, on: bool) -> None:
+    """ACX_OPT_X6_TAIL_SPLIT: K-split the partly filled last round of tiles of the bf16 x 6 products (default off: it gives the
+    tail rows of a launch another summation order than the rows before them)."""
+    h = L.ctx(device_index)
+    L.check(L.lib().acx_set_option(h, L.OPT_X6_TAIL_SPLIT, int(bool(on))), h)
+
+
 _SPLITK_WS: dict = {}
 _SPLITK_RETIRED: list = []
 
@@ -206,6 +213,11 @@ def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] =
     ws = None
     if split_k and tiles < 256 and K >= 384:
         ws = _splitk_workspace(a3.device, min(16, max(2, 512 // tiles)) * M * N * 4)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    elif split_k and amap == L.AMAP_IDENTITY and K >= 384:
+        # more tiles than CUs: scratch for the K split of a partly filled LAST round of tiles (acx_gemm splits the launch in two)
+        tn = (N + 255) // 256
+        ws = _splitk_workspace(a3.device, 4 * (256 // tn + 2) * 256 * N * 4)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a3)
     L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)

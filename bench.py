@@ -770,6 +770,22 @@ def main():
             extra["vit_chunk_256"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt256, 2),
                                       "ms_per_step": round(dt256 / k * 1e3, 3),
                                       "note": "config[2]'s literal batch: two 256-frame ViT launches per clip"}
+            if args.precision == "auto":
+                # the opt-in K split of the partly filled last round of tiles (ACX_OPT_X6_TAIL_SPLIT; off by default: it gives the
+                # tail rows of a launch another summation order than the rows before them)
+                from anomalyclip_amd import ops as _ops
+                try:
+                    _ops.set_x6_tail_split(local_rank, True)
+                    net.image_encoder.chunk = 256
+                    dt256t = timer.run(step_keep, k, 1)
+                    net.image_encoder.chunk = args.vit_chunk
+                    dt512t = timer.run(step_keep, k, 1)
+                finally:
+                    _ops.set_x6_tail_split(local_rank, False)
+                    net.image_encoder.chunk = args.vit_chunk
+                extra["x6_tail_split_opt_in"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt512t, 2),
+                                                 "frames_per_s_vit_chunk_256": round(FRAMES_PER_CLIP * k * world / dt256t, 2),
+                                                 "note": "acx_set_option(ACX_OPT_X6_TAIL_SPLIT, 1): not the default, not the headline"}
         if args.precision in ("auto", "f32"):
             # the OTHER f32-result path as a full leg: under the default (auto: the large GEMMs as f32-ACCURATE products on the
             # bf16 matrix cores -- three bf16 planes per operand, six cross products, f32 accumulation: acx_gemm_desc.pairs,

@@ -71,7 +71,13 @@ const char* acx_last_error(acx_ctx* ctx);
  *                           (and the K split is chosen for that many workgroups) so that the remaining CUs stay free for
  *                           kernels of OTHER streams -- the data-parallel step runs the text tower's ~160 few-row launches
  *                           beside the head's convolutions; 0 (default): all CUs. */
-enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2, ACX_OPT_TN_P256_MIN_ROWS = 3, ACX_OPT_X6_CUS = 4 };
+/*   ACX_OPT_X6_TAIL_SPLIT   pairs = 6 problems with more 256 x 256 tiles than CUs whose last round of tiles fills only part of the chip
+ *                           (and a caller-provided workspace): 1 = the whole tile rows of the full rounds as one launch, the
+ *                           remaining rows as a K-split problem + reduce launch (ViT c_proj at 512 frames: +0.7 %; the four
+ *                           products at 256 frames: +4-5 % frames/s).  The tail rows then sum K in another order than the
+ *                           rows before them: identical frames are no longer bit-identical wherever they sit in a launch, which
+ *                           is why the default is 0. */
+enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2, ACX_OPT_TN_P256_MIN_ROWS = 3, ACX_OPT_X6_CUS = 4, ACX_OPT_X6_TAIL_SPLIT = 5 };
 int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value);
 
 /* ------------------------------------------------------------------------------------------
@@ -143,6 +149,9 @@ typedef struct acx_gemm_desc {
   int32_t panels;         /* pairs = 6: bit 0 -- the A planes are in K-panel layout (ACX_BF16X3P, rows = a_plane_stride / (2 K));
                              bit 1 -- the W planes are (rows = N).  Identity row map only. */
   int64_t a_plane_stride, w_plane_stride;   /* bytes */
+  int64_t c_plane_rows;   /* plane outputs (ACX_BF16X3 / ACX_BF16X3P): rows of the WHOLE plane image when C addresses a row sub-range of
+                             it (plane p of the output at C + p * c_plane_rows * ldc elements; K-panel rows counted over c_plane_rows);
+                             0: M.  acx_gemm uses it itself when it splits a launch into full rounds of tiles + a K-split tail. */
 } acx_gemm_desc;
 int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
 

@@ -787,6 +787,47 @@ def test_gemm_x6_random_shapes_vs_fp64(seed):
             assert torch.equal(yp.float().sum(0), outs[(True, 0)])
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 70, 1024, 768), (256 * 100 - 37, 768, 1536), (256 * 90, 768, 3072)])
+def test_gemm_x6_partial_last_round_is_k_split(M, N, K):
+    """More 256 x 256 tiles than CUs with a last round that fills part of the chip (280 / 300 / 270 tiles on 256 CUs): acx_gemm
+    sends the whole tile rows of the full rounds out as one launch and the remaining rows as a K-split problem (+ reduce launch
+    with the epilogue).  Same product up to the summation order inside the tail rows: the rows of the full rounds are bit-identical
+    to the one-launch result, every element is within the f32 bound of fp64; residual in place, bf16 and plane outputs (row-major
+    and K-panel: acx_gemm_desc.c_plane_rows) of the split launch hold the f32 result.  Opt-in (ACX_OPT_X6_TAIL_SPLIT)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV)
+    a3, w3 = ops.split_bf16x3(a, panel=True), ops.split_bf16x3(w, panel=True)
+    y1 = ops.gemm_x6(a3, w3, bias=b, residual=r, split_k=False, panels=3)
+    x = r.clone()
+    dev = torch.device(DEV).index or 0
+    y2_off = ops.gemm_x6(a3, w3, bias=b, residual=r, split_k=True, panels=3)
+    assert torch.equal(y2_off, y1)                                                       # opt-in: off by default
+    ops.set_x6_tail_split(dev, True)
+    try:
+        _partial_last_round_checks(M, N, K, a, w, b, r, x, a3, w3, y1)
+    finally:
+        ops.set_x6_tail_split(dev, False)
+
+
+def _partial_last_round_checks(M, N, K, a, w, b, r, x, a3, w3, y1):
+    y2 = ops.gemm_x6(a3, w3, bias=b, residual=x, out=x, split_k=True, panels=3)          # in place, like the ViT's residual stream
+    ncu = torch.cuda.get_device_properties(torch.device(DEV)).multi_processor_count
+    tm, tn = (M + 255) // 256, (N + 255) // 256
+    row0 = ((tm * tn) // ncu * ncu) // tn * 256
+    assert 0 < row0 < M and torch.equal(y2[:row0], y1[:row0]) and not torch.equal(y2[row0:], y1[row0:])   # the tail took the split
+    ref = a.double() @ w.double().t() + b.double() + r.double()
+    bound = 2e-6 * (a.double().abs() @ w.double().abs().t() + b.double().abs() + r.double().abs()) + 1e-30
+    assert bool(((y2.double() - ref).abs() <= bound).all()) and bool(((y1.double() - ref).abs() <= bound).all())
+    y = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_QUICKGELU, split_k=True, panels=3)
+    yb = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_QUICKGELU, split_k=True, panels=3, out_dtype=torch.bfloat16)
+    yp = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_QUICKGELU, split_k=True, panels=3, planes_out=True)
+    ypp = ops.gemm_x6(a3, w3, bias=b, act=L.ACT_QUICKGELU, split_k=True, panels=3, planes_out=True, panel_out=True)
+    assert torch.equal(yb, y.to(torch.bfloat16)) and torch.equal(yp.float().sum(0), y) and torch.equal(ops.unpanel(ypp), yp)
+
+
 def test_x6_cus_option_caps_the_grid_same_product():
     """ACX_OPT_X6_CUS (ops.set_x6_cus): the persistent pairs = 6 kernels on fewer workgroups, K split chosen for that many -- a
     data-parallel rank leaves CUs to the text stream this way.  Same product up to the summation order of the K pieces (both
