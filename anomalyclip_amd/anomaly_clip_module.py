@@ -37,8 +37,10 @@ import torch
 from . import ops, parallel
 from .optim import AcxAdamW
 
-X6_RESERVE_ROWS = 8192     # rank shares of at most this many feature rows ...
+X6_RESERVE_ROWS = 16384    # rank shares of at most this many feature rows ...
 X6_RESERVE_CUS = 32        # ... keep this many CUs out of the persistent bf16 x 6 kernels' grids (train_batch)
+X6_SPLIT_ROWS = 8192       # up to here every convolution of the share is K-split anyway (fewer tiles than CUs); above, the capped
+                           # grid would turn 256 tiles into two rounds: the partly filled last round is K-split too (ACX_OPT_X6_TAIL_SPLIT)
 
 try:  # pragma: no cover - not installed in the build image
     from pytorch_lightning import LightningModule as _Base
@@ -565,21 +567,28 @@ class AnomalyCLIPModule(_Base):
         text stream for the duration of the step (eager launches and graph capture alike -- the grid and the K split are part
         of a captured launch): the head's bf16 x 6 convolutions are persistent one-workgroup-per-CU kernels that hold a CU's
         whole register file for ~90 us at a time, and the text tower's ~160 few-row launches (5-10 us each) otherwise queue
-        behind every one of them (emulated world 8: 2.74 -> 2.33 ms per step, world 4: 3.89 -> 3.74; at 16 384 rows and more
-        the convolutions need the whole chip: 6.04 -> 6.47, so nothing is reserved there).  The choice depends on the batch
-        geometry only: every rank makes the same one, the step graph and the autograd path stay bit-identical."""
+        behind every one of them (emulated world 8: 2.74 -> 2.33 ms per step, world 4: 3.89 -> 3.74).  At 16 384 rows (world 2)
+        the convolutions are 256 tiles, two rounds on a capped grid (6.04 -> 6.47 ms): there the partly filled last round is
+        K-split as well (ACX_OPT_X6_TAIL_SPLIT for the duration of the step: 6.14 -> 5.88 ms); at 32 768 rows the two cancel
+        (10.85 -> 10.83) and nothing is reserved.  The choice depends on the batch geometry only: every rank makes the same
+        one, the step graph and the autograd path stay bit-identical."""
         (nf, _), (af, _) = batch
         dev = af.device
         rows = (nf.numel() + af.numel()) // max(1, int(af.shape[-1]))            # feature rows of this rank's share
         reserve = dev.type == "cuda" and getattr(self.net, "precision", "auto") == "auto" and rows <= X6_RESERVE_ROWS
+        tail = reserve and rows > X6_SPLIT_ROWS
         if reserve:
             ncu = torch.cuda.get_device_properties(dev).multi_processor_count
             ops.set_x6_cus(dev.index or 0, max(1, ncu - X6_RESERVE_CUS))
+            if tail:
+                ops.set_x6_tail_split(dev.index or 0, True)
         try:
             yield
         finally:
             if reserve:
                 ops.set_x6_cus(dev.index or 0, 0)
+                if tail:
+                    ops.set_x6_tail_split(dev.index or 0, False)
 
     def _train_batch(self, batch, optimizer, batch_idx, buckets) -> torch.Tensor:
         sg = self._step_graph_for(batch, optimizer)

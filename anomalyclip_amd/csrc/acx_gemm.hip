@@ -607,14 +607,20 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   // the split model says >= 1 % (x6_choose_split's units).  Opt-in (ACX_OPT_X6_TAIL_SPLIT): the tail rows sum K in another order than
   // the rows before them, and the default keeps identical rows of one launch bit-identical.  Decided before the profiling scope:
   // the two calls are two launches.
-  if (d->pairs == 6 && d->amap == ACX_AMAP_IDENTITY && d->workspace && prec == ACX_PREC_BF16 && a_bf16 && !d->a_sub && !d->pos0 &&
+  if (d->pairs == 6 && (d->amap == ACX_AMAP_IDENTITY || d->amap == ACX_AMAP_CONV3X3) && d->workspace && prec == ACX_PREC_BF16 && a_bf16 &&
+      !d->a_sub && !d->pos0 &&
       d->K % 32 == 0 && ctx && ctx->opt_x6_tail) {
     int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
     if (ctx && ctx->opt_x6_cus > 0 && ctx->opt_x6_cus < ncu) ncu = ctx->opt_x6_cus;
     const int tm = (d->M + 255) / 256, tn = (d->N + 255) / 256, xt = tm * tn, nks = d->K / 32;
     const int rounds = xt / ncu, rem = xt - rounds * ncu;
     if (rounds >= 1 && rem > 0) {
-      const int tm_main = (rounds * ncu) / tn, xtail = (tm - tm_main) * tn;
+      int tm_main = (rounds * ncu) / tn;
+      if (d->amap == ACX_AMAP_CONV3X3) {           // the tail must begin at a token-grid boundary (its taps never leave a grid)
+        const int grid_tiles = (d->gn * d->gl + 255) / 256;
+        tm_main = (d->gn * d->gl) % 256 == 0 ? tm_main / grid_tiles * grid_tiles : 0;
+      }
+      const int xtail = (tm - tm_main) * tn;
       const int64_t row0 = (int64_t)tm_main * 256, m_tail = d->M - row0;
       if (tm_main >= 1 && xtail < ncu && m_tail > 0) {
         double tail_us = 0.0;

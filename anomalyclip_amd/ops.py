@@ -214,7 +214,7 @@ def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] =
     if split_k and tiles < 256 and K >= 384:
         ws = _splitk_workspace(a3.device, min(16, max(2, 512 // tiles)) * M * N * 4)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    elif split_k and amap == L.AMAP_IDENTITY and K >= 384:
+    elif split_k and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and K >= 384:
         # more tiles than CUs: scratch for the K split of a partly filled LAST round of tiles (acx_gemm splits the launch in two)
         tn = (N + 255) // 256
         ws = _splitk_workspace(a3.device, 4 * (256 // tn + 2) * 256 * N * 4)

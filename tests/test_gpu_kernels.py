@@ -828,6 +828,37 @@ def _partial_last_round_checks(M, N, K, a, w, b, r, x, a3, w3, y1):
     assert torch.equal(yb, y.to(torch.bfloat16)) and torch.equal(yp.float().sum(0), y) and torch.equal(ops.unpanel(ypp), yp)
 
 
+def test_conv3x3_x6_partial_last_round_is_k_split():
+    """The same for the implicit 3x3 convolution (a data-parallel rank of two runs its convolutions this way): 280 tiles, the
+    tail begins at a token-grid boundary (its taps never leave a grid); rows of the full rounds bit-identical to the one-launch
+    result, everything within the f32 bound of fp64."""
+    gn, gl, cin, cout, grids = 32, 16, 64, 256, 140
+    rows = grids * gn * gl
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(rows, cin, generator=g) * 0.7).to(DEV)
+    w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    x3, w3 = ops.split_bf16x3(x), ops.split_bf16x3(w)
+    run = lambda: ops.gemm_x6(x3, w3, bias=b, act=L.ACT_LEAKYRELU, amap=L.AMAP_CONV3X3, gn=gn, gl=gl, cin=cin)
+    y1 = run()
+    dev = torch.device(DEV).index or 0
+    ops.set_x6_tail_split(dev, True)
+    try:
+        y2 = run()
+    finally:
+        ops.set_x6_tail_split(dev, False)
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    row0 = (ncu // 2 * 2) * 256
+    assert row0 < rows and torch.equal(y2[:row0], y1[:row0]) and not torch.equal(y2[row0:], y1[row0:])
+    xp = torch.zeros(grids, gn + 2, gl + 2, cin, dtype=torch.float64, device=DEV)
+    xp[:, 1:-1, 1:-1] = x.double().view(grids, gn, gl, cin)
+    cols = torch.cat([xp[:, kh:kh + gn, kw:kw + gl] for kh in range(3) for kw in range(3)], dim=-1).reshape(rows, 9 * cin)
+    pre = cols @ w.double().t() + b.double()
+    ref = torch.where(pre > 0, pre, 0.01 * pre)
+    bound = 2e-6 * (cols.abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+    assert bool(((y2.double() - ref).abs() <= bound).all()) and bool(((y1.double() - ref).abs() <= bound).all())
+
+
 def test_x6_cus_option_caps_the_grid_same_product():
     """ACX_OPT_X6_CUS (ops.set_x6_cus): the persistent pairs = 6 kernels on fewer workgroups, K split chosen for that many -- a
     data-parallel rank leaves CUs to the text stream this way.  Same product up to the summation order of the K pieces (both

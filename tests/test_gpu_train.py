@@ -644,7 +644,7 @@ def test_ncentroid_from_frames_tiny(prompts_table):
 
 
 @pytest.mark.parametrize("cfg,B,precision", [("ucf", 4, "auto"), ("sht", 4, "auto"), ("ucf", 64, "auto"), ("sht", 16, "auto"),
-                                              ("ucf", 4, "f32"), ("ucf", 64, "f32")])
+                                              ("ucf", 4, "f32"), ("ucf", 64, "f32"), ("ucf", 32, "auto")])
 def test_full_config_train_step_vs_oracle(prompts_table, cfg, B, precision):
     """UCF (E=256, depth 1) and ShanghaiTech (concat on, depth 2) head configs, in both f32-result modes: loss and every trainable
     gradient against the oracle's autograd on the same seeded inputs.  B = 4 runs the single-video-sized GEMMs (split-K convs,
@@ -672,10 +672,22 @@ def test_full_config_train_step_vs_oracle(prompts_table, cfg, B, precision):
     net.train()
     net.selector_model.generate_mask = lambda b: (mask, mask)
     tap = net.temporal_model.__dict__["_act_tap"] = {}
-    with torch.enable_grad():
-        lg, lt, sc, ia, in_, ba = net(feats.to(DEV), labels.to(DEV), nc)
-        losses = crit(lg, lt, labels.to(DEV), sc, ia, in_, ba)
-        losses[0].backward()
+    # B = 32 (16 384 rows: a rank of two): train_batch runs such a share with 32 CUs left to the text stream and the partly
+    # filled last round of the convolutions' tiles K-split (AnomalyCLIPModule._x6_cu_reservation) -- the same options here
+    dp2 = B == 32
+    dev_i = torch.device(DEV).index or 0
+    if dp2:
+        ops.set_x6_cus(dev_i, torch.cuda.get_device_properties(dev_i).multi_processor_count - 32)
+        ops.set_x6_tail_split(dev_i, True)
+    try:
+        with torch.enable_grad():
+            lg, lt, sc, ia, in_, ba = net(feats.to(DEV), labels.to(DEV), nc)
+            losses = crit(lg, lt, labels.to(DEV), sc, ia, in_, ba)
+            losses[0].backward()
+    finally:
+        if dp2:
+            ops.set_x6_cus(dev_i, 0)
+            ops.set_x6_tail_split(dev_i, False)
     sides = _leaky_sides(tap, net.temporal_model, B)
     del net.temporal_model.__dict__["_act_tap"]
     names = [n for n, p in net.named_parameters() if p.requires_grad and n != "selector_model.logit_scale"]
@@ -849,7 +861,7 @@ def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom, B):
     assert torch.allclose(ma, mb, rtol=1e-6, atol=0) and mods[2][0]._meters.count == mods[1][0]._meters.count == 3
 
 
-@pytest.mark.parametrize("cfg,B", [("ucf", 8), ("sht", 4)])
+@pytest.mark.parametrize("cfg,B", [("ucf", 8), ("sht", 4), ("ucf", 32)])
 def test_step_graph_full_configs_bit_identical_to_autograd(prompts_table, cfg, B):
     """The whole-step graph at the reference's head configurations -- UCF (no concat: the temporal backward runs as its own
     graph beside the selector / text backward; B = 8 = a data-parallel rank's 4096 rows) and ShanghaiTech (concat on, depth

@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--temporal-graph", action="store_true", help="temporal model forward / backward as two replayed HIP graphs")
     ap.add_argument("--no-step-graph", action="store_true", help="autograd path instead of train_batch's whole-step graph")
     ap.add_argument("--x6-cus", type=int, default=-1, help="ACX_OPT_X6_CUS: CUs the bf16 x 6 kernels may hold (0 = all; -1 = the module's default)")
+    ap.add_argument("--x6-tail", action="store_true", help="ACX_OPT_X6_TAIL_SPLIT on (K-split a partly filled last round of tiles)")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32"], help="auto: the convolutions as bf16 x 6 products (default)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
@@ -147,6 +148,9 @@ def main():
     if args.x6_cus >= 0:
         from anomalyclip_amd import ops as ops_
         ops_.set_x6_cus(local_rank, args.x6_cus)
+    if args.x6_tail:
+        from anomalyclip_amd import ops as ops_
+        ops_.set_x6_tail_split(local_rank, True)
     if os.environ.get("ACX_TN_P256_MIN_ROWS"):           # development A/B: 2147483647 keeps the 128 x 128 weight-gradient kernels
         from anomalyclip_amd import _lib as L_
         L_.check(L_.lib().acx_set_option(L_.ctx(local_rank), L_.OPT_TN_P256_MIN_ROWS, int(os.environ["ACX_TN_P256_MIN_ROWS"])),
