@@ -123,7 +123,7 @@ class AnomalyCLIP(nn.Module):
                                         geom.transformer_layers, geom.embed_dim, head_precision)
         self.image_encoder = VisionTransformer(geom.image_resolution, geom.vision_patch_size, geom.vision_width,
                                                geom.vision_layers, geom.vision_heads, geom.embed_dim,
-                                               precision=vit_precision, chunk=g("vit_chunk", 256))
+                                               precision=vit_precision, chunk=g("vit_chunk", 512))
         self.selector_model = SelectorModel(classnames, self.normal_id, nn.Parameter(torch.tensor(2.6592601)),
                                             self.num_segments, self.seg_length, self.select_idx_dropout_topk,
                                             self.select_idx_dropout_bottomk, self.num_topk, self.num_bottomk)

@@ -142,7 +142,7 @@ class VisionTransformer(nn.Module):
     chunks of `chunk` frames (workspace is allocated once per chunk size and reused)."""
 
     def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int,
-                 output_dim: int, precision: str = "auto", chunk: int = 256):
+                 output_dim: int, precision: str = "auto", chunk: int = 512):
         super().__init__()
         self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
         self.width, self.layers, self.heads = width, layers, heads
