@@ -366,6 +366,36 @@ def test_attention(L_, heads, batch, causal):
     assert relerr(out, ref) < 3e-6
 
 
+def test_attention_every_length_both_precisions():
+    """acx_attention (f32, causal and not) and acx_attention_bf16 at EVERY sequence length 1 .. 224 (one batch of two sequences
+    and three heads each): every kernel choice, every tail / padding case, against fp64."""
+    g = torch.Generator().manual_seed(123)
+    heads, batch = 3, 2
+    W = heads * 64
+    worst32, worst16 = 0.0, 0.0
+    for L_ in range(1, 225):
+        qkv = torch.randn(batch * L_, 3 * W, generator=g)
+        q, k, v = qkv.view(batch, L_, 3, heads, 64).permute(2, 0, 3, 1, 4).double()
+        s = (q * 0.125) @ k.transpose(-1, -2)
+        qd = qkv.to(DEV)
+        for causal in ((False, True) if L_ <= 77 or L_ % 16 == 5 else (False,)):
+            sm = s + torch.full((L_, L_), float("-inf"), dtype=torch.float64).triu_(1) if causal else s
+            ref = (torch.softmax(sm, -1) @ v).transpose(1, 2).reshape(batch * L_, W)
+            out = ops.attention(qd, batch, L_, heads, causal)
+            e = relerr(out, ref)
+            worst32 = max(worst32, e)
+            assert e < 3e-6, (L_, causal, e)
+        ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(batch * L_, W)
+        ob = ops.attention_bf16(qd.to(torch.bfloat16), batch, L_, heads)
+        qb = qd.to(torch.bfloat16).double().cpu()
+        q2, k2, v2 = qb.view(batch, L_, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        refb = (torch.softmax((q2 * 0.125) @ k2.transpose(-1, -2), -1) @ v2).transpose(1, 2).reshape(batch * L_, W)
+        eb = relerr(ob.float(), refb)
+        worst16 = max(worst16, eb)
+        assert eb < 1.5e-2, (L_, eb)
+    print("worst relative error: f32", worst32, "bf16", worst16)
+
+
 @pytest.mark.parametrize("spike_key", [100, 3, 196])
 def test_attention_spiked_scores(spike_key):
     """one key dominating one query row (guide rule 26: force the extreme softmax case).  For the online-softmax kernel
