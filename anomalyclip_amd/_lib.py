@@ -16,6 +16,7 @@ ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1
 OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS, OPT_X6_CUS, OPT_X6_TAIL_SPLIT = 1, 2, 3, 4, 5
+OPT_X6_STRIP_TAIL, OPT_X6_MIN_TILES = 6, 7
 
 
 class GemmDesc(C.Structure):

@@ -41,6 +41,8 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->opt_tn_p256_min_rows = 4096;
   c->opt_x6_cus = 0;
   c->opt_x6_tail = 0;
+  c->opt_x6_strip = 1;
+  c->opt_x6_min_tiles = 18;
   c->err[0] = 0;
   c->prof_on = false;
   c->prof_gemm_only = false;
@@ -116,6 +118,14 @@ extern "C" int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value) {
     case ACX_OPT_X6_TAIL_SPLIT:
       ctx->opt_x6_tail = value != 0;
       return ACX_OK;
+    case ACX_OPT_X6_STRIP_TAIL:
+      if (value < 0 || value > 3) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: x6_strip_tail is 0 (off), 1 (cost model), 2 or 3 (forced strip width)%s");
+      ctx->opt_x6_strip = (int)value;
+      return ACX_OK;
+    case ACX_OPT_X6_MIN_TILES:
+      if (value < 1) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: x6_min_tiles must be >= 1%s");
+      ctx->opt_x6_min_tiles = (int)(value > 0x7fffffff ? 0x7fffffff : value);
+      return ACX_OK;
     case ACX_OPT_X6_CUS:
       if (value < 0) return acx_fail(ctx, ACX_E_BADARG, "acx_set_option: x6_cus must be >= 0%s");
       ctx->opt_x6_cus = (int)(value > 4096 ? 4096 : value);
@@ -169,8 +179,8 @@ TfWs carve_tf(char* base, int64_t rows, int W, int prec = ACX_PREC_F32) {
 bool x6_takes(acx_ctx* ctx, const TfWs& ws, int64_t M, int N, int K, int lda) {
   if (!ws.hp || !ACX_DBG_SWITCH("X6", true)) return false;
   const int64_t rtiles = ((M + 255) / 256) * ((N + 255) / 256);
-  const int ring_min = ctx ? ctx->opt_ring_min_tiles : 512;
-  return rtiles >= ring_min && K % 256 == 0 && N % 8 == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32) &&
+  const int x6_min = ctx ? ctx->opt_x6_min_tiles : 512;
+  return rtiles >= x6_min && K % 256 == 0 && N % 8 == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32) &&
          (size_t)N * K * 2 < ((size_t)1 << 32);
 }
 

@@ -75,6 +75,7 @@ struct Args {
   float* partial;          // [ksplit][M][N] raw partial sums (epilogue applied by splitk_reduce_kernel)
   const float* zeros;      // acx_gemm_desc.zero_page (conv taps outside the grid on the LDS-DMA kernels)
   unsigned int* counters;  // acx_gemm_desc.counters (few-row kernel's cross-workgroup K split: one arrival counter per tile)
+  int tile0, ntiles;       // gemm_x6_p4_kernel: the launch covers the full 256 x 256 tiles tile0 .. tile0 + ntiles (ntiles = 0: all)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -550,6 +551,15 @@ bool acx_gemm_takes_strip_stream(const acx_gemm_desc* d) {
   return tiles >= 1024 && (size_t)d->M * d->lda < ((size_t)1 << 31) && (size_t)d->N * d->ldw < ((size_t)1 << 31);
 }
 
+// Column strips for a partly filled last round of tiles (acx_gemm, pairs = 6): cost of a 256 x 128 / 256 x 64 strip relative
+// to a whole 256 x 256 tile (same A units, half / a quarter of the W units and MFMAs), and the switch (ACX_X6_STRIP=0 in tools
+// builds; ACX_OPT_X6_STRIP_TAIL at run time)
+// measured (profiles/r06_x6_strip_tail.txt): a round of 128-column strips takes 0.38-0.53 of a round of whole tiles at K = 768 (0.43-0.57
+// at K = 3072), growing with the number of strips in flight; 64-column strips 0.29-0.33 (0.38-0.45).  Upper ends here: strips are
+// taken for rem <= CUs / 2 (64-column ones for rem <= CUs / 4), which is where every measured case gains.
+static inline double x6_strip_cost(int ni) { return ni == 2 ? 0.55 : 0.45; }
+static inline bool x6_strip_enabled(const acx_ctx* ctx) { return ACX_DBG_SWITCH("X6_STRIP", true) && (!ctx || ctx->opt_x6_strip); }
+
 // K split of the plane-reuse kernel: `tiles` output tiles of `nks` K-steps on ncu persistent workgroups.  Cost of s pieces =
 // rounds(tiles s) x ceil(nks / s) K-steps (+ a term for the s partial images the reduce launch reads); every non-empty split
 // is allowed (the last K range of a tile takes what is left).  A pure function of the shape: fixed summation order.
@@ -658,6 +668,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
 #endif
   dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(NTHREADS);
   g.ksplit = 1; g.kchunk = 0; g.partial = nullptr; g.counters = nullptr;
+  g.tile0 = 0; g.ntiles = 0;
   g.zeros = (const float*)d->zero_page;
   const size_t lds = 4 * TILE_B;
   hipStream_t s = (hipStream_t)stream;
@@ -788,20 +799,44 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       const int xt = ((d->M + 255) / 256) * ((d->N + 255) / 256);
       const int nks = d->K / 32;
       int split = 1;
-      if (d->workspace && xt < ncu) split = x6_choose_split(xt, nks, ncu, (size_t)d->M * d->N * sizeof(float), d->workspace_bytes, 6);
+      double split_us = 0.0;
+      if (d->workspace && xt < ncu) split = x6_choose_split(xt, nks, ncu, (size_t)d->M * d->N * sizeof(float), d->workspace_bytes, 6, &split_us);
+      // A partly filled LAST round of tiles (N = 768 at 256 frames: 591 tiles = 2.3 rounds of 256 CUs) is cut into column STRIPS:
+      // the full rounds go out as whole tiles, the remaining `rem` tiles as 2 rem strips of 128 columns or 4 rem strips of 64
+      // (the NI = 2 / 1 instantiations, acx_gemm_x6.h) when that makes the last round shorter.  Strips leave every row's K order
+      // and product order untouched -- results are bit-identical to whole tiles (test_gemm_x6_strip_tail_bit_identical) -- so
+      // identical rows of one launch stay identical wherever they sit, which the K split of the tail (ACX_OPT_X6_TAIL_SPLIT) gave up.
+      // Cost of a strip relative to a whole tile: measured (profiles/r06_x6_strip_tail.txt).  Fewer tiles than workgroups: strips
+      // compete with the K split by the same cost model (x6_choose_split's units).
+      int strip_ni = 4, tile0_tail = 0, rem_tail = 0;
+      if (!conv && d->N % 256 == 0 && !c_bf16 && d->act != ACX_ACT_LEAKYRELU && x6_strip_enabled(ctx)) {
+        const int rounds = xt / ncu, rem = xt - rounds * ncu;
+        if (rem > 0) {
+          const double c2 = x6_strip_cost(2), c1 = x6_strip_cost(1);
+          const double cost2 = (double)((2 * rem + ncu - 1) / ncu) * c2, cost1 = (double)((4 * rem + ncu - 1) / ncu) * c1;
+          const double best = cost1 < cost2 ? cost1 : cost2;
+          const int force = ctx ? ctx->opt_x6_strip : 1;    // 2 / 3: always 128- / 64-column strips (measurements)
+          const double strip_us = (rounds + best) * (nks + 4.0) * 3.0;
+          if (force >= 2) { strip_ni = force == 2 ? 2 : 1; tile0_tail = rounds * ncu; rem_tail = rem; }
+          else if (best < 0.93 && (split == 1 || (strip_us < split_us && !(ctx && ctx->opt_x6_tail)))) { strip_ni = cost1 < cost2 ? 1 : 2; tile0_tail = rounds * ncu; rem_tail = rem; }
+          if (strip_ni < 4) split = 1;
+        }
+      }
       g.ksplit = split; g.kchunk = (nks + split - 1) / split; g.partial = split > 1 ? (float*)d->workspace : nullptr;
-      const int items = xt * split;
+      const int items = (strip_ni < 4 ? tile0_tail : xt) * split;
       const dim3 xgrid((unsigned)(items < ncu ? items : ncu));
-#define ACX_X6L(CM, ACT, RES, CV)                                                                   \
+      if (strip_ni < 4) { g.tile0 = 0; g.ntiles = tile0_tail; }
+#define ACX_X6L_(CM, ACT, RES, CV, NI_, GRID)                                                        \
   do {                                                                                              \
     static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                          \
     if (!attr_done) {                                                                               \
-      (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<CM, ACT, RES, CV>,                   \
+      (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<CM, ACT, RES, CV, 0, 0, NI_>,        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B);         \
       attr_done = true;                                                                             \
     }                                                                                               \
-    hipLaunchKernelGGL((gemm_x6_p4_kernel<CM, ACT, RES, CV>), xgrid, dim3(256), (size_t)X6_LDS_B, s, g); \
+    hipLaunchKernelGGL((gemm_x6_p4_kernel<CM, ACT, RES, CV, 0, 0, NI_>), GRID, dim3(256), (size_t)X6_LDS_B, s, g); \
   } while (0)
+#define ACX_X6L(CM, ACT, RES, CV) do { if (items > 0) ACX_X6L_(CM, ACT, RES, CV, 4, xgrid); } while (0)
 #define ACX_X6SEL(CV)                                                                               \
   do {                                                                                              \
     if (split > 1) ACX_X6L(0, 0, 0, CV);                                                            \
@@ -813,8 +848,25 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     else ACX_X6L(0, 0, 0, CV);                                                                      \
   } while (0)
       if (conv) ACX_X6SEL(1); else ACX_X6SEL(0);
+      if (strip_ni < 4) {
+        // the strips of the last round: identity rows only; epilogues of the ViT's products (plane outputs with / without QuickGELU,
+        // f32 with a residual / QuickGELU / plain) -- anything else keeps whole tiles (x6_strip_epilogue_ok)
+        g.tile0 = tile0_tail; g.ntiles = rem_tail;
+        const int sitems = rem_tail * (4 / strip_ni);
+        const dim3 sgrid((unsigned)(sitems < ncu ? sitems : ncu));
+#define ACX_X6S(NI_)                                                                                 \
+  do {                                                                                              \
+    if (c_x3_) { if (d->act == ACX_ACT_QUICKGELU) ACX_X6L_(2, 1, 0, 0, NI_, sgrid); else ACX_X6L_(2, 0, 0, 0, NI_, sgrid); } \
+    else if (d->residual) ACX_X6L_(0, 0, 1, 0, NI_, sgrid);                                         \
+    else if (d->act == ACX_ACT_QUICKGELU) ACX_X6L_(0, 1, 0, 0, NI_, sgrid);                         \
+    else ACX_X6L_(0, 0, 0, 0, NI_, sgrid);                                                          \
+  } while (0)
+        if (strip_ni == 2) ACX_X6S(2); else ACX_X6S(1);
+#undef ACX_X6S
+      }
 #undef ACX_X6SEL
 #undef ACX_X6L
+#undef ACX_X6L_
       if (split > 1) {
         // (shape_ok: N, ldc, ldr multiples of 4, 16-byte aligned bias / residual / C, no positional epilogue)
         const int64_t total4 = (int64_t)d->M * (d->N / 4);

@@ -69,7 +69,13 @@ __device__ __forceinline__ bf16x8 x6_tr_frag(const char* smem, int off_lo, int o
 // four units (A and W of two 32-wide K-steps) per super-step, 64 MFMAs per wave behind one barrier in four blocks of 16, the
 // fragments of block b + 1 read between the MFMAs of block b, the next super-step's four units requested between the MFMAs of the
 // first block (two unit parities in the eight LDS slots).  K % 64 == 0.
-template <int C_MODE, int ACT, int RES, int CONV, int TN = 0, int PLAIN = 0>
+// NI (4 / 2 / 1; NT products, not PLAIN): column blocks of 32 per wave -- the workgroup's tile is 256 rows x 64 NI columns (the wave
+// grid stays 2 x 2: 128 x 32 NI per wave).  NI < 4 are the SUB-TILE instantiations for a partly filled last round of tiles
+// (acx_gemm: g.tile0 / g.ntiles select the full 256 x 256 tiles of the launch, each is cut into 4 / NI column strips = work
+// items): every accumulator sees exactly the MFMA sequence it sees inside a full tile (same K order, same product order), so a
+// row's result does not depend on which instantiation produced it -- bit-identical -- while the last round's cost falls with
+// the strip width.  W units shrink with the tile (NI DMA instructions per wave and unit: waits vmcnt(NI) before Y).
+template <int C_MODE, int ACT, int RES, int CONV, int TN = 0, int PLAIN = 0, int NI = 4>
 __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
@@ -77,9 +83,12 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, hh = lane >> 5;
+  static_assert(NI == 4 || (NI > 0 && NI < 4 && NI != 3 && TN == 0 && PLAIN == 0), "sub-tile instantiations: NT products only");
+  constexpr int SUB = 4 / NI, TW = 64 * NI;      // work items per full tile (column strips), strip width
   const int tiles_n = (d.N + 255) / 256, tiles_m = (d.M + 255) / 256;
-  const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
-  const int nitems = tiles_m * tiles_n * ksplit;
+  const int ksplit = (NI == 4 && g.ksplit > 1) ? g.ksplit : 1;
+  const int ntiles = g.ntiles > 0 ? g.ntiles : tiles_m * tiles_n;   // full tiles of this launch: g.tile0 .. g.tile0 + ntiles
+  const int nitems = ntiles * (NI < 4 ? SUB : ksplit);
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
   const int b0 = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + ((int)blockIdx.x >> 3);
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   // ---- DMA: a unit is 16 wave-instructions of 1 KB (16 rows x 64 B); wave w issues instructions 4 w .. 4 w + 3.
   // lane -> row (lane >> 2) of the instruction's 16, LDS chunk position lane & 3 = global chunk ^ ((row >> 2) & 3)
   const int dr = 64 * wave + (lane >> 2);                        // + 16 i: this lane's unit row of instruction i
+  const int dwr = 16 * NI * wave + (lane >> 2);                  // the same for a W unit (64 NI rows: NI instructions per wave)
   const int dc = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;          // byte offset of its 16-byte piece inside the row's 64 B
   const char* zsrc = (CONV || TN) ? (const char*)g.zeros + (lane & 3) * 16 : nullptr;
   const int sh_gl = CONV ? __builtin_ctz((unsigned)d.gl) : 0;
@@ -107,9 +117,11 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 #define X6_SET_ITEM(S, jj)                                                                         \
   do {                                                                                             \
     const int L_ = b0 + min((jj), my_items - 1) * G;   /* past the end: re-read the last item (never consumed) */ \
-    const int tile_ = L_ / ksplit, ks_ = L_ - tile_ * ksplit;                                      \
+    const int ti_ = L_ / (NI < 4 ? SUB : ksplit), ks_ = NI < 4 ? 0 : L_ - ti_ * ksplit;            \
+    const int tile_ = g.tile0 + ti_;                                                               \
     const int tm_ = tile_ / tiles_n, tn_ = tile_ - tm_ * tiles_n;                                  \
-    S.m0 = tm_ * 256; S.n0 = tn_ * 256; S.kk = ks_ * spi; S.steps = min(spi, nks - ks_ * spi);     \
+    S.m0 = tm_ * 256; S.n0 = tn_ * 256 + (NI < 4 ? (L_ - ti_ * SUB) * TW : 0);                     \
+    S.kk = ks_ * spi; S.steps = min(spi, nks - ks_ * spi);                                         \
     S.dn = S.dl = 0; S.c0 = S.n0;                                                                  \
     if constexpr (TN != 0 && CONV != 0) {                                                          \
       const int tap_ = S.n0 / d.cin, t3_ = tap_ / 3;                                               \
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
       const int m_ = S.m0 + dr + 16 * i;                                                           \
       RA[i] = (unsigned)(CONV ? m_ : min(m_, d.M - 1)) * (apanel ? 64u : (unsigned)d.lda * 2u) + (unsigned)dc; \
-      RW[i] = (unsigned)min(S.n0 + dr + 16 * i, d.N - 1) * (wpanel ? 64u : (unsigned)d.ldw * 2u) + (unsigned)dc; \
+      RW[i] = (unsigned)min(S.n0 + dwr + 16 * (i < NI ? i : 0), d.N - 1) * (wpanel ? 64u : (unsigned)d.ldw * 2u) + (unsigned)dc; \
       if constexpr (CONV != 0) {                                                                   \
         const int n_ = (m_ >> sh_gl) & (d.gn - 1), l_c = m_ & (d.gl - 1);                          \
         const unsigned rn_ = (n_ > 0 ? 1u : 0u) | 2u | (n_ < d.gn - 1 ? 4u : 0u);   /* dn = -1, 0, +1 */ \
@@ -174,7 +186,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   } while (0)
 #define X6_DMA_W_K(S, KK, RW, pl, slot, i)                                                               \
   do {                                                                                             \
-    const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (4 * wave + (i)) * 1024;                       \
+    if ((i) >= NI) break;                          /* (constant after unrolling) */                 \
+    const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (NI * wave + (i)) * 1024;                      \
     if constexpr (TN != 0) {                                                                       \
       const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride;                 \
       const int m_ = (KK) * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   // ---- fragment addresses inside a unit: row, chunk 2 s + hh at position chunk ^ ((li >> 2) & 3); + 2048 per 32-row block
   const int sw = (li >> 2) & 3;
   const int fa0 = (wm * 128 + li) * 64 + ((0 + hh) ^ sw) * 16, fa1 = (wm * 128 + li) * 64 + ((2 + hh) ^ sw) * 16;
-  const int fw0 = (wn * 128 + li) * 64 + ((0 + hh) ^ sw) * 16, fw1 = (wn * 128 + li) * 64 + ((2 + hh) ^ sw) * 16;
+  const int fw0 = (wn * 32 * NI + li) * 64 + ((0 + hh) ^ sw) * 16, fw1 = (wn * 32 * NI + li) * 64 + ((2 + hh) ^ sw) * 16;
 
   // TN: transpose-read addresses of row block / column block blk, k half r (see x6_tr_frag); + 8192 for substep 1
   int trA[4][2], trW[4][2];
@@ -242,11 +255,11 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       trW[blk][r] = TN ? base_ + (((wn * 4 + blk) ^ x_) * 64) : 0;
     }
 
-  f32x16 acc[4][4];
+  f32x16 acc[4][NI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < NI; ++jj)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
   // fragment sets: [0..3] A.hi (X) / A.mid (Y) row blocks, [4..7] W.hi, [8..11] W.mid column blocks, [12..15] W.lo column
@@ -266,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   } while (0)
 #define X6_RD_X(F, s, q)                                                                           \
   do {                                                                                             \
+    if ((q) >= 4 && ((q) & 3) >= NI) break;        /* W column blocks the strip does not have */    \
     if ((q) < 4) X6_LOADF(F[q], X6_AH * X6_UNIT_B, trA, fa0, fa1, (q) & 3, s);                     \
     else if ((q) < 8) X6_LOADF(F[q], wpar + X6_WH0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);        \
     else if ((q) < 12) X6_LOADF(F[q], wpar + X6_WM0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);       \
@@ -273,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   } while (0)
 #define X6_RD_Y(F, s, q)                                                                           \
   do {                                                                                             \
+    if ((q) >= 4 && (q) < 12 && ((q) & 3) >= NI) break;                                            \
     if ((q) < 4) X6_LOADF(F[q], X6_AM * X6_UNIT_B, trA, fa0, fa1, (q) & 3, s);                     \
     else if ((q) < 8) X6_LOADF(F[q], wpar + X6_WH0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);        \
     else if ((q) < 12) X6_LOADF(F[q], wpar + X6_WM0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);       \
@@ -284,11 +299,13 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 #define X6_MM_X(F, q)                                                                              \
   do {                                                                                             \
     constexpr int p_ = (q) / 16, mi_ = ((q) % 16) / 4, ni_ = (q) % 4;                              \
+    if constexpr (ni_ < NI)                                                                        \
     acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[(p_ == 0 ? 12 : p_ == 1 ? 8 : 4) + ni_], F[mi_], acc[mi_][ni_], 0, 0, 0); \
   } while (0)
 #define X6_MM_Y(F, q)                                                                              \
   do {                                                                                             \
     constexpr int p_ = (q) / 16, mi_ = ((q) % 16) / 4, ni_ = (q) % 4;                              \
+    if constexpr (ni_ < NI)                                                                        \
     acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[(p_ == 1 ? 8 : 4) + ni_], F[(p_ == 0 ? 12 : 0) + mi_], acc[mi_][ni_], 0, 0, 0); \
   } while (0)
 #define X6_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       X6_REP48(X6_B2_X)
 #undef X6_B2_X
       // =========================================================================== half-step Y
-      if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");     // A.mid, A.lo landed (W.hi of the next K-step may be in flight)
+      if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NI) : "memory");     // A.mid, A.lo landed (W.hi of the next K-step -- NI instructions -- may be in flight)
       X6_FENCE();
       __builtin_amdgcn_s_barrier();
       X6_FENCE();
@@ -431,9 +448,10 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const int L = b0 + j * G;
-      const int tile = L / ksplit, ks = L - tile * ksplit;
+      const int ti = L / (NI < 4 ? SUB : ksplit), ks = NI < 4 ? 0 : L - ti * ksplit;
+      const int tile = g.tile0 + ti;
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-      const int m0 = tm * 256, n0 = tn * 256;
+      const int m0 = tm * 256, n0 = tn * 256 + (NI < 4 ? (L - ti * SUB) * TW : 0);
       const bool raw = ksplit > 1;               // split items: raw f32 partial tile [ks][M][N], epilogue in the reduce launch
       float* Cf = raw ? g.partial + (size_t)ks * d.M * d.N : (float*)d.C;
       const int ldc = raw ? d.N : d.ldc;
@@ -441,17 +459,17 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       // row-major: lane l owns 4 consecutive columns (l & 7) of row (l >> 3) + 8 pass: 4 stores of 8 rows x 128 B per tile.
       char* scr = smem + 8 * X6_UNIT_B + wave * 4096;
       const int rl = lane >> 3, cj = lane & 7;
-      const int colw = n0 + wn * 128 + 4 * cj;   // + 32 ni
+      const int colw = n0 + wn * 32 * NI + 4 * cj;   // + 32 ni
       const int roww = m0 + wm * 128 + rl;       // + 32 mi + 8 ps
       // bias of the four column blocks: consumed HERE, outside every store -- a load still pending when stores are issued
       // makes hipcc's counted waits cover the stores as well (one in-order vmcnt)
       // (plane outputs, C_MODE 2: lane l owns EIGHT consecutive columns (l & 3) of row (l >> 2) + 16 pass -- 16-byte bf16 stores,
       // 6 instead of 12 store instructions per tile: the store path takes ~64 cycles per wave-instruction whatever its width)
-      const int colp = n0 + wn * 128 + 8 * (lane & 3);   // + 32 ni
+      const int colp = n0 + wn * 32 * NI + 8 * (lane & 3);   // + 32 ni
       const int rowp = m0 + wm * 128 + (lane >> 2);      // + 32 mi + 16 pass
-      float4 bia[4], bib[4];
+      float4 bia[NI], bib[NI];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         bia[ni] = bib[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (d.bias && !raw) {
           if constexpr (C_MODE == 2) {
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
         }
       }
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         asm volatile("" : "+v"(bia[ni].x), "+v"(bia[ni].y), "+v"(bia[ni].z), "+v"(bia[ni].w));
         if constexpr (C_MODE == 2) asm volatile("" : "+v"(bib[ni].x), "+v"(bib[ni].y), "+v"(bib[ni].z), "+v"(bib[ni].w));
       }
@@ -552,13 +570,21 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;                          \
   } while (0)
       float4 R0[4], R1[4];
-      if (m0 + 256 <= d.M && n0 + 256 <= d.N) {
+      if (m0 + 256 <= d.M && n0 + TW <= d.N) {
         // full tile: unpredicated stores (straight-line code: hipcc's counted waits then leave the stores in flight), the
         // residual loaded TWO accumulator tiles ahead of its use -- a wait for it never covers the stores of the last two
 #define X6_FULL2(bi) X6_EPI_BLOCK(R0, bi, false); X6_RES_LOAD(R0, (bi) + 2); X6_EPI_BLOCK(R1, (bi) + 1, false); X6_RES_LOAD(R1, (bi) + 3);
         X6_RES_LOAD(R0, 0); X6_RES_LOAD(R1, 1);
-        X6_FULL2(0) X6_FULL2(2) X6_FULL2(4) X6_FULL2(6) X6_FULL2(8) X6_FULL2(10) X6_FULL2(12)
-        X6_EPI_BLOCK(R0, 14, false); X6_EPI_BLOCK(R1, 15, false);
+        if constexpr (NI == 4) {
+          X6_FULL2(0) X6_FULL2(2) X6_FULL2(4) X6_FULL2(6) X6_FULL2(8) X6_FULL2(10) X6_FULL2(12)
+          X6_EPI_BLOCK(R0, 14, false); X6_EPI_BLOCK(R1, 15, false);
+        } else if constexpr (NI == 2) {
+          X6_FULL2(0) X6_FULL2(2) X6_FULL2(4)
+          X6_EPI_BLOCK(R0, 6, false); X6_EPI_BLOCK(R1, 7, false);
+        } else {
+          X6_FULL2(0)
+          X6_EPI_BLOCK(R0, 2, false); X6_EPI_BLOCK(R1, 3, false);
+        }
 #undef X6_FULL2
       } else {
         // edge tile: rows / columns masked at the store (a pending residual load then makes every store block wait: one
@@ -572,8 +598,9 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     }                                                                                              \
     X6_EPI_BLOCK(R0, bi, true);                                                                    \
   } while (0);
-        X6_EDGE(0) X6_EDGE(1) X6_EDGE(2) X6_EDGE(3) X6_EDGE(4) X6_EDGE(5) X6_EDGE(6) X6_EDGE(7)
-        X6_EDGE(8) X6_EDGE(9) X6_EDGE(10) X6_EDGE(11) X6_EDGE(12) X6_EDGE(13) X6_EDGE(14) X6_EDGE(15)
+        X6_EDGE(0) X6_EDGE(1) X6_EDGE(2) X6_EDGE(3)
+        if constexpr (NI >= 2) { X6_EDGE(4) X6_EDGE(5) X6_EDGE(6) X6_EDGE(7) }
+        if constexpr (NI == 4) { X6_EDGE(8) X6_EDGE(9) X6_EDGE(10) X6_EDGE(11) X6_EDGE(12) X6_EDGE(13) X6_EDGE(14) X6_EDGE(15) }
 #undef X6_EDGE
       }
 #undef X6_EPI_BLOCK

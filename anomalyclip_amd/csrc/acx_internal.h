@@ -40,6 +40,8 @@ struct acx_ctx {
   int opt_tn_p256_min_rows; // ACX_OPT_TN_P256_MIN_ROWS
   int opt_x6_cus;           // ACX_OPT_X6_CUS (0: all)
   int opt_x6_tail;          // ACX_OPT_X6_TAIL_SPLIT (0: off)
+  int opt_x6_min_tiles;     // ACX_OPT_X6_MIN_TILES
+  int opt_x6_strip;         // ACX_OPT_X6_STRIP_TAIL (1: by the cost model, 0: off, 2 / 3: always 128- / 64-column strips)
   char err[512];
   bool prof_on;
   bool prof_gemm_only;   // acx_prof_enable(ctx, 2): event pairs around the GEMM launches only

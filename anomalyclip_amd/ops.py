@@ -57,6 +57,23 @@ def set_x6_cus(device_index: int, cus: int) -> None:
     the shape and of this value): set it BEFORE capturing graphs, and identically on every rank."""
     h = L.ctx(device_index)
     L.check(L.lib().acx_set_option(h, L.OPT_X6_CUS, int(cus)), h)
+    x6_options(device_index)["cus"] = int(cus)
+
+
+X6_MIN_TILES_DEFAULT = 18   # ACX_OPT_X6_MIN_TILES as acx_create sets it (tests restore it)
+_X6_OPTS: dict = {}     # device index -> {"cus": n, "tail_split": bool}: the wrapper's mirror of the context options it sizes scratch by
+
+
+def x6_options(device_index: int) -> dict:
+    return _X6_OPTS.setdefault(int(device_index), {"cus": 0, "tail_split": False})
+
+
+def x6_workgroups(device_index: int) -> int:
+    """Workgroups the persistent bf16 x 6 kernels launch on this device: its CU count, or ACX_OPT_X6_CUS when that is lower
+    (what acx_gemm's K-split model is evaluated for: the wrapper sizes the split workspace by the same number)."""
+    ncu = torch.cuda.get_device_properties(device_index).multi_processor_count
+    cap = x6_options(device_index)["cus"]
+    return min(ncu, cap) if cap > 0 else ncu
 
 
 def set_x6_tail_split(device_index: int, on: bool) -> None:
@@ -64,6 +81,21 @@ def set_x6_tail_split(device_index: int, on: bool) -> None:
     tail rows of a launch another summation order than the rows before them)."""
     h = L.ctx(device_index)
     L.check(L.lib().acx_set_option(h, L.OPT_X6_TAIL_SPLIT, int(bool(on))), h)
+    x6_options(device_index)["tail_split"] = bool(on)
+
+
+def set_x6_strip_tail(device_index: int, mode: int) -> None:
+    """ACX_OPT_X6_STRIP_TAIL: 1 (default) = a partly filled last round of 256 x 256 tiles is cut into 128- / 64-column strips when
+    that shortens it (bit-identical results: same K order per element); 0 = whole tiles only; 2 / 3 = always 128 / 64 columns."""
+    h = L.ctx(device_index)
+    L.check(L.lib().acx_set_option(h, L.OPT_X6_STRIP_TAIL, int(mode)), h)
+
+
+def set_x6_min_tiles(device_index: int, tiles: int) -> None:
+    """ACX_OPT_X6_MIN_TILES: the ACX_PREC_F32X6 drivers run a product with at least this many 256 x 256 output tiles as a bf16 x 6
+    product (smaller ones on the f32 MFMA kernels)."""
+    h = L.ctx(device_index)
+    L.check(L.lib().acx_set_option(h, L.OPT_X6_MIN_TILES, int(tiles)), h)
 
 
 _SPLITK_WS: dict = {}
@@ -209,16 +241,24 @@ def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] =
     d.amap, d.gn, d.gl, d.cin = amap, gn, gl, cin
     if amap == L.AMAP_CONV3X3:
         d.zero_page = _zero_page(a3.device).data_ptr()
-    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    tm, tn = (M + 255) // 256, (N + 255) // 256
+    tiles = tm * tn
+    dev_i = a3.device.index if a3.device.index is not None else torch.cuda.current_device()
+    wgs = x6_workgroups(dev_i)             # (the number acx_gemm evaluates its K-split model for: CUs, or ACX_OPT_X6_CUS)
     ws = None
-    if split_k and tiles < 256 and K >= 384:
-        ws = _splitk_workspace(a3.device, min(16, max(2, 512 // tiles)) * M * N * 4)
+    if split_k and tiles < wgs and K >= 384:
+        ws = _splitk_workspace(a3.device, min(16, max(2, 2 * wgs // tiles)) * M * N * 4)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    elif split_k and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and K >= 384:
-        # more tiles than CUs: scratch for the K split of a partly filled LAST round of tiles (acx_gemm splits the launch in two)
-        tn = (N + 255) // 256
-        ws = _splitk_workspace(a3.device, 4 * (256 // tn + 2) * 256 * N * 4)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    elif split_k and x6_options(dev_i)["tail_split"] and amap in (L.AMAP_IDENTITY, L.AMAP_CONV3X3) and K >= 384 and tiles % wgs:
+        # ACX_OPT_X6_TAIL_SPLIT only: scratch for the K split of a partly filled LAST round of tiles (acx_gemm splits the launch
+        # in two) -- sized from the tail's rows (the tile rows behind the full rounds), up to 4 pieces (8 when the tail is short)
+        tail_rows = M - min(M, (tiles // wgs * wgs) // tn * 256)
+        if amap == L.AMAP_CONV3X3 and (gn * gl) % 256 == 0:      # (the tail begins at a token-grid boundary)
+            gt = gn * gl // 256
+            tail_rows = M - min(M, ((tiles // wgs * wgs) // tn) // gt * gt * 256)
+        if tail_rows > 0:
+            ws = _splitk_workspace(a3.device, min(8, max(4, 2 * wgs // max(1, (tail_rows + 255) // 256 * tn))) * tail_rows * N * 4)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     h = _h(a3)
     L.check(L.lib().acx_gemm(h, C.byref(d), _stream()), h)
     return out

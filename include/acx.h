@@ -77,7 +77,16 @@ const char* acx_last_error(acx_ctx* ctx);
  *                           products at 256 frames: +4-5 % frames/s).  The tail rows then sum K in another order than the
  *                           rows before them: identical frames are no longer bit-identical wherever they sit in a launch, which
  *                           is why the default is 0. */
-enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2, ACX_OPT_TN_P256_MIN_ROWS = 3, ACX_OPT_X6_CUS = 4, ACX_OPT_X6_TAIL_SPLIT = 5 };
+/*   ACX_OPT_X6_STRIP_TAIL   pairs = 6 problems (identity rows, N % 256 == 0) whose last round of 256 x 256 tiles fills only part of the
+ *                           chip: 1 (default) = the tiles of that round are cut into 128- or 64-column strips (one work item each)
+ *                           when the cost model says the round gets shorter.  A strip runs the same K order and product order
+ *                           per output element as a whole tile: results are BIT-IDENTICAL to 0 (= whole tiles only); 2 / 3 force
+ *                           128- / 64-column strips (measurements). */
+/*   ACX_OPT_X6_MIN_TILES    ACX_PREC_F32X6 drivers (acx_vit_encode, acx_transformer_forward): a product with at least this many
+ *                           256 x 256 output tiles runs as a pairs = 6 product, smaller ones on the f32 MFMA kernels (default 18:
+ *                           the ViT from 8 frames per launch; measured crossover, profiles/r06_x6_strip_tail.txt). */
+enum { ACX_OPT_RING_MIN_TILES = 1, ACX_OPT_SK_MAX_M = 2, ACX_OPT_TN_P256_MIN_ROWS = 3, ACX_OPT_X6_CUS = 4, ACX_OPT_X6_TAIL_SPLIT = 5,
+       ACX_OPT_X6_STRIP_TAIL = 6, ACX_OPT_X6_MIN_TILES = 7 };
 int acx_set_option(acx_ctx* ctx, int32_t option, int64_t value);
 
 /* ------------------------------------------------------------------------------------------

@@ -858,6 +858,47 @@ def _partial_last_round_checks(M, N, K, a, w, b, r, x, a3, w3, y1):
     assert torch.equal(yb, y.to(torch.bfloat16)) and torch.equal(yp.float().sum(0), y) and torch.equal(ops.unpanel(ypp), yp)
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 70, 1024, 768), (256 * 100 - 37, 768, 1536), (256 * 115, 768, 768), (256 * 197, 768, 768),
+                                   (256 * 30 + 5, 768, 3072)])
+def test_gemm_x6_strip_tail_bit_identical(M, N, K):
+    """A partly filled last round of 256 x 256 tiles goes out as 128- / 64-column STRIPS (the NI = 2 / 1 instantiations of
+    gemm_x6_p4_kernel, ACX_OPT_X6_STRIP_TAIL; default: by the cost model).  A strip runs the same K order and product order per
+    output element as a whole tile, so -- unlike the K split of the tail -- the result is BIT-IDENTICAL to whole tiles: every
+    epilogue the strips carry (f32 plain / QuickGELU / residual in place, plane outputs row-major and K-panel), ragged last row
+    tile, forced strip widths, fewer tiles than CUs (30 x 3 = 90 tiles: one round of strips)."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV)
+    a3, w3 = ops.split_bf16x3(a, panel=True), ops.split_bf16x3(w, panel=True)
+    dev = torch.device(DEV).index or 0
+
+    def run_all():
+        x = r.clone()
+        outs = [ops.gemm_x6(a3, w3, bias=b, split_k=False, panels=3),
+                ops.gemm_x6(a3, w3, bias=b, act=L.ACT_QUICKGELU, split_k=False, panels=3),
+                ops.gemm_x6(a3, w3, bias=b, residual=x, out=x, split_k=False, panels=3).clone(),
+                ops.gemm_x6(a3, w3, bias=b, split_k=False, panels=3, planes_out=True),
+                ops.gemm_x6(a3, w3, bias=b, act=L.ACT_QUICKGELU, split_k=False, panels=3, planes_out=True, panel_out=True)]
+        torch.cuda.synchronize()
+        return outs
+
+    ops.set_x6_strip_tail(dev, 0)
+    try:
+        whole = run_all()
+        for mode in (1, 2, 3):
+            ops.set_x6_strip_tail(dev, mode)
+            for i, (y, y0) in enumerate(zip(run_all(), whole)):
+                assert torch.equal(y, y0), (mode, i)
+    finally:
+        ops.set_x6_strip_tail(dev, 1)
+    ref = a.double() @ w.double().t() + b.double()
+    bound = 2e-6 * (a.double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+    assert bool(((whole[0].double() - ref).abs() <= bound).all())
+    assert torch.equal(whole[3].float().sum(0), whole[0])
+
+
 def test_conv3x3_x6_partial_last_round_is_k_split():
     """The same for the implicit 3x3 convolution (a data-parallel rank of two runs its convolutions this way): 280 tiles, the
     tail begins at a token-grid boundary (its taps never leave a grid); rows of the full rounds bit-identical to the one-launch

@@ -8,6 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from anomalyclip_amd import init_weights as IW
+from anomalyclip_amd import ops
 from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP
 from anomalyclip_amd.components.clip_vit import VisionTransformer
 from anomalyclip_amd.components.temporal_model import TemporalModel
@@ -57,11 +58,11 @@ def test_vit_f32x6_small_launches_vs_reference(golden, which):
     vit, _ = make_vit(geom, int(g["seed"]), precision="f32x6")
     frames = torch.from_numpy(g["frames"]) if which == "vit_tiny" else R.vit_frames(int(g["seed"]), 2, 224)
     h = L.ctx(torch.cuda.current_device())
-    L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 1), h)
+    ops.set_x6_min_tiles(torch.cuda.current_device(), 1)
     try:
         out = vit(frames.to(DEV))
     finally:
-        L.check(L.lib().acx_set_option(h, L.OPT_RING_MIN_TILES, 512), h)
+        ops.set_x6_min_tiles(torch.cuda.current_device(), ops.X6_MIN_TILES_DEFAULT)
     assert relerr(out, g["out"]) < TOL and elem_ok(out, g["out"])
     vit32, _ = make_vit(geom, int(g["seed"]))
     assert relerr(out, vit32(frames.to(DEV))) < 5e-6                     # and round-off away from the f32 MFMA path
@@ -130,6 +131,34 @@ def test_vit_b16_full_clip_properties(golden, precision):
         # "auto" (the default: the large GEMMs as f32-accurate bf16 x 6 products; the 2-frame launch above ran the f32 kernels: too few rows
         # for the persistent kernel) meets the SAME bounds against the reference's output as the f32 MFMA path
         assert relerr(out[:2], g["out"]) < TOL and elem_ok(out[:2], g["out"])
+
+
+@pytest.mark.parametrize("chunk", [32, 64, 160, 256])
+def test_vit_b16_launch_sizes_auto(golden, chunk):
+    """The default precision at the launch sizes the reference's callers produce (anomaly_clip.py:119-123,158-161: whatever
+    b * ncrops * N * S * L the video gives): 32 / 64 / 160 (a 5-crop XD window) / 256 (BASELINE configs[2]'s literal batch) frames per
+    launch all take the bf16 x 6 route (round 5: only >= 222 frames did) -- few-tile launches split K for EVERY tile alike, a
+    partly filled last round of tiles goes out as column strips with unchanged K order -- so identical frames give bit-identical
+    rows wherever they sit in the launch, and the rows meet the golden bounds against the REFERENCE's output."""
+    g = golden("vit_b16")
+    vit, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="auto")
+    vit.chunk = chunk
+    base = R.vit_frames(int(g["seed"]), 2, 224)
+    extra = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    eight = torch.cat([base, extra], 0)
+    idx = torch.arange(chunk) % 8
+    idx[chunk - 12:] = torch.tensor([7, 3, 0, 1, 5, 5, 2, 6, 4, 0, 1, 7])    # break the period near the tail rows
+    out = vit(eight[idx].to(DEV))
+    assert out.shape == (chunk, 512) and torch.isfinite(out).all()
+    for k in range(8):
+        rows = out[idx == k]
+        assert torch.equal(rows, rows[:1].expand_as(rows)), k                  # bit-identical across ALL slots
+    first = [int((idx == k).nonzero()[0]) for k in (0, 1)]
+    assert relerr(out[first], g["out"]) < TOL and elem_ok(out[first], g["out"])
+    vit32, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="f32")
+    vit32.chunk = chunk
+    o32 = vit32(eight[idx].to(DEV))
+    assert relerr(out, o32) < 5e-6 and elem_ok(out, o32)                       # and round-off away from the f32 MFMA path, every frame
 
 
 def test_vit_b16_bf16_mode(golden):
