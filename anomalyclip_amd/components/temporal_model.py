@@ -132,10 +132,13 @@ class TemporalModel(nn.Module):
         self._prep = None
 
     def x6_convs(self) -> bool:
-        """the feed-forward convolutions as bf16 x 6 products: precision "auto", a power-of-two token grid, and channel counts
-        the weight-gradient kernel's 256-wide tiles divide (E % 256 == 0: the UCF-Crime / ShanghaiTech heads)"""
+        """the feed-forward convolutions as bf16 x 6 products: precision "auto", a power-of-two token grid of whole 256-row tiles
+        (the convolution kernel's M % 256 == 0 for any number of tiles), and channel counts the weight-gradient kernel's tiles
+        divide: E % 256 == 0 (UCF-Crime / ShanghaiTech: 256 x 256 tiles) or E == 128 (XD-Violence: 256 x 128 tiles inside one tap for
+        c1's gradient [512, 9 x 128], 128 x 256 tiles for c2's [128, 9 x 512]; acx_gemm_tn_x6's tile geometries)"""
         N, Lg = self.num_segments, self.seg_length
-        return (self.precision == "auto" and self.emb_size % 256 == 0 and N & (N - 1) == 0 and Lg & (Lg - 1) == 0)
+        return (self.precision == "auto" and self.emb_size % 128 == 0 and N & (N - 1) == 0 and Lg & (Lg - 1) == 0 and
+                (N * Lg) % 256 == 0)
 
     # ---- derived weight layouts for the kernels
     def _derived(self, train: bool):

@@ -796,7 +796,10 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     if (shape_ok) {
       int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
       if (ctx && ctx->opt_x6_cus > 0 && ctx->opt_x6_cus < ncu) ncu = ctx->opt_x6_cus;   // ACX_OPT_X6_CUS
-      const int xt = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+      // narrow convolution outputs (N <= 128: c2 and the input gradient of c1 in the XD-Violence head, E = 128): 256 x 128 tiles
+      // (the NI = 2 instantiation) instead of half-empty 256 x 256 ones; f32 outputs without an activation only (what the head asks for)
+      const bool narrow = conv && d->N <= 128 && !c_x3_ && !c_bf16 && d->act == ACX_ACT_NONE;
+      const int xt = ((d->M + 255) / 256) * (narrow ? 1 : (d->N + 255) / 256);
       const int nks = d->K / 32;
       int split = 1;
       double split_us = 0.0;
@@ -847,11 +850,13 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     else if (d->act == ACX_ACT_LEAKYRELU) ACX_X6L(0, 2, 0, CV);                                     \
     else ACX_X6L(0, 0, 0, CV);                                                                      \
   } while (0)
-      if (conv) ACX_X6SEL(1); else ACX_X6SEL(0);
+      if (narrow) { if (d->residual && split == 1) ACX_X6L_(0, 0, 1, 1, 2, xgrid); else ACX_X6L_(0, 0, 0, 1, 2, xgrid); }
+      else if (conv) ACX_X6SEL(1);
+      else ACX_X6SEL(0);
       if (strip_ni < 4) {
         // the strips of the last round: identity rows only; epilogues of the ViT's products (plane outputs with / without QuickGELU,
         // f32 with a residual / QuickGELU / plain) -- anything else keeps whole tiles (x6_strip_epilogue_ok)
-        g.tile0 = tile0_tail; g.ntiles = rem_tail;
+        g.tile0 = tile0_tail * (4 / strip_ni); g.ntiles = rem_tail * (4 / strip_ni);   // (in the strips' own numbering: N % 256 == 0)
         const int sitems = rem_tail * (4 / strip_ni);
         const dim3 sgrid((unsigned)(sitems < ncu ? sitems : ncu));
 #define ACX_X6S(NI_)                                                                                 \
@@ -1262,11 +1267,24 @@ extern "C" int acx_gemm_tn_group(acx_ctx* ctx, int32_t nprob, const acx_tn_probl
 
 // ---- weight gradient as an f32-accurate product of bf16 planes: C[N1, N2] = sum_m A[m, n1] B[m, n2], A and B as three bf16 planes
 // each (acx_split_bf16x3 of dY and of the layer input), the TN instantiation of the plane-reuse kernel (acx_gemm_x6.h)
-static int tn_x6_splits(int64_t M, int64_t N1, int64_t N2, int ncu, size_t workspace_bytes) {
-  return x6_choose_split((int)((N1 / 256) * (N2 / 256)), (int)((M + 31) / 32), ncu, (size_t)N1 * N2 * sizeof(float), workspace_bytes, 8);
+// Tile geometry by shape: 256 x 256 (N1, N2 multiples of 256; conv: cin % 256 == 0 -- the UCF / ShanghaiTech heads), 256 x 128
+// (N2 a multiple of 128 only, or cin == 128: a 128-column tile lies inside one tap -- c1 of the XD-Violence head: [512, 9 x 128]),
+// 128 x 256 with the 1 x 4 wave grid (N1 a multiple of 128 only -- c2 of the XD head: [128, 9 x 512]).  0: not supported.
+static int tn_x6_mode(int64_t N1, int64_t N2, int conv, int cin) {
+  if (N1 % 256 == 0 && N2 % 256 == 0 && (!conv || cin % 256 == 0)) return 1;
+  if (N1 % 256 == 0 && N2 % 128 == 0 && (!conv || cin % 128 == 0)) return 2;
+  if (N1 % 128 == 0 && N2 % 256 == 0 && (!conv || cin % 256 == 0)) return 3;
+  return 0;
+}
+static int tn_x6_tiles(int mode, int64_t N1, int64_t N2) {
+  return mode == 1 ? (int)((N1 / 256) * (N2 / 256)) : mode == 2 ? (int)((N1 / 256) * (N2 / 128)) : mode == 3 ? (int)((N1 / 128) * (N2 / 256)) : 0;
+}
+static int tn_x6_splits(int tiles, int64_t M, int64_t N1, int64_t N2, int ncu, size_t workspace_bytes) {
+  return x6_choose_split(tiles, (int)((M + 31) / 32), ncu, (size_t)N1 * N2 * sizeof(float), workspace_bytes, 8);
 }
 extern "C" size_t acx_gemm_tn_x6_workspace_bytes(int32_t M, int32_t N1, int32_t N2) {
-  const int tiles = (N1 / 256) * (N2 / 256);
+  // (the narrowest geometry any mode could pick for this shape: an upper bound on the pieces)
+  const int tiles = (int)(((N1 + 255) / 256) * ((N2 + 255) / 256));
   if (tiles <= 0) return 0;
   int s = 512 / tiles;
   if (s < 1) s = 1;
@@ -1278,14 +1296,16 @@ extern "C" int acx_gemm_tn_x6(acx_ctx* ctx, const void* A3, int64_t a_plane_stri
                               int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream) {
   if (!A3 || !B3 || !C || !zero_page) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_x6: null pointer (the zero page is required)%s");
   if (M <= 0 || N1 <= 0 || N2 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_x6: empty shape%s");
-  if (N1 % 256 || N2 % 256 || lda % 8 || ldb % 8 || ldc != N2 || ((a_plane_stride | b_plane_stride) & 15) ||
+  const int mode = tn_x6_mode(N1, N2, conv, cin);
+  if (!mode || lda % 8 || ldb % 8 || ldc != N2 || ((a_plane_stride | b_plane_stride) & 15) ||
       (((uintptr_t)A3 | (uintptr_t)B3 | (uintptr_t)C | (uintptr_t)zero_page) & 15))
-    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: N1 / N2 multiples of 256, lda / ldb of 8, dense C, 16-byte aligned planes%s");
-  if (conv && (cin <= 0 || cin % 256 || N2 != 9 * cin || gn <= 0 || gl <= 0 || (gl & (gl - 1)) || (gn & (gn - 1)) || M % (gn * gl)))
-    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: conv needs cin %% 256 == 0, N2 == 9 cin, a power-of-two grid, whole tiles%s");
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: N1 a multiple of 256 and N2 of 128, or N1 of 128 and N2 of 256 (conv: cin a multiple of the tile width); lda / ldb multiples of 8, dense C, 16-byte aligned planes%s");
+  if (conv && (cin <= 0 || N2 != 9 * cin || gn <= 0 || gl <= 0 || (gl & (gl - 1)) || (gn & (gn - 1)) || M % (gn * gl)))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm_tn_x6: conv needs N2 == 9 cin, a power-of-two grid, whole tiles%s");
   int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
   if (ctx && ctx->opt_x6_cus > 0 && ctx->opt_x6_cus < ncu) ncu = ctx->opt_x6_cus;   // ACX_OPT_X6_CUS
-  const int split = workspace ? tn_x6_splits(M, N1, N2, ncu, workspace_bytes) : 1;
+  const int tiles = tn_x6_tiles(mode, N1, N2);
+  const int split = workspace ? tn_x6_splits(tiles, M, N1, N2, ncu, workspace_bytes) : 1;
   Args g;
   memset(&g, 0, sizeof(g));
   g.d.A = A3; g.d.W = B3; g.d.C = C;
@@ -1295,21 +1315,22 @@ extern "C" int acx_gemm_tn_x6(acx_ctx* ctx, const void* A3, int64_t a_plane_stri
   g.d.amap = conv ? ACX_AMAP_CONV3X3 : ACX_AMAP_IDENTITY; g.d.gn = gn; g.d.gl = gl; g.d.cin = cin;
   g.ksplit = split; g.kchunk = ((int)((M + 31) / 32) + split - 1) / split; g.partial = split > 1 ? (float*)workspace : nullptr;
   g.zeros = (const float*)zero_page;
-  const int items = (N1 / 256) * (N2 / 256) * split;
+  const int items = tiles * split;
   const dim3 xgrid((unsigned)(items < ncu ? items : ncu));
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_GEMM_TN, s);
   if (ctx && ctx->prof_on) { ctx->prof_gemm_flops += 2.0 * M * (double)N1 * N2; ctx->prof_tn_flops += 2.0 * M * (double)N1 * N2; }
   const int dev_slot = (ctx ? ctx->device : 0) & 63;
-  if (conv) {
-    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<0, 0, 0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B); attr_done = true; }
-    hipLaunchKernelGGL((gemm_x6_p4_kernel<0, 0, 0, 1, 1>), xgrid, dim3(256), (size_t)X6_LDS_B, s, g);
-  } else {
-    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<0, 0, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B); attr_done = true; }
-    hipLaunchKernelGGL((gemm_x6_p4_kernel<0, 0, 0, 0, 1>), xgrid, dim3(256), (size_t)X6_LDS_B, s, g);
-  }
+#define ACX_TNX6(CV, NI_, W14_)                                                                      \
+  do {                                                                                              \
+    static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                          \
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<0, 0, 0, CV, 1, 0, NI_, W14_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B); attr_done = true; } \
+    hipLaunchKernelGGL((gemm_x6_p4_kernel<0, 0, 0, CV, 1, 0, NI_, W14_>), xgrid, dim3(256), (size_t)X6_LDS_B, s, g); \
+  } while (0)
+  if (mode == 1) { if (conv) ACX_TNX6(1, 4, 0); else ACX_TNX6(0, 4, 0); }
+  else if (mode == 2) { if (conv) ACX_TNX6(1, 2, 0); else ACX_TNX6(0, 2, 0); }
+  else { if (conv) ACX_TNX6(1, 2, 1); else ACX_TNX6(0, 2, 1); }
+#undef ACX_TNX6
   if (split > 1) {
     const int64_t n4 = (int64_t)N1 * N2 / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, n4, split);

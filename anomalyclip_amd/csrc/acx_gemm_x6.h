@@ -69,26 +69,31 @@ __device__ __forceinline__ bf16x8 x6_tr_frag(const char* smem, int off_lo, int o
 // four units (A and W of two 32-wide K-steps) per super-step, 64 MFMAs per wave behind one barrier in four blocks of 16, the
 // fragments of block b + 1 read between the MFMAs of block b, the next super-step's four units requested between the MFMAs of the
 // first block (two unit parities in the eight LDS slots).  K % 64 == 0.
-// NI (4 / 2 / 1; NT products, not PLAIN): column blocks of 32 per wave -- the workgroup's tile is 256 rows x 64 NI columns (the wave
-// grid stays 2 x 2: 128 x 32 NI per wave).  NI < 4 are the SUB-TILE instantiations for a partly filled last round of tiles
-// (acx_gemm: g.tile0 / g.ntiles select the full 256 x 256 tiles of the launch, each is cut into 4 / NI column strips = work
-// items): every accumulator sees exactly the MFMA sequence it sees inside a full tile (same K order, same product order), so a
-// row's result does not depend on which instantiation produced it -- bit-identical -- while the last round's cost falls with
-// the strip width.  W units shrink with the tile (NI DMA instructions per wave and unit: waits vmcnt(NI) before Y).
-template <int C_MODE, int ACT, int RES, int CONV, int TN = 0, int PLAIN = 0, int NI = 4>
+// NI (4 / 2 / 1; not PLAIN): column blocks of 32 per wave -- the workgroup's tile is 256 rows x 64 NI columns (the wave grid stays
+// 2 x 2: 128 x 32 NI per wave); the launch's tiles are numbered row-major over that geometry, g.tile0 / g.ntiles select a range
+// of them.  Uses: (a) the column STRIPS of a partly filled last round of 256 x 256 tiles (acx_gemm): every accumulator sees exactly
+// the MFMA sequence it sees inside a full tile (same K order, same product order), so a row's result does not depend on which
+// instantiation produced it -- bit-identical -- while the last round's cost falls with the strip width; (b) narrow outputs
+// (N = 128: the XD-Violence head's E = 128 convolutions) without a half-empty tile; (c) TN: a 128-column tile lies inside one
+// tap at cin = 128.  NT: W units shrink with the tile (NI DMA instructions per wave and unit: waits vmcnt(NI) before Y); TN units
+// stay [32 k][256 channels], the channels behind the tile come from the zero page.
+// W14 (TN only): wave grid 1 x 4 -- the tile is 128 rows x 128 NI columns (N1 = 128: the weight gradient of a convolution with
+// 128 output channels), the upper half of the A units from the zero page.
+template <int C_MODE, int ACT, int RES, int CONV, int TN = 0, int PLAIN = 0, int NI = 4, int W14 = 0>
 __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = W14 ? 0 : wave >> 1, wn = W14 ? wave : wave & 1;
   const int li = lane & 31, hh = lane >> 5;
-  static_assert(NI == 4 || (NI > 0 && NI < 4 && NI != 3 && TN == 0 && PLAIN == 0), "sub-tile instantiations: NT products only");
-  constexpr int SUB = 4 / NI, TW = 64 * NI;      // work items per full tile (column strips), strip width
-  const int tiles_n = (d.N + 255) / 256, tiles_m = (d.M + 255) / 256;
-  const int ksplit = (NI == 4 && g.ksplit > 1) ? g.ksplit : 1;
-  const int ntiles = g.ntiles > 0 ? g.ntiles : tiles_m * tiles_n;   // full tiles of this launch: g.tile0 .. g.tile0 + ntiles
-  const int nitems = ntiles * (NI < 4 ? SUB : ksplit);
+  static_assert(NI == 4 || ((NI == 2 || NI == 1) && PLAIN == 0), "narrow tiles: not for the PLAIN schedule");
+  static_assert(W14 == 0 || (TN != 0 && NI == 2), "1 x 4 wave grid: TN products, 128 x 256 tiles");
+  constexpr int TH = W14 ? 128 : 256, TW = W14 ? 128 * NI : 64 * NI;      // tile height / width
+  const int tiles_n = (d.N + TW - 1) / TW, tiles_m = (d.M + TH - 1) / TH;
+  const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
+  const int ntiles = g.ntiles > 0 ? g.ntiles : tiles_m * tiles_n;   // tiles of this launch: g.tile0 .. g.tile0 + ntiles (row-major over TH x TW tiles)
+  const int nitems = ntiles * ksplit;
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
   const int b0 = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + ((int)blockIdx.x >> 3);
@@ -117,10 +122,10 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
 #define X6_SET_ITEM(S, jj)                                                                         \
   do {                                                                                             \
     const int L_ = b0 + min((jj), my_items - 1) * G;   /* past the end: re-read the last item (never consumed) */ \
-    const int ti_ = L_ / (NI < 4 ? SUB : ksplit), ks_ = NI < 4 ? 0 : L_ - ti_ * ksplit;            \
+    const int ti_ = L_ / ksplit, ks_ = L_ - ti_ * ksplit;                                          \
     const int tile_ = g.tile0 + ti_;                                                               \
     const int tm_ = tile_ / tiles_n, tn_ = tile_ - tm_ * tiles_n;                                  \
-    S.m0 = tm_ * 256; S.n0 = tn_ * 256 + (NI < 4 ? (L_ - ti_ * SUB) * TW : 0);                     \
+    S.m0 = tm_ * TH; S.n0 = tn_ * TW;                                                              \
     S.kk = ks_ * spi; S.steps = min(spi, nks - ks_ * spi);                                         \
     S.dn = S.dl = 0; S.c0 = S.n0;                                                                  \
     if constexpr (TN != 0 && CONV != 0) {                                                          \
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     if constexpr (TN != 0) {                                                                       \
       const int m_ = (KK) * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
       const char* p_ = b_ + ((size_t)(unsigned)m_ * (size_t)(d.lda * 2) + (size_t)(S.m0 * 2 + X6_TCH(i))); \
-      X6_GLDS_V(m_ < d.K ? p_ : zsrc, l_);                                                         \
+      X6_GLDS_V((m_ < d.K && (TH == 256 || X6_TCH(i) < TH * 2)) ? p_ : zsrc, l_);                  \
     } else if constexpr (CONV != 0) {                                                              \
       const int tap_ = (KK) / steps_per_tap, kc_ = (KK) - tap_ * steps_per_tap;                    \
       const int t3_ = tap_ / 3;                                                                    \
@@ -186,12 +191,12 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   } while (0)
 #define X6_DMA_W_K(S, KK, RW, pl, slot, i)                                                               \
   do {                                                                                             \
-    if ((i) >= NI) break;                          /* (constant after unrolling) */                 \
-    const unsigned l_ = lds0 + (slot) * X6_UNIT_B + (NI * wave + (i)) * 1024;                      \
+    if (TN == 0 && (i) >= NI) break;               /* (constant after unrolling) */                 \
+    const unsigned l_ = lds0 + (slot) * X6_UNIT_B + ((TN ? 4 : NI) * wave + (i)) * 1024;           \
     if constexpr (TN != 0) {                                                                       \
       const char* b_ = (const char*)d.W + (size_t)(pl) * (size_t)d.w_plane_stride;                 \
       const int m_ = (KK) * 32 + 8 * wave + 2 * (i) + (lane >> 5);                                 \
-      bool ok_ = m_ < d.K;                                                                         \
+      bool ok_ = m_ < d.K && (TW >= 256 || X6_TCH(i) < TW * 2);   /* channels behind a narrow tile: zero page */ \
       int row_ = m_;                                                                               \
       if constexpr (CONV != 0) {                                                                   \
         const int n_ = (m_ >> sh_gl) & (d.gn - 1), l_c = m_ & (d.gl - 1);                          \
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       const int i16 = lane & 15, x_ = 4 * r + (i16 >> 2);
       const int base_ = (8 * hh + x_) * 512 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
       trA[blk][r] = TN ? base_ + (((wm * 4 + blk) ^ x_) * 64) : 0;
-      trW[blk][r] = TN ? base_ + (((wn * 4 + blk) ^ x_) * 64) : 0;
+      trW[blk][r] = TN ? base_ + (((wn * NI + (blk < NI ? blk : 0)) ^ x_) * 64) : 0;
     }
 
   f32x16 acc[4][NI];
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       X6_REP48(X6_B2_X)
 #undef X6_B2_X
       // =========================================================================== half-step Y
-      if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NI) : "memory");     // A.mid, A.lo landed (W.hi of the next K-step -- NI instructions -- may be in flight)
+      if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(TN ? 4 : NI) : "memory");     // A.mid, A.lo landed (W.hi of the next K-step -- NI instructions -- may be in flight)
       X6_FENCE();
       __builtin_amdgcn_s_barrier();
       X6_FENCE();
@@ -448,10 +453,10 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const int L = b0 + j * G;
-      const int ti = L / (NI < 4 ? SUB : ksplit), ks = NI < 4 ? 0 : L - ti * ksplit;
+      const int ti = L / ksplit, ks = L - ti * ksplit;
       const int tile = g.tile0 + ti;
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-      const int m0 = tm * 256, n0 = tn * 256 + (NI < 4 ? (L - ti * SUB) * TW : 0);
+      const int m0 = tm * TH, n0 = tn * TW;
       const bool raw = ksplit > 1;               // split items: raw f32 partial tile [ks][M][N], epilogue in the reduce launch
       float* Cf = raw ? g.partial + (size_t)ks * d.M * d.N : (float*)d.C;
       const int ldc = raw ? d.N : d.ldc;
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;                          \
   } while (0)
       float4 R0[4], R1[4];
-      if (m0 + 256 <= d.M && n0 + TW <= d.N) {
+      if (m0 + TH <= d.M && n0 + TW <= d.N) {
         // full tile: unpredicated stores (straight-line code: hipcc's counted waits then leave the stores in flight), the
         // residual loaded TWO accumulator tiles ahead of its use -- a wait for it never covers the stores of the last two
 #define X6_FULL2(bi) X6_EPI_BLOCK(R0, bi, false); X6_RES_LOAD(R0, (bi) + 2); X6_EPI_BLOCK(R1, (bi) + 1, false); X6_RES_LOAD(R1, (bi) + 3);

@@ -553,8 +553,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, b_sub=None, conv=False, gn=0, g
 
 def gemm_tn_x6(a3: torch.Tensor, b3: torch.Tensor, *, conv=False, gn=0, gl=0, cin=0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[N1, N2] = sum_m A[m, n1] * bmap(B)[m, n2] with A = sum of the planes a3 [3, M, N1], B = sum of b3 [3, M, cin or N2]
-    (split_bf16x3): the weight gradient as an f32-accurate product on the bf16 matrix cores (acx_gemm_tn_x6).  N1, N2
-    multiples of 256 (conv: cin % 256 == 0)."""
+    (split_bf16x3): the weight gradient as an f32-accurate product on the bf16 matrix cores (acx_gemm_tn_x6).  N1 a multiple of
+    256 and N2 of 128, or N1 of 128 and N2 of 256 (conv: cin a multiple of the tile width the library picks: 256 / 128)."""
     assert a3.dim() == 3 and b3.dim() == 3 and a3.shape[0] == 3 and b3.shape[0] == 3 and a3.dtype == _BF16 and b3.dtype == _BF16
     assert a3.is_contiguous() and b3.is_contiguous() and a3.shape[1] == b3.shape[1]
     _, M, N1 = a3.shape

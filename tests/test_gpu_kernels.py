@@ -966,10 +966,12 @@ def test_x6_cus_option_caps_the_grid_same_product():
 
 
 @pytest.mark.parametrize("cin,cout,tiles,act,res", [(64, 256, 1, 2, 0), (256, 1024, 2, 2, 0), (1024, 256, 8, 0, 1), (128, 512, 40, 0, 0),
-                                                     (256, 1024, 64, 2, 0)])
+                                                     (256, 1024, 64, 2, 0), (512, 128, 8, 0, 1), (512, 128, 64, 0, 0), (512, 128, 1, 0, 1),
+                                                     (128, 512, 64, 2, 0), (512, 128, 150, 0, 1)])
 def test_conv3x3_x6_vs_f32_conv(cin, cout, tiles, act, res):
     """pairs = 6 with AMAP_CONV3X3 (per-tap source rows, zero page outside the 32 x 16 token grid) against the f32 MFMA
-    convolution and fp64: the head's convolutions at 1 .. 64 tiles (K split across workgroups below 256 output tiles)."""
+    convolution and fp64: the head's convolutions at 1 .. 64 tiles (K split across workgroups below 256 output tiles); cout = 128
+    (the XD-Violence head's c2 and the input gradient of its c1): 256 x 128 tiles, with and without the K split."""
     gn, gl = 32, 16
     rows = tiles * gn * gl
     g = torch.Generator().manual_seed(cin + cout + tiles)

@@ -70,10 +70,12 @@ def test_conv_grads_256_tiles(cin, cout, tiles):
     assert R.elem_excess(got, wt.grad, rtol=1e-4, afrac=2e-6) <= 1
 
 
-@pytest.mark.parametrize("M,N1,N2", [(4096, 256, 512), (2048 + 32, 512, 256), (1000, 256, 256), (32768, 256, 768)])
+@pytest.mark.parametrize("M,N1,N2", [(4096, 256, 512), (2048 + 32, 512, 256), (1000, 256, 256), (32768, 256, 768),
+                                     (4096, 512, 1152), (3000, 256, 128), (4096, 128, 512), (1000, 384, 768), (32768, 128, 4608)])
 def test_gemm_tn_x6_plain(M, N1, N2):
     """acx_gemm_tn_x6 (the TN instantiation of the plane-reuse kernel: LDS transpose reads, rows split across workgroups,
-    ragged last K-step from the zero page) against fp64 and the f32 MFMA weight-gradient kernel."""
+    ragged last K-step from the zero page) against fp64 and the f32 MFMA weight-gradient kernel.  The last five shapes take
+    the narrow tile geometries (round 6: 256 x 128 tiles for N2 % 256 != 0, 128 x 256 tiles on the 1 x 4 wave grid for N1 % 256 != 0)."""
     g = torch.Generator().manual_seed(M + N1)
     a = (torch.randn(M, N1, generator=g) * torch.exp2(torch.randint(-3, 3, (M, 1), generator=g).float())).to(DEV)
     b = torch.randn(M, N2, generator=g).to(DEV)
@@ -126,10 +128,12 @@ def test_gemm_tn_x6_random_shapes_vs_fp64(seed):
         assert bool((e <= bound).all()), (seed, M, N1, ncol, conv, gn, gl, cus, float((e / bound).max()))
 
 
-@pytest.mark.parametrize("cin,cout,tiles", [(256, 1024, 8), (1024, 256, 16), (256, 256, 1), (256, 1024, 64)])
+@pytest.mark.parametrize("cin,cout,tiles", [(256, 1024, 8), (1024, 256, 16), (256, 256, 1), (256, 1024, 64),
+                                            (128, 512, 8), (512, 128, 8), (128, 512, 64), (512, 128, 64), (128, 256, 3)])
 def test_conv_weight_grad_x6(cin, cout, tiles):
     """the 3x3 convolution's weight gradient [cout, 9 cin] from planes (per-tap shifted rows of the layer input, zero page
-    outside the 32 x 16 token grid) against fp64 by explicit im2col and against the f32 kernel."""
+    outside the 32 x 16 token grid) against fp64 by explicit im2col and against the f32 kernel.  cin = 128 / cout = 128: the
+    XD-Violence head (E = 128) -- 256 x 128 tiles inside one tap, 128 x 256 tiles on the 1 x 4 wave grid."""
     gn, gl = 32, 16
     rows = tiles * gn * gl
     g = torch.Generator().manual_seed(cin + cout + tiles)
@@ -144,7 +148,12 @@ def test_conv_weight_grad_x6(cin, cout, tiles):
     bound = 2e-6 * (dy.double().abs().t() @ cols.abs()) + 1e-30
     e6, e32 = (y6.double() - ref).abs(), (y32.double() - ref).abs()
     assert bool((e6 <= bound).all()), float((e6 / bound).max())
-    assert float(e6.max()) <= 1.5 * float(e32.max()) + 1e-12
+    # against the f32 MFMA kernel's own error: the two kernels cut the rows into different numbers of pieces (f32 accumulation
+    # chains of different length: at [512, 9 x 128] the f32 kernel's are a third shorter, rms error 3.3e-5 against 4.5e-5, max ratio
+    # 1.3-1.75 over seeds: tools/probes/tn_x6_err_probe.py) -- the narrow geometries get 2 x on the maximum and 1.5 x on the rms
+    narrow = cin % 256 != 0 or cout % 256 != 0
+    assert float(e6.max()) <= (2.0 if narrow else 1.5) * float(e32.max()) + 1e-12
+    assert float(e6.pow(2).mean().sqrt()) <= 1.5 * float(e32.pow(2).mean().sqrt()) + 1e-12
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 256), (256, 64)])
@@ -644,13 +653,16 @@ def test_ncentroid_from_frames_tiny(prompts_table):
 
 
 @pytest.mark.parametrize("cfg,B,precision", [("ucf", 4, "auto"), ("sht", 4, "auto"), ("ucf", 64, "auto"), ("sht", 16, "auto"),
-                                              ("ucf", 4, "f32"), ("ucf", 64, "f32"), ("ucf", 32, "auto")])
+                                              ("ucf", 4, "f32"), ("ucf", 64, "f32"), ("ucf", 32, "auto"),
+                                              ("xd", 16, "auto"), ("xd", 16, "f32"), ("xd", 4, "auto")])
 def test_full_config_train_step_vs_oracle(prompts_table, cfg, B, precision):
-    """UCF (E=256, depth 1) and ShanghaiTech (concat on, depth 2) head configs, in both f32-result modes: loss and every trainable
+    """UCF (E=256, depth 1), ShanghaiTech (concat on, depth 2) and XD-Violence (E = 128, 7 classes: round 6 -- its convolutions and
+    weight gradients on the bf16 x 6 kernels' narrow tile geometries) head configs, in both f32-result modes: loss and every trainable
     gradient against the oracle's autograd on the same seeded inputs.  B = 4 runs the single-video-sized GEMMs (split-K convs,
     64x64 tiles); B = 64 is BASELINE.json configs[1] itself (32 768 features per step: the 8-wave conv / GEMM kernels
     and the cost-model split counts of the weight-gradient GEMMs that the features/s numbers are measured on)."""
-    hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD}[cfg]
+    import dataclasses
+    hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD, "xd": dataclasses.replace(IW.XD_HEAD, ncrops=1)}[cfg]   # (training: one crop)
     net, sd, eot = build_net("ViT-B/16", hc, cfg, 11, prompts_table, precision=precision)
     # "auto" (the default): the feed-forward convolutions and their input / weight gradients as bf16 x 6 products; "f32": the
     # f32 MFMA kernels everywhere -- the same bounds for both
@@ -861,7 +873,7 @@ def test_text_graph_path_is_bit_identical_to_eager(prompts_table, geom, B):
     assert torch.allclose(ma, mb, rtol=1e-6, atol=0) and mods[2][0]._meters.count == mods[1][0]._meters.count == 3
 
 
-@pytest.mark.parametrize("cfg,B", [("ucf", 8), ("sht", 4), ("ucf", 32)])
+@pytest.mark.parametrize("cfg,B", [("ucf", 8), ("sht", 4), ("ucf", 32), ("xd", 8)])
 def test_step_graph_full_configs_bit_identical_to_autograd(prompts_table, cfg, B):
     """The whole-step graph at the reference's head configurations -- UCF (no concat: the temporal backward runs as its own
     graph beside the selector / text backward; B = 8 = a data-parallel rank's 4096 rows) and ShanghaiTech (concat on, depth
@@ -869,7 +881,8 @@ def test_step_graph_full_configs_bit_identical_to_autograd(prompts_table, cfg, B
     eager autograd path: three optimisation steps with an LR change in between (the in-graph AdamW reads lr from device
     memory), bit-identical losses, gradients, parameters, AdamW moments and BatchNorm running statistics."""
     from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
-    hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD}[cfg]
+    import dataclasses
+    hc = {"ucf": IW.UCF_HEAD, "sht": IW.SHT_HEAD, "xd": dataclasses.replace(IW.XD_HEAD, ncrops=1)}[cfg]
     mods = []
     for _ in range(2):
         net, sd, eot = build_net("ViT-B/16", hc, cfg, 23, prompts_table)
