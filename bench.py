@@ -64,13 +64,14 @@ HBM_PEAK_TBPS = 8.0                   # HBM3E nominal (MI355X_MICROARCH.md; ~6.3
 HEAD_BATCH = 64                       # configs[1] / configs[3]: 64 videos x 512 features x 512-d per step
 
 
-def build_net(precision, device, vit_chunk=256):
+def build_net(precision, device, vit_chunk=256, cfg="ucf"):
+    import dataclasses
     from anomalyclip_amd import init_weights as IW
     from anomalyclip_amd.components.anomaly_clip import AnomalyCLIP, lookup_prompts
-    hc = IW.UCF_HEAD
-    tab = lookup_prompts(key="ucf")
+    hc = {"ucf": IW.UCF_HEAD, "xd": dataclasses.replace(IW.XD_HEAD, ncrops=1)}[cfg]      # (xd: the training shape, one crop)
+    tab = lookup_prompts(key=cfg)
     toks = torch.tensor(tab["tokenized_prompts"], dtype=torch.int32)
-    net = AnomalyCLIP(arch="ViT-B/16", labels_key="ucf", emb_size=hc.emb_size, depth=hc.depth, heads=hc.heads,
+    net = AnomalyCLIP(arch="ViT-B/16", labels_key=cfg, emb_size=hc.emb_size, depth=hc.depth, heads=hc.heads,
                       dim_heads=None, num_segments=32, seg_length=16, concat_features=False, normal_id=hc.normal_id,
                       stride=1, load_from_features=False, select_idx_dropout_topk=0.7, select_idx_dropout_bottomk=0.7,
                       ncrops=1, num_topk=3, num_bottomk=3, n_ctx=8, shared_context=False, ctx_init="",
@@ -192,13 +193,14 @@ class Prof:
         return gf.value, ms.value, n.value
 
 
-def head_batch(B_global, world, rank, dev, step_seed=1):
-    """UCF-shaped synthetic batch: B videos x 512 x 512-d, first half abnormal (13 classes cycling),
+def head_batch(B_global, world, rank, dev, step_seed=1, num_classes=14, normal_id=7):
+    """UCF-shaped synthetic batch: B videos x 512 x 512-d, first half abnormal (the abnormal classes cycling),
     second half normal; this rank's abnormal/normal-balanced shard as the datamodule's (nbatch, abatch) pair."""
     from anomalyclip_amd import parallel
     g = torch.Generator().manual_seed(step_seed)
     feats = torch.randn(B_global, 1, 512, 512, generator=g) * 0.3
-    labels = torch.tensor([i % 13 + (1 if i % 13 >= 7 else 0) for i in range(B_global // 2)] + [7] * (B_global // 2))
+    na = num_classes - 1
+    labels = torch.tensor([i % na + (1 if i % na >= normal_id else 0) for i in range(B_global // 2)] + [normal_id] * (B_global // 2))
     idx = parallel.shard_videos(B_global, world, rank)
     f_loc, l_loc = feats[idx].to(dev), labels[idx].to(dev)
     h = len(idx) // 2
@@ -308,6 +310,7 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
         dt = timer.run(fwd, steps, warmup)
         out["head"]["fwd_features_per_s"] = round(feats * steps / dt, 1)
         out["head"]["fwd_ms_per_step"] = round(dt / steps * 1e3, 3)
+        out["head"]["xd_train"] = xd_train_leg(dev, timer, steps, warmup)
 
     # ---- configs[3]: data-parallel training (N = 1 gives T1 of both curves)
     dp = {"workload": "configs[3]: UCF-shaped 512-d feature sequences, DP training step = forward + 7-term loss + backward "
@@ -358,6 +361,41 @@ def head_legs(net, dev, dist, rank, world, local_rank, steps, warmup, timer):
     net.load_from_features = False
     net.eval()
     return out
+
+
+def xd_train_leg(dev, timer, steps, warmup):
+    """The XD-Violence head's TRAINING shape (configs/model/anomaly_clip_xdviolence.yaml: E = 128, 7 classes; one crop), 64 videos x 512
+    x 512-d per step: round 6 put its convolutions and weight gradients on the bf16 x 6 kernels (256 x 128 / 128 x 256 tile
+    geometries); the f32 MFMA kernels beside it.  Only the head: the frozen ViT is not built."""
+    from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
+    from anomalyclip_amd.components.loss import ComputeLoss
+    ent = {"workload": "XD-Violence head (E = 128, 7 classes, one crop): 64 videos x 512 x 512-d, training step = forward + loss + backward + AdamW"}
+    for precision in ("auto", "f32"):
+        try:
+            net, _, _, hc = build_net(precision, dev, cfg="xd")
+            net.load_from_features = True
+            crit = ComputeLoss(hc.normal_id, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+            mod = AnomalyCLIPModule(net, None, None, crit, num_classes=hc.num_classes, solver={"lr": 1e-5}).to(dev)
+            mod.ncentroid = torch.zeros(512, device=dev)
+            opt = mod.configure_optimizers()["optimizer"]
+            batch, idx = head_batch(HEAD_BATCH, 1, 0, dev, num_classes=hc.num_classes, normal_id=hc.normal_id)
+            net.train()
+            step_i = [0]
+
+            def step():
+                torch.manual_seed(step_i[0])
+                step_i[0] += 1
+                m_top, m_bot = type(net.selector_model).generate_mask(net.selector_model, HEAD_BATCH)
+                net.selector_model.generate_mask = lambda b, mt=m_top[idx], mb=m_bot[idx]: (mt, mb)
+                mod.train_batch(batch, opt)
+            dt = timer.run(step, steps, warmup)
+            ent[precision] = {"train_ms_per_step": round(dt / steps * 1e3, 3), "train_features_per_s": round(HEAD_BATCH * 512 * steps / dt, 1),
+                              "x6_convs": bool(net.temporal_model.x6_convs()), "loss": float(mod.last_losses[0].detach()),
+                              "whole_step_graph": getattr(mod, "step_graph_error", None) is None}
+            del mod, net, opt
+        except Exception as e:  # noqa: BLE001
+            ent[precision] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return ent
 
 
 def _event_time(fn, iters, warm=3):

@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--x6-cus", type=int, default=-1, help="ACX_OPT_X6_CUS: CUs the bf16 x 6 kernels may hold (0 = all; -1 = the module's default)")
     ap.add_argument("--x6-tail", action="store_true", help="ACX_OPT_X6_TAIL_SPLIT on (K-split a partly filled last round of tiles)")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32"], help="auto: the convolutions as bf16 x 6 products (default)")
+    ap.add_argument("--config", default="ucf", choices=["ucf", "xd"], help="head configuration (xd: E = 128, 7 classes, one crop)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local_rank)
@@ -121,14 +122,14 @@ def main():
     from anomalyclip_amd.anomaly_clip_module import AnomalyCLIPModule
     from anomalyclip_amd.components.loss import ComputeLoss
 
-    net, sd, eot, hc = B.build_net(args.precision, dev)
+    net, sd, eot, hc = B.build_net(args.precision, dev, cfg=args.config)
     net.load_from_features = True
     net.text_class_parallel = not args.no_text_shard
     net.text_graph = bool(args.text_graph)
     net.temporal_model.graph = bool(args.temporal_graph)
     net.step_graph = not args.no_step_graph
-    crit = ComputeLoss(7, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
-    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=14, solver={"lr": 1e-5}).to(dev)
+    crit = ComputeLoss(hc.normal_id, 3, 1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3, 16, 32)
+    mod = AnomalyCLIPModule(net, None, None, crit, num_classes=hc.num_classes, solver={"lr": 1e-5}).to(dev)
     mod.ncentroid = torch.zeros(512, device=dev)
     opt = mod.configure_optimizers()["optimizer"]
     timer = B.Timer(dist, dev)
@@ -139,7 +140,7 @@ def main():
         assert world == 1
         eff_world = args.emulate_world
     B_global = args.batch if args.scaling == "strong" else args.batch * eff_world
-    batch, idx = B.head_batch(B_global, eff_world, rank, dev)
+    batch, idx = B.head_batch(B_global, eff_world, rank, dev, num_classes=hc.num_classes, normal_id=hc.normal_id)
     if args.emulate_world > 1:
         stub_collectives(eff_world, net)
 
