@@ -561,6 +561,19 @@ class AnomalyCLIPModule(_Base):
         with self._x6_cu_reservation(batch):
             return self._train_batch(batch, optimizer, batch_idx, buckets)
 
+    # The Lightning entry point (automatic optimisation: training_step -> backward -> optimizer.step, all between these two hooks)
+    # runs under the SAME per-step options as train_batch: the two entry points give the same bits for the same batch, and the
+    # cached graphs (their keys carry the option state) are shared between them.
+    def on_train_batch_start(self, batch: Any, batch_idx: int = 0, *unused):
+        cm = self._x6_cu_reservation(batch)
+        cm.__enter__()
+        self.__dict__.setdefault("_x6_batch_cms", []).append(cm)
+
+    def on_train_batch_end(self, outputs: Any = None, batch: Any = None, batch_idx: int = 0, *unused):
+        cms = self.__dict__.get("_x6_batch_cms") or []
+        if cms:
+            cms.pop().__exit__(None, None, None)
+
     @contextlib.contextmanager
     def _x6_cu_reservation(self, batch):
         """A small rank share (<= X6_RESERVE_ROWS feature rows: 4 or more ranks at the UCF batch) leaves X6_RESERVE_CUS CUs to the
@@ -577,6 +590,9 @@ class AnomalyCLIPModule(_Base):
         rows = (nf.numel() + af.numel()) // max(1, int(af.shape[-1]))            # feature rows of this rank's share
         reserve = dev.type == "cuda" and getattr(self.net, "precision", "auto") == "auto" and rows <= X6_RESERVE_ROWS
         tail = reserve and rows > X6_SPLIT_ROWS
+        depth = self.__dict__.get("_x6_res_depth", 0)             # re-entrant: train_batch inside the Lightning hooks
+        self.__dict__["_x6_res_depth"] = depth + 1
+        reserve = reserve and depth == 0
         if reserve:
             ncu = torch.cuda.get_device_properties(dev).multi_processor_count
             ops.set_x6_cus(dev.index or 0, max(1, ncu - X6_RESERVE_CUS))
@@ -585,6 +601,7 @@ class AnomalyCLIPModule(_Base):
         try:
             yield
         finally:
+            self.__dict__["_x6_res_depth"] = depth
             if reserve:
                 ops.set_x6_cus(dev.index or 0, 0)
                 if tail:

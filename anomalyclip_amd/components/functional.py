@@ -669,8 +669,11 @@ class _TemporalGraphs:
     @staticmethod
     def make_key(tm, feats, a_sub, need_dfeats):
         plist = _temporal_param_list(tm)
+        # (the bf16 x 6 launches' grid and K split -- ACX_OPT_X6_CUS / X6_TAIL_SPLIT -- are part of a captured launch: a graph
+        # captured under one setting is never replayed under another)
+        x6 = ops.x6_options(feats.device.index if feats.device.index is not None else torch.cuda.current_device())
         return (tuple(feats.shape), feats.dtype, None if a_sub is None else a_sub.data_ptr(), bool(need_dfeats),
-                tm.precision) + tuple(p.data_ptr() for p in plist)
+                tm.precision, int(x6["cus"]), bool(x6["tail_split"])) + tuple(p.data_ptr() for p in plist)
 
 
 class TemporalGraphFn(torch.autograd.Function):

@@ -224,7 +224,9 @@ class TrainStepGraph:
         net = module.net
         par = _par()
         nc = module.ncentroid
+        x6 = ops.x6_options(torch.cuda.current_device())       # grid / K split of the captured bf16 x 6 launches
         return (n_abnormal, n_normal, frames, id(optimizer), par.is_distributed(), par.world_size(), par.rank(),
+                int(x6["cus"]), bool(x6["tail_split"]),
                 None if nc is None else nc.data_ptr(), bool(net.concat_features), int(getattr(net, "text_len", 0)),
                 bool(getattr(net, "text_class_parallel", True)), torch.cuda.current_stream().cuda_stream,
                 net.eot_index.data_ptr(), net.eot_index._version) + tuple(      # the EOT row table is baked into the capture

@@ -185,7 +185,6 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
 
   // epilogue geometry: lane -> (row tr + 8 i, 4 columns at tc) of a 32 x 32 tile; wave-private 4 KB transposer, element
   // (row, col) at row * 32 + (col ^ 4 (row & 7)) floats (conflict-free ds_write_b32 and ds_read_b128)
-  const int tr = lane >> 3, tc = 4 * (lane & 7);
   const bool vec = d.N % 4 == 0 && d.ldc % 4 == 0 && !((uintptr_t)d.C & 15) && !((uintptr_t)d.bias & 15) &&
                    (RES == 0 || (d.ldr % 4 == 0 && !((uintptr_t)d.residual & 15)));
 
@@ -209,6 +208,11 @@ __global__ __launch_bounds__(1024, 4) void gemm_f32_p256_kernel(const Args g) {
     // ---- epilogue of the tile; stage cur ^ 1 (the one just consumed) serves as transposer space
     const int m0 = cc.ru * 64, n0 = cc.col * P2_BN;
     if (active) {
+      // (per-lane epilogue constants re-derived per tile from an opaque copy of the lane id: hoisted out of the tile loop they
+      // stay live across the K loop at the 128-register budget -- the convolution instantiations spilled one)
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int tr = le >> 3, tc = 4 * (le & 7), li = le & 31, hh = le >> 5;
       float* sT = reinterpret_cast<float*>(smem + (cur ^ 1) * P2_STAGE_B) + wave * 1024;
       float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;          // loaded before the first store of the tile
       if (RES == 0 && d.bias && vec) {        // RES: loaded per accumulator tile next to the residual (register budget)

@@ -230,8 +230,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p8_kernel(const Args g) {
       const int m0 = tm * 256, n0 = tn * 256;
       // each 32x32 accumulator tile goes through this wave's private 4 KB of LDS (XOR-swizzled 128-B rows) and comes
       // back row-major: lane l owns 4 consecutive columns (l & 7) of row (l >> 3) + 8 pass (see gemm_bf16_ring_kernel)
+      // (the epilogue's per-lane constants are re-derived HERE, once per tile, from an opaque copy of the lane id: hoisted out of
+      // the tile loop they stay live across the K loop, which runs at the full 256-register budget -- 4 of them were spilled)
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int li = le & 31, hh = le >> 5;
       char* scr = smem + 2 * P8_SLOT_B + wave * 4096;
-      const int rl = lane >> 3, cj = lane & 7;
+      const int rl = le >> 3, cj = le & 7;
       const int col0 = n0 + wn * 64 + 4 * cj, col1 = col0 + 32;
       float4 bb0 = make_float4(0.f, 0.f, 0.f, 0.f), bb1 = bb0;
       if (d.bias) {

@@ -32,6 +32,22 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().acx_version() == 100
 
 
+def test_no_kernel_spills_or_uses_scratch():
+    """Kernel hygiene of the library AS BUILT (hipcc's kernel-resource-usage remarks, written next to libacx.so by the build): no
+    kernel of libacx.so may use scratch memory or spill a register -- a kernel that silently spills runs its hot loop through
+    memory (round 1: a demoted staging array cost the f32 GEMM 7 %; round 5: 20 bytes per lane in the bf16 256 x 256 kernel)."""
+    from anomalyclip_amd import _build, _lib
+    _lib.lib()                                              # builds when stale
+    assert os.path.exists(_build.RESOURCES), "resource table missing: python -m anomalyclip_amd._build --force"
+    assert os.path.getmtime(_build.RESOURCES) >= os.path.getmtime(_build.LIB) - 5
+    rows = _build.kernel_resources()
+    assert len(rows) >= 300, len(rows)
+    assert any("gemm_x6_p4_kernel" in k for k in rows) and any("gemm_bf16_p8_kernel" in k for k in rows)
+    bad = {k: (v.get("ScratchSize [bytes/lane]"), v.get("VGPRs Spill")) for k, v in rows.items()
+           if v.get("ScratchSize [bytes/lane]", 0) != 0 or v.get("VGPRs Spill", 0) != 0}
+    assert not bad, bad
+
+
 def test_product_path_has_no_cpu_fallback():
     from anomalyclip_amd import ops, _lib
     with pytest.raises(_lib.AcxError):

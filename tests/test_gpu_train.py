@@ -793,11 +793,15 @@ def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom, path
             if bucketed:
                 mod.train_batch(batch, opt)
             else:
+                # the Lightning order of calls (automatic optimisation): the batch hooks apply the per-step kernel options
+                # train_batch applies (CU reservation for small rank shares: another K split of the convolutions)
                 opt.zero_grad(set_to_none=True)
-                # (train_batch's CU reservation for small rank shares changes the convolutions' K split: same option here)
-                with torch.enable_grad(), mod._x6_cu_reservation(batch):
-                    mod.training_step(batch)["loss"].backward()
+                mod.on_train_batch_start(batch, step)
+                with torch.enable_grad():
+                    out = mod.training_step(batch, step)
+                    out["loss"].backward()
                 opt.step()
+                mod.on_train_batch_end(out, batch, step)
         gb = mods[0][0]._buckets
         for i, p in enumerate(gb.params):
             lo, hi = gb._views[i]
