@@ -32,7 +32,9 @@ def _parse_resources(src: str, text: str, rows: dict) -> str:
                     cur[k] = int(m.group(1))
             continue
         keep.append(line)
-    return "\n".join(keep)
+    text = "\n".join(keep)
+    # (each remark drags its source-context lines along: without a real diagnostic in the output there is nothing to show)
+    return text if ("warning:" in text or "error:" in text) else ""
 
 
 def kernel_resources() -> dict:

@@ -194,9 +194,13 @@ __global__ __launch_bounds__(512) void gemm_f32_sk_kernel(const Args g) {
     __hip_atomic_store(mine + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) last = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ksplit - 1;
+    if (t == 0) {
+      ACX_HANDOFF_RELEASE();
+      last = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ksplit - 1;
+    }
     __syncthreads();
     if (!last) return;
+    ACX_HANDOFF_ACQUIRE();
     float2 tot = make_float2(0.f, 0.f);
     for (int q = 0; q < ksplit; ++q) {
       if (q == (int)blockIdx.y) { tot.x += v.x; tot.y += v.y; continue; }

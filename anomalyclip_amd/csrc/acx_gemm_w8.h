@@ -244,10 +244,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_w8_kernel(const Args g) {
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+      ACX_HANDOFF_RELEASE();
       last_piece = __hip_atomic_fetch_add(g.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.ksplit - 1;
+    }
     __syncthreads();
     if (!last_piece) return;
+    ACX_HANDOFF_ACQUIRE();
     // every piece -- this block's own included: it was published like the others -- is read back in piece order ((0 + p0) + p1
     // + ..., the reduce kernel's order, bit for bit)
 #pragma unroll

@@ -199,10 +199,13 @@ __device__ __forceinline__ void colsum_fused_body(const float* __restrict__ x, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
+    ACX_HANDOFF_RELEASE();
     last = __hip_atomic_fetch_add(&counters[cg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nslab - 1;
+  }
   __syncthreads();
   if (!last) return;
+  ACX_HANDOFF_ACQUIRE();
   // last block of the column group to arrive: LANES float4 columns x NS slab lanes; lane l adds slabs l, l + NS, ... in order
   // (four slabs = sixteen scalar loads in flight), the NS lane sums are then added in lane order -- a fixed tree
   {

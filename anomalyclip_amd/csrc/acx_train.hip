@@ -1392,10 +1392,12 @@ __global__ __launch_bounds__(256) void loss_fused_kernel(const LossArgs a, float
   else loss_topk_body<true>(a, part2, b - np1, red);
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ACX_HANDOFF_RELEASE();
     last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(np1 + np2) - 1;
   }
   __syncthreads();
   if (!last) return;
+  ACX_HANDOFF_ACQUIRE();
   const int k = threadIdx.x >> 5, j = threadIdx.x & 31;
   if (k < 7) {
     double acc = 0.0;

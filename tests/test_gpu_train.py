@@ -768,6 +768,44 @@ def _dp_batch(B, D, seed, n_cls=14, normal_id=7):
     return feats, labels, masks
 
 
+@pytest.mark.parametrize("B", [64, 8])
+def test_determinism_soak_300_steps(prompts_table, B):
+    """300 optimisation steps of the UCF head through train_batch's whole-step graph, TWICE from the same state: bit-identical losses
+    along the way and bit-identical parameters / Adam moments at the end.  Every reduction on the path has a fixed order and the
+    fence-free last-arriver hand-offs (column sums, the one-launch loss, K pieces of the few-row / strip GEMMs: sc1 stores + s_waitcnt
+    + relaxed agent counter, acx_internal.h) race nothing -- under the uneven load of two streams (text tower pipelined beside the
+    main chain).  B = 64: BASELINE configs[1]; B = 8: a data-parallel rank's share of it (CU reservation, K-split convolutions).
+    A compiler or driver change that reorders a hand-off shows up here as a differing bit."""
+    runs = []
+    for rep in range(2):
+        mod, net = _dp_module(prompts_table, geom="ViT-B/16")
+        opt = mod.configure_optimizers()["optimizer"]
+        mod.ncentroid = (torch.randn(512, generator=torch.Generator().manual_seed(3)) * 0.05).to(DEV)
+        batches = []
+        for k in range(4):                                   # four batches cycled: the graph's static inputs are reloaded every step
+            feats, labels, masks = _dp_batch(B, 512, 700 + k)
+            f, l = feats.to(DEV), labels.to(DEV)
+            batches.append((((f[B // 2:], l[B // 2:]), (f[:B // 2], l[:B // 2])), masks))
+        trace = []
+        for step in range(300):
+            batch, masks = batches[step % 4]
+            net.selector_model.generate_mask = lambda b, m=masks: (m[0], m[1])
+            mod.train_batch(batch, opt)
+            if step % 25 == 24:
+                trace.append(torch.stack([x.detach().clone() for x in mod.last_losses]))
+        torch.cuda.synchronize()
+        assert getattr(mod, "step_graph_error", None) is None and any(v is not None for v in mod.__dict__.get("_step_graphs", {}).values())
+        state = {n: p.detach().clone() for n, p in net.named_parameters() if p.requires_grad}
+        moments = [v.detach().clone() for st in opt.state.values() for v in st.values() if torch.is_tensor(v)]
+        runs.append((torch.stack(trace), state, moments))
+        del mod, net, opt
+    assert torch.isfinite(runs[0][0]).all()
+    assert torch.equal(runs[0][0], runs[1][0])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+    assert len(runs[0][2]) == len(runs[1][2]) and all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
 @pytest.mark.parametrize("path", ["step_graph", "autograd"])
 @pytest.mark.parametrize("geom", ["tiny", "ViT-B/16"])
 def test_train_batch_gradbuckets_equals_plain_backward(prompts_table, geom, path):
