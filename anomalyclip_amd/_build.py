@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["acx_api.hip", "acx_gemm.hip", "acx_norm.hip", "acx_attn.hip", "acx_head.hip", "acx_train.hip", "acx_metrics.hip", "acx_probe.hip", "acx_step.hip"]
+SOURCES = ["acx_api.hip", "acx_gemm.hip", "acx_norm.hip", "acx_attn.hip", "acx_head.hip", "acx_train.hip", "acx_metrics.hip", "acx_probe.hip", "acx_step.hip", "acx_comm.hip"]
 LIB = os.path.join(CSRC, "libacx.so")
 RESOURCES = os.path.join(CSRC, "libacx.resources.tsv")    # per-kernel registers / scratch / occupancy of the build (kernel_resources())
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -17,6 +17,9 @@ AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1
 OPT_RING_MIN_TILES, OPT_SK_MAX_M, OPT_TN_P256_MIN_ROWS, OPT_X6_CUS, OPT_X6_TAIL_SPLIT = 1, 2, 3, 4, 5
 OPT_X6_STRIP_TAIL, OPT_X6_MIN_TILES = 6, 7
+ACX_F64, ACX_I64 = 16, 17                              # element types of the collectives only (acx_allreduce / acx_allgather)
+COMM_SUM, COMM_MAX, COMM_MIN = 0, 1, 2
+COMM_ID_BYTES = 128
 
 
 class GemmDesc(C.Structure):
@@ -108,6 +111,12 @@ _SIGS = {
     "acx_probe_copy": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "acx_split_bf16x3_multi": (C.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acx_probe_read": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "acx_comm_unique_id": (C.c_int, [c_void_p, c_size_t]),
+    "acx_comm_init": (C.c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    "acx_comm_destroy": (C.c_int, [c_void_p]),
+    "acx_comm_info": (C.c_int, [c_void_p, C.POINTER(c_int32), C.POINTER(c_int32)]),
+    "acx_allreduce": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "acx_allgather": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "acx_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "acx_bn_combine": (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acx_bn_stats": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

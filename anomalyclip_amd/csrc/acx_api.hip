@@ -42,6 +42,7 @@ extern "C" int acx_create(acx_ctx** out, int device) {
   c->opt_x6_cus = 0;
   c->opt_x6_tail = 0;
   c->opt_x6_strip = 1;
+  c->comm = nullptr; c->comm_rank = 0; c->comm_world = 0;
   c->opt_x6_min_tiles = 18;
   c->err[0] = 0;
   c->prof_on = false;

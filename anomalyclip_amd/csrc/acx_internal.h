@@ -72,6 +72,8 @@ struct acx_ctx {
   double prof_gemm_flops;   // 2*M*N*K summed over acx_gemm / acx_gemm_tn launches while recording
   double prof_tn_flops, prof_tn_ms;   // the acx_gemm_tn share of it; its summed launch time (filled by acx_prof_collect)
   int prof_tn_count;
+  void* comm;               // RCCL communicator (acx_comm_init), nullptr: none
+  int comm_rank, comm_world;
 };
 
 struct AcxProfScope {

@@ -32,7 +32,8 @@ enum {
   ACX_E_BADARG = -1,   /* null pointer, bad shape, misaligned leading dimension */
   ACX_E_UNSUPPORTED = -2, /* dtype / geometry this build has no kernel for */
   ACX_E_HIP = -3,      /* a HIP runtime call failed (text in acx_last_error) */
-  ACX_E_WORKSPACE = -4 /* workspace too small */
+  ACX_E_WORKSPACE = -4, /* workspace too small */
+  ACX_E_RCCL = -5      /* RCCL could not be opened, or an RCCL call failed (acx_comm_* / acx_allreduce / acx_allgather) */
 };
 
 enum { ACX_F32 = 0, ACX_BF16 = 1,                    /* storage dtypes */
@@ -623,6 +624,29 @@ int acx_probe_copy(acx_ctx* ctx, const void* src, void* dst, int64_t bytes, void
 /* acx_probe_read: reads `bytes` once (16 bytes per lane, grid-stride), writes nothing: the floor of a one-shot launch over an
  * input of that size -- the denominator for the head's skinny reductions (selector projection, column sums). */
 int acx_probe_read(acx_ctx* ctx, const void* src, int64_t bytes, float* sink, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Collectives (acx_comm_init / acx_allreduce).  The reference exchanges gradients and SyncBatchNorm statistics
+ * through Lightning DDP over NCCL (configs/trainer/ddp.yaml:1-9).  The Python host of this repository issues the same exchange through
+ * torch.distributed -- backend "nccl" is RCCL on ROCm -- and that remains its default ("collectives"); these entry
+ * points are the torch-free form of it for a C / C++ host: thin RCCL calls on the CALLER's stream (so they order with the library's
+ * kernels like any launch, and a capturing stream records them into its HIP graph).  RCCL is opened with dlopen on first use
+ * (libacx.so has no link-time dependency on it; a process that already loaded an RCCL -- PyTorch-ROCm -- shares that copy);
+ * ACX_E_RCCL when it cannot be opened or a call fails.  One communicator per context, bound to the context's device.
+ *   acx_comm_unique_id  rank 0: fills ACX_COMM_ID_BYTES opaque bytes (ncclGetUniqueId) that the host transports to every rank
+ *   acx_comm_init       every rank, collectively: ncclCommInitRank(world, id, rank)
+ *   acx_allreduce       in place over `count` elements of `dtype` (ACX_F32 / ACX_BF16 / ACX_F64 / ACX_I64), op ACX_COMM_SUM / MAX / MIN
+ *   acx_allgather       `count` elements from every rank, rank-major, into recv[world * count]
+ *   acx_comm_destroy    releases the communicator (acx_destroy does NOT: collective teardown is the caller's to order) */
+#define ACX_COMM_ID_BYTES 128
+enum { ACX_F64 = 16, ACX_I64 = 17 };                  /* element types of the collectives only */
+enum { ACX_COMM_SUM = 0, ACX_COMM_MAX = 1, ACX_COMM_MIN = 2 };
+int acx_comm_unique_id(void* id_out, size_t id_bytes);
+int acx_comm_init(acx_ctx* ctx, int32_t rank, int32_t world, const void* unique_id);
+int acx_comm_destroy(acx_ctx* ctx);
+int acx_comm_info(acx_ctx* ctx, int32_t* rank, int32_t* world);   /* world = 0: no communicator */
+int acx_allreduce(acx_ctx* ctx, void* buf, int64_t count, int32_t dtype, int32_t op, void* stream);
+int acx_allgather(acx_ctx* ctx, const void* send, void* recv, int64_t count, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }
