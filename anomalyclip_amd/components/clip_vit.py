@@ -173,6 +173,11 @@ class VisionTransformer(nn.Module):
             cb, pb = ops.cast_bf16(conv), ops.cast_bf16(proj_t)
             keep += [cb, pb]
             w.conv1_w_bf16, w.proj_t_bf16 = cb.data_ptr(), pb.data_ptr()
+        elif prec == L.PREC_F32X6:
+            # the patch embedding as a bf16 x 6 product: the weight's three planes in K-panel layout (ACX_BF16X3P)
+            cb = ops.split_bf16x3(conv, panel=True)
+            keep.append(cb)
+            w.conv1_w_bf16 = cb.data_ptr()
         w.class_embedding = self.class_embedding.data_ptr()
         w.positional_embedding = self.positional_embedding.data_ptr()
         w.ln_pre_w, w.ln_pre_b = self.ln_pre.weight.data_ptr(), self.ln_pre.bias.data_ptr()

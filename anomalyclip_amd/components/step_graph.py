@@ -42,6 +42,8 @@ import os as _os
 # development probe (timing only, results are garbage): replay the main chain without the text stream's graphs, to see what the
 # text tower still costs the step when it runs beside it
 _SKIP_TEXT = _os.environ.get("ACX_STEP_SKIP_TEXT") == "1"
+# development probe: host time stamps of every replayed item of every step (ACX_STEP_HOST_TRACE=1; read step_graph._HOST_TRACE)
+_HOST_TRACE = [] if _os.environ.get("ACX_STEP_HOST_TRACE") == "1" else None
 
 
 class _Program:
@@ -594,8 +596,18 @@ class TrainStepGraph:
         if self.in_graph_adamw and self._text_state == self._text_param_state():
             items = items[self.n_prologue:]          # this step's text features were computed at the end of the previous step
         skip_x = _SKIP_TEXT
+        trace = _HOST_TRACE
+        if trace is not None:
+            import time as _time
+            rec = [("begin", _time.perf_counter())]
         for it in items:
             kind = it[0]
+            if trace is not None:
+                rec.append((kind + ":" + str(it[2] if kind == "graph" else (it[1] if isinstance(it[1], (int, str)) else "")), _time.perf_counter()))
+                if kind == "graph" and it[2] == "main":      # device time stamps in front of every main-stream segment
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(main)
+                    rec.append(("ev", ev))
             if skip_x and (kind == "x_eager" or (kind == "graph" and it[2] != "main")):
                 continue
             if kind == "graph":
@@ -617,6 +629,12 @@ class TrainStepGraph:
                 self.ev_x[it[1]].record(self.tstream)
             elif kind == "main_wait_x":
                 main.wait_event(self.ev_x[it[1]])
+        if trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(main)
+            rec.append(("ev", ev))
+            rec.append(("end", _time.perf_counter()))
+            trace.append(rec)
         if self.in_graph_adamw:
             ops.WEIGHT_EPOCH[0] += 1
             self._text_state = self._text_param_state()

@@ -270,13 +270,6 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
   const int hdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   const size_t esz = prec == ACX_PREC_BF16 ? 2 : 4;
   int rc;
-  // the four large GEMMs of a layer in ACX_PREC_F32X6: split the f32 input into planes, multiply on the bf16 matrix cores
-#define X6_LINEAR(Af32, lda_, planes_, Wplanes_, wpb_, Cout_, ldc_, N_, K_, bias_, act_, res_)                          \
-  do {                                                                                                                 \
-    if ((rc = acx_split_bf16x3_panel(ctx, (const float*)(Af32), (lda_), (planes_), (int64_t)rows * (K_) * 2, rows, (K_), s))) return rc;  \
-    if ((rc = linear_x6(ctx, (planes_), (K_), rows, (Wplanes_), (wpb_), (K_), (Cout_), (ldc_), (int)rows, (N_), (K_), (bias_),  \
-                        (act_), (res_), s))) return rc;                                                                \
-  } while (0)
   for (int l = 0; l < layers; ++l) {
     const acx_block_weights& b = blk[l];
     if (cls_ws && l == layers - 1) {
@@ -285,16 +278,21 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
       float* x1 = attc + (size_t)batch * W;      // [batch, W]
       char* hc = (char*)(x1 + (size_t)batch * W);          // [batch, W]   (f32 or bf16)
       char* mc = hc + (size_t)batch * W * 4;               // [batch, 4W]  (f32 or bf16)
-      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+      const bool kv_x6 = x6mode && x6_takes(ctx, ws, rows, 2 * W, W, W);
       // K | V for every token: rows [W, 3W) of in_proj
-      if (x6mode && x6_takes(ctx, ws, rows, 2 * W, W, W)) {
+      if (kv_x6) {
+        // LayerNorm writes the product's three planes itself (all rows) and the f32 rows of the CLS tokens (Q below reads only those)
         if (!b.in_proj_w_bf16) return acx_fail(ctx, ACX_E_BADARG, "driver: missing bf16 x 3 weight planes for ACX_PREC_F32X6%s");
-        X6_LINEAR(ws.h, W, ws.hp, (const char*)b.in_proj_w_bf16 + (size_t)W * 64 /* row W of every K-panel */, (int64_t)3 * W * W * 2, (float*)ws.qkv + W,
-                  3 * W, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr);
-      } else
+        if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, ACX_BF16X3P, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+        if ((rc = acx_layernorm(ctx, x, (int64_t)L * W, b.ln1_w, b.ln1_b, ws.h, (int64_t)L * W, hdt, batch, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+        if ((rc = linear_x6(ctx, ws.hp, W, rows, (const char*)b.in_proj_w_bf16 + (size_t)W * 64 /* row W of every K-panel */, (int64_t)3 * W * W * 2, W,
+                            (float*)ws.qkv + W, 3 * W, (int)rows, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr, s))) return rc;
+      } else {
+      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
       if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w + (size_t)W * W,
                        b.in_proj_w_bf16 ? (const char*)b.in_proj_w_bf16 + (size_t)W * W * 2 : nullptr, W,
                        (float*)ws.qkv + W, ACX_F32, 3 * W, (int)rows, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr, s))) return rc;
+      }
       // Q for the CLS rows only (A rows strided by one sequence)
       if ((rc = linear(ctx, prec, ws.h, hdt, L * W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, ACX_F32, L * 3 * W, batch, W, W,
                        b.in_proj_b, ACX_ACT_NONE, nullptr, s))) return rc;
@@ -370,7 +368,6 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     if ((rc = linear(ctx, prec, ws.mlp, hdt, 4 * W, b.proj_w, b.proj_w_bf16, 4 * W, x, ACX_F32, W, (int)rows, W, 4 * W,
                      b.proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
   }
-#undef X6_LINEAR
   return ACX_OK;
 }
 
@@ -406,7 +403,7 @@ VitWs carve_vit(char* base, const acx_vit_desc* d, int F) {
   const int K = 3 * d->patch * d->patch;
   VitWs w;
   size_t off = 0;
-  w.patches = base + off;   off += al((size_t)F * T * K * 4);
+  w.patches = base + off;   off += al((size_t)F * T * K * (d->prec == ACX_PREC_F32X6 ? 6 : 4));   // (F32X6: three bf16 planes)
   w.patch_out = base + off; off += al((size_t)F * T * W * 4);
   w.x = base + off;         off += al((size_t)F * (T + 1) * W * 4);
   w.cls = base + off;       off += al((size_t)F * W * 4);
@@ -439,13 +436,21 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   const int pdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   int rc;
   // conv1 as GEMM over im2col'ed patches                               clip/model.py:267-269
+  const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W, d->prec);
+  if (d->prec == ACX_PREC_F32X6 && w->conv1_w_bf16 && K % 32 == 0 && x6_takes(ctx, tf, (int64_t)F * T, W, K, K)) {
+    // ACX_PREC_F32X6: im2col writes the three bf16 planes of the pixels (K-panel layout), the embedding is a pairs = 6 product
+    // like the layers' GEMMs (conv1_w_bf16: the weight's three K-panel planes); scratch for a K-split tail: the f32 q | k | v buffer
+    if ((rc = acx_vit_patches(ctx, frames, ws.patches, ACX_BF16X3P, F, d->resolution, d->patch, s))) return rc;
+    if ((rc = linear_x6(ctx, ws.patches, K, (int64_t)F * T, w->conv1_w_bf16, (int64_t)W * K * 2, K, ws.patch_out, W, F * T, W, K, nullptr,
+                        ACX_ACT_NONE, nullptr, s, 0, ACX_F32, tf.qkv, (size_t)F * (T + 1) * 3 * W * 4))) return rc;
+  } else {
   if ((rc = acx_vit_patches(ctx, frames, ws.patches, pdt, F, d->resolution, d->patch, s))) return rc;
-  if ((rc = linear(ctx, prec, ws.patches, pdt, K, w->conv1_w, w->conv1_w_bf16, K, ws.patch_out, ACX_F32, W, F * T, W, K,
+  if ((rc = linear(ctx, prec, ws.patches, pdt, K, w->conv1_w, prec == ACX_PREC_BF16 ? w->conv1_w_bf16 : nullptr, K, ws.patch_out, ACX_F32, W, F * T, W, K,
                    nullptr, ACX_ACT_NONE, nullptr, s))) return rc;
+  }
   // CLS + positional embedding + ln_pre                                :270-279
   if ((rc = acx_vit_embed(ctx, (const float*)ws.patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
                           w->ln_pre_b, (float*)ws.x, F, T, W, s))) return rc;
-  const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W, d->prec);
   const bool prune = ACX_DBG_SWITCH("VIT_PRUNE", true);
   if ((rc = transformer_layers(ctx, (float*)ws.x, F, T + 1, W, d->heads, d->layers, 0, d->prec, w->blocks, tf, s,
                                prune ? (float*)ws.cls_ws : nullptr))) return rc;

@@ -3,7 +3,8 @@
 // uses them:
 //   acx_probe_mfma  -- register-only MFMA loop (v_mfma_f32_32x32x2_f32 or v_mfma_f32_32x32x16_bf16), four independent
 //                      accumulator chains per wave, `waves_per_simd` waves on every SIMD of the chip: the issue-rate
-//                      ceiling of the matrix pipe at the clock the chip sustains under that load;
+//                      ceiling of the matrix pipe at the clock the chip sustains under that load (bf16 = 1: constant operands;
+//                      bf16 = 2: random operands -- the rate the power limit leaves with operands that toggle like data);
 //   acx_probe_copy  -- 16-byte-per-lane grid-stride copy (global_load_dwordx4 / global_store_dwordx4): the HBM stream
 //                      ceiling (read + write) the row kernels are measured against.
 #include "acx_internal.h"
@@ -17,7 +18,32 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, float* __res
 #pragma unroll
   for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; a2[e] = 0.f; a3[e] = 0.f; }
   const float x = 1.0f + (float)(threadIdx.x & 7) * 0.125f, y = 0.5f;
-  if constexpr (BF16) {
+  if constexpr (BF16 == 2) {
+    // RANDOM operands: four different (A, B) fragment pairs per lane, bf16 values with random sign / mantissa and exponents in
+    // [2^-3, 2^1) -- the matrix pipe's sustained rate at the chip's power limit with operands that toggle like real data (the
+    // constant-operand loop above measures the issue rate at a clock real operands do not sustain)
+    bf16x8 ra[4], rb[4];
+    unsigned st = (unsigned)(blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      typedef unsigned short u16x8_ __attribute__((ext_vector_type(8)));
+      u16x8_ va, vb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        st = st * 1664525u + 1013904223u;
+        va[e] = (unsigned short)(((st >> 16) & 0x807fu) | ((124u + ((st >> 9) & 3u)) << 7));
+        st = st * 1664525u + 1013904223u;
+        vb[e] = (unsigned short)(((st >> 16) & 0x807fu) | ((124u + ((st >> 9) & 3u)) << 7));
+      }
+      ra[q] = __builtin_bit_cast(bf16x8, va); rb[q] = __builtin_bit_cast(bf16x8, vb);
+    }
+    for (int i = 0; i < iters; ++i) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[0], rb[0], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[1], rb[1], a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[2], rb[2], a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[3], rb[3], a3, 0, 0, 0);
+    }
+  } else if constexpr (BF16 == 1) {
     bf16x8 xa, xb;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { xa[e] = (__bf16)x; xb[e] = (__bf16)y; }
@@ -91,7 +117,8 @@ extern "C" int acx_probe_mfma(acx_ctx* ctx, int32_t bf16, int32_t iters, int32_t
   const int ncu = ctx && ctx->multiprocessors > 0 ? ctx->multiprocessors : 256;
   const dim3 grid((unsigned)(ncu * waves_per_simd)), block(256);           // 4 waves per block = one per SIMD
   hipStream_t s = (hipStream_t)stream;
-  if (bf16) hipLaunchKernelGGL((probe_mfma_kernel<1>), grid, block, 0, s, iters, sink);
+  if (bf16 == 2) hipLaunchKernelGGL((probe_mfma_kernel<2>), grid, block, 0, s, iters, sink);
+  else if (bf16) hipLaunchKernelGGL((probe_mfma_kernel<1>), grid, block, 0, s, iters, sink);
   else hipLaunchKernelGGL((probe_mfma_kernel<0>), grid, block, 0, s, iters, sink);
   if (flops_out) *flops_out = (double)grid.x * 4.0 * (double)iters * 4.0 * (bf16 ? 32768.0 : 4096.0);
   ACX_CHECK_LAUNCH(ctx, "acx_probe_mfma");

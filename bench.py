@@ -431,6 +431,22 @@ def peaks_measured(dev, local_rank):
             dt = _event_time(run, 5, 2)
             best = max(best, fl.value / dt / 1e12)
         out[name] = {"measured": round(best, 1), "nominal": nominal, "ratio": round(best / nominal, 4)}
+    # the same bf16 loop with RANDOM operands (four different fragment pairs per lane), sustained for ~0.2 s: what the chip's power
+    # limit leaves of the issue rate when the operands toggle like data -- the constant-operand loop above runs at a clock real
+    # operands do not sustain.  One wave per SIMD (the plane-reuse kernel's occupancy) and two.
+    rnd = {}
+    for wps in (1, 2):
+        fl = ctypes.c_double(0.0)
+
+        def run_r(wps=wps, fl=fl):
+            L.check(lib.acx_probe_mfma(h, 2, 200000, wps, sink.data_ptr(), ctypes.byref(fl), st), h)
+        dt = _event_time(run_r, 12 // wps, 2)
+        rnd[f"waves_per_simd_{wps}"] = round(fl.value / dt / 1e12, 1)
+    best_r = max(rnd.values())
+    out["mfma_bf16_random_operands_tflops"] = {"measured": best_r, "by_occupancy": rnd, "nominal": PEAK_TFLOPS["bf16"],
+                                               "ratio": round(best_r / PEAK_TFLOPS["bf16"], 4),
+                                               "note": "register-only v_mfma_f32_32x32x16_bf16 loop, random bf16 operands, ~0.2 s sustained: "
+                                                       "the matrix pipe's rate at the power limit with toggling operands, no memory traffic"}
     n = 1 << 30
     src = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
     dst = torch.empty_like(src)
@@ -957,6 +973,10 @@ def main():
                          "frac_of_measured_mfma_peak": (round((6 if args.precision == "auto" else 1) * achieved / extra["peaks_measured"][
                              "mfma_f32_tflops" if args.precision == "f32" else "mfma_bf16_tflops"]["measured"], 4)
                              if "peaks_measured" in extra else None),
+                         # against the register-only loop with RANDOM operands (the rate the power limit leaves with toggling data)
+                         "frac_of_sustained_mfma_rate_random_operands": (
+                             round(6 * achieved / extra["peaks_measured"]["mfma_bf16_random_operands_tflops"]["measured"], 4)
+                             if args.precision == "auto" and "mfma_bf16_random_operands_tflops" in extra.get("peaks_measured", {}) else None),
                          "traffic": traffic, "traffic_source": pmc_src,
                          # counter bytes / algorithmic bytes of a GEMM launch (A + W read once, C written once; residuals and
                          # biases included): > 1 = re-reads through the fabric

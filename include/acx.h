@@ -205,7 +205,8 @@ int acx_attention_cls(acx_ctx* ctx, const float* qkv, int64_t ldqkv, float* out,
 
 /* ------------------------------------------------------------------------------------------
  * acx_vit_patches: im2col of 16x16/16 patches (clip/model.py:246-252,267-269).
- * frames [F,3,R,R] f32 -> patches [F*g*g, 3*P*P] (k = c*P*P + ky*P + kx, token = gy*g+gx). */
+ * frames [F,3,R,R] f32 -> patches [F*g*g, 3*P*P] (k = c*P*P + ky*P + kx, token = gy*g+gx); out_dtype ACX_F32, ACX_BF16, or
+ * ACX_BF16X3P (three bf16 planes of the f32 pixels in K-panel layout: the patch embedding's A operand in ACX_PREC_F32X6). */
 int acx_vit_patches(acx_ctx* ctx, const float* frames, void* patches, int32_t out_dtype,
                     int32_t F, int32_t R, int32_t P, void* stream);
 /* acx_vit_embed: x[f,0,:] = cls + pos[0]; x[f,1+t,:] = patch_out[f,t,:] + pos[1+t]; then ln_pre

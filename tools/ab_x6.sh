@@ -10,7 +10,7 @@ mkdir -p /root/repo/tools/ab_libs
 if [ "$mode" = build ]; then
   cd /root/repo/anomalyclip_amd/csrc
   others=""
-  for o in acx_api acx_gemm acx_norm acx_attn acx_head acx_train acx_metrics acx_probe acx_step; do
+  for o in acx_api acx_gemm acx_norm acx_attn acx_head acx_train acx_metrics acx_probe acx_step acx_comm; do
     [ "$o.hip" = "$SRC" ] || others="$others $o.o"
   done
   for spec in "$@"; do
