@@ -160,6 +160,10 @@ _SIGS = {
     "acx_scatter_segments": (C.c_int, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "acx_mil_loss": (C.c_int, [c_void_p] * 13 + [c_size_t] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p]),
     "acx_mil_loss_one": (C.c_int, [c_void_p] * 13 + [c_size_t] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acx_mil_loss_bn": (C.c_int, [c_void_p] * 14 + [c_size_t, c_void_p, c_size_t] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acx_selector_tail": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32] + [c_void_p] * 7 + [c_float, c_float, c_void_p, c_int64] +
+                          [c_void_p] * 6 + [c_int32] * 7 + [c_float, c_void_p]),
+    "acx_text_directions_bwd_parts": (C.c_int, [c_void_p] * 4 + [c_int32, c_int64, c_void_p] + [c_int32] * 3 + [c_void_p]),
     "acx_adamw": (C.c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int32, c_void_p]),
     "acx_multi_axpy": (C.c_int, [c_void_p, c_int32, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int64), c_float, c_void_p]),
     "acx_adamw_multi": (C.c_int, [c_void_p, c_int32] + [C.POINTER(c_void_p)] * 4 + [C.POINTER(c_int64), C.POINTER(C.c_double),
@@ -184,6 +188,8 @@ _SIGS = {
                                         C.POINTER(c_int32), c_void_p]),
     "acx_gemm_tn_zp": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                  c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "acx_gemm_tn_parts": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                    c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, C.POINTER(c_int32), c_void_p]),
     "acx_gemm_tn_x6_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "acx_gemm_tn_x6": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -395,8 +395,7 @@ class SelectorTrainFn(torch.autograd.Function):
         if par.is_distributed():
             par.all_reduce_sum_(sums)
         draw = ops.bn_bwd_apply(logits, dl, var_b, sums, total_rows, sel.bn_layer.eps)     # [rows, C1 padded to 4]
-        d_dirs = ops.gemm_tn(draw, x, b_sub=nc)[:C1].contiguous()                          # [C1, D]
-        d_text = ops.text_directions_bwd(tf, nc, d_dirs, sel.normal_id)
+        d_text = ops.selector_dirs_grad(draw, x, nc, tf, sel.normal_id, C1)                # d_dirs = draw^T (x - nc), then dirs' backward
         return d_text, None, None, None, None, None, None
 
 

@@ -44,6 +44,8 @@ import os as _os
 _SKIP_TEXT = _os.environ.get("ACX_STEP_SKIP_TEXT") == "1"
 # development probe: host time stamps of every replayed item of every step (ACX_STEP_HOST_TRACE=1; read step_graph._HOST_TRACE)
 _HOST_TRACE = [] if _os.environ.get("ACX_STEP_HOST_TRACE") == "1" else None
+# development A/B: the step's middle section as the separate launches of the autograd path (no acx_selector_tail / acx_mil_loss_bn)
+_UNFUSED = _os.environ.get("ACX_STEP_UNFUSED") == "1"
 
 
 class _Program:
@@ -360,16 +362,28 @@ class TrainStepGraph:
         dirs = ops.text_directions(tf, nc, sel.normal_id)
         raw, mean, var_b, var_u = ops.selector_project_stats(x, nc, dirs)
         total_rows = rows
+        bn = sel.bn_layer
+        # the forward tail (BatchNorm, running statistics, picks, gather of the top-k segments) as ONE launch per step when a
+        # video's logits fit the LDS (acx_selector_tail: bit-identical to the separate launches below, which the autograd path uses)
+        fuse_tail = ((N * Lg * C1 + N * C1 + 2 * N + 2 * C1 + sel.num_topk + sel.num_bottomk) * 4 <= 160 * 1024 and C1 <= 64
+                     and not _UNFUSED)
         if dist_on:                                                      # SyncBatchNorm (configs/trainer/ddp.yaml:9)
             ops.bn_pack(mean, var_b, rows, out=self.bn_local)
             pg.eager(lambda: par.all_gather_into(self.bn_gathered, self.bn_local))
             pg.begin()
-            mean, var_b, var_u, total_rows = ops.bn_combine(self.bn_gathered, C1)
-        bn = sel.bn_layer
-        logits = ops.selector_bn(raw, mean, var_b, bn.eps)
-        ops.bn_running_update_(bn, mean, var_u)
-        idx_top, idx_bot = ops.select_idx(logits, labels, mt, mb, N, Lg, sel.normal_id, sel.num_topk, sel.num_bottomk)
-        logits_topk = ops.gather_segments(logits, idx_top, N, Lg)
+            if not fuse_tail:
+                mean, var_b, var_u, total_rows = ops.bn_combine(self.bn_gathered, C1)
+        if fuse_tail:
+            logits, idx_top, idx_bot, logits_topk, st = ops.selector_tail(
+                raw, labels, mt, mb, N, Lg, sel.normal_id, sel.num_topk, sel.num_bottomk, bn.eps,
+                gathered=self.bn_gathered if dist_on else None, stats=None if dist_on else (mean, var_b, var_u), bn=bn)
+            if dist_on:
+                mean, var_b, var_u, total_rows = st
+        else:
+            logits = ops.selector_bn(raw, mean, var_b, bn.eps)
+            ops.bn_running_update_(bn, mean, var_u)
+            idx_top, idx_bot = ops.select_idx(logits, labels, mt, mb, N, Lg, sel.normal_id, sel.num_topk, sel.num_bottomk)
+            logits_topk = ops.gather_segments(logits, idx_top, N, Lg)
         half = B // 2
         ia, in_, ba = idx_top[:half], idx_top[half:], idx_bot[:half]
         if concat:
@@ -380,10 +394,21 @@ class TrainStepGraph:
         crit = mod.criterion
         lambdas = (crit.lambda_dir_abn, crit.lambda_dir_nor, crit.lambda_topk_abn, crit.lambda_bottomk_abn,
                    crit.lambda_topk_nor, crit.lambda_smooth, crit.lambda_sparse)
-        losses, dsim, dtopk, dsc = ops.mil_loss(logits, logits_topk, labels, scores, ia, in_, ba, crit.num_segments,
-                                                crit.frames_per_segment, crit.num_topk, crit.normal_id, lambdas)
+        # loss + `meter += losses` + the scatter of the top-k rows' gradient + the BatchNorm backward sums as ONE launch
+        # (acx_mil_loss_bn: bit-identical to the four separate steps) when nothing sits between the loss and the selector's backward
+        fuse_loss = (not concat and rows % 256 == 0 and rows <= 131072 and C1 <= 64 and crit.num_segments == N
+                     and crit.frames_per_segment == Lg and crit.num_topk == sel.num_topk and not _UNFUSED)
+        bn_sums = None
+        if fuse_loss:
+            losses, dsim, dsc, bn_sums = ops.mil_loss_bn(logits, logits_topk, labels, scores, ia, in_, ba, crit.num_segments,
+                                                         crit.frames_per_segment, crit.num_topk, crit.normal_id, lambdas,
+                                                         meter=self.meter_sum)
+            dtopk = None
+        else:
+            losses, dsim, dtopk, dsc = ops.mil_loss(logits, logits_topk, labels, scores, ia, in_, ba, crit.num_segments,
+                                                    crit.frames_per_segment, crit.num_topk, crit.normal_id, lambdas)
+            ops.axpby_(self.meter_sum, losses, 1.0, 1.0)                 # the eight running loss sums (module's meters)
         self.losses = losses
-        ops.axpby_(self.meter_sum, losses, 1.0, 1.0)                     # the eight running loss sums (module's meters)
         keep.extend([dsc, cT, scores, logits, x])
         d_scores = dsc.view(-1, 1)
         g_ctx, g_P = self.gviews[ctx_p], self.gviews[P_p]
@@ -392,14 +417,16 @@ class TrainStepGraph:
             return Fn.TemporalFn.backward(cT, d_scores)[0]
 
         def selector_bwd(dl):
-            ops.scatter_segments_(dl, dtopk, idx_top, N, Lg)
-            sums = ops.bn_bwd_stats(logits, dl)
+            if bn_sums is not None:                                      # (dl already holds the scattered top-k gradient)
+                sums = bn_sums
+            else:
+                ops.scatter_segments_(dl, dtopk, idx_top, N, Lg)
+                sums = ops.bn_bwd_stats(logits, dl)
             if dist_on:
                 pg.eager(lambda: par.all_reduce_sum_(sums))
                 pg.begin()
             draw = ops.bn_bwd_apply(logits, dl, var_b, sums, total_rows, bn.eps)
-            d_dirs = ops.gemm_tn(draw, x, b_sub=nc)[:C1]
-            d_text = ops.text_directions_bwd(tf, nc, d_dirs, sel.normal_id)
+            d_text = ops.selector_dirs_grad(draw, x, nc, tf, sel.normal_id, C1)
             if cp:
                 pg.eager(lambda: par.all_reduce_sum_(d_text))
             return d_text

@@ -1356,9 +1356,26 @@ extern "C" int acx_gemm_tn(acx_ctx* ctx, const float* A, int32_t lda, const floa
   return acx_gemm_tn_zp(ctx, A, lda, B, ldb, C, ldc, M, N1, N2, b_sub, conv, gn, gl, cin, workspace, workspace_bytes, nullptr, stream);
 }
 
+// splits_out != nullptr (acx_gemm_tn_parts): no reduce launch -- *splits_out = the number of K-split partial images left in
+// `workspace` ([splits][N1][N2] f32, image order = tn_reduce_kernel's summation order); 1: C holds the result itself
+static int gemm_tn_impl(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                        int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                        int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, int32_t* splits_out, void* stream);
 extern "C" int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                               int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
                               int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream) {
+  return gemm_tn_impl(ctx, A, lda, B, ldb, C, ldc, M, N1, N2, b_sub, conv, gn, gl, cin, workspace, workspace_bytes, zero_page, nullptr, stream);
+}
+extern "C" int acx_gemm_tn_parts(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                                 int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                                 int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, int32_t* splits_out,
+                                 void* stream) {
+  if (!splits_out) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn_parts: null splits_out%s");
+  return gemm_tn_impl(ctx, A, lda, B, ldb, C, ldc, M, N1, N2, b_sub, conv, gn, gl, cin, workspace, workspace_bytes, zero_page, splits_out, stream);
+}
+static int gemm_tn_impl(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                        int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                        int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, int32_t* splits_out, void* stream) {
   if (!A || !B || !C) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: null pointer%s");
   if (M <= 0 || N1 <= 0 || N2 <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_gemm_tn: empty shape%s");
   if (N1 % 4 || N2 % 4 || lda % 4 || ldb % 4 || ldc != N2 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15))
@@ -1400,7 +1417,8 @@ extern "C" int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const f
       }
       const int tiles = ((N1 + 255) / 256) * ((N2 + 255) / 256);
       hipLaunchKernelGGL(gemm_tn_p256_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(1024), (size_t)TP_LDS_B, s, g, zeros);
-      if (splits > 1) {
+      if (splits_out) *splits_out = splits;
+      if (splits > 1 && !splits_out) {
         const int64_t n4 = (int64_t)N1 * N2 / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, n4,
                            splits);
@@ -1443,7 +1461,8 @@ extern "C" int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const f
     hipLaunchKernelGGL(gemm_tn_w8_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(512), lds, s, g);
   } else
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(NTHREADS), lds, s, g);
-  if (splits > 1) {
+  if (splits_out) *splits_out = splits;
+  if (splits > 1 && !splits_out) {
     const int64_t n4 = (int64_t)N1 * N2 / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, n4,
                        splits);

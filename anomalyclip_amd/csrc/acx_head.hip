@@ -396,8 +396,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   if (rl < RL) {
     for (int64_t r = r0 + rl; r < r1; r += RL) {
       const double v = (double)a[r * C1 + c];
-      if constexpr (K2 == 0) { s += v; qq += v * v; }
-      else { const double g = (double)b[r * C1 + c]; s += g; qq += g * v; }
+      double g = 0.0;
+      if constexpr (K2 != 0) g = (double)b[r * C1 + c];
+      acx_bn_acc<K2>(s, qq, v, g);
     }
   }
   red[0][threadIdx.x] = s;
@@ -409,34 +410,6 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     for (int l = 0; l < RL; ++l) v += red[k][l * C1 + cc];
     part[((size_t)blockIdx.x * 2 + k) * CP + cc] = v;
   }
-}
-// stage 2: 256 threads; pair p = (kind, column) < 2*C1 is summed by G = 256 / (2*C1) threads, thread g of a pair taking blocks
-// g, g + G, ... in order; the G partial sums meet in LDS and are added in g order -- a pure function of (nblocks, C1), so
-// results are run-to-run identical.  (One thread per pair walking 512 blocks took 120 us: a chain of dependent L2 misses.)
-__device__ __forceinline__ double bn_pair_total(const double* __restrict__ part, int nblocks, int CP, int C1, double* red) {
-  const int P = 2 * C1, G = 256 / P;
-  const int p = threadIdx.x % P, g = threadIdx.x / P;
-  double v = 0.0;
-  if (g < G) {
-    const int k = p / C1, c = p - k * C1;
-    const double* src = part + (size_t)k * CP + c;
-    const size_t bs = (size_t)2 * CP;
-    int b = g;
-    for (; b + 7 * G < nblocks; b += 8 * G) {                         // eight independent loads in flight, added in block order
-      double t8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t8[u] = src[(size_t)(b + u * G) * bs];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += t8[u];
-    }
-    for (; b < nblocks; b += G) v += src[(size_t)b * bs];
-  }
-  red[threadIdx.x] = v;
-  __syncthreads();
-  double tot = 0.0;
-  if ((int)threadIdx.x < P)
-    for (int gg = 0; gg < G; ++gg) tot += red[gg * P + threadIdx.x];
-  return tot;                                                          // valid for threadIdx.x < 2*C1: pair (k = t / C1, c = t % C1)
 }
 // mean / biased / unbiased variance from the (sum, sum of squares) partials: var = E[x^2] - mean^2 in f64 (the column
 // values are O(1): 53 bits leave ~1e-13 after the cancellation)
@@ -465,7 +438,7 @@ __global__ __launch_bounds__(256) void selector_bn_kernel(const float* __restric
   if (i >= total) return;
   const int64_t r = i / C1;
   const int c = (int)(i - r * C1);
-  logits[r * ldl + c] = (raw[i] - mean[c]) / sqrtf(var[c] + eps);
+  logits[r * ldl + c] = acx_bn_apply(raw[i], mean[c], var[c], eps);
 }
 
 // ------------------------------------------------------------------ axial attention core
@@ -863,21 +836,13 @@ __global__ __launch_bounds__(64) void bn_combine_kernel(const float* __restrict_
                                                         float* __restrict__ var_b, float* __restrict__ var_u,
                                                         float* __restrict__ total) {
   const int c = threadIdx.x;
-  const int ld = 2 * C + 1;
-  float n = 0.f;
-  for (int r = 0; r < R; ++r) n += g[(size_t)r * ld + 2 * C];
+  float n, m, vb, vu;
+  acx_bn_combine_col(g, R, C, c < C ? c : 0, n, m, vb, vu);
   if (c == 0) total[0] = n;
   if (c >= C) return;
-  float m = 0.f;
-  for (int r = 0; r < R; ++r) m += g[(size_t)r * ld + c] * (g[(size_t)r * ld + 2 * C] / n);
-  float m2 = 0.f;
-  for (int r = 0; r < R; ++r) {
-    const float dm = g[(size_t)r * ld + c] - m;
-    m2 += g[(size_t)r * ld + C + c] + g[(size_t)r * ld + 2 * C] * (dm * dm);
-  }
   mean[c] = m;
-  var_b[c] = m2 / n;
-  var_u[c] = m2 / fmaxf(n - 1.f, 1.f);
+  var_b[c] = vb;
+  var_u[c] = vu;
 }
 }  // namespace
 

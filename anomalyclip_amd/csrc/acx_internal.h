@@ -148,6 +148,70 @@ __device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {   // two values 
 }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// ---- BatchNorm arithmetic shared between the stand-alone kernels and the fused step kernels (acx_train.hip): ONE expression
+// tree per quantity, so that hipcc's contraction choices -- and the bits -- are the same wherever it is inlined
+// SyncBN combine (Chan et al.) of column c: gathered[r] = (mean[C], biased_var[C] * rows_r, rows_r) of rank r, ranks in order
+__device__ __forceinline__ void acx_bn_combine_col(const float* __restrict__ g, int R, int C, int c, float& n_out, float& mean,
+                                                   float& var_b, float& var_u) {
+  const int ld = 2 * C + 1;
+  float n = 0.f;
+  for (int r = 0; r < R; ++r) n += g[(size_t)r * ld + 2 * C];
+  float m = 0.f;
+  for (int r = 0; r < R; ++r) m += g[(size_t)r * ld + c] * (g[(size_t)r * ld + 2 * C] / n);
+  float m2 = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float dm = g[(size_t)r * ld + c] - m;
+    m2 += g[(size_t)r * ld + C + c] + g[(size_t)r * ld + 2 * C] * (dm * dm);
+  }
+  n_out = n; mean = m; var_b = m2 / n; var_u = m2 / fmaxf(n - 1.f, 1.f);
+}
+// nn.BatchNorm1d running statistic: r = (1 - momentum) r + momentum x
+__device__ __forceinline__ float acx_bn_running(float momentum, float om, float x, float r) { return momentum * x + om * r; }
+// training BatchNorm output
+__device__ __forceinline__ float acx_bn_apply(float raw, float mean, float var, float eps) { return (raw - mean) / sqrtf(var + eps); }
+// f64 column sums of stage 1: (x, x^2) for the forward statistics (K2 = 0), (dl, dl * xhat) for the backward ones (K2 = 1)
+template <int K2>
+__device__ __forceinline__ void acx_bn_acc(double& s, double& qq, double v, double g) {
+  if constexpr (K2 == 0) { s += v; qq += v * v; }
+  else { s += g; qq += g * v; }
+}
+// stage 2: 256 threads; pair p = (kind, column) < 2*C1 is summed by G = 256 / (2*C1) threads, thread g of a pair taking blocks
+// g, g + G, ... in order; the G partial sums meet in LDS and are added in g order -- a pure function of (nblocks, C1), so
+// results are run-to-run identical.  (One thread per pair walking 512 blocks took 120 us: a chain of dependent L2 misses.)
+// COHERENT: the partials were published by other workgroups of the SAME launch (agent-scope atomic loads: last-arriver form)
+template <bool COHERENT = false>
+__device__ __forceinline__ double bn_pair_total(const double* __restrict__ part, int nblocks, int CP, int C1, double* red) {
+  const int P = 2 * C1, G = 256 / P;
+  const int p = threadIdx.x % P, g = threadIdx.x / P;
+  double v = 0.0;
+  if (g < G) {
+    const int k = p / C1, c = p - k * C1;
+    const double* src = part + (size_t)k * CP + c;
+    const size_t bs = (size_t)2 * CP;
+    int b = g;
+    for (; b + 7 * G < nblocks; b += 8 * G) {                         // eight independent loads in flight, added in block order
+      double t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if constexpr (COHERENT) t8[u] = __hip_atomic_load(src + (size_t)(b + u * G) * bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else t8[u] = src[(size_t)(b + u * G) * bs];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t8[u];
+    }
+    for (; b < nblocks; b += G) {
+      if constexpr (COHERENT) v += __hip_atomic_load(src + (size_t)b * bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else v += src[(size_t)b * bs];
+    }
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  double tot = 0.0;
+  if ((int)threadIdx.x < P)
+    for (int gg = 0; gg < G; ++gg) tot += red[gg * P + threadIdx.x];
+  return tot;                                                          // valid for threadIdx.x < 2*C1: pair (k = t / C1, c = t % C1)
+}
+
 // ---- wave-per-row register layout shared by the row kernels
 // lane owns elements: VPL%4==0 -> float4 groups at 4*lane + 256*i ; else scalar at lane + 64*i
 template <int VPL>

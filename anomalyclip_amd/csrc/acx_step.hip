@@ -341,8 +341,8 @@ __global__ void bn_running_kernel(const float* __restrict__ mean, const float* _
                                   float* __restrict__ rv, long long* __restrict__ nbt, int C, float momentum, float om) {
   const int i = threadIdx.x;
   if (i < C) {
-    rm[i] = momentum * mean[i] + om * rm[i];
-    rv[i] = momentum * var_u[i] + om * rv[i];
+    rm[i] = acx_bn_running(momentum, om, mean[i], rm[i]);
+    rv[i] = acx_bn_running(momentum, om, var_u[i], rv[i]);
   }
   if (i == 0 && nbt) *nbt += 1;
 }

@@ -1073,13 +1073,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sdx, float* __restrict__ draw, int ldo,
                                                            int64_t total, int C1, float eps, float inv_rows_host,
                                                            const float* __restrict__ total_rows_dev) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  // one thread per element of draw [rows, ldo]: the pad columns c >= C1 (the TN product's 4-column granularity) are zeroed here
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total) return;
+  const int64_t r = j / ldo;
+  const int c = (int)(j - r * ldo);
+  if (c >= C1) { draw[j] = 0.f; return; }
+  const int64_t i = r * C1 + c;
   const float inv_rows = total_rows_dev ? 1.f / total_rows_dev[0] : inv_rows_host;
-  const int c = (int)(i % C1);
-  const int64_t r = i / C1;
   const float rstd = 1.f / sqrtf(var_b[c] + eps);
-  draw[r * ldo + c] = rstd * (dl[i] - sdl[c] * inv_rows - logits[i] * sdx[c] * inv_rows);
+  draw[j] = rstd * (dl[i] - sdl[c] * inv_rows - logits[i] * sdx[c] * inv_rows);
 }
 // y = a*x + b*y  (running-statistics update of BatchNorm1d, momentum 0.1)
 __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, int n, float a, float b) {
@@ -1123,9 +1126,11 @@ __global__ __launch_bounds__(256) void colsum_part4_kernel(const float* __restri
 }
 
 // d_text from d_dirs: dirs = v/|v|, v = text[src] - nc  (selector_model.py:44-59)
+// nparts > 1: d_dirs arrives as the K-split partial images of the TN product that forms it (acx_gemm_tn_parts: image s at ddirs +
+// s * part_stride), added here in image order exactly as tn_reduce_kernel adds them -- one launch less in the step's middle
 __global__ __launch_bounds__(256) void text_dirs_bwd_kernel(const float* __restrict__ text, const float* __restrict__ nc,
                                                             const float* __restrict__ ddirs, float* __restrict__ dtext,
-                                                            int C, int D, int normal_id) {
+                                                            int C, int D, int normal_id, int nparts, int64_t part_stride) {
   __shared__ float red[4];
   const int row = blockIdx.x;              // row of text (0..C-1)
   if (row == normal_id) {
@@ -1133,40 +1138,55 @@ __global__ __launch_bounds__(256) void text_dirs_bwd_kernel(const float* __restr
     return;
   }
   const int c = row < normal_id ? row : row - 1;
+  auto dd = [&](int e) {
+    float v = ddirs[(size_t)c * D + e];
+    for (int k = 1; k < nparts; ++k) v += ddirs[(size_t)k * part_stride + (size_t)c * D + e];
+    return v;
+  };
+  // this thread's d_dirs values (columns t, t + 256, ...): summed once, kept in registers for both passes (D <= 2048; beyond: re-summed)
+  float dv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dv[q] = (int)threadIdx.x + 256 * q < D ? dd(threadIdx.x + 256 * q) : 0.f;
   float ss = 0.f, dot = 0.f;
-  for (int e = threadIdx.x; e < D; e += 256) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = threadIdx.x + 256 * q;
+    if (e < D) {
+      const float v = text[(size_t)row * D + e] - nc[e];
+      ss += v * v;
+      dot += v * dv[q];
+    }
+  }
+  for (int e = threadIdx.x + 2048; e < D; e += 256) {
     const float v = text[(size_t)row * D + e] - nc[e];
     ss += v * v;
-    dot += v * ddirs[(size_t)c * D + e];
+    dot += v * dd(e);
   }
   const float tss = block_sum(ss, red);
   const float tdot = block_sum(dot, red);
   const float norm = sqrtf(tss);
-  for (int e = threadIdx.x; e < D; e += 256) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = threadIdx.x + 256 * q;
+    if (e < D) {
+      const float v = text[(size_t)row * D + e] - nc[e];
+      dtext[(size_t)row * D + e] = (dv[q] - v * tdot / tss) / norm;
+    }
+  }
+  for (int e = threadIdx.x + 2048; e < D; e += 256) {
     const float v = text[(size_t)row * D + e] - nc[e];
-    dtext[(size_t)row * D + e] = (ddirs[(size_t)c * D + e] - v * tdot / tss) / norm;
+    dtext[(size_t)row * D + e] = (dd(e) - v * tdot / tss) / norm;
   }
 }
 
 // ------------------------------------------------------------------ MIL top-k / bottom-k selection
 // one block per video.  seg[n][c] = sum_l logits[(v,n,l)][c]; masked to -/+1e6; abnormal half: own-class
 // column; normal half: sum over classes; k largest / smallest, ties -> lower index first.
-__global__ __launch_bounds__(256) void select_idx_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                         const float* __restrict__ mask_top, const float* __restrict__ mask_bot,
-                                                         int64_t* __restrict__ idx_top, int64_t* __restrict__ idx_bot,
-                                                         int B, int N, int Lg, int C1, int normal_id, int ktop, int kbot) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* seg = reinterpret_cast<float*>(smem);       // [N][C1]
-  float* keyt = seg + N * C1;                        // [N]
-  float* keyb = keyt + N;                            // [N]
-  const int v = blockIdx.x;
-  for (int i = threadIdx.x; i < N * C1; i += 256) {
-    const int n = i / C1, c = i - n * C1;
-    float s = 0.f;
-    for (int l = 0; l < Lg; ++l) s += logits[(((size_t)v * N + n) * Lg + l) * C1 + c];   // torch.sum over dim 2, in order
-    seg[i] = s;
-  }
-  __syncthreads();
+// keys + picks of video v from its segment sums seg [N][C1] (LDS); the picks also land in pick[0 .. ktop + kbot) (LDS) when given
+__device__ __forceinline__ void select_from_seg(float* seg, float* keyt, float* keyb, const int64_t* __restrict__ labels,
+                                                const float* __restrict__ mask_top, const float* __restrict__ mask_bot,
+                                                int64_t* __restrict__ idx_top, int64_t* __restrict__ idx_bot, int* pick, int v, int B,
+                                                int N, int C1, int normal_id, int ktop, int kbot) {
   const bool abn = v < B / 2;
   int col = 0;
   if (abn) {
@@ -1199,6 +1219,7 @@ __global__ __launch_bounds__(256) void select_idx_kernel(const float* __restrict
       for (int n = 1; n < N; ++n)
         if (keyt[n] > keyt[best]) best = n;                    // ties -> lower index first
       idx_top[v * ktop + k] = best;
+      if (pick) pick[k] = best;
       keyt[best] = -__builtin_huge_valf();
     }
   } else if (threadIdx.x == 64) {
@@ -1207,8 +1228,99 @@ __global__ __launch_bounds__(256) void select_idx_kernel(const float* __restrict
       for (int n = 1; n < N; ++n)
         if (keyb[n] < keyb[best]) best = n;
       idx_bot[v * kbot + k] = best;
+      if (pick) pick[ktop + k] = best;
       keyb[best] = __builtin_huge_valf();
     }
+  }
+}
+__global__ __launch_bounds__(256) void select_idx_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ mask_top, const float* __restrict__ mask_bot,
+                                                         int64_t* __restrict__ idx_top, int64_t* __restrict__ idx_bot,
+                                                         int B, int N, int Lg, int C1, int normal_id, int ktop, int kbot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* seg = reinterpret_cast<float*>(smem);       // [N][C1]
+  float* keyt = seg + N * C1;                        // [N]
+  float* keyb = keyt + N;                            // [N]
+  const int v = blockIdx.x;
+  for (int i = threadIdx.x; i < N * C1; i += 256) {
+    const int n = i / C1, c = i - n * C1;
+    float s = 0.f;
+    for (int l = 0; l < Lg; ++l) s += logits[(((size_t)v * N + n) * Lg + l) * C1 + c];   // torch.sum over dim 2, in order
+    seg[i] = s;
+  }
+  __syncthreads();
+  select_from_seg(seg, keyt, keyb, labels, mask_top, mask_bot, idx_top, idx_bot, nullptr, v, B, N, C1, normal_id, ktop, kbot);
+}
+
+// The selector's forward tail as ONE launch, one workgroup per video (the whole-step graph; selector_model.py:60-99,119-225):
+// [SyncBN combine of the gathered statistics] -> BatchNorm of the video's rows -> [running statistics, block 0] -> segment sums ->
+// top-k / bottom-k picks -> gather of the top-k segments' logits.  Every quantity is formed by the same expressions, in the same
+// order, as in acx_bn_combine / acx_selector_bn / acx_bn_running_update / acx_select_idx / acx_gather_segments: bit-identical
+// results (tests/test_gpu_train.py::test_selector_tail_equals_separate_launches), five launches (four without SyncBN) less.
+struct SelTailArgs {
+  const float* raw;                                   // [rows][C1]
+  const float* gathered; int R;                       // SyncBN: [R][2 C1 + 1] (nullptr: mean_in / var_b_in / var_u_in)
+  const float *mean_in, *var_b_in, *var_u_in;
+  float* stat_out;                                    // SyncBN: [3 C1 + 1] mean | biased var | unbiased var | total rows
+  float *rm, *rv; long long* nbt; float momentum, om; // running statistics (nullptr: none)
+  float* logits; int64_t ldl;
+  const int64_t* labels; const float *mask_top, *mask_bot;
+  int64_t *idx_top, *idx_bot; float* logits_topk;
+  int B, N, Lg, C1, normal_id, ktop, kbot; float eps;
+};
+__global__ __launch_bounds__(256) void selector_tail_kernel(const SelTailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.N, Lg = a.Lg, C1 = a.C1, per = N * Lg;
+  float* slog = reinterpret_cast<float*>(smem);      // [N Lg][C1] this video's logits
+  float* seg = slog + (size_t)per * C1;              // [N][C1]
+  float* keyt = seg + N * C1;                        // [N]
+  float* keyb = keyt + N;                            // [N]
+  float* smean = keyb + N;                           // [C1]
+  float* svar = smean + C1;                          // [C1]
+  int* pick = reinterpret_cast<int*>(svar + C1);     // [ktop + kbot]
+  const int v = blockIdx.x;
+  if ((int)threadIdx.x < C1) {
+    const int c = threadIdx.x;
+    float n = 0.f, m, vb, vu;
+    if (a.gathered) {
+      acx_bn_combine_col(a.gathered, a.R, C1, c, n, m, vb, vu);
+      if (v == 0) {
+        a.stat_out[c] = m; a.stat_out[C1 + c] = vb; a.stat_out[2 * C1 + c] = vu;
+        if (c == 0) a.stat_out[3 * C1] = n;
+      }
+    } else {
+      m = a.mean_in[c]; vb = a.var_b_in[c]; vu = a.var_u_in[c];
+    }
+    smean[c] = m; svar[c] = vb;
+    if (v == 0 && a.rm) {
+      a.rm[c] = acx_bn_running(a.momentum, a.om, m, a.rm[c]);
+      a.rv[c] = acx_bn_running(a.momentum, a.om, vu, a.rv[c]);
+      if (c == 0 && a.nbt) *a.nbt += 1;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < per * C1; i += 256) {
+    const int rl = i / C1, c = i - rl * C1;
+    const int64_t r = (int64_t)v * per + rl;
+    const float y = acx_bn_apply(a.raw[r * C1 + c], smean[c], svar[c], a.eps);
+    a.logits[r * a.ldl + c] = y;
+    slog[i] = y;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * C1; i += 256) {
+    const int n = i / C1, c = i - n * C1;
+    float s = 0.f;
+    for (int l = 0; l < Lg; ++l) s += slog[((size_t)n * Lg + l) * C1 + c];   // torch.sum over dim 2, in order
+    seg[i] = s;
+  }
+  __syncthreads();
+  select_from_seg(seg, keyt, keyb, a.labels, a.mask_top, a.mask_bot, a.idx_top, a.idx_bot, pick, v, a.B, N, C1, a.normal_id, a.ktop,
+                  a.kbot);
+  __syncthreads();
+  // logits_topk[(v K + k) Lg + l][:] = logits[(v, idx_top[v][k], l)][:]
+  for (int i = threadIdx.x; i < a.ktop * Lg * C1; i += 256) {
+    const int k = i / (Lg * C1), rem = i - k * Lg * C1;
+    a.logits_topk[((size_t)v * a.ktop + k) * Lg * C1 + rem] = slog[(size_t)pick[k] * Lg * C1 + rem];
   }
 }
 
@@ -1250,8 +1362,11 @@ struct LossArgs {
 };
 // thread per frame row; block partial sums of the 7 terms -> part[blk][8].  PUBLISH: the partials leave as agent-scope
 // (write-through) stores for the one-launch form, whose last-arriving block adds them up (see loss_fused_kernel)
-template <bool PUBLISH>
-__device__ __forceinline__ void loss_rows_body(const LossArgs& a, const int blk, float* red) {
+// FOLD (acx_mil_loss_bn): the gradient of the gathered top-k rows (loss_topk_body's dsim_topk: the constant -l_dir_abn gout / RA in the
+// own-class column of an abnormal video's top-k segments, zero elsewhere) is added to this row's dsim HERE, after the row's own terms --
+// the value and the order of acx_scatter_segments(dsim, dsim_topk, idx_topk) -- and the finished row is mirrored into sdl [256][C1] (LDS)
+template <bool PUBLISH, bool FOLD = false>
+__device__ __forceinline__ void loss_rows_body(const LossArgs& a, const int blk, float* red, float* sdl = nullptr) {
   const int64_t R = (int64_t)a.B * a.N * a.Lg;
   const int64_t r = (int64_t)blk * 256 + threadIdx.x;
   const float gout = a.gout_ptr ? a.gout_ptr[0] : 1.f;
@@ -1286,6 +1401,7 @@ __device__ __forceinline__ void loss_rows_body(const LossArgs& a, const int blk,
         const float w = a.l_topk_abn / cntK * gout;
         for (int c = 0; c < C1; ++c) dsim[c] += w * (expf(s[c] - mx) / sum - (c == y ? 1.f : 0.f));
         ds += -w / sc;
+        if constexpr (FOLD) dsim[y] += -a.l_dir_abn * gout / cntK;      // (cntK == (float)RA of loss_topk_body)
       }
       if (in_bot) {   // NLL(log(1 - score))
         t_bot_abn = -logf(1.f - sc);
@@ -1314,6 +1430,8 @@ __device__ __forceinline__ void loss_rows_body(const LossArgs& a, const int blk,
       }
     }
     a.dscores[r] = ds;
+    if constexpr (FOLD)
+      for (int c = 0; c < C1; ++c) sdl[threadIdx.x * C1 + c] = dsim[c];
   }
   float vals[6] = {t_dir_nor, t_topk_abn, t_bot_abn, t_topk_nor, t_smooth, t_sparse};
 #pragma unroll
@@ -1330,7 +1448,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(const LossArgs a) {
   loss_rows_body<false>(a, (int)blockIdx.x, red);
 }
 // thread per row of sim_topk (abnormal part only contributes): ldir_abn = -mean(own-class logit)
-template <bool PUBLISH>
+template <bool PUBLISH, bool FOLD = false>
 __device__ __forceinline__ void loss_topk_body(const LossArgs& a, float* __restrict__ part2, const int blk, float* red) {
   const int64_t RT = (int64_t)a.B * a.K * a.Lg;
   const int64_t RA = (int64_t)(a.B / 2) * a.K * a.Lg;
@@ -1338,13 +1456,14 @@ __device__ __forceinline__ void loss_topk_body(const LossArgs& a, float* __restr
   const float gout = a.gout_ptr ? a.gout_ptr[0] : 1.f;
   float t = 0.f;
   if (r < RT) {
-    for (int c = 0; c < a.C1; ++c) a.dsim_topk[r * a.C1 + c] = 0.f;
+    if constexpr (!FOLD)
+      for (int c = 0; c < a.C1; ++c) a.dsim_topk[r * a.C1 + c] = 0.f;
     if (r < RA) {
       const int v = (int)(r / ((int64_t)a.K * a.Lg));
       const int64_t lab = a.labels[v];
       const int y = (int)(lab > a.normal_id ? lab - 1 : lab);
       t = a.sim_topk[r * a.C1 + y];
-      a.dsim_topk[r * a.C1 + y] = -a.l_dir_abn * gout / (float)RA;
+      if constexpr (!FOLD) a.dsim_topk[r * a.C1 + y] = -a.l_dir_abn * gout / (float)RA;
     }
   }
   const float tot = block_sum(t, red);
@@ -1376,6 +1495,34 @@ __global__ void loss_final_kernel(const LossArgs a, const float* __restrict__ pa
   losses[1] = ldir_abn; losses[2] = ldir_nor; losses[3] = ltopk_abn; losses[4] = lbot_abn;
   losses[5] = ltopk_nor; losses[6] = lsmooth; losses[7] = lsparse;
   losses[0] = ldir_abn + ldir_nor + ltopk_abn + lbot_abn + ltopk_nor + lsmooth + lsparse;
+}
+
+// the eight loss terms from the 7 x 32 lane sums of the last arriver (thread 0): a fixed tree; meter != nullptr: meter += losses
+__device__ __forceinline__ void loss_terms_from_sums(const LossArgs& a, const double (*fin)[32], float* __restrict__ losses,
+                                                     float* __restrict__ meter) {
+  double t[7];
+  for (int q = 0; q < 7; ++q) {
+    double sacc = 0.0;
+    for (int l = 0; l < 32; ++l) sacc += fin[q][l];
+    t[q] = sacc;
+  }
+  const double d = t[6];
+  const double per = (double)a.N * a.Lg, Bh = a.B / 2, Bn = a.B - a.B / 2;
+  const float ldir_abn = (float)(-a.l_dir_abn * d / (Bh * a.K * a.Lg));
+  const float ldir_nor = (float)(a.l_dir_nor * t[0] / (Bn * per));
+  const float ltopk_abn = (float)(a.l_topk_abn * t[1] / (Bh * a.K * a.Lg));
+  const float lbot_abn = (float)(a.l_bottomk_abn * t[2] / (Bh * a.K * a.Lg));
+  const float ltopk_nor = (float)(a.l_topk_nor * t[3] / (Bn * a.K * a.Lg));
+  const float lsmooth = (float)(a.l_smooth * t[4]);
+  const float lsparse = (float)(a.l_sparse * t[5] / (Bh * per));
+  float out[8];
+  out[1] = ldir_abn; out[2] = ldir_nor; out[3] = ltopk_abn; out[4] = lbot_abn;
+  out[5] = ltopk_nor; out[6] = lsmooth; out[7] = lsparse;
+  out[0] = ldir_abn + ldir_nor + ltopk_abn + lbot_abn + ltopk_nor + lsmooth + lsparse;
+  for (int i = 0; i < 8; ++i) {
+    losses[i] = out[i];
+    if (meter) meter[i] = 1.f * out[i] + 1.f * meter[i];       // acx_axpby(meter, losses, 1, 1)
+  }
 }
 
 // The three launches above as ONE: blocks [0, np1) run the frame rows, blocks [np1, np1 + np2) the top-k rows; every block
@@ -1411,24 +1558,83 @@ __global__ __launch_bounds__(256) void loss_fused_kernel(const LossArgs a, float
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  double t[7];
-  for (int q = 0; q < 7; ++q) {
-    double sacc = 0.0;
-    for (int l = 0; l < 32; ++l) sacc += fin[q][l];
-    t[q] = sacc;
+  loss_terms_from_sums(a, fin, losses, nullptr);
+  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// acx_mil_loss_bn -- the loss, its gradients and the selector BatchNorm's backward statistics as ONE launch (whole-step graph):
+//   blocks [0, np1): frame rows (loss_rows_body<.., FOLD>: dsim already holds the scattered top-k gradient = dlogits), then the
+//     f64 column sums (dl, dl * xhat) of the SAME 256 rows -- slab b of bn_partial_kernel<1> when rows % 256 == 0 and rows / 256 <= 512
+//     (dlogits from LDS, the arithmetic and the order of acx_bn_bwd_stats);
+//   blocks [np1, np1 + np2): the gathered top-k rows (their term of the loss; their gradient is folded into the frame rows);
+//   the last block to arrive forms the eight loss terms, adds them to the module's running sums (meter: y = 1 x + 1 y of acx_axpby) and
+//     the BatchNorm sums (bn_pair_total: acx_bn_bwd_stats' stage 2).
+// Replaces acx_mil_loss_one + acx_axpby + acx_scatter_segments + acx_bn_bwd_stats (two launches): five launches -> one, same bits.
+__global__ __launch_bounds__(256) void loss_bn_kernel(const LossArgs a, float* __restrict__ part2, int np1, int np2,
+                                                      float* __restrict__ losses, float* __restrict__ meter, double* __restrict__ bn_part,
+                                                      float* __restrict__ bn_sums, unsigned int* __restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sdl = reinterpret_cast<float*>(smem);       // [256][C1] dlogits of this block's rows
+  __shared__ float red[4];
+  __shared__ double fin[7][32];
+  __shared__ double redd[2][256];
+  __shared__ bool last;
+  const int b = (int)blockIdx.x, C1 = a.C1;
+  constexpr int CP = 64;
+  if (b < np1) {
+    loss_rows_body<true, true>(a, b, red, sdl);
+    __syncthreads();
+    const int RL = 256 / C1;
+    const int c = threadIdx.x % C1, rl = threadIdx.x / C1;
+    const int64_t r0 = (int64_t)b * 256;
+    double s = 0.0, qq = 0.0;
+    if (rl < RL) {
+      for (int rr = rl; rr < 256; rr += RL) {
+        const double v = (double)a.sim[(r0 + rr) * C1 + c];
+        const double g = (double)sdl[rr * C1 + c];
+        acx_bn_acc<1>(s, qq, v, g);
+      }
+    }
+    redd[0][threadIdx.x] = s;
+    redd[1][threadIdx.x] = qq;
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C1) {
+      const int k = threadIdx.x / C1, cc = threadIdx.x - k * C1;
+      double v = 0.0;
+      for (int l = 0; l < RL; ++l) v += redd[k][l * C1 + cc];
+      __hip_atomic_store(bn_part + ((size_t)b * 2 + k) * CP + cc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every lane's published partials have left before the barrier below
+    __syncthreads();
+  } else {
+    loss_topk_body<true, true>(a, part2, b - np1, red);
   }
-  const double d = t[6];
-  const double per = (double)a.N * a.Lg, Bh = a.B / 2, Bn = a.B - a.B / 2;
-  const float ldir_abn = (float)(-a.l_dir_abn * d / (Bh * a.K * a.Lg));
-  const float ldir_nor = (float)(a.l_dir_nor * t[0] / (Bn * per));
-  const float ltopk_abn = (float)(a.l_topk_abn * t[1] / (Bh * a.K * a.Lg));
-  const float lbot_abn = (float)(a.l_bottomk_abn * t[2] / (Bh * a.K * a.Lg));
-  const float ltopk_nor = (float)(a.l_topk_nor * t[3] / (Bn * a.K * a.Lg));
-  const float lsmooth = (float)(a.l_smooth * t[4]);
-  const float lsparse = (float)(a.l_sparse * t[5] / (Bh * per));
-  losses[1] = ldir_abn; losses[2] = ldir_nor; losses[3] = ltopk_abn; losses[4] = lbot_abn;
-  losses[5] = ltopk_nor; losses[6] = lsmooth; losses[7] = lsparse;
-  losses[0] = ldir_abn + ldir_nor + ltopk_abn + lbot_abn + ltopk_nor + lsmooth + lsparse;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ACX_HANDOFF_RELEASE();
+    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(np1 + np2) - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  ACX_HANDOFF_ACQUIRE();
+  {
+    const int k = threadIdx.x >> 5, j = threadIdx.x & 31;
+    if (k < 7) {
+      double acc = 0.0;
+      if (k < 6) {
+        for (int p = j; p < np1; p += 32)
+          acc += (double)__hip_atomic_load(a.part + (size_t)p * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        for (int p = j; p < np2; p += 32) acc += (double)__hip_atomic_load(part2 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fin[k][j] = acc;
+    }
+  }
+  __syncthreads();
+  const double tot = bn_pair_total<true>(bn_part, np1, CP, C1, &redd[0][0]);
+  if ((int)threadIdx.x < 2 * C1) bn_sums[threadIdx.x] = (float)tot;
+  if (threadIdx.x != 0) return;
+  loss_terms_from_sums(a, fin, losses, meter);
   __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1797,7 +2003,8 @@ extern "C" int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* 
   if (!total_rows_dev && total_rows <= 0) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_apply: total_rows must be positive%s");
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_OTHER, s);
-  const int64_t total = rows * C1;
+  if (ldo < C1) return acx_fail(ctx, ACX_E_BADARG, "acx_bn_bwd_apply: ldo < C1%s");
+  const int64_t total = rows * ldo;      // (pad columns included: the kernel zeroes them)
   hipLaunchKernelGGL(bn_bwd_apply_kernel, GRID1(total), dim3(256), 0, s, logits, dlogits, var_biased, sums, sums + C1, draw, ldo,
                      total, C1, eps, total_rows > 0 ? 1.f / (float)total_rows : 0.f, total_rows_dev);
   ACX_CHECK_LAUNCH(ctx, "acx_bn_bwd_apply");
@@ -1832,8 +2039,21 @@ extern "C" int acx_text_directions_bwd(acx_ctx* ctx, const float* text, const fl
                                        int32_t C, int32_t D, int32_t normal_id, void* stream) {
   if (!text || !ncentroid || !ddirs || !dtext) return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions_bwd: null pointer%s");
   AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
-  hipLaunchKernelGGL(text_dirs_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, text, ncentroid, ddirs, dtext, C, D, normal_id);
+  hipLaunchKernelGGL(text_dirs_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, text, ncentroid, ddirs, dtext, C, D, normal_id, 1,
+                     (int64_t)0);
   ACX_CHECK_LAUNCH(ctx, "acx_text_directions_bwd");
+  return ACX_OK;
+}
+extern "C" int acx_text_directions_bwd_parts(acx_ctx* ctx, const float* text, const float* ncentroid, const float* ddirs_parts,
+                                             int32_t nparts, int64_t part_stride, float* dtext, int32_t C, int32_t D, int32_t normal_id,
+                                             void* stream) {
+  if (!text || !ncentroid || !ddirs_parts || !dtext) return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions_bwd_parts: null pointer%s");
+  if (nparts < 1 || (nparts > 1 && part_stride < (int64_t)(C - 1) * D))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_text_directions_bwd_parts: nparts >= 1, part_stride >= (C - 1) * D%s");
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  hipLaunchKernelGGL(text_dirs_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, text, ncentroid, ddirs_parts, dtext, C, D, normal_id,
+                     nparts, part_stride);
+  ACX_CHECK_LAUNCH(ctx, "acx_text_directions_bwd_parts");
   return ACX_OK;
 }
 
@@ -1911,6 +2131,74 @@ extern "C" int acx_mil_loss_one(acx_ctx* ctx, const float* sim, const float* sim
   hipLaunchKernelGGL(loss_topk_kernel, dim3(np2), dim3(256), 0, s, a, part2);
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, a, (const float*)workspace, np1, (const float*)part2, np2, losses);
   ACX_CHECK_LAUNCH(ctx, "acx_mil_loss");
+  return ACX_OK;
+}
+
+extern "C" int acx_mil_loss_bn(acx_ctx* ctx, const float* sim, const float* sim_topk, const int64_t* labels, const float* scores,
+                               const int64_t* idx_topk_abn, const int64_t* idx_topk_nor, const int64_t* idx_bottomk_abn,
+                               float* dlogits, float* dscores, float* losses, float* meter, float* bn_sums, float* workspace,
+                               size_t workspace_floats, void* bn_workspace, size_t bn_workspace_bytes, int32_t B, int32_t N, int32_t Lg,
+                               int32_t C1, int32_t K, int32_t normal_id, const float* lambdas /* [7] */, const float* gout,
+                               uint32_t* counter, void* stream) {
+  if (!sim || !sim_topk || !labels || !scores || !idx_topk_abn || !idx_topk_nor || !idx_bottomk_abn || !dlogits || !dscores ||
+      !losses || !bn_sums || !workspace || !bn_workspace || !lambdas || !counter)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_mil_loss_bn: null pointer%s");
+  if (B <= 0 || B % 2 || C1 <= 0 || C1 > 64) return acx_fail(ctx, ACX_E_BADARG, "acx_mil_loss_bn: need even B, 1 <= C-1 <= 64%s");
+  const int64_t R = (int64_t)B * N * Lg, RT = (int64_t)B * K * Lg;
+  // the block of 256 frame rows must BE the slab of acx_bn_bwd_stats' stage 1 (bn_blocks: ceil(rows / 256) blocks, at most 512)
+  if (R % 256 || R / 256 > 512) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_mil_loss_bn: B N Lg must be a multiple of 256, at most 131072 rows%s");
+  const int np1 = (int)(R / 256), np2 = (int)((RT + 255) / 256);
+  if ((size_t)np1 * 8 + np2 > workspace_floats) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_mil_loss_bn: workspace too small%s");
+  if (bn_workspace_bytes < (size_t)np1 * 2 * 64 * sizeof(double) || ((uintptr_t)bn_workspace & 7))
+    return acx_fail(ctx, ACX_E_WORKSPACE, "acx_mil_loss_bn: BatchNorm workspace too small (acx_bn_workspace_bytes) or misaligned%s");
+  LossArgs a;
+  a.sim = sim; a.sim_topk = sim_topk; a.labels = labels; a.scores = scores;
+  a.idx_topk_abn = idx_topk_abn; a.idx_topk_nor = idx_topk_nor; a.idx_bottomk_abn = idx_bottomk_abn;
+  a.dsim = dlogits; a.dsim_topk = nullptr; a.dscores = dscores; a.part = workspace;
+  a.B = B; a.N = N; a.Lg = Lg; a.C1 = C1; a.K = K; a.normal_id = normal_id;
+  a.l_dir_abn = lambdas[0]; a.l_dir_nor = lambdas[1]; a.l_topk_abn = lambdas[2]; a.l_bottomk_abn = lambdas[3];
+  a.l_topk_nor = lambdas[4]; a.l_smooth = lambdas[5]; a.l_sparse = lambdas[6];
+  a.gout_ptr = gout;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+  hipLaunchKernelGGL(loss_bn_kernel, dim3(np1 + np2), dim3(256), (size_t)256 * C1 * sizeof(float), s, a, workspace + (size_t)np1 * 8, np1,
+                     np2, losses, meter, (double*)bn_workspace, bn_sums, counter);
+  ACX_CHECK_LAUNCH(ctx, "acx_mil_loss_bn");
+  return ACX_OK;
+}
+
+extern "C" int acx_selector_tail(acx_ctx* ctx, const float* raw, const float* gathered, int32_t ranks, const float* mean,
+                                 const float* var_biased, const float* var_unbiased, float* stat_out, float* running_mean,
+                                 float* running_var, int64_t* num_batches_tracked, float momentum, float one_minus, float* logits,
+                                 int64_t ldl, const int64_t* labels, const float* mask_top, const float* mask_bot, int64_t* idx_top, int64_t* idx_bot,
+                                 float* logits_topk, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t normal_id, int32_t ktop,
+                                 int32_t kbot, float eps, void* stream) {
+  if (!raw || !logits || !labels || !mask_top || !mask_bot || !idx_top || !idx_bot || !logits_topk)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_selector_tail: null pointer%s");
+  if (gathered ? (!stat_out || ranks < 1) : (!mean || !var_biased || !var_unbiased))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_selector_tail: gathered statistics need stat_out and ranks >= 1, local ones mean / var%s");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return acx_fail(ctx, ACX_E_BADARG, "acx_selector_tail: running_mean and running_var come together%s");
+  if (B <= 0 || B % 2 || ktop > N || kbot > N || ktop < 0 || kbot < 0 || C1 <= 0 || C1 > 64 || ldl < C1)
+    return acx_fail(ctx, ACX_E_BADARG, "acx_selector_tail: need even B, k <= N, 1 <= C-1 <= 64, ldl >= C-1%s");
+  const size_t lds = ((size_t)N * Lg * C1 + (size_t)N * C1 + 2 * (size_t)N + 2 * (size_t)C1) * 4 + (size_t)(ktop + kbot) * 4;
+  if (lds > 160 * 1024) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_selector_tail: a video's logits exceed the 160 KB of LDS%s");
+  SelTailArgs a;
+  a.raw = raw; a.gathered = gathered; a.R = ranks; a.mean_in = mean; a.var_b_in = var_biased; a.var_u_in = var_unbiased;
+  a.stat_out = stat_out; a.rm = running_mean; a.rv = running_var; a.nbt = (long long*)num_batches_tracked;
+  a.momentum = momentum; a.om = one_minus;
+  a.logits = logits; a.ldl = ldl; a.labels = labels; a.mask_top = mask_top; a.mask_bot = mask_bot;
+  a.idx_top = idx_top; a.idx_bot = idx_bot; a.logits_topk = logits_topk;
+  a.B = B; a.N = N; a.Lg = Lg; a.C1 = C1; a.normal_id = normal_id; a.ktop = ktop; a.kbot = kbot; a.eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  AcxProfScope prof__(ctx, ACX_K_OTHER, s);
+  const int dev_slot = (ctx ? ctx->device : 0) & 63;
+  static size_t attr_dev_[64] = {};
+  if (lds > 64 * 1024 && attr_dev_[dev_slot] < lds) {
+    (void)hipFuncSetAttribute((const void*)selector_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_dev_[dev_slot] = lds;
+  }
+  hipLaunchKernelGGL(selector_tail_kernel, dim3(B), dim3(256), lds, s, a);
+  ACX_CHECK_LAUNCH(ctx, "acx_selector_tail");
   return ACX_OK;
 }
 

@@ -784,7 +784,7 @@ def bn_bwd_apply(logits, dlogits, var_biased, sums, total_rows, eps=1e-5, pad_to
     int, or a device f32 scalar tensor (SyncBN: the all-gathered row count never visits the host)."""
     rows, C1 = logits.shape
     C1p = (C1 + pad_to - 1) // pad_to * pad_to
-    draw = zeros(rows, C1p, device=logits.device)
+    draw = torch.empty(rows, C1p, dtype=torch.float32, device=logits.device)      # (the kernel zeroes the pad columns)
     h = _h(logits)
     dev_n = total_rows if torch.is_tensor(total_rows) else None
     if dev_n is not None:
@@ -924,6 +924,96 @@ def text_directions_bwd(text, ncentroid, ddirs, normal_id) -> torch.Tensor:
     L.check(L.lib().acx_text_directions_bwd(h, text.data_ptr(), ncentroid.data_ptr(), ddirs.data_ptr(), dtext.data_ptr(), Cc, D,
                                             normal_id, _stream()), h)
     return dtext
+
+
+def selector_dirs_grad(draw, x, ncentroid, text, normal_id, C1: int) -> torch.Tensor:
+    """d_text [C, D] from draw [rows, C1 padded] and the features x [rows, D]: d_dirs = draw^T (x - ncentroid) (acx_gemm_tn) and the
+    direction normalisation's backward (acx_text_directions_bwd) -- the TN product's K-split partial images are added by the second
+    kernel itself (acx_gemm_tn_parts + acx_text_directions_bwd_parts): no reduce launch, the same sums in the same order."""
+    assert draw.dim() == 2 and x.dim() == 2 and draw.is_contiguous() and x.is_contiguous() and draw.shape[0] == x.shape[0]
+    M, N1 = draw.shape
+    D = x.shape[1]
+    Cc = text.shape[0]
+    assert Cc - 1 == C1 <= N1 and text.shape[1] == D
+    lib = L.lib()
+    nbytes = lib.acx_gemm_tn_workspace_bytes(M, N1, D)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    out = torch.empty(N1, D, dtype=torch.float32, device=x.device)
+    splits = C.c_int32(0)
+    h = _h(x)
+    L.check(lib.acx_gemm_tn_parts(h, draw.data_ptr(), draw.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(), D, M, N1, D,
+                                  _ptr(ncentroid), 0, 0, 0, 0, ws.data_ptr(), ws.numel(), _zero_page(x.device).data_ptr(),
+                                  C.byref(splits), _stream()), h)
+    dtext = torch.empty_like(text)
+    n = int(splits.value)
+    src = ws if n > 1 else out
+    L.check(lib.acx_text_directions_bwd_parts(h, text.data_ptr(), ncentroid.data_ptr(), src.data_ptr(), n, N1 * D, dtext.data_ptr(), Cc, D,
+                                              normal_id, _stream()), h)
+    return dtext
+
+
+def selector_tail(raw, labels, mask_top, mask_bot, N, Lg, normal_id, ktop, kbot, eps, *, gathered=None, stats=None, bn=None):
+    """BatchNorm of the selector's raw projections, [running statistics], top-k / bottom-k picks and the gather of the top-k
+    segments in ONE launch (acx_selector_tail; bit-identical to selector_bn + bn_running_update_ + select_idx + gather_segments,
+    and to bn_combine in front of them when `gathered` [ranks, 2 C1 + 1] is given instead of `stats` = (mean, var_biased,
+    var_unbiased)).  Returns (logits, idx_top, idx_bot, logits_topk, (mean, var_biased, var_unbiased, total_rows or None))."""
+    rows, C1 = raw.shape
+    B = labels.shape[0]
+    dev = raw.device
+    logits = torch.empty(rows, C1, dtype=torch.float32, device=dev)
+    it = torch.empty(B, ktop, dtype=torch.int64, device=dev)
+    ib = torch.empty(B, kbot, dtype=torch.int64, device=dev)
+    topk = torch.empty(B * ktop * Lg, C1, dtype=torch.float32, device=dev)
+    stat_out = None
+    if gathered is not None:
+        assert gathered.is_cuda and gathered.dtype == torch.float32 and gathered.is_contiguous() and gathered.shape[1] == 2 * C1 + 1
+        stat_out = torch.empty(3 * C1 + 1, dtype=torch.float32, device=dev)
+        mean = var_b = var_u = None
+    else:
+        mean, var_b, var_u = stats
+    h = _h(raw)
+    rm = rv = nbt = None
+    mom = 0.0
+    if bn is not None:
+        rm, rv, nbt, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
+        assert nbt.dtype == torch.int64 and nbt.is_cuda
+    L.check(L.lib().acx_selector_tail(h, raw.data_ptr(), _ptr(gathered), gathered.shape[0] if gathered is not None else 0,
+                                      _ptr(mean), _ptr(var_b), _ptr(var_u), _ptr(stat_out), _ptr(rm), _ptr(rv), _ptr(nbt), mom,
+                                      float(1.0 - mom), logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask_top.data_ptr(),
+                                      mask_bot.data_ptr(), it.data_ptr(), ib.data_ptr(), topk.data_ptr(), B, N, Lg, C1, normal_id, ktop,
+                                      kbot, float(eps), _stream()), h)
+    if stat_out is not None:
+        st = (stat_out[:C1], stat_out[C1:2 * C1], stat_out[2 * C1:3 * C1], stat_out[3 * C1:])
+    else:
+        st = (mean, var_b, var_u, None)
+    return logits, it, ib, topk, st
+
+
+def mil_loss_bn(sim, sim_topk, labels, scores, idx_topk_abn, idx_topk_nor, idx_bottomk_abn, N, Lg, K, normal_id, lambdas,
+                meter: Optional[torch.Tensor] = None, gout: Optional[torch.Tensor] = None):
+    """loss + its gradients + `meter += losses` + the scatter of the top-k rows' gradient + the selector BatchNorm's backward sums in
+    ONE launch (acx_mil_loss_bn; bit-identical to mil_loss + axpby_ + scatter_segments_ + bn_bwd_stats).  Returns (losses [8],
+    dlogits, dscores, bn_sums [2 C1]); raises AcxError(ACX_E_UNSUPPORTED) when B N Lg is not a multiple of 256."""
+    import ctypes
+    B = labels.shape[0]
+    C1 = sim.shape[1]
+    dev = sim.device
+    dl = torch.empty_like(sim)
+    dsc = torch.empty_like(scores)
+    losses = torch.empty(8, dtype=torch.float32, device=dev)
+    sums = torch.empty(2 * C1, dtype=torch.float32, device=dev)
+    nws = (B * N * Lg + 255) // 256 * 8 + (B * K * Lg + 255) // 256
+    ws = torch.empty(nws, dtype=torch.float32, device=dev)
+    bws = _bn_workspace(sim, sim.shape[0], C1)
+    lam = (ctypes.c_float * 7)(*[float(x) for x in lambdas])
+    h = _h(sim)
+    ctr = _colsum_counters(dev)[_CTR_N - 1:]                # the last arrival counter of the stream's table: the loss's own
+    L.check(L.lib().acx_mil_loss_bn(h, sim.data_ptr(), sim_topk.data_ptr(), labels.data_ptr(), scores.data_ptr(),
+                                    idx_topk_abn.data_ptr(), idx_topk_nor.data_ptr(), idx_bottomk_abn.data_ptr(), dl.data_ptr(),
+                                    dsc.data_ptr(), losses.data_ptr(), _ptr(meter), sums.data_ptr(), ws.data_ptr(), nws, bws.data_ptr(),
+                                    bws.numel() * 8, B, N, Lg, C1, K, normal_id, ctypes.cast(lam, ctypes.c_void_p), _ptr(gout),
+                                    ctr.data_ptr(), _stream()), h)
+    return losses, dl, dsc, sums
 
 
 def select_idx(logits, labels, mask_top, mask_bot, N, Lg, normal_id, ktop, kbot):

@@ -391,6 +391,12 @@ int acx_gemm_tn_group(acx_ctx* ctx, int32_t nprob, const acx_tn_problem* probs, 
 int acx_gemm_tn_zp(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                 int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
                 int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, void* stream);
+/* acx_gemm_tn_zp WITHOUT its reduce launch: *splits_out (host) = number of K-split partial images left in `workspace`
+ * ([splits][N1][N2] f32; their sum in image order is what acx_gemm_tn_zp writes to C); 1: C holds the result.  For consumers that
+ * add the images themselves (acx_text_directions_bwd_parts). */
+int acx_gemm_tn_parts(acx_ctx* ctx, const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                      int32_t M, int32_t N1, int32_t N2, const float* b_sub, int32_t conv, int32_t gn, int32_t gl,
+                      int32_t cin, void* workspace, size_t workspace_bytes, const void* zero_page, int32_t* splits_out, void* stream);
 /* The same weight gradient as an f32-ACCURATE product on the bf16 matrix cores: A (dY, [M, lda]) and B (the layer input,
  * [M, ldb]) as three bf16 planes each (acx_split_bf16x3: plane p at base + p * plane_stride bytes), the six leading cross
  * products with f32 accumulation -- the TN instantiation of the plane-reuse kernel (acx_gemm_desc.pairs = 6).  N1, N2 multiples
@@ -443,6 +449,7 @@ int acx_bn_bwd_apply(acx_ctx* ctx, const float* logits, const float* dlogits, co
                      const float* sums, float* draw, int32_t ldo, int64_t rows, int64_t total_rows, int32_t C1,
                      float eps, const float* total_rows_dev /* device scalar overriding total_rows, or NULL: SyncBN keeps
                      the all-gathered row count on the device instead of synchronising the host for it */, void* stream);
+/* (draw is [rows, ldo], ldo >= C1: the kernel writes the pad columns C1 .. ldo - 1 as zeros itself) */
 /* y = a*x + b*y (BatchNorm running-statistics update, selector_model.py:30 momentum 0.1) */
 int acx_axpby(acx_ctx* ctx, const float* x, float* y, int32_t n, float a, float b, void* stream);
 /* deterministic column sums: part[blk][D] partials over rows_per_block rows each (then acx_reduce_rows) */
@@ -477,6 +484,32 @@ int acx_mil_loss_one(acx_ctx* ctx, const float* sim, const float* sim_topk, cons
                  float* dsim, float* dsim_topk, float* dscores, float* losses, float* workspace,
                  size_t workspace_floats, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K, int32_t normal_id,
                  const float* lambdas, const float* gout, uint32_t* counter, void* stream);
+/* The loss, its gradients AND the selector BatchNorm's backward statistics as ONE launch (the whole-step graph's middle):
+ * acx_mil_loss_one + acx_axpby(meter += losses) + acx_scatter_segments(dsim += dsim_topk at the top-k segments) + acx_bn_bwd_stats in
+ * one kernel with the SAME arithmetic in the same order (bit-identical outputs): dlogits [B N Lg, C1] = the gradient wrt the logits
+ * incl. the gathered top-k rows' share, bn_sums [2 C1] = (sum dl, sum dl * xhat), meter [8] (may be NULL) += losses.  Needs
+ * B N Lg % 256 == 0 and <= 131072 rows (a block of 256 frame rows is a slab of acx_bn_bwd_stats); ACX_E_UNSUPPORTED otherwise.
+ * workspace: ceil(B N Lg / 256) * 8 + ceil(B K Lg / 256) floats; bn_workspace: acx_bn_workspace_bytes; counter as acx_mil_loss_one. */
+int acx_mil_loss_bn(acx_ctx* ctx, const float* sim, const float* sim_topk, const int64_t* labels, const float* scores,
+                    const int64_t* idx_topk_abn, const int64_t* idx_topk_nor, const int64_t* idx_bottomk_abn, float* dlogits,
+                    float* dscores, float* losses, float* meter, float* bn_sums, float* workspace, size_t workspace_floats,
+                    void* bn_workspace, size_t bn_workspace_bytes, int32_t B, int32_t N, int32_t Lg, int32_t C1, int32_t K,
+                    int32_t normal_id, const float* lambdas, const float* gout, uint32_t* counter, void* stream);
+/* The selector's forward tail as ONE launch, one workgroup per video (selector_model.py:60-99,119-225): [SyncBN combine of
+ * `gathered` [ranks, 2 C1 + 1] -> stat_out [3 C1 + 1] = mean | biased var | unbiased var | total rows; gathered == NULL: the local
+ * statistics mean / var_biased / var_unbiased] -> logits = BatchNorm(raw) [rows, ldl] -> [running statistics, NULL: none] ->
+ * top-k / bottom-k segment picks (acx_select_idx) -> logits_topk [B ktop Lg, C1] (acx_gather_segments of idx_top).  The same
+ * expressions in the same order as acx_bn_combine / acx_selector_bn / acx_bn_running_update / acx_select_idx /
+ * acx_gather_segments: bit-identical results, four or five launches less. */
+int acx_selector_tail(acx_ctx* ctx, const float* raw, const float* gathered, int32_t ranks, const float* mean,
+                      const float* var_biased, const float* var_unbiased, float* stat_out, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, float one_minus, float* logits, int64_t ldl, const int64_t* labels,
+                      const float* mask_top, const float* mask_bot, int64_t* idx_top, int64_t* idx_bot, float* logits_topk, int32_t B,
+                      int32_t N, int32_t Lg, int32_t C1, int32_t normal_id, int32_t ktop, int32_t kbot, float eps, void* stream);
+/* acx_text_directions_bwd with d_dirs given as the K-split partial images of the TN product that forms it (acx_gemm_tn_parts:
+ * image s at ddirs_parts + s * part_stride floats, rows = direction index, row stride D), summed here in image order. */
+int acx_text_directions_bwd_parts(acx_ctx* ctx, const float* text, const float* ncentroid, const float* ddirs_parts, int32_t nparts,
+                                  int64_t part_stride, float* dtext, int32_t C, int32_t D, int32_t normal_id, void* stream);
 /* acx_adamw: one torch.optim.AdamW step (decoupled weight decay, bias correction; step counts from 1). */
 int acx_adamw(acx_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int32_t step, void* stream);

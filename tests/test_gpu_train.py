@@ -456,6 +456,83 @@ def test_mil_loss_golden(golden):
     assert R.elem_excess(s3.grad, 2 * g["g_scores"]) <= 1
 
 
+@pytest.mark.parametrize("B,C1,ranks", [(8, 13, 0), (64, 13, 0), (8, 13, 8), (4, 6, 2), (16, 16, 3)])
+def test_selector_tail_equals_separate_launches(B, C1, ranks):
+    """acx_selector_tail (the whole-step graph's forward tail: [SyncBN combine], BatchNorm, running statistics, picks, gather) against
+    the separate launches of the autograd path: every output bit-identical, indices included."""
+    torch.manual_seed(B + C1)
+    N, Lg = 32, 16
+    rows = B * N * Lg
+    raw = (torch.randn(rows, C1) * 3 + torch.arange(C1) * 0.3).to(DEV)
+    labels = torch.cat([torch.randint(1, C1 + 1, (B // 2,)), torch.zeros(B // 2, dtype=torch.int64)]).to(DEV)
+    mt = (torch.rand(B, N) > 0.3).float().to(DEV)
+    mb = (torch.rand(B, N) > 0.3).float().to(DEV)
+    bn_a, bn_b = torch.nn.BatchNorm1d(C1, affine=False).to(DEV), torch.nn.BatchNorm1d(C1, affine=False).to(DEV)
+    for bn in (bn_a, bn_b):
+        bn.running_mean.copy_(torch.linspace(-1, 1, C1))
+        bn.running_var.copy_(torch.linspace(0.5, 2, C1))
+    if ranks:
+        g = torch.rand(ranks, 2 * C1 + 1, device=DEV) + 0.5
+        g[:, 2 * C1] = torch.randint(100, 5000, (ranks,), device=DEV).float()
+        mean, var_b, var_u, total = ops.bn_combine(g, C1)
+    else:
+        g = None
+        mean, var_b, var_u = ops.bn_stats(raw)
+    logits = ops.selector_bn(raw, mean, var_b, 1e-5)
+    ops.bn_running_update_(bn_a, mean, var_u)
+    it, ib = ops.select_idx(logits, labels, mt, mb, N, Lg, 0, 3, 3)
+    topk = ops.gather_segments(logits, it, N, Lg)
+    l2, it2, ib2, topk2, st = ops.selector_tail(raw, labels, mt, mb, N, Lg, 0, 3, 3, 1e-5, gathered=g,
+                                                stats=None if ranks else (mean, var_b, var_u), bn=bn_b)
+    assert torch.equal(l2, logits) and torch.equal(it2, it) and torch.equal(ib2, ib) and torch.equal(topk2, topk)
+    assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+    assert int(bn_b.num_batches_tracked) == int(bn_a.num_batches_tracked) == 1
+    if ranks:
+        assert torch.equal(st[0], mean) and torch.equal(st[1], var_b) and torch.equal(st[2], var_u) and torch.equal(st[3], total)
+
+
+@pytest.mark.parametrize("B,C1", [(8, 13), (64, 13), (4, 6), (16, 16)])
+def test_mil_loss_bn_equals_separate_launches(B, C1):
+    """acx_mil_loss_bn (loss + meter + scatter of the top-k rows' gradient + BatchNorm backward sums in one launch) against
+    mil_loss + axpby_ + scatter_segments_ + bn_bwd_stats: the losses, dlogits, dscores and the sums bit-identical; then
+    selector_dirs_grad (TN product's partial images added by the consumer) against gemm_tn + text_directions_bwd."""
+    torch.manual_seed(7 * B + C1)
+    N, Lg, K = 32, 16, 3
+    rows = B * N * Lg
+    logits = torch.randn(rows, C1).to(DEV)
+    scores = torch.rand(rows).mul(0.98).add(0.01).to(DEV)
+    labels = torch.cat([torch.randint(1, C1 + 1, (B // 2,)), torch.zeros(B // 2, dtype=torch.int64)]).to(DEV)
+    mt = (torch.rand(B, N) > 0.3).float().to(DEV)
+    it, ib = ops.select_idx(logits, labels, mt, mt, N, Lg, 0, K, K)
+    topk = ops.gather_segments(logits, it, N, Lg)
+    ia, in_, ba = it[:B // 2].contiguous(), it[B // 2:].contiguous(), ib[:B // 2].contiguous()
+    lam = (1.0, 1.0, 1.0, 1.0, 1.0, 8e-4, 8e-3)
+    meter_a = torch.arange(8, dtype=torch.float32, device=DEV) * 0.37
+    meter_b = meter_a.clone()
+    losses, dsim, dtopk, dsc = ops.mil_loss(logits, topk, labels, scores, ia, in_, ba, N, Lg, K, 0, lam)
+    ops.axpby_(meter_a, losses, 1.0, 1.0)
+    dl = dsim.clone()
+    ops.scatter_segments_(dl, dtopk, it, N, Lg)
+    sums = ops.bn_bwd_stats(logits, dl)
+    l2, dl2, dsc2, sums2 = ops.mil_loss_bn(logits, topk, labels, scores, ia, in_, ba, N, Lg, K, 0, lam, meter=meter_b)
+    assert torch.equal(l2, losses) and torch.equal(dl2, dl) and torch.equal(dsc2, dsc) and torch.equal(sums2, sums)
+    assert torch.equal(meter_a, meter_b)
+    # twice in a row: the arrival counter is left at zero
+    l3, dl3, _, sums3 = ops.mil_loss_bn(logits, topk, labels, scores, ia, in_, ba, N, Lg, K, 0, lam)
+    assert torch.equal(l3, losses) and torch.equal(dl3, dl) and torch.equal(sums3, sums)
+    # the selector's direction gradient
+    D = 512
+    x = torch.randn(rows, D, device=DEV)
+    nc = torch.randn(D, device=DEV) * 0.1
+    text = torch.randn(C1 + 1, D, device=DEV)
+    var_b = torch.rand(C1, device=DEV) + 0.5
+    draw = ops.bn_bwd_apply(logits, dl, var_b, sums, rows, 1e-5)
+    assert draw.shape[1] % 4 == 0 and bool((draw[:, C1:] == 0).all())
+    d_dirs = ops.gemm_tn(draw, x, b_sub=nc)[:C1].contiguous()
+    ref = ops.text_directions_bwd(text, nc, d_dirs, 0)
+    assert torch.equal(ops.selector_dirs_grad(draw, x, nc, text, 0, C1), ref)
+
+
 def test_adamw_matches_torch():
     g = torch.Generator().manual_seed(4)
     p0 = torch.randn(1000, generator=g)
