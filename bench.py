@@ -551,6 +551,17 @@ def hbm_kernel_legs(dev, copy_TBps, fill_TBps=None):
     entry("mil_loss", (2 * rows * C1 + 2 * simk.numel() + 2 * rows) * 4,
           _event_time(lambda: ops.mil_loss(sim, simk, labels, sc, idx, idx, idx, 32, 16, 3, 7, lam), 24),
           "reads logits/top-k/scores, writes their gradients; one launch (last-arriver reduction)")
+    # the whole-step graph's two fused middle launches (configs[1] batch): selector tail and loss + BatchNorm backward sums
+    mt_ = torch.ones(B, 32, device=dev)
+    lab_ = labels
+    entry("selector_tail", 2 * rows * C1 * 4,
+          _event_time(lambda: ops.selector_tail(nxt(raws), lab_, mt_, mt_, 32, 16, 7, 3, 3, 1e-5, stats=(mean, var, var)), 24),
+          "BatchNorm + picks + top-k gather of a step in ONE launch (one workgroup per video: 64 workgroups, latency bound); "
+          "replaces selector_bn + bn_running_update + select_idx + gather_segments")
+    entry("mil_loss_bn", (3 * rows * C1 + simk.numel() + 2 * rows) * 4,
+          _event_time(lambda: ops.mil_loss_bn(sim, simk, lab_, sc, idx, idx, idx, 32, 16, 3, 7, lam), 24),
+          "loss + gradients + scatter of the top-k gradient + BatchNorm backward sums in ONE launch; replaces mil_loss + axpby + "
+          "scatter_segments + bn_bwd_stats (five launches)")
     del raws, dls
     # AdamW over the UCF head's trainable set: one multi-tensor launch, 16 B read + 12 B written per value
     n_par = 10_430_466

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copies what tools/refresh_profiles.sh left under gpurun_out/ into profiles/<tag>_* (run in the development container after
-# the gpurun call merged its outputs back).  usage: tools/collect_profiles.sh [tag]   (default r05)
+# the gpurun call merged its outputs back).  usage: tools/collect_profiles.sh [tag]   (default r06)
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(cd "$(dirname "$0")/.." && pwd)
 G=$R/gpurun_out
 P=$R/profiles
@@ -21,6 +21,8 @@ for n in 1 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_be
 cp $G/refresh/bench_head_emulated_world8_eager.json $P/${TAG}_bench_head_emulated_world8_eager.json
 for v in world8_autograd_graphs world8_main_chain_only world1_main_chain_only; do cp $G/refresh/bench_head_emulated_$v.json $P/${TAG}_bench_head_emulated_$v.json; done
 cp $G/refresh/dp8_step_timeline.txt $P/${TAG}_dp8_step_timeline.txt
+[ -f $G/refresh/step_middle_fused_ab.txt ] && cp $G/refresh/step_middle_fused_ab.txt $P/${TAG}_step_middle_fused_ab.txt
+[ -f $G/refresh/step_segments.txt ] && cp $G/refresh/step_segments.txt $P/${TAG}_step_segments.txt
 cp $G/refresh/bench_xd_bf16.json $P/${TAG}_bench_xd_bf16.json
 grep '^{' $G/refresh/bench_gloo2_smoke.json > $P/${TAG}_bench_gloo2_smoke.json   # gloo prints its own connection lines to stdout
 cp $G/refresh/bench_metrics.txt $P/${TAG}_bench_metrics.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One pass over everything profiles/r05_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
+# One pass over everything profiles/r06_* is made from (run on the GPU box through gpurun; outputs under gpurun_out/refresh/).
 set -x
 R=/root/repo
 OUT=$R/gpurun_out/refresh
@@ -19,6 +19,11 @@ python tools/bench_head.py --steps 20 --no-step-graph > $OUT/bench_head_eager.js
 for n in 1 2 4 8; do python tools/bench_head.py --steps 40 --warmup 5 --emulate-world $n > $OUT/bench_head_emulated_world$n.json 2>/dev/null; done
 python tools/bench_head.py --steps 20 --emulate-world 8 --no-step-graph > $OUT/bench_head_emulated_world8_eager.json 2>/dev/null
 python tools/bench_head.py --steps 20 --emulate-world 8 --no-step-graph --text-graph --temporal-graph > $OUT/bench_head_emulated_world8_autograd_graphs.json 2>/dev/null
+# the step's middle section as the separate launches of the autograd path (round 5's form) against the fused launches, interleaved
+for rep in 1 2; do for u in 0 1; do for n in 1 8; do echo "ACX_STEP_UNFUSED=$u emulate-world $n: $(ACX_STEP_UNFUSED=$u python tools/bench_head.py --steps 60 --warmup 10 --emulate-world $n 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["train_ms_per_step"], "ms/step, loss", d["loss"])')"; done; done; done > $OUT/step_middle_fused_ab.txt 2>&1
+# device time stamps in front of every main-stream segment of the replayed step (no profiler attached), with and without the text stream
+for n in 1 8; do { echo "# emulate-world $n"; python tools/probes/step_host_trace.py --steps 30 --warmup 5 --emulate-world $n 2>&1 | grep -v '^{' | grep -E 'device|step:' | cut -c1-600 | tail -4;
+  echo "# emulate-world $n, ACX_STEP_SKIP_TEXT=1 (main chain only)"; ACX_STEP_SKIP_TEXT=1 python tools/probes/step_host_trace.py --steps 30 --warmup 5 --emulate-world $n 2>&1 | grep -v '^{' | grep device | cut -c1-400 | tail -2; } ; done > $OUT/step_segments.txt 2>&1
 ACX_STEP_SKIP_TEXT=1 python tools/bench_head.py --steps 40 --warmup 5 --emulate-world 8 > $OUT/bench_head_emulated_world8_main_chain_only.json 2>/dev/null
 ACX_STEP_SKIP_TEXT=1 python tools/bench_head.py --steps 40 --warmup 5 --emulate-world 1 > $OUT/bench_head_emulated_world1_main_chain_only.json 2>/dev/null
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp8 -o dp8 -- python $R/tools/bench_head.py --emulate-world 8 --steps 10 --warmup 2 > /dev/null 2>&1; cp $(find /tmp/pp8 -name '*kernel_stats.csv' | head -1) $OUT/dp8_rank_share_kernel_stats.csv)
