@@ -21,8 +21,9 @@ for n in 1 2 4 8; do cp $G/refresh/bench_head_emulated_world$n.json $P/${TAG}_be
 cp $G/refresh/bench_head_emulated_world8_eager.json $P/${TAG}_bench_head_emulated_world8_eager.json
 for v in world8_autograd_graphs world8_main_chain_only world1_main_chain_only; do cp $G/refresh/bench_head_emulated_$v.json $P/${TAG}_bench_head_emulated_$v.json; done
 cp $G/refresh/dp8_step_timeline.txt $P/${TAG}_dp8_step_timeline.txt
-[ -f $G/refresh/step_middle_fused_ab.txt ] && cp $G/refresh/step_middle_fused_ab.txt $P/${TAG}_step_middle_fused_ab.txt
-[ -f $G/refresh/step_segments.txt ] && cp $G/refresh/step_segments.txt $P/${TAG}_step_segments.txt
+# (the refresh script runs under `set -x`: drop its trace lines)
+[ -f $G/refresh/step_middle_fused_ab.txt ] && { echo "# tools/bench_head.py --steps 60 --warmup 10 --emulate-world N: the step's middle as fused launches (default) vs the autograd path's separate launches (ACX_STEP_UNFUSED=1), interleaved on one box"; grep -v '^+' $G/refresh/step_middle_fused_ab.txt; } > $P/${TAG}_step_middle_fused_ab.txt
+[ -f $G/refresh/step_segments.txt ] && { echo "# tools/probes/step_host_trace.py: HIP-event time stamps in front of every main-stream graph segment of the replayed training step (no profiler): [temporal forward | selector forward .. loss | (SyncBN exchange pieces at N > 1) | temporal backward | optimizer], and the host time per replayed item"; grep -v '^+' $G/refresh/step_segments.txt; } > $P/${TAG}_step_segments.txt
 cp $G/refresh/bench_xd_bf16.json $P/${TAG}_bench_xd_bf16.json
 grep '^{' $G/refresh/bench_gloo2_smoke.json > $P/${TAG}_bench_gloo2_smoke.json   # gloo prints its own connection lines to stdout
 cp $G/refresh/bench_metrics.txt $P/${TAG}_bench_metrics.txt
