@@ -142,7 +142,7 @@ class VisionTransformer(nn.Module):
     chunks of `chunk` frames (workspace is allocated once per chunk size and reused)."""
 
     def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int,
-                 output_dim: int, precision: str = "auto", chunk: int = 512):
+                 output_dim: int, precision: str = "auto", chunk: int = 512, streams: int = 1):
         super().__init__()
         self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
         self.width, self.layers, self.heads = width, layers, heads
@@ -156,8 +156,15 @@ class VisionTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self.precision = precision
         self.chunk = chunk
+        # streams = 2 (opt-in): every chunk runs as TWO half chunks on two side streams with their own workspaces -- one half's
+        # memory-bound launches (LayerNorm, attention) then run beside the other half's matrix-bound GEMMs (+1-2 % frames/s at 512
+        # frames, tools/probes/vit_two_streams.py).  Same kernels, same per-row arithmetic: the features are those of two launches of
+        # chunk / 2 frames.  Not the default: per-launch timings of overlapping kernels (bench.py's roofline) stop meaning anything.
+        self.streams = streams
         self._wcache = None
         self._ws: Optional[torch.Tensor] = None
+        self._ws2: Optional[torch.Tensor] = None
+        self._side = None
 
     def _weights(self, prec: int):
         key = (prec, ops.WEIGHT_EPOCH[0]) + tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -203,9 +210,35 @@ class VisionTransformer(nn.Module):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         h = ops._h(x)
+        if self.streams == 2 and chunk >= 32 and x.is_cuda:
+            return self._forward_two_streams(x, out, d, w, chunk, nbytes, h)
         s = ops._stream()
         for f0 in range(0, F, chunk):
             n = min(chunk, F - f0)
             L.check(lib.acx_vit_encode(h, C.byref(d), C.byref(w), x[f0:f0 + n].data_ptr(), n, out[f0:f0 + n].data_ptr(),
                                        self._ws.data_ptr(), self._ws.numel(), s), h)
+        return out
+
+    def _forward_two_streams(self, x, out, d, w, chunk, nbytes, h):
+        lib = L.lib()
+        F = x.shape[0]
+        half = (chunk + 1) // 2
+        if self._ws2 is None or self._ws2.numel() < nbytes or self._ws2.device != x.device:
+            self._ws2 = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        if self._side is None or self._side[0].device != x.device:
+            self._side = (torch.cuda.Stream(device=x.device), torch.cuda.Stream(device=x.device))
+        cur = torch.cuda.current_stream()
+        wss = (self._ws, self._ws2)
+        for st in self._side:
+            st.wait_stream(cur)                     # the frames (and the workspaces' previous readers) are ordered before
+        k = 0
+        for f0 in range(0, F, half):
+            n = min(half, F - f0)
+            st, ws = self._side[k % 2], wss[k % 2]
+            with torch.cuda.stream(st):
+                L.check(lib.acx_vit_encode(h, C.byref(d), C.byref(w), x[f0:f0 + n].data_ptr(), n, out[f0:f0 + n].data_ptr(),
+                                           ws.data_ptr(), ws.numel(), st.cuda_stream), h)
+            k += 1
+        for st in self._side:
+            cur.wait_stream(st)
         return out

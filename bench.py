@@ -835,6 +835,16 @@ def main():
             extra["vit_chunk_256"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt256, 2),
                                       "ms_per_step": round(dt256 / k * 1e3, 3),
                                       "note": "config[2]'s literal batch: two 256-frame ViT launches per clip"}
+            # opt-in: the clip as two 256-frame half batches on two streams (VisionTransformer.streams = 2): one half's LayerNorm /
+            # attention launches run beside the other half's GEMMs.  Not the headline: overlapping launches have no per-launch time
+            try:
+                net.image_encoder.streams = 2
+                dt2s = timer.run(step_keep, k, 1)
+                extra["vit_two_streams"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt2s, 2), "ms_per_step": round(dt2s / k * 1e3, 3),
+                                            "note": "VisionTransformer(streams = 2), opt-in: two 256-frame halves of the clip on two HIP streams with "
+                                                    "their own workspaces; same kernels and bits as two 256-frame launches"}
+            finally:
+                net.image_encoder.streams = 1
             if args.precision == "auto":
                 # the opt-in K split of the partly filled last round of tiles (ACX_OPT_X6_TAIL_SPLIT; off by default: it gives the
                 # tail rows of a launch another summation order than the rows before them)
@@ -1011,6 +1021,7 @@ def main():
         # the secondary figures a reader wants next to `value`, lifted to the top level
         out["value_vit_chunk_256"] = extra.get("vit_chunk_256", {}).get("frames_per_s")
         out["value_f32_mfma_path"] = extra.get("f32_mfma_path", {}).get("frames_per_s")
+        out["value_vit_two_streams_opt_in"] = extra.get("vit_two_streams", {}).get("frames_per_s")
         out["value_text_recomputed_every_step"] = extra.get("text_recomputed_every_step", {}).get("frames_per_s")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, eot, hc)

@@ -161,6 +161,23 @@ def test_vit_b16_launch_sizes_auto(golden, chunk):
     assert relerr(out, o32) < 5e-6 and elem_ok(out, o32)                       # and round-off away from the f32 MFMA path, every frame
 
 
+def test_vit_two_streams_equals_sequential_half_launches(golden):
+    """VisionTransformer(streams = 2) (opt-in): the chunk as two half chunks on two side streams with their own workspaces -- the
+    features are bit for bit those of the same half chunks launched one after the other, for an even and a ragged frame count, and
+    a second call (workspaces and streams reused) reproduces them."""
+    g = golden("vit_b16")
+    vit, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="auto")
+    frames = torch.randn(150, 3, 224, 224, generator=torch.Generator().manual_seed(11)).to(DEV)
+    vit.chunk = 64
+    ref = vit(frames)                               # launches of 64, 64, 22 frames
+    vit.chunk = 128
+    vit.streams = 2                                 # halves of 64: the same launches, pairwise concurrent
+    out = vit(frames)
+    assert torch.equal(out, ref)
+    assert torch.equal(vit(frames), ref)
+    vit.streams = 1
+
+
 def test_vit_b16_bf16_mode(golden):
     """bf16 MFMA mode: NOT the parity path; documents its distance from the f32 reference."""
     g = golden("vit_b16")
