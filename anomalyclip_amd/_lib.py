@@ -11,7 +11,7 @@ from . import _build
 c_void_p, c_int32, c_int64, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 ACX_F32, ACX_BF16, BF16X3, BF16X3P = 0, 1, 2, 3      # BF16X3 / BF16X3P: output only (three bf16 planes hi | mid | lo; P: K-panel layout)
-PREC_F32, PREC_BF16, PREC_F32X6 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_F32X6, PREC_F32X3 = 0, 1, 2, 3
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1

@@ -26,7 +26,8 @@ from .. import ops
 # error against fp64 than the f32 MFMA kernels at ~0.6 of their time (gfx950's f32 MFMA peak is 1/16 of its bf16 peak); problems
 # too small for that kernel (few-frame launches, the text tower, CLS-only rows) run on the f32 MFMA kernels.  "f32": the f32 MFMA
 # kernels everywhere (v_mfma_f32_32x32x2_f32: an fmaf chain).  "bf16": bf16 operands, not a parity path.
-PRECISIONS = {"auto": L.PREC_F32X6, "f32": L.PREC_F32, "bf16": L.PREC_BF16, "f32x6": L.PREC_F32X6}
+# "bf16x3" (opt-in, NOT f32-accurate): the plane kernels with the three leading cross products only (ACX_PREC_F32X3)
+PRECISIONS = {"auto": L.PREC_F32X6, "f32": L.PREC_F32, "bf16": L.PREC_BF16, "f32x6": L.PREC_F32X6, "bf16x3": L.PREC_F32X3}
 
 
 class LayerNorm(nn.Module):
@@ -106,7 +107,7 @@ class Transformer(nn.Module):
             w.out_proj_w, w.out_proj_b = b.attn.out_proj.weight.data_ptr(), b.attn.out_proj.bias.data_ptr()
             w.fc_w, w.fc_b = b.mlp.c_fc.weight.data_ptr(), b.mlp.c_fc.bias.data_ptr()
             w.proj_w, w.proj_b = b.mlp.c_proj.weight.data_ptr(), b.mlp.c_proj.bias.data_ptr()
-            if prec in (L.PREC_BF16, L.PREC_F32X6):
+            if prec in (L.PREC_BF16, L.PREC_F32X6, L.PREC_F32X3):
                 for name, p in (("in_proj_w_bf16", b.attn.in_proj_weight), ("out_proj_w_bf16", b.attn.out_proj.weight),
                                 ("fc_w_bf16", b.mlp.c_fc.weight), ("proj_w_bf16", b.mlp.c_proj.weight)):
                     # bf16 mode: one rounded copy; f32x6: the three planes hi | mid | lo of the f32 weight, each in K-panel
@@ -180,7 +181,7 @@ class VisionTransformer(nn.Module):
             cb, pb = ops.cast_bf16(conv), ops.cast_bf16(proj_t)
             keep += [cb, pb]
             w.conv1_w_bf16, w.proj_t_bf16 = cb.data_ptr(), pb.data_ptr()
-        elif prec == L.PREC_F32X6:
+        elif prec in (L.PREC_F32X6, L.PREC_F32X3):
             # the patch embedding as a bf16 x 6 product: the weight's three planes in K-panel layout (ACX_BF16X3P)
             cb = ops.split_bf16x3(conv, panel=True)
             keep.append(cb)

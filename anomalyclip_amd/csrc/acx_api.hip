@@ -153,6 +153,10 @@ struct TfWs {   // transformer scratch carved from the caller's workspace
   size_t splitk_bytes, total;
 };
 
+// the plane modes of the drivers: ACX_PREC_F32X6 (six products: f32-accurate) and ACX_PREC_F32X3 (the three leading products)
+static inline bool is_xmode(int prec) { return prec == ACX_PREC_F32X6 || prec == ACX_PREC_F32X3; }
+static thread_local int tl_x_pairs = 6;          // acx_gemm_desc.pairs of the driver's plane products (set at the driver's entry)
+
 TfWs carve_tf(char* base, int64_t rows, int W, int prec = ACX_PREC_F32) {
   TfWs w;
   size_t off = 0;
@@ -165,7 +169,7 @@ TfWs carve_tf(char* base, int64_t rows, int W, int prec = ACX_PREC_F32) {
   w.splitk_bytes = rows <= 4096 ? (size_t)8 * rows * 4 * W * 4 : (size_t)4 * 256 * 128 * 128 * 4;
   w.splitk = base + off; off += al(w.splitk_bytes);
   w.hp = w.mp = w.qkv3 = nullptr;
-  if (prec == ACX_PREC_F32X6) {
+  if (is_xmode(prec)) {
     w.hp = base + off; off += al((size_t)3 * rows * W * 2);
     w.mp = base + off; off += al((size_t)3 * rows * 4 * W * 2);
     w.qkv3 = base + off; off += al((size_t)3 * rows * 3 * W * 2);
@@ -198,7 +202,7 @@ int linear_x6(acx_ctx* ctx, const void* A3, int lda, int64_t a_rows, const void*
   d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc;
   d.a_dtype = ACX_BF16; d.c_dtype = c_dtype; d.prec = ACX_PREC_BF16;
   d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
-  d.pairs = 6; d.a_plane_stride = a_rows * (int64_t)lda * 2; d.w_plane_stride = w_plane_bytes;
+  d.pairs = tl_x_pairs; d.a_plane_stride = a_rows * (int64_t)lda * 2; d.w_plane_stride = w_plane_bytes;
   d.panels = 3;
   // scratch for the K split of a partly filled last round of tiles (acx_gemm: row-major outputs only)
   d.workspace = tail_ws; d.workspace_bytes = tail_ws ? tail_bytes : 0;
@@ -265,7 +269,7 @@ int linear(acx_ctx* ctx, int prec, const void* A, int a_dtype, int lda, const fl
 int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int heads, int layers, int causal, int prec,
                        const acx_block_weights* blk, const TfWs& ws, hipStream_t s, float* cls_ws = nullptr) {
   const int64_t rows = (int64_t)batch * L;
-  const bool x6mode = prec == ACX_PREC_F32X6;
+  const bool x6mode = is_xmode(prec);
   if (x6mode) prec = ACX_PREC_F32;               // everything that is not one of the four large GEMMs runs as in f32 mode
   const int hdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   const size_t esz = prec == ACX_PREC_BF16 ? 2 : 4;
@@ -388,8 +392,9 @@ extern "C" int acx_transformer_forward(acx_ctx* ctx, float* x, int32_t batch, in
   // ACX_PREC_F32X6 with a workspace sized for it (acx_transformer_workspace_bytes_prec); a smaller (f32-sized) workspace runs
   // the f32 kernels
   TfWs ws = carve_tf((char*)workspace, (int64_t)batch * L, width, prec);
-  if (ws.total > workspace_bytes && prec == ACX_PREC_F32X6) ws = carve_tf((char*)workspace, (int64_t)batch * L, width);
+  if (ws.total > workspace_bytes && is_xmode(prec)) ws = carve_tf((char*)workspace, (int64_t)batch * L, width);
   if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_transformer_forward: workspace too small%s");
+  tl_x_pairs = prec == ACX_PREC_F32X3 ? 3 : 6;
   return transformer_layers(ctx, x, batch, L, width, heads, layers, causal, prec, blocks, ws, (hipStream_t)stream);
 }
 
@@ -403,7 +408,7 @@ VitWs carve_vit(char* base, const acx_vit_desc* d, int F) {
   const int K = 3 * d->patch * d->patch;
   VitWs w;
   size_t off = 0;
-  w.patches = base + off;   off += al((size_t)F * T * K * (d->prec == ACX_PREC_F32X6 ? 6 : 4));   // (F32X6: three bf16 planes)
+  w.patches = base + off;   off += al((size_t)F * T * K * (is_xmode(d->prec) ? 6 : 4));   // (plane modes: three bf16 planes)
   w.patch_out = base + off; off += al((size_t)F * T * W * 4);
   w.x = base + off;         off += al((size_t)F * (T + 1) * W * 4);
   w.cls = base + off;       off += al((size_t)F * W * 4);
@@ -432,12 +437,13 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   const VitWs ws = carve_vit((char*)workspace, d, F);
   if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_vit_encode: workspace too small%s");
   hipStream_t s = (hipStream_t)stream;
-  const int prec = d->prec == ACX_PREC_F32X6 ? ACX_PREC_F32 : d->prec;   // patch embedding / final projection: small, f32 kernels
+  const int prec = is_xmode(d->prec) ? ACX_PREC_F32 : d->prec;   // final projection (and small launches): f32 kernels
+  tl_x_pairs = d->prec == ACX_PREC_F32X3 ? 3 : 6;
   const int pdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   int rc;
   // conv1 as GEMM over im2col'ed patches                               clip/model.py:267-269
   const TfWs tf = carve_tf((char*)workspace + ws.tf_off, (int64_t)F * (T + 1), W, d->prec);
-  if (d->prec == ACX_PREC_F32X6 && w->conv1_w_bf16 && K % 32 == 0 && x6_takes(ctx, tf, (int64_t)F * T, W, K, K)) {
+  if (is_xmode(d->prec) && w->conv1_w_bf16 && K % 32 == 0 && x6_takes(ctx, tf, (int64_t)F * T, W, K, K)) {
     // ACX_PREC_F32X6: im2col writes the three bf16 planes of the pixels (K-panel layout), the embedding is a pairs = 6 product
     // like the layers' GEMMs (conv1_w_bf16: the weight's three K-panel planes); scratch for a K-split tail: the f32 q | k | v buffer
     if ((rc = acx_vit_patches(ctx, frames, ws.patches, ACX_BF16X3P, F, d->resolution, d->patch, s))) return rc;

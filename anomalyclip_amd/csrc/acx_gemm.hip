@@ -594,7 +594,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   if (d->a_sub && (a_bf16 || ((uintptr_t)d->a_sub & 15)))
     return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: a_sub needs f32 A and 16-byte alignment%s");
   if (d->amap == ACX_AMAP_CONV3X3) {
-    const int ke = (prec == ACX_PREC_F32 || d->pairs == 6) ? 32 : 64;   // (the plane-reuse kernel's K-steps are 32 wide)
+    const int ke = (prec == ACX_PREC_F32 || d->pairs == 6 || d->pairs == 3) ? 32 : 64;   // (the plane-reuse kernel's K-steps are 32 wide)
     if (d->cin <= 0 || d->K != 9 * d->cin || d->cin % ke || d->gn <= 0 || d->gl <= 0 || d->M % (d->gn * d->gl))
       return acx_fail(ctx, ACX_E_BADARG, "acx_gemm: bad conv3x3 geometry%s");
     if (d->a_sub) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: a_sub with conv3x3%s");
@@ -781,8 +781,11 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   // ---- pairs = 6 (f32-accurate product from three bf16 planes per operand): the one-wave-per-SIMD plane-reuse kernel
   // (acx_gemm_x6.h) -- identity rows or the implicit 3x3 convolution; K split across workgroups when the tiles alone
   // would not fill the chip (caller-provided workspace)
-  if (d->pairs == 6 && ACX_DBG_SWITCH("X6P4", true)) {
+  if ((d->pairs == 6 || d->pairs == 3) && ACX_DBG_SWITCH("X6P4", true)) {
     const bool conv = d->amap == ACX_AMAP_CONV3X3;
+    const bool x3 = d->pairs == 3;               // the three leading products only (acx_gemm_x6.h, X3): identity rows
+    if (x3 && (conv || c_bf16 || d->act == ACX_ACT_LEAKYRELU))
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 3 takes identity rows, f32 or plane outputs, bias / QuickGELU / residual epilogues%s");
     const bool c_x3_ = d->c_dtype == ACX_BF16X3 || d->c_dtype == ACX_BF16X3P;
     const bool shape_ok = prec == ACX_PREC_BF16 && a_bf16 && (d->amap == ACX_AMAP_IDENTITY || conv) && !d->a_sub && !d->pos0 &&
         d->K % 32 == 0 && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
@@ -831,6 +834,18 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       if (strip_ni < 4) { g.tile0 = 0; g.ntiles = tile0_tail; }
 #define ACX_X6L_(CM, ACT, RES, CV, NI_, GRID)                                                        \
   do {                                                                                              \
+    if constexpr ((CV) == 0 && (CM) != 1 && (ACT) != 2) {   /* (the ViT's epilogues: f32 / plane outputs, bias, QuickGELU, residual) */ \
+      if (x3) {                                                                                     \
+        static bool attr3_dev_[64] = {}; bool& attr3_done = attr3_dev_[dev_slot];                   \
+        if (!attr3_done) {                                                                          \
+          (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<CM, ACT, RES, 0, 0, 0, NI_, 0, 1>, \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B);     \
+          attr3_done = true;                                                                        \
+        }                                                                                           \
+        hipLaunchKernelGGL((gemm_x6_p4_kernel<CM, ACT, RES, 0, 0, 0, NI_, 0, 1>), GRID, dim3(256), (size_t)X6_LDS_B, s, g); \
+        break;                                                                                      \
+      }                                                                                             \
+    }                                                                                               \
     static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];                          \
     if (!attr_done) {                                                                               \
       (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<CM, ACT, RES, CV, 0, 0, NI_>,        \
@@ -1016,6 +1031,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: c_dtype ACX_BF16X3 needs the persistent 256x256 bf16 kernel and no residual%s");
   // (pairs = 6 problems were taken by the plane-reuse kernel above; the PAIRS instantiation of the kernel below -- round 4's route,
   // six plain products one after the other -- is no longer built)
+  if (d->pairs == 3) return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 3 needs bf16 planes, identity rows, K %% 32 == 0 (the plane-reuse kernel)%s");
   if (d->pairs > 1)
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 6 needs bf16 planes (16-byte aligned strides), K %% 32 == 0, N %% 4 == 0 (plane output: N %% 8 == 0), identity rows or CONV3X3 on a power-of-two grid%s");
   if (ring_ok) {

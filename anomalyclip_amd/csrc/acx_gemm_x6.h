@@ -79,8 +79,15 @@ __device__ __forceinline__ bf16x8 x6_tr_frag(const char* smem, int off_lo, int o
 // stay [32 k][256 channels], the channels behind the tile come from the zero page.
 // W14 (TN only): wave grid 1 x 4 -- the tile is 128 rows x 128 NI columns (N1 = 128: the weight gradient of a convolution with
 // 128 output channels), the upper half of the A units from the zero page.
-template <int C_MODE, int ACT, int RES, int CONV, int TN = 0, int PLAIN = 0, int NI = 4, int W14 = 0>
+// X3 (acx_gemm_desc.pairs = 3; identity rows, NT): the THREE leading cross products only -- (A.mid, W.hi) (A.hi, W.mid) (A.hi, W.hi):
+// every bf16 x bf16 product exact, the dropped terms <= 2^-16 of the leading one (an error of ~1e-5 of sum |a||w|: sixteen significant
+// bits per operand, between TF32's ten and f32's twenty-four) -- on the same frame: a K-step is ONE half-step with the Y half-step's
+// fragment / MFMA pattern (its "A.mid" is A.hi, its "A.lo" is A.mid), all four units (A.hi, A.mid, W.hi, W.mid) double-buffered by
+// K-step parity in the eight slots (A.hi: AH / AM, A.mid: WL / AL) and restaged a K-step ahead: 96 MFMAs per wave and K-step behind
+// one barrier, 16 LDS-DMA instructions between them.  The lo planes are never read.
+template <int C_MODE, int ACT, int RES, int CONV, int TN = 0, int PLAIN = 0, int NI = 4, int W14 = 0, int X3 = 0>
 __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
+  static_assert(X3 == 0 || (CONV == 0 && TN == 0 && PLAIN == 0 && W14 == 0), "three-product mode: identity rows, NT");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const acx_gemm_desc& d = g.d;
   const int t = threadIdx.x, lane = t & 63;
@@ -227,6 +234,16 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     for (int i = 0; i < 4; ++i) X6_DMA_W_K(c0, 2 * c0.kk, rw0, 0, 2, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) X6_DMA_W_K(c0, 2 * c0.kk + 1, rw0, 0, 3, i);
+  } else if constexpr (X3 != 0) {
+    // ---- prologue (X3): W.hi, W.mid, A.hi, A.mid of K-step 0 -> the parity-0 slots WH0, WM0, AH, WL
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_W(c0, rw0, 0, X6_WH0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_W(c0, rw0, 1, X6_WM0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_A(c0, ra0, vm0, 0, X6_AH, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X6_DMA_A(c0, ra0, vm0, 1, X6_WL, i);
   } else {
   // ---- prologue: W.hi, W.mid, A.hi, W.lo of K-step 0 (parity 0 slots)
 #pragma unroll
@@ -375,6 +392,55 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       }
       const int wnext = wpar ? 0 : 6 * X6_UNIT_B;
       const int slot_wh_next = wpar ? X6_WH0 : X6_WH1, slot_wm_next = wpar ? X6_WM0 : X6_WM1;
+      if constexpr (X3 != 0) {
+        // ======================================================================= one K-step of the three-product mode (half-step Z)
+        const int apar = wpar ? 2 * X6_UNIT_B : 0;                            // A.hi: AH / AM, A.mid: WL / AL by K-step parity
+        const int sa_next = wpar ? X6_AH : X6_AM, sm_next = wpar ? X6_WL : X6_AL;
+        if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        X6_FENCE();
+        __builtin_amdgcn_s_barrier();
+        X6_FENCE();
+#define X6_RD_Z(F, s, q)                                                                           \
+  do {                                                                                             \
+    if ((q) >= 4 && (q) < 12 && ((q) & 3) >= NI) break;                                            \
+    if ((q) < 4) X6_LOADF(F[q], apar + X6_AH * X6_UNIT_B, trA, fa0, fa1, (q) & 3, s);              \
+    else if ((q) < 8) X6_LOADF(F[q], wpar + X6_WH0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);        \
+    else if ((q) < 12) X6_LOADF(F[q], wpar + X6_WM0 * X6_UNIT_B, trW, fw0, fw1, (q) & 3, s);       \
+    else X6_LOADF(F[q], apar + X6_WL * X6_UNIT_B, trA, fa0, fa1, (q) & 3, s);                      \
+  } while (0)
+        // block 1: the previous K-step's second substep (F1; zero at an item's first K-step) with this K-step's first-substep reads
+        // (-> F0) and the 16 DMA instructions of the NEXT K-step's four units (other parity) between the MFMAs
+#define X6_B1_Z(q)                                                                                 \
+  do {                                                                                             \
+    if constexpr ((q) < 16) X6_RD_Z(F0, 0, (q) & 15);                                              \
+    if constexpr ((q) >= 16 && (q) < 48 && (((q) - 16) % 2) == 0) {                                \
+      constexpr int u_ = (((q) - 16) / 8) & 3, i_ = (((q) - 16) / 2) & 3;                          \
+      if (u_ == 0) X6_DMA_W(c1, rw1, 0, slot_wh_next, i_);                                         \
+      else if (u_ == 1) X6_DMA_W(c1, rw1, 1, slot_wm_next, i_);                                    \
+      else if (u_ == 2) X6_DMA_A(c1, ra1, vm1, 0, sa_next, i_);                                    \
+      else X6_DMA_A(c1, ra1, vm1, 1, sm_next, i_);                                                 \
+    }                                                                                              \
+    X6_MM_Y(F1, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+        X6_REP48(X6_B1_Z)
+#undef X6_B1_Z
+#define X6_B2_Z(q)                                                                                 \
+  do {                                                                                             \
+    if constexpr ((q) < 16) X6_RD_Z(F1, 1, (q) & 15);                                              \
+    X6_MM_Y(F0, (q));                                                                              \
+    X6_FENCE();                                                                                    \
+  } while (0);
+        X6_REP48(X6_B2_Z)
+#undef X6_B2_Z
+#undef X6_RD_Z
+        wpar = wnext;
+        c0 = c1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra0[i] = ra1[i]; rw0[i] = rw1[i]; vm0[i] = vm1[i]; }
+        X6_ADVANCE(c1, ra1, rw1, vm1);
+        continue;
+      }
       // =========================================================================== half-step X
       if (ACX_X6_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       X6_FENCE();

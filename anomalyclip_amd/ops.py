@@ -211,7 +211,7 @@ def unpanel(planes: torch.Tensor) -> torch.Tensor:
 
 def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, act=L.ACT_NONE,
             residual=None, out_dtype=torch.float32, amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, M: Optional[int] = None,
-            planes_out: bool = False, split_k: bool = True, panels: int = 0, panel_out: bool = False) -> torch.Tensor:
+            planes_out: bool = False, split_k: bool = True, panels: int = 0, panel_out: bool = False, pairs: int = 6) -> torch.Tensor:
     """out[M, N] = epilogue(amap(A) W^T) with A = sum of the three bf16 planes a3 [3, rows, Ka] and W = sum of w3 [3, N, K]
     (split_bf16x3): the six leading cross products on the bf16 matrix cores, f32 accumulation -- the accuracy of an f32
     product (acx_gemm_desc.pairs = 6; acx_gemm_x6.h).  amap = AMAP_CONV3X3: implicit 3x3 convolution over the (gn, gl) token
@@ -236,7 +236,7 @@ def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] =
     d.a_dtype, d.c_dtype, d.prec = _dt(a3), ((L.BF16X3P if panel_out else L.BF16X3) if planes_out else _dt(out)), L.PREC_BF16
     d.bias, d.act = _ptr(bias), act
     d.residual, d.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
-    d.pairs, d.a_plane_stride, d.w_plane_stride = 6, rows * Ka * 2, N * K * 2
+    d.pairs, d.a_plane_stride, d.w_plane_stride = int(pairs), rows * Ka * 2, N * K * 2      # (pairs = 3: the three leading products only)
     d.panels = panels                      # bit 0: a3 in K-panel memory order (split_bf16x3(panel=True)), bit 1: w3
     d.amap, d.gn, d.gl, d.cin = amap, gn, gl, cin
     if amap == L.AMAP_CONV3X3:

@@ -45,6 +45,10 @@ enum { ACX_F32 = 0, ACX_BF16 = 1,                    /* storage dtypes */
                              dense).  The plane-reuse kernel then stages a 256-row x 32-column unit from ONE contiguous 16 KB block
                              instead of 256 half cache lines (acx_gemm_desc.panels) */
 enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1,          /* MFMA arithmetic: exact f32 (v_mfma_f32_32x32x2_f32) or bf16 in / f32 acc */
+       ACX_PREC_F32X3 = 3,    /* the same drivers and plane layouts with the THREE leading products only (acx_gemm_desc.pairs = 3:
+                                 (mid, hi) (hi, mid) (hi, hi)): sixteen significant bits per operand -- an error of ~1e-5 of sum |a||w| per
+                                 product, between TF32 and f32 -- at about twice the GEMM rate of ACX_PREC_F32X6.  NOT an f32-accurate
+                                 path: opt-in (precision "bf16x3"); the attention keeps its six-product form */
        ACX_PREC_F32X6 = 2 };  /* acx_vit_encode / acx_transformer_forward only: f32 everywhere, the four large GEMMs of a layer as
                                  f32-accurate bf16 x 6 products (acx_gemm_desc.pairs); the *_w_bf16 weight fields then hold THREE
                                  planes each (acx_split_bf16x3 of the f32 weight) */
@@ -155,7 +159,10 @@ typedef struct acx_gemm_desc {
                              maps IDENTITY and CONV3X3 (power-of-two grid, cin % 32 == 0, M % 256 == 0, zero_page); epilogues bias,
                              QuickGELU / LeakyReLU, residual (f32 C), c_dtype ACX_F32 / ACX_BF16 / ACX_BF16X3[P] (plane output:
                              N % 8 == 0, no residual).  With `workspace`, launches of fewer output tiles than CUs split K across
-                             workgroups (fixed split per shape; partial tiles + the generic reduce launch). */
+                             workgroups (fixed split per shape; partial tiles + the generic reduce launch).
+                             3: the same planes and kernel with the THREE leading products only -- (mid,hi) (hi,mid) (hi,hi); the lo
+                             planes are never read.  The dropped terms are <= 2^-16 of the leading one: NOT f32-accurate (about 1e-5 of
+                             sum |a||w|).  Identity rows, f32 or plane outputs, bias / QuickGELU / residual epilogues. */
   int32_t panels;         /* pairs = 6: bit 0 -- the A planes are in K-panel layout (ACX_BF16X3P, rows = a_plane_stride / (2 K));
                              bit 1 -- the W planes are (rows = N).  Identity row map only. */
   int64_t a_plane_stride, w_plane_stride;   /* bytes */

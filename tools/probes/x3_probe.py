@@ -1,0 +1,51 @@
+"""Development probe: the three-product mode of the plane-reuse kernel (acx_gemm_desc.pairs = 3, precision "bf16x3") -- error against
+fp64 and time against the six-product form on the ViT's shapes, then the ViT encode in both modes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench as B
+from anomalyclip_amd import ops, _lib as L
+from bench import _event_time
+
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(3)
+for (M, N, K, act, res) in ((4096, 768, 768, L.ACT_NONE, False), (100864, 2304, 768, L.ACT_NONE, False), (100864, 768, 3072, L.ACT_NONE, True),
+                            (100864, 3072, 768, L.ACT_QUICKGELU, False), (50432, 768, 768, L.ACT_NONE, True)):
+    a = torch.randn(M, K, generator=g, device=dev)
+    a[:, 5] *= 60.0
+    w = torch.randn(N, K, generator=g, device=dev) * 0.03
+    a3, w3 = ops.split_bf16x3(a, panel=True), ops.split_bf16x3(w, panel=True)
+    r = torch.randn(M, N, generator=g, device=dev) if res else None
+    outs = {}
+    for pairs in (6, 3):
+        fn = lambda: ops.gemm_x6(a3, w3, act=act, residual=r, panels=3, pairs=pairs)
+        outs[pairs] = fn()
+        t = _event_time(fn, 6)
+        print(f"M {M} N {N} K {K} act {act} res {res} pairs {pairs}: {t * 1e3:.3f} ms  {2 * M * N * K / t / 1e12:.1f} TFLOP/s f32-equivalent", flush=True)
+    if M <= 8192:
+        ref = a.double() @ w.double().t()
+        den = (a.double().abs() @ w.double().abs().t())
+        for pairs in (6, 3):
+            e = (outs[pairs].double() - ref).abs()
+            print(f"   pairs {pairs}: max err / max|ref| {float(e.max() / ref.abs().max()):.3e}   max err / sum|a||w| {float((e / den).max()):.3e}")
+    else:
+        e = (outs[3] - outs[6]).abs().max() / outs[6].abs().max()
+        print(f"   pairs 3 vs 6: max |diff| / max|out| {float(e):.3e}")
+    del a, w, a3, w3, r, outs
+
+net, sd, eot, hc = B.build_net("auto", dev, 512)
+vit = net.image_encoder
+frames = torch.randn(512, 3, 224, 224, generator=g, device=dev)
+feats = {}
+for prec in ("auto", "bf16x3", "f32"):
+    vit.precision = prec
+    feats[prec] = vit(frames).clone()
+    t = _event_time(lambda: vit(frames), 4)
+    print(f"ViT-B/16 encode, 512 frames, precision {prec}: {512 / t:.0f} frames/s ({t * 1e3:.2f} ms)", flush=True)
+ref = feats["f32"]
+for prec in ("auto", "bf16x3"):
+    d = (feats[prec] - ref).abs()
+    print(f"features {prec} vs f32 MFMA path: max |diff| / max|ref| {float(d.max() / ref.abs().max()):.3e}, max elementwise rel (|ref| > 1e-2 max) "
+          f"{float((d / ref.abs().clamp_min(1e-2 * float(ref.abs().max()))).max()):.3e}")
