@@ -79,6 +79,10 @@ class AnomalyCLIP(nn.Module):
         if self.precision == "f32x6":
             self.precision = "auto"
         vit_precision = self.precision
+        if self.precision == "bf16x3":
+            # opt-in, NOT f32-accurate: the ViT's plane products with the three leading cross products only (ACX_PREC_F32X3: sixteen
+            # significant bits per operand); the head keeps the default's arithmetic
+            self.precision = "auto"
         head_precision = "f32" if self.precision == "auto" else self.precision      # text tower (too small for the bf16 x 6 kernel)
         geom = g("clip_geometry") or _ARCH[self.arch]
         if isinstance(geom, dict):

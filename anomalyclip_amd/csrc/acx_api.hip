@@ -270,6 +270,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
                        const acx_block_weights* blk, const TfWs& ws, hipStream_t s, float* cls_ws = nullptr) {
   const int64_t rows = (int64_t)batch * L;
   const bool x6mode = is_xmode(prec);
+  const int pdt3 = prec == ACX_PREC_F32X3 ? ACX_BF16X2P : ACX_BF16X3P;    // LayerNorm's plane output (three products: hi and mid only)
   if (x6mode) prec = ACX_PREC_F32;               // everything that is not one of the four large GEMMs runs as in f32 mode
   const int hdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   const size_t esz = prec == ACX_PREC_BF16 ? 2 : 4;
@@ -287,7 +288,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
       if (kv_x6) {
         // LayerNorm writes the product's three planes itself (all rows) and the f32 rows of the CLS tokens (Q below reads only those)
         if (!b.in_proj_w_bf16) return acx_fail(ctx, ACX_E_BADARG, "driver: missing bf16 x 3 weight planes for ACX_PREC_F32X6%s");
-        if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, ACX_BF16X3P, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+        if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, pdt3, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
         if ((rc = acx_layernorm(ctx, x, (int64_t)L * W, b.ln1_w, b.ln1_b, ws.h, (int64_t)L * W, hdt, batch, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
         if ((rc = linear_x6(ctx, ws.hp, W, rows, (const char*)b.in_proj_w_bf16 + (size_t)W * 64 /* row W of every K-panel */, (int64_t)3 * W * W * 2, W,
                             (float*)ws.qkv + W, 3 * W, (int)rows, 2 * W, W, b.in_proj_b + W, ACX_ACT_NONE, nullptr, s))) return rc;
@@ -317,7 +318,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     const bool x6_qkv = x6mode && x6_takes(ctx, ws, rows, 3 * W, W, W), x6_out = x6mode && x6_takes(ctx, ws, rows, W, W, W);
     const bool x6_fc = x6mode && x6_takes(ctx, ws, rows, 4 * W, W, W), x6_proj = x6mode && x6_takes(ctx, ws, rows, W, 4 * W, 4 * W);
     if (x6_qkv) {
-      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, ACX_BF16X3P, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+      if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.hp, W, pdt3, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     } else
     if ((rc = acx_layernorm(ctx, x, W, b.ln1_w, b.ln1_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     // bf16 mode, non-causal (the ViT): q/k/v, the attention and its output stay bf16 end to end -- half the
@@ -337,7 +338,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     if (ab) {
       if ((rc = acx_attention_bf16(ctx, ws.qkv, 3 * W, ws.att, W, batch, L, heads, s))) return rc;
     } else if (att_p3) {   // planes in, planes out
-      if ((rc = acx_attention_p3(ctx, ws.qkv3, ws.hp, batch, L, heads, s))) return rc;
+      if ((rc = acx_attention_p3n(ctx, ws.qkv3, ws.hp, batch, L, heads, tl_x_pairs, s))) return rc;
     } else if (att_x3) {   // the attention writes the out-projection's three planes itself
       if ((rc = acx_attention_x3_panel(ctx, (const float*)ws.qkv, 3 * W, ws.hp, W, batch, L, heads, s))) return rc;
     } else {
@@ -353,7 +354,7 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
                      b.out_proj_b, ACX_ACT_NONE, x, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     // x = x + mlp(ln_2(x))                                           clip/model.py:216
     if (x6_fc) {
-      if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.hp, W, ACX_BF16X3P, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
+      if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.hp, W, pdt3, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     } else
     if ((rc = acx_layernorm(ctx, x, W, b.ln2_w, b.ln2_b, ws.h, W, hdt, rows, W, 1e-5f, ACX_NORM_LAYER, s))) return rc;
     if (x6_fc) {
@@ -446,7 +447,7 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   if (is_xmode(d->prec) && w->conv1_w_bf16 && K % 32 == 0 && x6_takes(ctx, tf, (int64_t)F * T, W, K, K)) {
     // ACX_PREC_F32X6: im2col writes the three bf16 planes of the pixels (K-panel layout), the embedding is a pairs = 6 product
     // like the layers' GEMMs (conv1_w_bf16: the weight's three K-panel planes); scratch for a K-split tail: the f32 q | k | v buffer
-    if ((rc = acx_vit_patches(ctx, frames, ws.patches, ACX_BF16X3P, F, d->resolution, d->patch, s))) return rc;
+    if ((rc = acx_vit_patches(ctx, frames, ws.patches, d->prec == ACX_PREC_F32X3 ? ACX_BF16X2P : ACX_BF16X3P, F, d->resolution, d->patch, s))) return rc;
     if ((rc = linear_x6(ctx, ws.patches, K, (int64_t)F * T, w->conv1_w_bf16, (int64_t)W * K * 2, K, ws.patch_out, W, F * T, W, K, nullptr,
                         ACX_ACT_NONE, nullptr, s, 0, ACX_F32, tf.qkv, (size_t)F * (T + 1) * 3 * W * 4))) return rc;
   } else {

@@ -630,8 +630,12 @@ __device__ __forceinline__ void ap3_split8(const float (&p)[8], bf16x8& hi, bf16
   hi = __builtin_bit_cast(bf16x8, hv); mid = __builtin_bit_cast(bf16x8, mv); lo = __builtin_bit_cast(bf16x8, lv);
 }
 
+// NPROD = 3 (ACX_PREC_F32X3): the three leading products of both contractions only -- (hi, mid) (mid, hi) (hi, hi); the lo planes of
+// K and V are neither staged nor read, P is split into two planes, the output's lo plane is not written (its consumer does not read it)
+template <int NPROD>
 __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__ qkv3, int64_t plane_elems, int64_t rows_total,
                                                          u16* __restrict__ out3, int64_t out_plane_elems, int L, int heads, int nitems) {
+  constexpr int NPL = NPROD == 3 ? 2 : 3;               // planes of K / V / Q / the output in use
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
   do {                                                                                             \
     const int b_ = (it) / heads, h_ = (it) - b_ * heads;                                           \
     const unsigned vc_ = (unsigned)(((SWZ) ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)) * 16); \
-    _Pragma("unroll 1") for (int pc = 0; pc < 6; ++pc) {                                           \
+    _Pragma("unroll 1") for (int pc = 0; pc < 2 * NPL; ++pc) {                                     \
       const u16* src_ = qkv3 + (int64_t)(pc >> 1) * plane_elems + ((int64_t)((which) * np + 2 * h_ + (pc & 1)) * rows_total + (int64_t)b_ * L) * 32; \
       _Pragma("unroll 1") for (int j = 0; j < 13; ++j) {                                           \
         const unsigned r_ = min(16u * (unsigned)j + (unsigned)(lane >> 2), (unsigned)(L - 1));   /* behind the sequence: a finite duplicate */ \
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
   do {                                                                                             \
     const int b_ = (it) / heads, h_ = (it) - b_ * heads;                                           \
     const unsigned vc_ = (unsigned)(((SWZ) ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)) * 16); \
-    _Pragma("unroll 1") for (int idx = wave; idx < 78; idx += 8) {                                 \
+    _Pragma("unroll 1") for (int idx = wave; idx < 26 * NPL; idx += 8) {                           \
       const int pc = idx / 13, j = idx - 13 * pc;                                                  \
       const u16* src_ = qkv3 + (int64_t)(pc >> 1) * plane_elems + ((int64_t)((which) * np + 2 * h_ + (pc & 1)) * rows_total + (int64_t)b_ * L) * 32; \
       const unsigned r_ = min(16u * (unsigned)j + (unsigned)(lane >> 2), (unsigned)(L - 1));       \
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
     // ---------------------------------------------------------------- phase A: S^T = K Q^T
     bf16x8 qf[3][4];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NPL; ++p)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         qf[p][ks] = *reinterpret_cast<const bf16x8*>(qkv3 + (int64_t)p * plane_elems +
@@ -727,12 +731,14 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
         const int cst = (ks >> 1) * AP3_BLK_B + 32 * kt * 64;        // panel of the d step, key tile (swizzle: row bits 2..3 = li's)
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + cst);
         const bf16x8 km = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + 2 * AP3_BLK_B + cst);
-        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1l : ka0l) + cst);
         // smallest cross terms first: (hi,lo) (mid,mid) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
+        if constexpr (NPROD == 6) {
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1l : ka0l) + cst);
         if ((AP3_ABL & 8) && nitems != 12345) { sacc[kt][0] += (float)kh[0] + (float)km[0] + (float)kl[0]; continue; }
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[2][ks], sacc[kt], 0, 0, 0);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[1][ks], sacc[kt], 0, 0, 0);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ks], sacc[kt], 0, 0, 0);
+        }
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][ks], sacc[kt], 0, 0, 0);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][ks], sacc[kt], 0, 0, 0);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ks], sacc[kt], 0, 0, 0);
@@ -777,12 +783,12 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
                            sacc[kt][8 * u + 4], sacc[kt][8 * u + 5], sacc[kt][8 * u + 6], sacc[kt][8 * u + 7]};
       bf16x8 ph, pm, pl;
       if ((AP3_ABL & 32) && nitems != 12345) { ph = pm = pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&pv[0])); } else
-      ap3_split8(pv, ph, pm, pl);
+      ap3_split8(pv, ph, pm, pl);                       // (NPROD == 3: pl is dead code)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         bf16x8 vf[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
           const char* vb = smem + (p == 2 ? va2 : va) + ((p == 2 ? 0 : 2 * p) + dt) * AP3_BLK_B + (16 * st) * 64;
           const ap3_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ap3_lds_s16x4*)(vb));
           const ap3_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ap3_lds_s16x4*)(vb + 8 * 64));
@@ -790,10 +796,12 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
           const s16x8_ v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
           vf[p] = __builtin_bit_cast(bf16x8, v8);
         }
+        if constexpr (NPROD == 6) {
         if ((AP3_ABL & 4) && nitems != 12345) { oacc[dt][0] += (float)vf[0][0] + (float)vf[1][0] + (float)vf[2][0] + (float)ph[0] + (float)pm[0] + (float)pl[0]; continue; }
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], ph, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pm, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pl, oacc[dt], 0, 0, 0);
+        }
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], ph, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pm, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, oacc[dt], 0, 0, 0);
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
           pl_[z][0] = ph2; pl_[z][1] = pm2; pl_[z][2] = pl2;
         }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
           // swap(X = piece of g4 = 2 gp, Y = piece of g4 = 2 gp + 1): half 0 gets (own X, partner's X), half 1 (partner's Y, own Y)
           typedef unsigned ap3_u2 __attribute__((ext_vector_type(2)));
           const ap3_u2 w0 = __builtin_amdgcn_permlane32_swap(pl_[0][p].x, pl_[1][p].x, false, false);
@@ -851,7 +859,14 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
 // attention output as three bf16 planes in K-panel layout ([heads * 64 / 32][batch * L][32]); 128 < L <= 208, non-causal
 extern "C" int acx_attention_p3(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads,
                                 void* stream) {
+  return acx_attention_p3n(ctx, qkv_planes, out_planes, batch, L, heads, 6, stream);
+}
+// products = 6: the f32-accurate form; 3: the three leading products of both contractions (ACX_PREC_F32X3: the lo planes of the
+// operands are not read, the output's lo plane is not written)
+extern "C" int acx_attention_p3n(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads,
+                                 int32_t products, void* stream) {
   if (!qkv_planes || !out_planes) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_p3: null pointer%s");
+  if (products != 6 && products != 3) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_p3n: products must be 6 or 3%s");
   if (batch <= 0) return ACX_OK;
   if (L <= 192 || L > AP3_ROWS || heads <= 0 || (((uintptr_t)qkv_planes | (uintptr_t)out_planes) & 15))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention_p3: 192 < L <= 208, 16-byte aligned planes%s");
@@ -862,8 +877,16 @@ extern "C" int acx_attention_p3(acx_ctx* ctx, const void* qkv_planes, void* out_
   AcxProfScope prof__(ctx, ACX_K_ATTN, s);
   const int dev_slot = (ctx ? ctx->device : 0) & 63;
   static bool attr_dev_[64] = {}; bool& attr_done = attr_dev_[dev_slot];
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_p3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B); attr_done = true; }
-  hipLaunchKernelGGL(attn_p3_kernel, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_p3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B);
+    (void)hipFuncSetAttribute((const void*)attn_p3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B);
+    attr_done = true;
+  }
+  if (products == 3)
+    hipLaunchKernelGGL(attn_p3_kernel<3>, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
+                       rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems);
+  else
+  hipLaunchKernelGGL(attn_p3_kernel<6>, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
                      rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems);
   ACX_CHECK_LAUNCH(ctx, "acx_attention_p3");
   return ACX_OK;

@@ -607,6 +607,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
           u16* dst = (u16*)d.C + (cpanel ? ((size_t)(colq >> 5) * crows_ + row) * 32 + (colq & 31) : (size_t)row * d.ldc + colq); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&ph), reinterpret_cast<u32x4_*>(dst)); \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pm), reinterpret_cast<u32x4_*>(dst + pe)); \
+          if constexpr (X3 == 0)   /* (three-product mode: the consumer never reads the lo plane) */   \
           __builtin_nontemporal_store(*reinterpret_cast<const u32x4_*>(&pl), reinterpret_cast<u32x4_*>(dst + 2 * pe)); \
         }                                                                                          \
       }                                                                                            \

@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ 
   const int tok = (int)(row - f * g * g), gy = tok / g, gx = tok - gy * g;
   const float4 v = *reinterpret_cast<const float4*>(
       frames + ((f * 3 + c) * R + gy * P + ky) * (int64_t)R + gx * P + kx);
-  if constexpr (OUT_BF16 == 2) {
-    // three bf16 planes hi | mid | lo of the f32 pixel in K-panel layout (ACX_BF16X3P: plane = [K / 32][rows][32]): the A operand
+  if constexpr (OUT_BF16 >= 2) {
+    // three bf16 planes hi | mid | lo of the f32 pixel in K-panel layout (OUT_BF16 == 3, ACX_BF16X2P: hi and mid only) (ACX_BF16X3P: plane = [K / 32][rows][32]): the A operand
     // of the patch embedding as a pairs = 6 product (ACX_PREC_F32X6)
     const float x[4] = {v.x, v.y, v.z, v.w};
     u16 h[4], m[4], l[4];
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ 
     u16* d0 = (u16*)out + ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
     *reinterpret_cast<uint2*>(d0) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
     *reinterpret_cast<uint2*>(d0 + plane) = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
-    *reinterpret_cast<uint2*>(d0 + 2 * plane) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    if constexpr (OUT_BF16 == 2)
+      *reinterpret_cast<uint2*>(d0 + 2 * plane) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
   } else if constexpr (OUT_BF16 == 1) {
     uint2 pk;
     pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
@@ -681,8 +682,10 @@ extern "C" int acx_vit_patches(acx_ctx* ctx, const float* frames, void* patches,
   const int64_t total4 = (int64_t)F * g * g * 3 * P * P / 4;
   const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (out_dtype == ACX_BF16X3P) {
+  if (out_dtype == ACX_BF16X3P || out_dtype == ACX_BF16X2P) {
     if ((3 * P * P) % 32) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_patches: K-panel planes need 3 P P %% 32 == 0%s");
+    if (out_dtype == ACX_BF16X2P) hipLaunchKernelGGL((patches_kernel<3>), grid, block, 0, s, frames, patches, total4, R, P, g);
+    else
     hipLaunchKernelGGL((patches_kernel<2>), grid, block, 0, s, frames, patches, total4, R, P, g);
   } else if (out_dtype == ACX_BF16) hipLaunchKernelGGL((patches_kernel<1>), grid, block, 0, s, frames, patches, total4, R, P, g);
   else hipLaunchKernelGGL((patches_kernel<0>), grid, block, 0, s, frames, patches, total4, R, P, g);

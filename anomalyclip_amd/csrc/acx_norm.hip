@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // (one per 32-column panel: half lines; 0.157 ms per ViT LayerNorm against 0.12 for row-major planes).  Here lane pairs trade
 // halves -- the even lane of a pair ends up with eight consecutive elements of row r, the odd lane with the same eight of row r + 1
 // -- so that eight lanes write the 128 contiguous bytes rows r, r + 1 occupy in a panel with 16-byte stores.  Same arithmetic.
-template <int VPL>
+// TWO (ACX_BF16X2P): the hi and mid planes only (the lo plane is left untouched: a pairs = 3 product does not read it)
+template <int VPL, bool TWO = false>
 __global__ __launch_bounds__(256) void layernorm_panel2_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                                const float* __restrict__ b, u16* __restrict__ y, int64_t rows,
                                                                float eps, int mode) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_panel2_kernel(const float* __re
                                (uint32_t)a[4] | ((uint32_t)a[5] << 16), (uint32_t)a[6] | ((uint32_t)a[7] << 16))
     *reinterpret_cast<uint4*>(dst) = LNP_PACK(hh);
     *reinterpret_cast<uint4*>(dst + plane) = LNP_PACK(mm);
-    *reinterpret_cast<uint4*>(dst + 2 * plane) = LNP_PACK(ll);
+    if constexpr (!TWO) *reinterpret_cast<uint4*>(dst + 2 * plane) = LNP_PACK(ll);
 #undef LNP_PACK
   }
 }
@@ -246,10 +247,15 @@ extern "C" int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const fl
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
-  if (y_dtype == ACX_BF16X3P) {        // three planes in K-panel layout [D / 32][rows][32] each (ldy == D), y + p * rows * ldy
+  if (y_dtype == ACX_BF16X3P || y_dtype == ACX_BF16X2P) {   // three planes in K-panel layout [D / 32][rows][32] each (ldy == D), y + p * rows * ldy
     if (ldy != D || D % 256) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm: ACX_BF16X3P needs ldy == D, D %% 256 == 0%s");
     if (!((uintptr_t)y & 15) && !((rows * (int64_t)D * 2) & 15)) {                // 16-byte stores: two rows per wave
       const dim3 grid2((unsigned)((rows + 7) / 8));
+      if (y_dtype == ACX_BF16X2P && D == 768) {                                   // (hi and mid planes only: the ViT width)
+        layernorm_panel2_kernel<12, true><<<grid2, block, 0, s>>>(x, ldx, w, b, (u16*)y, rows, eps, mode);
+        ACX_CHECK_LAUNCH(ctx, "acx_layernorm");
+        return ACX_OK;
+      }
       switch (D / 64) {
         case 4: layernorm_panel2_kernel<4><<<grid2, block, 0, s>>>(x, ldx, w, b, (u16*)y, rows, eps, mode); break;
         case 8: layernorm_panel2_kernel<8><<<grid2, block, 0, s>>>(x, ldx, w, b, (u16*)y, rows, eps, mode); break;

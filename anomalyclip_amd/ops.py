@@ -354,15 +354,15 @@ def attention(qkv: torch.Tensor, batch: int, L_: int, heads: int, causal: bool) 
     return out
 
 
-def attention_p3(qkv3: torch.Tensor, batch: int, L_: int, heads: int) -> torch.Tensor:
+def attention_p3(qkv3: torch.Tensor, batch: int, L_: int, heads: int, products: int = 6) -> torch.Tensor:
     """the ViT attention on the bf16 matrix cores at f32 accuracy (acx_attention_p3): qkv3 [3, batch * L, 3 * heads * 64] = the
     three bf16 planes of q | k | v in K-panel memory order (split_bf16x3(panel=True)); returns the three planes of the output
     [3, batch * L, heads * 64], K-panel memory order as well (unpanel() for row-major)."""
     W = heads * 64
     assert qkv3.dtype == _BF16 and qkv3.is_contiguous() and qkv3.shape == (3, batch * L_, 3 * W)
-    out = torch.empty(3, batch * L_, W, dtype=_BF16, device=qkv3.device)
+    out = (torch.zeros if products == 3 else torch.empty)(3, batch * L_, W, dtype=_BF16, device=qkv3.device)   # (3 products: lo plane unwritten)
     h = _h(qkv3)
-    L.check(L.lib().acx_attention_p3(h, qkv3.data_ptr(), out.data_ptr(), batch, L_, heads, _stream()), h)
+    L.check(L.lib().acx_attention_p3n(h, qkv3.data_ptr(), out.data_ptr(), batch, L_, heads, int(products), _stream()), h)
     return out
 
 

@@ -44,6 +44,9 @@ enum { ACX_F32 = 0, ACX_BF16 = 1,                    /* storage dtypes */
                              of all rows are contiguous (element (r, c) at ((c / 32) * rows + r) * 32 + c % 32; ld % 32 == 0,
                              dense).  The plane-reuse kernel then stages a 256-row x 32-column unit from ONE contiguous 16 KB block
                              instead of 256 half cache lines (acx_gemm_desc.panels) */
+enum { ACX_BF16X2P = 4 };  /* acx_layernorm y_dtype / acx_vit_patches out_dtype: the ACX_BF16X3P image with the hi and mid planes written
+                              only (the lo plane's bytes are left as they are): the A operand of a pairs = 3 product, which never reads
+                              the lo plane.  A producer that does not special-case it writes all three planes. */
 enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1,          /* MFMA arithmetic: exact f32 (v_mfma_f32_32x32x2_f32) or bf16 in / f32 acc */
        ACX_PREC_F32X3 = 3,    /* the same drivers and plane layouts with the THREE leading products only (acx_gemm_desc.pairs = 3:
                                  (mid, hi) (hi, mid) (hi, hi)): sixteen significant bits per operand -- an error of ~1e-5 of sum |a||w| per
@@ -197,6 +200,10 @@ int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_pl
  * accumulation, softmax in f32; output = three bf16 planes of [batch * L, heads * 64] in K-panel layout (the out-projection's
  * A operand).  Non-causal, 192 < L <= 208 (seven 32-query tiles: the ViT-B/16 sequence of 197). */
 int acx_attention_p3(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads, void* stream);
+/* ... with the number of cross products per contraction: 6 (= acx_attention_p3) or 3 (the three leading ones: the operands' lo planes
+ * are not read, the output's lo plane is not written -- the ACX_PREC_F32X3 mode, not f32-accurate) */
+int acx_attention_p3n(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads, int32_t products,
+                      void* stream);
 /* ... with the planes in K-panel layout (ACX_BF16X3P: [ldo / 32][batch * L][32] each; ldo == heads * 64) */
 int acx_attention_x3_panel(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_planes, int64_t ldo,
                            int32_t batch, int32_t L, int32_t heads, void* stream);

@@ -631,6 +631,75 @@ def test_gemm_bf16x6_is_f32_accurate(M, N, K, act, res):
         ops.gemm_x6(a3[:, :, :40].contiguous(), w3[:, :, :40].contiguous(), bias=bd)
 
 
+@pytest.mark.parametrize("M,N,K,act,res,panels", [(2048, 768, 768, 0, 1, 0), (1536, 2304, 768, 0, 0, 3), (1024, 3072, 768, 1, 0, 3), (1000, 772, 3072, 0, 1, 0),
+                                                  (70144, 768, 768, 0, 1, 3), (64, 768, 3072, 0, 0, 3)])
+def test_gemm_three_products_error_and_bits(M, N, K, act, res, panels):
+    """acx_gemm_desc.pairs = 3 (opt-in precision "bf16x3": the three leading cross products of the plane split only; NOT an f32-accurate
+    path): against fp64 element-wise within 3e-5 * sum_k |a||w| (dropped terms <= 2^-16 of the leading one, three of them), at least an
+    order of magnitude below a plain bf16 product, for row-major and K-panel planes, whole tiles, column strips (70144 rows = 822 tiles:
+    a partly filled last round) and a K-split single row tile; run-to-run identical; the lo planes are never read (filled with NaN)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())
+    a[:, 3] *= 60.0
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    x = torch.randn(M, N, generator=g) if res else None
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    xd = x.to(DEV) if res else None
+    a3, w3 = ops.split_bf16x3(ad, panel=bool(panels)), ops.split_bf16x3(wd, panel=bool(panels))
+    a3[2].fill_(float("nan"))
+    w3[2].fill_(float("nan"))
+    kw = dict(bias=bd, act=L.ACT_QUICKGELU if act else L.ACT_NONE, residual=xd, panels=panels, pairs=3)
+    y3 = ops.gemm_x6(a3, w3, **kw)
+    assert torch.isfinite(y3).all()
+    assert torch.equal(y3, ops.gemm_x6(a3, w3, **kw))
+    if M > 8192:                                        # (fp64 reference on the GPU for the big case)
+        pre = ad.double() @ wd.double().t() + bd.double()
+        mag = ad.double().abs() @ wd.double().abs().t() + bd.double().abs()
+        ref = pre + (xd.double() if res else 0.0)
+        e3 = (y3.double() - ref).abs()
+    else:
+        pre = a.double() @ w.double().t() + b.double()
+        mag = a.double().abs() @ w.double().abs().t() + b.double().abs()
+        ref = pre * torch.sigmoid(1.702 * pre) if act else pre
+        if res:
+            ref = ref + x.double()
+        e3 = (y3.cpu().double() - ref).abs()
+    assert bool((e3 <= 3e-5 * mag + 1e-30).all()), float((e3 / mag).max())
+    print("pairs = 3: max err / sum|a||w|", float((e3 / mag).max()))
+    if not act and M <= 8192 and N % 8 == 0:
+        # plane output of the three-product mode: hi and mid planes only; their sum is the f32 result to 2^-16
+        o3 = ops.gemm_x6(a3, w3, bias=bd, panels=panels, pairs=3, planes_out=True, panel_out=bool(panels))
+        two = (ops.unpanel(o3) if panels else o3)[:2].float().sum(0)
+        yb = ops.gemm_x6(a3, w3, bias=bd, panels=panels, pairs=3)
+        assert bool(((two - yb).abs() <= 2.0 ** -15 * yb.abs() + 1e-30).all())
+
+
+@pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (40, 197, 12)])
+def test_attention_three_products_vs_fp64(batch, L_, heads):
+    """acx_attention_p3n(products = 3): the three leading products of QK^T and PV (precision "bf16x3"); against fp64 within 1e-4 of the
+    largest output, the operands' lo planes never read (NaN-filled), identical sequences bit-identical wherever they sit."""
+    W = heads * 64
+    g = torch.Generator().manual_seed(batch * 1000 + L_)
+    qkv = torch.randn(batch * L_, 3 * W, generator=g) * 1.7
+    qkv[:, :W] *= 1.5
+    if batch > 2:
+        qkv[(batch - 1) * L_:] = qkv[:L_]
+    qd = qkv.to(DEV)
+    q3 = ops.split_bf16x3(qd, panel=True)
+    q3[2].fill_(float("nan"))
+    o3 = ops.attention_p3(q3, batch, L_, heads, products=3)
+    out = ops.unpanel(o3)[:2].float().sum(0)
+    x = qd.double().view(batch, L_, 3, heads, 64)
+    q_, k_, v_ = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q_ @ k_.transpose(-1, -2) / 8.0, dim=-1) @ v_).transpose(1, 2).reshape(batch * L_, W)
+    e3 = (out.double() - ref).abs().max().item()
+    print("three products: max |err| / max|ref| vs fp64", e3 / ref.abs().max().item())
+    assert torch.isfinite(out).all() and e3 <= 1e-4 * ref.abs().max().item()
+    if batch > 2:
+        assert torch.equal(out[(batch - 1) * L_:], out[:L_])
+
+
 @pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (1, 193, 1), (40, 197, 12)] + [(3, l_, 3) for l_ in range(194, 208) if l_ != 197])
 def test_attention_p3_vs_fp64(batch, L_, heads):
     """acx_attention_p3 (q, k, v as three bf16 planes in K-panel layout; QK^T and PV as bf16 x 6 products, softmax in f32) against

@@ -161,6 +161,34 @@ def test_vit_b16_launch_sizes_auto(golden, chunk):
     assert relerr(out, o32) < 5e-6 and elem_ok(out, o32)                       # and round-off away from the f32 MFMA path, every frame
 
 
+@pytest.mark.parametrize("chunk", [64, 256])
+def test_vit_b16_three_product_mode(golden, chunk):
+    """precision "bf16x3" (opt-in; ACX_PREC_F32X3: the plane kernels with the three leading cross products, sixteen significant bits
+    per operand -- NOT the f32-accurate default): documents its distance from the REFERENCE's output (within 5e-5 of the largest
+    feature: two orders of magnitude inside BASELINE.json's 1e-3, two orders below the bf16 mode) and from the f32 MFMA path, and
+    keeps the default's position independence (identical frames -> bit-identical rows wherever they sit in the launch)."""
+    g = golden("vit_b16")
+    vit, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="bf16x3")
+    vit.chunk = chunk
+    base = R.vit_frames(int(g["seed"]), 2, 224)
+    extra = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    eight = torch.cat([base, extra], 0)
+    idx = torch.arange(chunk) % 8
+    idx[chunk - 12:] = torch.tensor([7, 3, 0, 1, 5, 5, 2, 6, 4, 0, 1, 7])
+    out = vit(eight[idx].to(DEV))
+    assert out.shape == (chunk, 512) and torch.isfinite(out).all()
+    for k in range(8):
+        rows = out[idx == k]
+        assert torch.equal(rows, rows[:1].expand_as(rows)), k
+    first = [int((idx == k).nonzero()[0]) for k in (0, 1)]
+    e = relerr(out[first], g["out"])
+    print("bf16x3 ViT-B/16 rel err vs reference:", e)
+    assert e < 5e-5
+    vit32, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="f32")
+    vit32.chunk = chunk
+    assert relerr(out, vit32(eight[idx].to(DEV))) < 5e-5
+
+
 def test_vit_two_streams_equals_sequential_half_launches(golden):
     """VisionTransformer(streams = 2) (opt-in): the chunk as two half chunks on two side streams with their own workspaces -- the
     features are bit for bit those of the same half chunks launched one after the other, for an even and a ragged frame count, and
