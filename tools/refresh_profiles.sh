@@ -13,6 +13,8 @@ python bench.py --steps 10 --warmup 3 --precision f32 --no-cpu-baseline > $OUT/b
 python tools/probes/x6_probe.py > $OUT/x6_probe.txt 2>&1
 python tools/probes/x6_time.py all > $OUT/x6_time.txt 2>&1
 python tools/probes/attn_p3_time.py > $OUT/attn_p3_time.txt 2>&1
+python tools/probes/x3_probe.py > $OUT/x3_probe.txt 2>&1
+python tools/probes/vit_two_streams.py > $OUT/vit_two_streams.txt 2>&1
 # train_batch's default = the whole-step graph; --no-step-graph = its autograd fallback (with / without its own graphs)
 python tools/bench_head.py --steps 40 --warmup 5 > $OUT/bench_head.json 2>/dev/null
 python tools/bench_head.py --steps 20 --no-step-graph > $OUT/bench_head_eager.json 2>/dev/null
