@@ -189,6 +189,29 @@ def test_vit_b16_three_product_mode(golden, chunk):
     assert relerr(out, vit32(eight[idx].to(DEV))) < 5e-5
 
 
+def test_model_precision_bf16x3_end_to_end(prompts_table):
+    """AnomalyCLIP(precision = "bf16x3") from FRAMES at the ViT-B/16 geometry (512 frames = one test tile, UCF head): the ViT runs the
+    three-product plane kernels, the head the default's arithmetic; similarity logits and scores stay within 1e-4 (relative to the
+    largest value) of the default precision's on the same weights and frames -- an order of magnitude inside BASELINE.json's 1e-3."""
+    hc = IW.UCF_HEAD
+    frames = torch.randn(1, 512, 3, 224, 224, generator=torch.Generator().manual_seed(21)) * 0.7
+    nc = torch.randn(512, generator=torch.Generator().manual_seed(22)) * 0.05
+    out = {}
+    for precision in ("auto", "bf16x3"):
+        net, sd, eot = build_net("ViT-B/16", hc, "ucf", 31, prompts_table, precision=precision)
+        net.load_from_features = False
+        net.eval()
+        assert net.image_encoder.precision == precision and net.temporal_model.precision == "auto"
+        with torch.no_grad():
+            out[precision] = tuple(t.clone() for t in net(frames.to(DEV), None, nc.to(DEV), 1, True))
+        del net
+    (s6, c6), (s3, c3) = out["auto"], out["bf16x3"]
+    assert torch.isfinite(s3).all() and torch.isfinite(c3).all()
+    print("bf16x3 vs auto: similarity", relerr(s3, s6), "scores", relerr(c3, c6))
+    assert relerr(s3, s6) < 1e-4 and relerr(c3, c6) < 1e-4
+    assert not torch.equal(s3, s6)                      # (the mode is really in use)
+
+
 def test_vit_two_streams_equals_sequential_half_launches(golden):
     """VisionTransformer(streams = 2) (opt-in): the chunk as two half chunks on two side streams with their own workspaces -- the
     features are bit for bit those of the same half chunks launched one after the other, for an even and a ragged frame count, and
