@@ -605,8 +605,11 @@ namespace {
 #ifndef AP3_NOFENCE
 #define AP3_NOFENCE 0
 #endif
+#ifndef AP3_TRACE
+#define AP3_TRACE 0
+#endif
 #ifndef AP3_ABL
-#define AP3_ABL 0   // timing ablations (wrong results): 1 no exp, 2 no output stores, 4 no P V MFMAs, 8 no Q K^T MFMAs, 16 no staging, 32 no plane split of P, 64 no V fragment reads
+#define AP3_ABL 0   // timing ablations (wrong results): 1 no exp, 2 no output stores, 4 no P V MFMAs, 8 no Q K^T MFMAs, 16 no staging, 32 no plane split of P, 64 no V fragment reads, 128 no K fragment reads
 #endif
 constexpr int AP3_ROWS = 208;                         // key rows staged per (plane, panel) block: 13 DMA instructions of 16 rows
 constexpr int AP3_BLK_B = AP3_ROWS * 64;              // 13312
@@ -634,8 +637,20 @@ __device__ __forceinline__ void ap3_split8(const float (&p)[8], bf16x8& hi, bf16
 // K and V are neither staged nor read, P is split into two planes, the output's lo plane is not written (its consumer does not read it)
 template <int NPROD>
 __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__ qkv3, int64_t plane_elems, int64_t rows_total,
-                                                         u16* __restrict__ out3, int64_t out_plane_elems, int L, int heads, int nitems) {
+                                                         u16* __restrict__ out3, int64_t out_plane_elems, int L, int heads, int nitems,
+                                                         long long* __restrict__ trace) {
   constexpr int NPL = NPROD == 3 ? 2 : 3;               // planes of K / V / Q / the output in use
+  // development timeline (-DAP3_TRACE=1 builds + ACX_TRACE_PTR): workgroup 0's waves stamp s_memrealtime (100 MHz) at the phase
+  // boundaries of their first AP3_TRACE_ITEMS items: trace[(item_ordinal * 8 + wave) * 8 + point]
+#if AP3_TRACE
+#ifndef AP3_TRACE_FIRST
+#define AP3_TRACE_FIRST 0
+#endif
+#define AP3_STAMP(ord, pt) do { if (trace && blockIdx.x == 0 && (ord) >= AP3_TRACE_FIRST && (ord) < AP3_TRACE_FIRST + 16 && lane == 0) trace[(((ord) - AP3_TRACE_FIRST) * 8 + wave) * 8 + (pt)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AP3_STAMP(ord, pt) do { } while (0)
+#endif
+  int ord = 0;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -685,13 +700,20 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
     // ================================================================ the stager
     AP3_STAGE(item, 1, 0, 1);                           // K of the first item
     for (; item < nitems; item += (int)gridDim.x) {
+      AP3_STAMP(ord, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K(item) landed
+      AP3_STAMP(ord, 1);
       __builtin_amdgcn_s_barrier();                     // B1: ... and everybody is done with V(previous item)
+      AP3_STAMP(ord, 2);
       AP3_STAGE_SHARED(item, 2, 6, 0);                  // this wave's share of V(item): needed after phase A
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      AP3_STAMP(ord, 3);
       __builtin_amdgcn_s_barrier();                     // B2: V(item) landed, everybody is done with K(item)
+      AP3_STAMP(ord, 4);
       const int nxt = item + (int)gridDim.x;
       if (nxt < nitems) AP3_STAGE(nxt, 1, 0, 1);        // K(next item) during this item's phase B
+      AP3_STAMP(ord, 5);
+      ++ord;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may still be writing this workgroup's LDS at exit
     return;
@@ -719,8 +741,11 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
       for (int ks = 0; ks < 4; ++ks)
         qf[p][ks] = *reinterpret_cast<const bf16x8*>(qkv3 + (int64_t)p * plane_elems +
                                                      ((int64_t)(2 * h + (ks >> 1)) * rows_total + (int64_t)b * L + qrow) * 32 + ((ks & 1) * 2 + hh) * 8);
+    AP3_STAMP(ord, 0);
     __builtin_amdgcn_s_barrier();                       // B1
+    AP3_STAMP(ord, 1);
     AP3_STAGE_SHARED(item, 2, 6, 0);                    // this wave's share of V(item)
+    AP3_STAMP(ord, 2);
     f32x16 sacc[7];
 #pragma unroll
     for (int kt = 0; kt < 7; ++kt) {
@@ -729,11 +754,12 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int cst = (ks >> 1) * AP3_BLK_B + 32 * kt * 64;        // panel of the d step, key tile (swizzle: row bits 2..3 = li's)
-        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + cst);
-        const bf16x8 km = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + 2 * AP3_BLK_B + cst);
+        const bool nok_ = (AP3_ABL & 128) && nitems != 12345;                        // (timing ablation: no K fragment reads)
+        const bf16x8 kh = nok_ ? qf[0][ks] : *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + cst);
+        const bf16x8 km = nok_ ? qf[1][ks] : *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1 : ka0) + 2 * AP3_BLK_B + cst);
         // smallest cross terms first: (hi,lo) (mid,mid) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
         if constexpr (NPROD == 6) {
-        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1l : ka0l) + cst);
+        const bf16x8 kl = nok_ ? qf[2][ks] : *reinterpret_cast<const bf16x8*>(smem + ((ks & 1) ? ka1l : ka0l) + cst);
         if ((AP3_ABL & 8) && nitems != 12345) { sacc[kt][0] += (float)kh[0] + (float)km[0] + (float)kl[0]; continue; }
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[2][ks], sacc[kt], 0, 0, 0);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[1][ks], sacc[kt], 0, 0, 0);
@@ -747,9 +773,14 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
       __builtin_amdgcn_sched_barrier(0);                // keep the tiles' fragment loads from piling up (register budget)
 #endif
     }
+    AP3_STAMP(ord, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of V(item) landed
     __builtin_amdgcn_s_barrier();                       // B2
+    AP3_STAMP(ord, 4);
     // ---------------------------------------------------------------- phase B: softmax, O^T = V^T P^T
+    // (measured in round 6: the softmax moved IN FRONT of this barrier -- it needs neither K nor V, and the two waves of a SIMD leave
+    // phase A 2-3 us apart, the older one winning the matrix pipe -- shortens the traced critical path by ~2 us per item and changes
+    // the kernel's time by nothing: profiles/r06_attention_notes.txt)
     // lane (query li, half hh) holds the scores of keys 32 kt + (e & 3) + 8 (e >> 2) + 4 hh
     float mx = -INFINITY;
 #pragma unroll
@@ -773,6 +804,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
         sum += sacc[kt][e];
       }
     sum += __shfl_xor(sum, 32, 64);
+    AP3_STAMP(ord, 5);                                  // softmax done
     f32x16 oacc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
@@ -789,6 +821,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
         bf16x8 vf[3];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
+          if ((AP3_ABL & 64) && nitems != 12345) { vf[p] = qf[p][dt]; continue; }     // (timing ablation: no V fragment reads)
           const char* vb = smem + (p == 2 ? va2 : va) + ((p == 2 ? 0 : 2 * p) + dt) * AP3_BLK_B + (16 * st) * 64;
           const ap3_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ap3_lds_s16x4*)(vb));
           const ap3_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ap3_lds_s16x4*)(vb + 8 * 64));
@@ -810,6 +843,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
       __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+    AP3_STAMP(ord, 6);                                  // P V done
     // normalise, split into planes, store: lane (query li, hh) holds d = 32 dt + (e & 3) + 8 (e >> 2) + 4 hh, i.e. for every
     // group g4 of four registers an 8-byte piece of its row; v_permlane32_swap pairs the pieces of the two lane halves -- half
     // 0 ends up with d = 16 gp .. + 7, half 1 with d = 16 gp + 8 .. + 15 of the row: 16-byte stores, 12 per wave and item
@@ -848,7 +882,10 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
           }
         }
       }
+    AP3_STAMP(ord, 7);
+    ++ord;
   }
+#undef AP3_STAMP
 #undef AP3_STAGE_SHARED
 #undef AP3_STAGE
 #undef AP3_GLDS
@@ -882,12 +919,17 @@ extern "C" int acx_attention_p3n(acx_ctx* ctx, const void* qkv_planes, void* out
     (void)hipFuncSetAttribute((const void*)attn_p3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B);
     attr_done = true;
   }
+#if AP3_TRACE
+  long long* trace_ = getenv("ACX_TRACE_PTR") ? (long long*)strtoull(getenv("ACX_TRACE_PTR"), nullptr, 0) : nullptr;
+#else
+  long long* trace_ = nullptr;
+#endif
   if (products == 3)
     hipLaunchKernelGGL(attn_p3_kernel<3>, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
-                       rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems);
+                       rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems, trace_);
   else
   hipLaunchKernelGGL(attn_p3_kernel<6>, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
-                     rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems);
+                     rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems, trace_);
   ACX_CHECK_LAUNCH(ctx, "acx_attention_p3");
   return ACX_OK;
 }
