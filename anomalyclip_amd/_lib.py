@@ -11,7 +11,8 @@ from . import _build
 c_void_p, c_int32, c_int64, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 ACX_F32, ACX_BF16, BF16X3, BF16X3P = 0, 1, 2, 3      # BF16X3 / BF16X3P: output only (three bf16 planes hi | mid | lo; P: K-panel layout)
-PREC_F32, PREC_BF16, PREC_F32X6, PREC_F32X3 = 0, 1, 2, 3
+BF16X2P, ACX_F16, F16X2P = 4, 5, 6                     # hi + mid planes only; fp16 planes of the two-plane split (pairs = 3); their K-panel output
+PREC_F32, PREC_BF16, PREC_F32X6, PREC_F32X3, PREC_F16X3 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICKGELU, ACT_LEAKYRELU = 0, 1, 2
 AMAP_IDENTITY, AMAP_CONV3X3, AMAP_TESTTILE, AMAP_TILETABLE = 0, 1, 2, 3
 NORM_LAYER, NORM_CHAN = 0, 1
@@ -39,7 +40,7 @@ class GemmDesc(C.Structure):
         ("counters", c_void_p), ("n_counters", c_int32),
         ("tile_table", c_void_p),
         ("pairs", c_int32), ("panels", c_int32), ("a_plane_stride", c_int64), ("w_plane_stride", c_int64),
-        ("c_plane_rows", c_int64),
+        ("c_plane_rows", c_int64), ("out_scale", c_float),
     ]
 
 
@@ -189,6 +190,7 @@ _SIGS = {
                                         C.POINTER(c_int32), c_void_p]),
     "acx_gemm_tn_zp": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                  c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "acx_split_f16x2": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_float, c_int32, c_void_p]),
     "acx_gemm_tn_parts": (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                     c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, C.POINTER(c_int32), c_void_p]),
     "acx_gemm_tn_x6_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

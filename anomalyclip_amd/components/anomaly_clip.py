@@ -79,7 +79,7 @@ class AnomalyCLIP(nn.Module):
         if self.precision == "f32x6":
             self.precision = "auto"
         vit_precision = self.precision
-        if self.precision == "bf16x3":
+        if self.precision in ("bf16x3", "f16x3"):
             # opt-in, NOT f32-accurate: the ViT's plane products with the three leading cross products only (ACX_PREC_F32X3: sixteen
             # significant bits per operand); the head keeps the default's arithmetic
             self.precision = "auto"

@@ -27,7 +27,10 @@ from .. import ops
 # too small for that kernel (few-frame launches, the text tower, CLS-only rows) run on the f32 MFMA kernels.  "f32": the f32 MFMA
 # kernels everywhere (v_mfma_f32_32x32x2_f32: an fmaf chain).  "bf16": bf16 operands, not a parity path.
 # "bf16x3" (opt-in, NOT f32-accurate): the plane kernels with the three leading cross products only (ACX_PREC_F32X3)
-PRECISIONS = {"auto": L.PREC_F32X6, "f32": L.PREC_F32, "bf16": L.PREC_BF16, "f32x6": L.PREC_F32X6, "bf16x3": L.PREC_F32X3}
+# "f16x3" (opt-in): TWO fp16 planes per operand, three exact products -- f32-MFMA-level results for operands inside fp16's range
+PRECISIONS = {"auto": L.PREC_F32X6, "f32": L.PREC_F32, "bf16": L.PREC_BF16, "f32x6": L.PREC_F32X6, "bf16x3": L.PREC_F32X3,
+              "f16x3": L.PREC_F16X3}
+F16X3_WSCALE = 1024.0                                  # include/acx.h ACX_F16X3_WSCALE
 
 
 class LayerNorm(nn.Module):
@@ -107,12 +110,15 @@ class Transformer(nn.Module):
             w.out_proj_w, w.out_proj_b = b.attn.out_proj.weight.data_ptr(), b.attn.out_proj.bias.data_ptr()
             w.fc_w, w.fc_b = b.mlp.c_fc.weight.data_ptr(), b.mlp.c_fc.bias.data_ptr()
             w.proj_w, w.proj_b = b.mlp.c_proj.weight.data_ptr(), b.mlp.c_proj.bias.data_ptr()
-            if prec in (L.PREC_BF16, L.PREC_F32X6, L.PREC_F32X3):
+            if prec in (L.PREC_BF16, L.PREC_F32X6, L.PREC_F32X3, L.PREC_F16X3):
                 for name, p in (("in_proj_w_bf16", b.attn.in_proj_weight), ("out_proj_w_bf16", b.attn.out_proj.weight),
                                 ("fc_w_bf16", b.mlp.c_fc.weight), ("proj_w_bf16", b.mlp.c_proj.weight)):
                     # bf16 mode: one rounded copy; f32x6: the three planes hi | mid | lo of the f32 weight, each in K-panel
                     # layout [K / 32][N][32] (ACX_BF16X3P: what acx_transformer_forward's bf16 x 6 products read)
-                    t = ops.cast_bf16(p.detach()) if prec == L.PREC_BF16 else ops.split_bf16x3(p.detach(), panel=True)
+                    if prec == L.PREC_F16X3:            # two fp16 planes of 2^10 w (K-panel layout)
+                        t = ops.split_f16x2(p.detach(), panel=True, scale=F16X3_WSCALE)
+                    else:
+                        t = ops.cast_bf16(p.detach()) if prec == L.PREC_BF16 else ops.split_bf16x3(p.detach(), panel=True)
                     keep.append(t)
                     setattr(w, name, t.data_ptr())
         self._cache = (key, (arr, keep))
@@ -181,9 +187,9 @@ class VisionTransformer(nn.Module):
             cb, pb = ops.cast_bf16(conv), ops.cast_bf16(proj_t)
             keep += [cb, pb]
             w.conv1_w_bf16, w.proj_t_bf16 = cb.data_ptr(), pb.data_ptr()
-        elif prec in (L.PREC_F32X6, L.PREC_F32X3):
+        elif prec in (L.PREC_F32X6, L.PREC_F32X3, L.PREC_F16X3):
             # the patch embedding as a bf16 x 6 product: the weight's three planes in K-panel layout (ACX_BF16X3P)
-            cb = ops.split_bf16x3(conv, panel=True)
+            cb = ops.split_f16x2(conv, panel=True, scale=F16X3_WSCALE) if prec == L.PREC_F16X3 else ops.split_bf16x3(conv, panel=True)
             keep.append(cb)
             w.conv1_w_bf16 = cb.data_ptr()
         w.class_embedding = self.class_embedding.data_ptr()

@@ -154,8 +154,10 @@ struct TfWs {   // transformer scratch carved from the caller's workspace
 };
 
 // the plane modes of the drivers: ACX_PREC_F32X6 (six products: f32-accurate) and ACX_PREC_F32X3 (the three leading products)
-static inline bool is_xmode(int prec) { return prec == ACX_PREC_F32X6 || prec == ACX_PREC_F32X3; }
+static inline bool is_xmode(int prec) { return prec == ACX_PREC_F32X6 || prec == ACX_PREC_F32X3 || prec == ACX_PREC_F16X3; }
 static thread_local int tl_x_pairs = 6;          // acx_gemm_desc.pairs of the driver's plane products (set at the driver's entry)
+static thread_local bool tl_x_f16 = false;       // ACX_PREC_F16X3: two fp16 planes per operand (weights scaled by ACX_F16X3_WSCALE)
+static inline void set_xmode(int prec) { tl_x_pairs = (prec == ACX_PREC_F32X3 || prec == ACX_PREC_F16X3) ? 3 : 6; tl_x_f16 = prec == ACX_PREC_F16X3; }
 
 TfWs carve_tf(char* base, int64_t rows, int W, int prec = ACX_PREC_F32) {
   TfWs w;
@@ -200,7 +202,8 @@ int linear_x6(acx_ctx* ctx, const void* A3, int lda, int64_t a_rows, const void*
   memset(&d, 0, sizeof(d));
   d.A = A3; d.W = W3; d.C = C;
   d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc;
-  d.a_dtype = ACX_BF16; d.c_dtype = c_dtype; d.prec = ACX_PREC_BF16;
+  d.a_dtype = tl_x_f16 ? ACX_F16 : ACX_BF16; d.c_dtype = (tl_x_f16 && c_dtype == ACX_BF16X3P) ? ACX_F16X2P : c_dtype; d.prec = ACX_PREC_BF16;
+  d.out_scale = tl_x_f16 ? 1.f / ACX_F16X3_WSCALE : 0.f;
   d.bias = bias; d.act = act; d.residual = residual; d.ldr = ldr ? ldr : ldc;
   d.pairs = tl_x_pairs; d.a_plane_stride = a_rows * (int64_t)lda * 2; d.w_plane_stride = w_plane_bytes;
   d.panels = 3;
@@ -270,7 +273,8 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
                        const acx_block_weights* blk, const TfWs& ws, hipStream_t s, float* cls_ws = nullptr) {
   const int64_t rows = (int64_t)batch * L;
   const bool x6mode = is_xmode(prec);
-  const int pdt3 = prec == ACX_PREC_F32X3 ? ACX_BF16X2P : ACX_BF16X3P;    // LayerNorm's plane output (three products: hi and mid only)
+  const int pdt3 = prec == ACX_PREC_F16X3 ? ACX_F16X2P : prec == ACX_PREC_F32X3 ? ACX_BF16X2P : ACX_BF16X3P;   // LayerNorm's plane output
+  const bool f16mode = prec == ACX_PREC_F16X3;
   if (x6mode) prec = ACX_PREC_F32;               // everything that is not one of the four large GEMMs runs as in f32 mode
   const int hdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   const size_t esz = prec == ACX_PREC_BF16 ? 2 : 4;
@@ -335,10 +339,12 @@ int transformer_layers(acx_ctx* ctx, float* x, int batch, int L, int W, int head
     if ((rc = linear(ctx, prec, ws.h, hdt, W, b.in_proj_w, b.in_proj_w_bf16, W, ws.qkv, qdt, 3 * W, (int)rows, 3 * W, W,
                      b.in_proj_b, ACX_ACT_NONE, nullptr, s, 0, ws.splitk, ws.splitk_bytes))) return rc;
     const bool att_x3 = x6_out && !causal && L > 128 && L <= 224 && ACX_DBG_SWITCH("ATTN16", true);
+    if (f16mode && (x6_qkv || x6_out || x6_fc || x6_proj) && !(att_p3 && x6_fc && x6_proj))
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "driver: ACX_PREC_F16X3 needs the planes attention (192 < L <= 208) and all four products on the plane kernel%s");
     if (ab) {
       if ((rc = acx_attention_bf16(ctx, ws.qkv, 3 * W, ws.att, W, batch, L, heads, s))) return rc;
     } else if (att_p3) {   // planes in, planes out
-      if ((rc = acx_attention_p3n(ctx, ws.qkv3, ws.hp, batch, L, heads, tl_x_pairs, s))) return rc;
+      if ((rc = acx_attention_p3n(ctx, ws.qkv3, ws.hp, batch, L, heads, f16mode ? 103 : tl_x_pairs, s))) return rc;
     } else if (att_x3) {   // the attention writes the out-projection's three planes itself
       if ((rc = acx_attention_x3_panel(ctx, (const float*)ws.qkv, 3 * W, ws.hp, W, batch, L, heads, s))) return rc;
     } else {
@@ -395,7 +401,7 @@ extern "C" int acx_transformer_forward(acx_ctx* ctx, float* x, int32_t batch, in
   TfWs ws = carve_tf((char*)workspace, (int64_t)batch * L, width, prec);
   if (ws.total > workspace_bytes && is_xmode(prec)) ws = carve_tf((char*)workspace, (int64_t)batch * L, width);
   if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_transformer_forward: workspace too small%s");
-  tl_x_pairs = prec == ACX_PREC_F32X3 ? 3 : 6;
+  set_xmode(prec);
   return transformer_layers(ctx, x, batch, L, width, heads, layers, causal, prec, blocks, ws, (hipStream_t)stream);
 }
 
@@ -439,7 +445,7 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   if (ws.total > workspace_bytes) return acx_fail(ctx, ACX_E_WORKSPACE, "acx_vit_encode: workspace too small%s");
   hipStream_t s = (hipStream_t)stream;
   const int prec = is_xmode(d->prec) ? ACX_PREC_F32 : d->prec;   // final projection (and small launches): f32 kernels
-  tl_x_pairs = d->prec == ACX_PREC_F32X3 ? 3 : 6;
+  set_xmode(d->prec);
   const int pdt = prec == ACX_PREC_BF16 ? ACX_BF16 : ACX_F32;
   int rc;
   // conv1 as GEMM over im2col'ed patches                               clip/model.py:267-269
@@ -447,7 +453,8 @@ extern "C" int acx_vit_encode(acx_ctx* ctx, const acx_vit_desc* d, const acx_vit
   if (is_xmode(d->prec) && w->conv1_w_bf16 && K % 32 == 0 && x6_takes(ctx, tf, (int64_t)F * T, W, K, K)) {
     // ACX_PREC_F32X6: im2col writes the three bf16 planes of the pixels (K-panel layout), the embedding is a pairs = 6 product
     // like the layers' GEMMs (conv1_w_bf16: the weight's three K-panel planes); scratch for a K-split tail: the f32 q | k | v buffer
-    if ((rc = acx_vit_patches(ctx, frames, ws.patches, d->prec == ACX_PREC_F32X3 ? ACX_BF16X2P : ACX_BF16X3P, F, d->resolution, d->patch, s))) return rc;
+    if ((rc = acx_vit_patches(ctx, frames, ws.patches, d->prec == ACX_PREC_F16X3 ? ACX_F16X2P : d->prec == ACX_PREC_F32X3 ? ACX_BF16X2P : ACX_BF16X3P,
+                              F, d->resolution, d->patch, s))) return rc;
     if ((rc = linear_x6(ctx, ws.patches, K, (int64_t)F * T, w->conv1_w_bf16, (int64_t)W * K * 2, K, ws.patch_out, W, F * T, W, K, nullptr,
                         ACX_ACT_NONE, nullptr, s, 0, ACX_F32, tf.qkv, (size_t)F * (T + 1) * 3 * W * 4))) return rc;
   } else {

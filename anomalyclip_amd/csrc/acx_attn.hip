@@ -619,14 +619,15 @@ typedef short ap3_s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) ap3_s16x4 ap3_lds_s16x4;
 typedef __attribute__((address_space(3))) void ap3_lds_void;
 
+template <int F16 = 0>
 __device__ __forceinline__ void ap3_split8(const float (&p)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
   uint32_t h[4], m[4], l[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    h[e] = f2bf2(p[2 * e], p[2 * e + 1]);
-    const float r0 = p[2 * e] - __uint_as_float(h[e] << 16), r1 = p[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
-    m[e] = f2bf2(r0, r1);
-    l[e] = f2bf2(r0 - __uint_as_float(m[e] << 16), r1 - __uint_as_float(m[e] & 0xffff0000u));
+    h[e] = acx_pk2<F16>(p[2 * e], p[2 * e + 1]);
+    const float r0 = p[2 * e] - acx_unpk_lo<F16>(h[e]), r1 = p[2 * e + 1] - acx_unpk_hi<F16>(h[e]);
+    m[e] = acx_pk2<F16>(r0, r1);
+    l[e] = f2bf2(r0 - acx_unpk_lo<F16>(m[e]), r1 - acx_unpk_hi<F16>(m[e]));
   }
   typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
   const u32x4_ hv = {h[0], h[1], h[2], h[3]}, mv = {m[0], m[1], m[2], m[3]}, lv = {l[0], l[1], l[2], l[3]};
@@ -635,7 +636,18 @@ __device__ __forceinline__ void ap3_split8(const float (&p)[8], bf16x8& hi, bf16
 
 // NPROD = 3 (ACX_PREC_F32X3): the three leading products of both contractions only -- (hi, mid) (mid, hi) (hi, hi); the lo planes of
 // K and V are neither staged nor read, P is split into two planes, the output's lo plane is not written (its consumer does not read it)
-template <int NPROD>
+// F16 (with NPROD = 3: ACX_PREC_F16X3): the planes are TWO fp16 planes (hi | lo of the two-plane fp16 split), the products run on
+// v_mfma_f32_32x32x16_f16, P and the output are split into fp16 pairs
+template <int F16>
+__device__ __forceinline__ f32x16 ap3_mfma(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (F16 != 0) {
+    typedef _Float16 ap3_h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ap3_h8, a), __builtin_bit_cast(ap3_h8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+}
+template <int NPROD, int F16 = 0>
 __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__ qkv3, int64_t plane_elems, int64_t rows_total,
                                                          u16* __restrict__ out3, int64_t out_plane_elems, int L, int heads, int nitems,
                                                          long long* __restrict__ trace) {
@@ -765,9 +777,9 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[1][ks], sacc[kt], 0, 0, 0);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ks], sacc[kt], 0, 0, 0);
         }
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][ks], sacc[kt], 0, 0, 0);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][ks], sacc[kt], 0, 0, 0);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = ap3_mfma<F16>(kh, qf[1][ks], sacc[kt]);
+        sacc[kt] = ap3_mfma<F16>(km, qf[0][ks], sacc[kt]);
+        sacc[kt] = ap3_mfma<F16>(kh, qf[0][ks], sacc[kt]);
       }
 #if !AP3_NOFENCE
       __builtin_amdgcn_sched_barrier(0);                // keep the tiles' fragment loads from piling up (register budget)
@@ -815,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
                            sacc[kt][8 * u + 4], sacc[kt][8 * u + 5], sacc[kt][8 * u + 6], sacc[kt][8 * u + 7]};
       bf16x8 ph, pm, pl;
       if ((AP3_ABL & 32) && nitems != 12345) { ph = pm = pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&pv[0])); } else
-      ap3_split8(pv, ph, pm, pl);                       // (NPROD == 3: pl is dead code)
+      ap3_split8<F16>(pv, ph, pm, pl);                  // (NPROD == 3: pl is dead code)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         bf16x8 vf[3];
@@ -835,9 +847,9 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pm, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pl, oacc[dt], 0, 0, 0);
         }
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], ph, oacc[dt], 0, 0, 0);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pm, oacc[dt], 0, 0, 0);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, oacc[dt], 0, 0, 0);
+        oacc[dt] = ap3_mfma<F16>(vf[1], ph, oacc[dt]);
+        oacc[dt] = ap3_mfma<F16>(vf[0], pm, oacc[dt]);
+        oacc[dt] = ap3_mfma<F16>(vf[0], ph, oacc[dt]);
       }
 #if !AP3_NOFENCE
       __builtin_amdgcn_sched_barrier(0);
@@ -860,10 +872,10 @@ __global__ __launch_bounds__(512, 2) void attn_p3_kernel(const u16* __restrict__
           const int g4 = 2 * gp + z;
           const float ov[4] = {oacc[dt][4 * g4] * inv, oacc[dt][4 * g4 + 1] * inv, oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv};
           uint2 ph2, pm2, pl2;
-          ph2.x = f2bf2(ov[0], ov[1]); ph2.y = f2bf2(ov[2], ov[3]);
-          const float r0 = ov[0] - __uint_as_float(ph2.x << 16), r1 = ov[1] - __uint_as_float(ph2.x & 0xffff0000u);
-          const float r2 = ov[2] - __uint_as_float(ph2.y << 16), r3 = ov[3] - __uint_as_float(ph2.y & 0xffff0000u);
-          pm2.x = f2bf2(r0, r1); pm2.y = f2bf2(r2, r3);
+          ph2.x = acx_pk2<F16>(ov[0], ov[1]); ph2.y = acx_pk2<F16>(ov[2], ov[3]);
+          const float r0 = ov[0] - acx_unpk_lo<F16>(ph2.x), r1 = ov[1] - acx_unpk_hi<F16>(ph2.x);
+          const float r2 = ov[2] - acx_unpk_lo<F16>(ph2.y), r3 = ov[3] - acx_unpk_hi<F16>(ph2.y);
+          pm2.x = acx_pk2<F16>(r0, r1); pm2.y = acx_pk2<F16>(r2, r3);
           pl2.x = f2bf2(r0 - __uint_as_float(pm2.x << 16), r1 - __uint_as_float(pm2.x & 0xffff0000u));
           pl2.y = f2bf2(r2 - __uint_as_float(pm2.y << 16), r3 - __uint_as_float(pm2.y & 0xffff0000u));
           pl_[z][0] = ph2; pl_[z][1] = pm2; pl_[z][2] = pl2;
@@ -903,7 +915,9 @@ extern "C" int acx_attention_p3(acx_ctx* ctx, const void* qkv_planes, void* out_
 extern "C" int acx_attention_p3n(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads,
                                  int32_t products, void* stream) {
   if (!qkv_planes || !out_planes) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_p3: null pointer%s");
-  if (products != 6 && products != 3) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_p3n: products must be 6 or 3%s");
+  const bool f16 = products == 103;                     // 103: three products on TWO fp16 planes (ACX_PREC_F16X3)
+  if (f16) products = 3;
+  if (products != 6 && products != 3) return acx_fail(ctx, ACX_E_BADARG, "acx_attention_p3n: products must be 6, 3 or 103 (3 on fp16 planes)%s");
   if (batch <= 0) return ACX_OK;
   if (L <= 192 || L > AP3_ROWS || heads <= 0 || (((uintptr_t)qkv_planes | (uintptr_t)out_planes) & 15))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_attention_p3: 192 < L <= 208, 16-byte aligned planes%s");
@@ -917,6 +931,7 @@ extern "C" int acx_attention_p3n(acx_ctx* ctx, const void* qkv_planes, void* out
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)attn_p3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B);
     (void)hipFuncSetAttribute((const void*)attn_p3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B);
+    (void)hipFuncSetAttribute((const void*)attn_p3_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP3_LDS_B);
     attr_done = true;
   }
 #if AP3_TRACE
@@ -924,7 +939,10 @@ extern "C" int acx_attention_p3n(acx_ctx* ctx, const void* qkv_planes, void* out
 #else
   long long* trace_ = nullptr;
 #endif
-  if (products == 3)
+  if (f16)
+    hipLaunchKernelGGL((attn_p3_kernel<3, 1>), dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
+                       rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems, trace_);
+  else if (products == 3)
     hipLaunchKernelGGL(attn_p3_kernel<3>, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), (size_t)AP3_LDS_B, s, (const u16*)qkv_planes,
                        rows * 3 * heads * 64, rows, (u16*)out_planes, rows * heads * 64, L, heads, nitems, trace_);
   else

@@ -583,7 +583,12 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   const int prec = d->prec;
   if (prec != ACX_PREC_F32 && prec != ACX_PREC_BF16)
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: unknown precision%s");
-  const int a_bf16 = d->a_dtype == ACX_BF16, c_bf16 = d->c_dtype == ACX_BF16;
+  // ACX_F16: fp16 planes of the two-plane split (pairs = 3 only: the X3 = 2 instantiation of the plane-reuse kernel); handled with the
+  // bf16 planes' checks below (16-bit elements)
+  const int a_f16 = d->a_dtype == ACX_F16;
+  if (a_f16 != (d->c_dtype == ACX_F16X2P ? 1 : a_f16) || (a_f16 && d->pairs != 3) || (d->c_dtype == ACX_F16X2P && !a_f16))
+    return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: fp16 planes (ACX_F16 / ACX_F16X2P) come with pairs = 3%s");
+  const int a_bf16 = d->a_dtype == ACX_BF16 || a_f16, c_bf16 = d->c_dtype == ACX_BF16;
   if (prec == ACX_PREC_F32 && (a_bf16))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: PREC_F32 needs f32 A%s");
   const int kal = prec == ACX_PREC_F32 ? 4 : 8;
@@ -786,14 +791,16 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
     const bool x3 = d->pairs == 3;               // the three leading products only (acx_gemm_x6.h, X3): identity rows
     if (x3 && (conv || c_bf16 || d->act == ACX_ACT_LEAKYRELU))
       return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: pairs = 3 takes identity rows, f32 or plane outputs, bias / QuickGELU / residual epilogues%s");
-    const bool c_x3_ = d->c_dtype == ACX_BF16X3 || d->c_dtype == ACX_BF16X3P;
+    const bool c_x3_ = d->c_dtype == ACX_BF16X3 || d->c_dtype == ACX_BF16X3P || d->c_dtype == ACX_F16X2P;
+    if (a_f16 && c_x3_ && d->c_dtype != ACX_F16X2P)
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: fp16 operand planes write fp16 output planes (ACX_F16X2P)%s");
     const bool shape_ok = prec == ACX_PREC_BF16 && a_bf16 && (d->amap == ACX_AMAP_IDENTITY || conv) && !d->a_sub && !d->pos0 &&
         d->K % 32 == 0 && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && (!d->residual || d->ldr % 4 == 0) &&
         !(((uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) && d->a_plane_stride > 0 && d->w_plane_stride > 0 &&
         !((d->a_plane_stride | d->w_plane_stride) & 15) && (size_t)d->M * d->lda * 2 < ((size_t)1 << 32) &&
         (size_t)d->N * d->ldw * 2 < ((size_t)1 << 32) && !(d->act == ACX_ACT_QUICKGELU && d->residual) &&
         !(d->act == ACX_ACT_LEAKYRELU && d->residual) && !(c_x3_ && (d->residual || d->N % 8 || d->ldc % 8)) && !(c_bf16 && d->residual) &&
-        (!d->panels || (!conv && d->K % 32 == 0 && d->lda == d->K && d->ldw == d->K)) && (d->c_dtype != ACX_BF16X3P || d->ldc == d->N) &&
+        (!d->panels || (!conv && d->K % 32 == 0 && d->lda == d->K && d->ldw == d->K)) && ((d->c_dtype != ACX_BF16X3P && d->c_dtype != ACX_F16X2P) || d->ldc == d->N) &&
         (!conv || (d->zero_page && !((uintptr_t)d->zero_page & 15) && d->cin % 32 == 0 && !(d->gl & (d->gl - 1)) &&
                    !(d->gn & (d->gn - 1)) && d->M % 256 == 0));
     if (shape_ok) {
@@ -806,7 +813,8 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
       const int nks = d->K / 32;
       int split = 1;
       double split_us = 0.0;
-      if (d->workspace && xt < ncu) split = x6_choose_split(xt, nks, ncu, (size_t)d->M * d->N * sizeof(float), d->workspace_bytes, 6, &split_us);
+      if (d->workspace && xt < ncu && !(a_f16 && c_x3_))   // (no reduce launch writes fp16 planes: such launches keep whole K per tile)
+        split = x6_choose_split(xt, nks, ncu, (size_t)d->M * d->N * sizeof(float), d->workspace_bytes, 6, &split_us);
       // A partly filled LAST round of tiles (N = 768 at 256 frames: 591 tiles = 2.3 rounds of 256 CUs) is cut into column STRIPS:
       // the full rounds go out as whole tiles, the remaining `rem` tiles as 2 rem strips of 128 columns or 4 rem strips of 64
       // (the NI = 2 / 1 instantiations, acx_gemm_x6.h) when that makes the last round shorter.  Strips leave every row's K order
@@ -835,6 +843,16 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
 #define ACX_X6L_(CM, ACT, RES, CV, NI_, GRID)                                                        \
   do {                                                                                              \
     if constexpr ((CV) == 0 && (CM) != 1 && (ACT) != 2) {   /* (the ViT's epilogues: f32 / plane outputs, bias, QuickGELU, residual) */ \
+      if (x3 && a_f16) {                                                                            \
+        static bool attr4_dev_[64] = {}; bool& attr4_done = attr4_dev_[dev_slot];                   \
+        if (!attr4_done) {                                                                          \
+          (void)hipFuncSetAttribute((const void*)gemm_x6_p4_kernel<CM, ACT, RES, 0, 0, 0, NI_, 0, 2>, \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_B);     \
+          attr4_done = true;                                                                        \
+        }                                                                                           \
+        hipLaunchKernelGGL((gemm_x6_p4_kernel<CM, ACT, RES, 0, 0, 0, NI_, 0, 2>), GRID, dim3(256), (size_t)X6_LDS_B, s, g); \
+        break;                                                                                      \
+      }                                                                                             \
       if (x3) {                                                                                     \
         static bool attr3_dev_[64] = {}; bool& attr3_done = attr3_dev_[dev_slot];                   \
         if (!attr3_done) {                                                                          \

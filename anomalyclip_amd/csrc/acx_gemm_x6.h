@@ -79,6 +79,22 @@ __device__ __forceinline__ bf16x8 x6_tr_frag(const char* smem, int off_lo, int o
 // stay [32 k][256 channels], the channels behind the tile come from the zero page.
 // W14 (TN only): wave grid 1 x 4 -- the tile is 128 rows x 128 NI columns (N1 = 128: the weight gradient of a convolution with
 // 128 output channels), the upper half of the A units from the zero page.
+// one MFMA of the plane products: bf16 planes (F16 = 0) or fp16 planes (F16 = 1: the two-plane fp16 split of X3 = 2)
+template <int F16>
+__device__ __forceinline__ f32x16 x6_mfma(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (F16 != 0) {
+    typedef _Float16 x6_h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x6_h8, a), __builtin_bit_cast(x6_h8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+}
+
+// X3 = 2: the same three-product schedule on TWO fp16 planes per operand (x = hi + lo, hi = fp16(x), lo = fp16(x - hi): 11 + 11
+// significant bits + the sign trick of round-to-nearest = x to 2^-24 while lo is a normal number): (lo, hi) (hi, lo) (hi, hi) on
+// v_mfma_f32_32x32x16_f16, every fp16 x fp16 product exact in f32, the dropped (lo, lo) term <= 2^-22 of the leading one -- an error of
+// ~2^-22 of sum |a||w|, the f32 MFMA kernel's level, for operands inside fp16's range (|x| < 65504; elements below ~2^-3 carry an
+// ABSOLUTE error of <= 2^-25: rows that are tiny as a whole lose relative accuracy).  Plane outputs are fp16 pairs as well.
 // X3 (acx_gemm_desc.pairs = 3; identity rows, NT): the THREE leading cross products only -- (A.mid, W.hi) (A.hi, W.mid) (A.hi, W.hi):
 // every bf16 x bf16 product exact, the dropped terms <= 2^-16 of the leading one (an error of ~1e-5 of sum |a||w|: sixteen significant
 // bits per operand, between TF32's ten and f32's twenty-four) -- on the same frame: a K-step is ONE half-step with the Y half-step's
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   const bool apanel = !CONV && !TN && (d.panels & 1), wpanel = !TN && (d.panels & 2);
   const size_t a_kstride = apanel ? (size_t)d.a_plane_stride / (size_t)(d.K / 32) : (size_t)64;
   const size_t w_kstride = wpanel ? (size_t)d.w_plane_stride / (size_t)(d.K / 32) : (size_t)64;
-  const bool cpanel = C_MODE == 2 && d.c_dtype == ACX_BF16X3P;
+  const bool cpanel = C_MODE == 2 && (d.c_dtype == ACX_BF16X3P || d.c_dtype == ACX_F16X2P);
   // TN: byte offset of this lane's 16-byte piece of instruction i inside the row's 512-byte tile slice (source-side swizzle)
 #define X6_TCH(i) ((((((lane & 31) >> 2) ^ ((2 * (i) + (lane >> 5)) & 7)) << 2) | (lane & 3)) * 16)
 #define X6_SET_ITEM(S, jj)                                                                         \
@@ -322,13 +338,13 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
   do {                                                                                             \
     constexpr int p_ = (q) / 16, mi_ = ((q) % 16) / 4, ni_ = (q) % 4;                              \
     if constexpr (ni_ < NI)                                                                        \
-    acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[(p_ == 0 ? 12 : p_ == 1 ? 8 : 4) + ni_], F[mi_], acc[mi_][ni_], 0, 0, 0); \
+    acc[mi_][ni_] = x6_mfma<0>(F[(p_ == 0 ? 12 : p_ == 1 ? 8 : 4) + ni_], F[mi_], acc[mi_][ni_]); \
   } while (0)
 #define X6_MM_Y(F, q)                                                                              \
   do {                                                                                             \
     constexpr int p_ = (q) / 16, mi_ = ((q) % 16) / 4, ni_ = (q) % 4;                              \
     if constexpr (ni_ < NI)                                                                        \
-    acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[(p_ == 1 ? 8 : 4) + ni_], F[(p_ == 0 ? 12 : 0) + mi_], acc[mi_][ni_], 0, 0, 0); \
+    acc[mi_][ni_] = x6_mfma<(X3 == 2)>(F[(p_ == 1 ? 8 : 4) + ni_], F[(p_ == 0 ? 12 : 0) + mi_], acc[mi_][ni_]); \
   } while (0)
 #define X6_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define X6_REP48(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32) M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40) M(41) M(42) M(43) M(44) M(45) M(46) M(47)
@@ -529,6 +545,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
       // each 32x32 accumulator tile goes through this wave's private 4 KB of LDS (XOR-swizzled 128-B rows) and comes back
       // row-major: lane l owns 4 consecutive columns (l & 7) of row (l >> 3) + 8 pass: 4 stores of 8 rows x 128 B per tile.
       char* scr = smem + 8 * X6_UNIT_B + wave * 4096;
+      // fp16 planes (X3 = 2): the operands' power-of-two scales leave here; the other instantiations multiply by the CONSTANT 1 (no code)
+      const float osc_ = (X3 == 2) ? (d.out_scale != 0.f ? d.out_scale : 1.f) : 1.f;
       const int rl = lane >> 3, cj = lane & 7;
       const int colw = n0 + wn * 32 * NI + 4 * cj;   // + 32 ni
       const int roww = m0 + wm * 128 + rl;       // + 32 mi + 8 ps
@@ -579,8 +597,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
         const int rr_ = (lane >> 2) + 16 * ps;                                                     \
         const float4 va_ = *reinterpret_cast<const float4*>(scr + rr_ * 128 + (((2 * (lane & 3)) ^ (rr_ & 7)) * 16));     \
         const float4 vb_ = *reinterpret_cast<const float4*>(scr + rr_ * 128 + (((2 * (lane & 3) + 1) ^ (rr_ & 7)) * 16)); \
-        float ov[8] = {va_.x + bia[ni].x, va_.y + bia[ni].y, va_.z + bia[ni].z, va_.w + bia[ni].w,                          \
-                       vb_.x + bib[ni].x, vb_.y + bib[ni].y, vb_.z + bib[ni].z, vb_.w + bib[ni].w};                          \
+        float ov[8] = {va_.x * osc_ + bia[ni].x, va_.y * osc_ + bia[ni].y, va_.z * osc_ + bia[ni].z, va_.w * osc_ + bia[ni].w,  \
+                       vb_.x * osc_ + bib[ni].x, vb_.y * osc_ + bib[ni].y, vb_.z * osc_ + bib[ni].z, vb_.w * osc_ + bib[ni].w};  \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                            \
           if constexpr (ACT == ACX_ACT_QUICKGELU) ov[e] = acx_quickgelu(ov[e]);                    \
           else if constexpr (ACT == ACX_ACT_LEAKYRELU) ov[e] = ov[e] > 0.f ? ov[e] : 0.01f * ov[e]; \
@@ -588,15 +606,16 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
         /* three bf16 planes hi | mid | lo of the f32 value (ACX_BF16X3): the next pairs = 6 product's A operand */ \
         uint4 ph, pm, pl;                                                                          \
         float r1[8], r2[8];                                                                        \
-        ph.x = f2bf2(ov[0], ov[1]); ph.y = f2bf2(ov[2], ov[3]); ph.z = f2bf2(ov[4], ov[5]); ph.w = f2bf2(ov[6], ov[7]); \
+        constexpr int PF_ = (X3 == 2);             /* plane format: bf16 triples, or fp16 pairs (X3 = 2) */ \
+        ph.x = acx_pk2<PF_>(ov[0], ov[1]); ph.y = acx_pk2<PF_>(ov[2], ov[3]); ph.z = acx_pk2<PF_>(ov[4], ov[5]); ph.w = acx_pk2<PF_>(ov[6], ov[7]); \
         const unsigned hw_[4] = {ph.x, ph.y, ph.z, ph.w};                                          \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-          r1[2 * e] = ov[2 * e] - __uint_as_float(hw_[e] << 16); r1[2 * e + 1] = ov[2 * e + 1] - __uint_as_float(hw_[e] & 0xffff0000u); \
+          r1[2 * e] = ov[2 * e] - acx_unpk_lo<PF_>(hw_[e]); r1[2 * e + 1] = ov[2 * e + 1] - acx_unpk_hi<PF_>(hw_[e]); \
         }                                                                                          \
-        pm.x = f2bf2(r1[0], r1[1]); pm.y = f2bf2(r1[2], r1[3]); pm.z = f2bf2(r1[4], r1[5]); pm.w = f2bf2(r1[6], r1[7]); \
+        pm.x = acx_pk2<PF_>(r1[0], r1[1]); pm.y = acx_pk2<PF_>(r1[2], r1[3]); pm.z = acx_pk2<PF_>(r1[4], r1[5]); pm.w = acx_pk2<PF_>(r1[6], r1[7]); \
         const unsigned mw_[4] = {pm.x, pm.y, pm.z, pm.w};                                          \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-          r2[2 * e] = r1[2 * e] - __uint_as_float(mw_[e] << 16); r2[2 * e + 1] = r1[2 * e + 1] - __uint_as_float(mw_[e] & 0xffff0000u); \
+          r2[2 * e] = r1[2 * e] - acx_unpk_lo<PF_>(mw_[e]); r2[2 * e + 1] = r1[2 * e + 1] - acx_unpk_hi<PF_>(mw_[e]); \
         }                                                                                          \
         pl.x = f2bf2(r2[0], r2[1]); pl.y = f2bf2(r2[2], r2[3]); pl.z = f2bf2(r2[4], r2[5]); pl.w = f2bf2(r2[6], r2[7]); \
         const int row = rowp + mi * 32 + 16 * ps, colq = colp + 32 * ni;                           \
@@ -615,6 +634,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_p4_kernel(const Args g) {
     _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                             \
       const int rr_ = rl + 8 * ps;                                                                 \
       float4 v = *reinterpret_cast<const float4*>(scr + rr_ * 128 + ((cj ^ (rr_ & 7)) * 16));     \
+      if constexpr (X3 == 2) { v.x *= osc_; v.y *= osc_; v.z *= osc_; v.w *= osc_; }               \
       v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;                                          \
       if constexpr (ACT == ACX_ACT_QUICKGELU) {                                                    \
         v.x = acx_quickgelu(v.x); v.y = acx_quickgelu(v.y);                                        \

@@ -27,6 +27,16 @@ __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ 
     // of the patch embedding as a pairs = 6 product (ACX_PREC_F32X6)
     const float x[4] = {v.x, v.y, v.z, v.w};
     u16 h[4], m[4], l[4];
+    if constexpr (OUT_BF16 == 4) {                     // (ACX_F16X2P: two fp16 planes)
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const uint32_t ph_ = f2h2(x[e], x[e + 1]);
+        const uint32_t pl_ = f2h2(x[e] - h2f_lo(ph_), x[e + 1] - h2f_hi(ph_));
+        h[e] = (u16)(ph_ & 0xffffu); h[e + 1] = (u16)(ph_ >> 16);
+        m[e] = (u16)(pl_ & 0xffffu); m[e + 1] = (u16)(pl_ >> 16);
+        l[e] = l[e + 1] = 0;
+      }
+    } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       h[e] = f2bf(x[e]);
@@ -34,6 +44,7 @@ __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ 
       const float r1 = x[e] - bf2f(h[e]);
       m[e] = f2bf(r1);
       l[e] = f2bf(r1 - bf2f(m[e]));
+    }
     }
     const int64_t rows = total4 / K4, plane = rows * K;
     u16* d0 = (u16*)out + ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
@@ -543,9 +554,11 @@ __global__ __launch_bounds__(256) void class_probs_kernel(const float* __restric
 }
 
 // x = hi + mid + lo with three bf16 (8 significant bits each: 24 in all); x - hi and (x - hi) - mid are exact in f32
-template <int PANEL>
+// F16: two fp16 planes hi | lo of scale * x (scale: a power of two -- exact; the ACX_PREC_F16X3 weights are lifted into fp16's normal
+// range by it) instead of three bf16 planes; the third plane is not written
+template <int PANEL, int F16 = 0>
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, int64_t ld, u16* __restrict__ dst,
-                                                           int64_t plane, int64_t rows, int cols4) {
+                                                           int64_t plane, int64_t rows, int cols4, float scale = 1.f) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * cols4) return;
   const int64_t r = i / cols4;
@@ -553,6 +566,16 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   const float4 v = *reinterpret_cast<const float4*>(src + r * ld + 4 * c4);
   const float x[4] = {v.x, v.y, v.z, v.w};
   u16 h[4], m[4], l[4];
+  if constexpr (F16 != 0) {
+    const int64_t o = PANEL ? ((int64_t)(c4 >> 3) * rows + r) * 32 + 4 * (c4 & 7) : r * (int64_t)cols4 * 4 + 4 * c4;
+    uint2 ph, pl;
+    ph.x = f2h2(x[0] * scale, x[1] * scale); ph.y = f2h2(x[2] * scale, x[3] * scale);
+    pl.x = f2h2(x[0] * scale - h2f_lo(ph.x), x[1] * scale - h2f_hi(ph.x));
+    pl.y = f2h2(x[2] * scale - h2f_lo(ph.y), x[3] * scale - h2f_hi(ph.y));
+    *reinterpret_cast<uint2*>(dst + o) = ph;
+    *reinterpret_cast<uint2*>(dst + plane + o) = pl;
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     h[k] = f2bf(x[k]);
@@ -682,9 +705,10 @@ extern "C" int acx_vit_patches(acx_ctx* ctx, const float* frames, void* patches,
   const int64_t total4 = (int64_t)F * g * g * 3 * P * P / 4;
   const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (out_dtype == ACX_BF16X3P || out_dtype == ACX_BF16X2P) {
+  if (out_dtype == ACX_BF16X3P || out_dtype == ACX_BF16X2P || out_dtype == ACX_F16X2P) {
     if ((3 * P * P) % 32) return acx_fail(ctx, ACX_E_BADARG, "acx_vit_patches: K-panel planes need 3 P P %% 32 == 0%s");
-    if (out_dtype == ACX_BF16X2P) hipLaunchKernelGGL((patches_kernel<3>), grid, block, 0, s, frames, patches, total4, R, P, g);
+    if (out_dtype == ACX_F16X2P) hipLaunchKernelGGL((patches_kernel<4>), grid, block, 0, s, frames, patches, total4, R, P, g);
+    else if (out_dtype == ACX_BF16X2P) hipLaunchKernelGGL((patches_kernel<3>), grid, block, 0, s, frames, patches, total4, R, P, g);
     else
     hipLaunchKernelGGL((patches_kernel<2>), grid, block, 0, s, frames, patches, total4, R, P, g);
   } else if (out_dtype == ACX_BF16) hipLaunchKernelGGL((patches_kernel<1>), grid, block, 0, s, frames, patches, total4, R, P, g);
@@ -1170,6 +1194,27 @@ extern "C" int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void
 extern "C" int acx_split_bf16x3_panel(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
                                       int64_t cols, void* stream) {
   return split_bf16x3_impl(ctx, src, ld, dst, plane_stride_bytes, rows, cols, stream, 1);
+}
+
+// TWO fp16 planes hi | lo of scale * src (scale: a power of two; dst: 2 planes of rows * cols fp16, plane stride in bytes), row-major
+// or in K-panel layout: the operands of the ACX_PREC_F16X3 products (acx_gemm_desc.a_dtype = ACX_F16)
+extern "C" int acx_split_f16x2(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows,
+                               int64_t cols, float scale, int32_t panel, void* stream) {
+  AcxProfScope prof__(ctx, ACX_K_OTHER, (hipStream_t)stream);
+  if (!src || !dst) return acx_fail(ctx, ACX_E_BADARG, "acx_split_f16x2: null pointer%s");
+  if (rows <= 0 || cols <= 0) return ACX_OK;
+  if (cols % 4 || ld % 4 || (((uintptr_t)src | (uintptr_t)dst) & 7) || (plane_stride_bytes & 7) || plane_stride_bytes < rows * cols * 2 ||
+      (panel && cols % 32) || !(scale > 0.f))
+    return acx_fail(ctx, ACX_E_BADARG, "acx_split_f16x2: cols / ld multiples of 4 (panel layout: cols of 32), aligned pointers, planes of >= rows * cols fp16, scale > 0%s");
+  const int64_t n4 = rows * (cols / 4);
+  if (panel)
+    hipLaunchKernelGGL((split_bf16x3_kernel<1, 1>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, (u16*)dst,
+                       plane_stride_bytes / 2, rows, (int)(cols / 4), scale);
+  else
+    hipLaunchKernelGGL((split_bf16x3_kernel<0, 1>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, (u16*)dst,
+                       plane_stride_bytes / 2, rows, (int)(cols / 4), scale);
+  ACX_CHECK_LAUNCH(ctx, "acx_split_f16x2");
+  return ACX_OK;
 }
 
 extern "C" int acx_colsum(acx_ctx* ctx, const float* x, float* acc, int64_t rows, int32_t D, void* stream) {

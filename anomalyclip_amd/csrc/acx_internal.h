@@ -147,6 +147,21 @@ __device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {   // two values 
   return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+// f32 -> fp16 (round-to-nearest-even, v_cvt_pk_f16_f32) for the TWO-plane fp16 split of the ACX_PREC_F16X3 mode: x = hi + lo with
+// hi = fp16(x), lo = fp16(x - hi); x - hi is exact in f32, hi + lo reproduces x to 2^-24 |x| while lo is a normal fp16 number (|x| above
+// ~2^-3: below, lo's error is at most 2^-25 ABSOLUTE), |x| < 65504
+typedef _Float16 acx_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2h2(float lo, float hi) {    // two values -> one packed dword of fp16
+  const acx_f32x2 v = {lo, hi};
+  const acx_f16x2 r = __builtin_convertvector(v, acx_f16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float h2f_lo(uint32_t p) { return (float)__builtin_bit_cast(acx_f16x2, p)[0]; }
+__device__ __forceinline__ float h2f_hi(uint32_t p) { return (float)__builtin_bit_cast(acx_f16x2, p)[1]; }
+// one packed pair of either plane format (FMT 0: bf16, the three-plane split; 1: fp16, the two-plane split) and its value back in f32
+template <int FMT> __device__ __forceinline__ uint32_t acx_pk2(float a, float b) { if constexpr (FMT) return f2h2(a, b); else return f2bf2(a, b); }
+template <int FMT> __device__ __forceinline__ float acx_unpk_lo(uint32_t p) { if constexpr (FMT) return h2f_lo(p); else return __uint_as_float(p << 16); }
+template <int FMT> __device__ __forceinline__ float acx_unpk_hi(uint32_t p) { if constexpr (FMT) return h2f_hi(p); else return __uint_as_float(p & 0xffff0000u); }
 
 // ---- BatchNorm arithmetic shared between the stand-alone kernels and the fused step kernels (acx_train.hip): ONE expression
 // tree per quantity, so that hipcc's contraction choices -- and the bits -- are the same wherever it is inlined

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // halves -- the even lane of a pair ends up with eight consecutive elements of row r, the odd lane with the same eight of row r + 1
 // -- so that eight lanes write the 128 contiguous bytes rows r, r + 1 occupy in a panel with 16-byte stores.  Same arithmetic.
 // TWO (ACX_BF16X2P): the hi and mid planes only (the lo plane is left untouched: a pairs = 3 product does not read it)
-template <int VPL, bool TWO = false>
+// F16 (ACX_F16X2P): two fp16 planes hi | lo (hi = fp16(y), lo = fp16(y - hi)) instead of bf16 planes
+template <int VPL, bool TWO = false, bool F16 = false>
 __global__ __launch_bounds__(256) void layernorm_panel2_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                                const float* __restrict__ b, u16* __restrict__ y, int64_t rows,
                                                                float eps, int mode) {
@@ -141,12 +142,23 @@ __global__ __launch_bounds__(256) void layernorm_panel2_kernel(const float* __re
       o8[4 + k] = odd ? ob[k] : got;                                             // elements 8 j + 4 + k
     }
     u16 hh[8], mm[8], ll[8];
+    if constexpr (F16) {
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const uint32_t ph_ = f2h2(o8[k], o8[k + 1]);
+        const uint32_t pl_ = f2h2(o8[k] - h2f_lo(ph_), o8[k + 1] - h2f_hi(ph_));
+        hh[k] = (u16)(ph_ & 0xffffu); hh[k + 1] = (u16)(ph_ >> 16);
+        mm[k] = (u16)(pl_ & 0xffffu); mm[k + 1] = (u16)(pl_ >> 16);
+        ll[k] = ll[k + 1] = 0;
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       hh[k] = f2bf(o8[k]);
       const float r1 = o8[k] - bf2f(hh[k]);
       mm[k] = f2bf(r1);
       ll[k] = f2bf(r1 - bf2f(mm[k]));
+    }
     }
     const int e8 = 8 * (lane >> 1) + 256 * i;
     const int64_t row = r0 + odd;
@@ -247,6 +259,13 @@ extern "C" int acx_layernorm(acx_ctx* ctx, const float* x, int64_t ldx, const fl
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   AcxProfScope prof__(ctx, ACX_K_NORM, s);
+  if (y_dtype == ACX_F16X2P) {         // two fp16 planes in K-panel layout (the ViT width only: the ACX_PREC_F16X3 driver)
+    if (ldy != D || D != 768 || ((uintptr_t)y & 15) || ((rows * (int64_t)D * 2) & 15))
+      return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_layernorm: ACX_F16X2P needs ldy == D == 768 and 16-byte aligned planes%s");
+    layernorm_panel2_kernel<12, true, true><<<dim3((unsigned)((rows + 7) / 8)), block, 0, s>>>(x, ldx, w, b, (u16*)y, rows, eps, mode);
+    ACX_CHECK_LAUNCH(ctx, "acx_layernorm");
+    return ACX_OK;
+  }
   if (y_dtype == ACX_BF16X3P || y_dtype == ACX_BF16X2P) {   // three planes in K-panel layout [D / 32][rows][32] each (ldy == D), y + p * rows * ldy
     if (ldy != D || D % 256) return acx_fail(ctx, ACX_E_BADARG, "acx_layernorm: ACX_BF16X3P needs ldy == D, D %% 256 == 0%s");
     if (!((uintptr_t)y & 15) && !((rows * (int64_t)D * 2) & 15)) {                // 16-byte stores: two rows per wave

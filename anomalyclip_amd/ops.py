@@ -37,6 +37,8 @@ def _dt(t: torch.Tensor) -> int:
         return L.ACX_F32
     if t.dtype == _BF16:
         return L.ACX_BF16
+    if t.dtype == torch.float16:
+        return L.ACX_F16
     raise L.AcxError(f"unsupported dtype {t.dtype}")
 
 
@@ -203,22 +205,39 @@ def split_bf16x3_multi(pairs) -> None:
     L.check(L.lib().acx_split_bf16x3_multi(h, args[0], args[1], args[2], args[3], _stream()), h)
 
 
+def split_f16x2(x: torch.Tensor, panel: bool = False, scale: float = 1.0) -> torch.Tensor:
+    """[2, rows, cols] fp16: the two planes hi = fp16(scale x), lo = fp16(scale x - hi) of an f32 matrix (acx_split_f16x2; scale a power
+    of two), row-major or K-panel memory order: operands of gemm_x6(..., pairs=3, f16=True) -- the ACX_PREC_F16X3 arithmetic."""
+    x = x.contiguous().float()
+    rows, cols = x.shape
+    out = torch.empty(2, rows, cols, dtype=torch.float16, device=x.device)
+    h = _h(x)
+    L.check(L.lib().acx_split_f16x2(h, x.data_ptr(), x.stride(0), out.data_ptr(), rows * cols * 2, rows, cols, float(scale), int(panel),
+                                    _stream()), h)
+    return out
+
+
 def unpanel(planes: torch.Tensor) -> torch.Tensor:
     """[3, rows, cols] planes in K-panel memory order -> the same values in row-major order (tests / debugging)"""
-    _, rows, cols = planes.shape
-    return planes.reshape(3, cols // 32, rows, 32).permute(0, 2, 1, 3).reshape(3, rows, cols).contiguous()
+    npl, rows, cols = planes.shape
+    return planes.reshape(npl, cols // 32, rows, 32).permute(0, 2, 1, 3).reshape(npl, rows, cols).contiguous()
 
 
 def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, act=L.ACT_NONE,
             residual=None, out_dtype=torch.float32, amap=L.AMAP_IDENTITY, gn=0, gl=0, cin=0, M: Optional[int] = None,
-            planes_out: bool = False, split_k: bool = True, panels: int = 0, panel_out: bool = False, pairs: int = 6) -> torch.Tensor:
+            planes_out: bool = False, split_k: bool = True, panels: int = 0, panel_out: bool = False, pairs: int = 6,
+            out_scale: float = 0.0) -> torch.Tensor:
     """out[M, N] = epilogue(amap(A) W^T) with A = sum of the three bf16 planes a3 [3, rows, Ka] and W = sum of w3 [3, N, K]
     (split_bf16x3): the six leading cross products on the bf16 matrix cores, f32 accumulation -- the accuracy of an f32
     product (acx_gemm_desc.pairs = 6; acx_gemm_x6.h).  amap = AMAP_CONV3X3: implicit 3x3 convolution over the (gn, gl) token
     grid (K = 9 cin, a3 [3, rows, cin]).  planes_out: the result as three bf16 planes [3, M, N] (the next product's A operand).
     Few output tiles: K is split across workgroups (split_k, workspace owned by this module)."""
-    assert a3.dim() == 3 and w3.dim() == 3 and a3.shape[0] == 3 and w3.shape[0] == 3 and a3.dtype == _BF16 and w3.dtype == _BF16
-    assert a3.is_contiguous() and w3.is_contiguous()
+    f16 = a3.dtype == torch.float16          # two fp16 planes per operand (split_f16x2): pairs = 3 only, out_scale undoes the planes' scales
+    if f16:
+        assert pairs == 3 and a3.shape[0] == 2 and w3.shape[0] == 2 and w3.dtype == torch.float16 and (panel_out or not planes_out)
+    else:
+        assert a3.shape[0] == 3 and w3.shape[0] == 3 and a3.dtype == _BF16 and w3.dtype == _BF16
+    assert a3.dim() == 3 and w3.dim() == 3 and a3.is_contiguous() and w3.is_contiguous()
     _, rows, Ka = a3.shape
     N, K = w3.shape[1], w3.shape[2]
     if amap == L.AMAP_CONV3X3:
@@ -228,12 +247,14 @@ def gemm_x6(a3: torch.Tensor, w3: torch.Tensor, *, out: Optional[torch.Tensor] =
     if M is None:
         M = rows
     if out is None:
-        out = torch.empty((3, M, N) if planes_out else (M, N), dtype=_BF16 if planes_out else out_dtype, device=a3.device)
+        out = torch.empty(((2 if f16 else 3), M, N) if planes_out else (M, N), dtype=(torch.float16 if f16 else _BF16) if planes_out else out_dtype,
+                          device=a3.device)
     d = L.GemmDesc()
     d.A, d.W, d.C = a3.data_ptr(), w3.data_ptr(), out.data_ptr()
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldw, d.ldc = Ka, K, out.stride(-2)
-    d.a_dtype, d.c_dtype, d.prec = _dt(a3), ((L.BF16X3P if panel_out else L.BF16X3) if planes_out else _dt(out)), L.PREC_BF16
+    d.a_dtype, d.c_dtype, d.prec = _dt(a3), ((L.F16X2P if f16 else L.BF16X3P if panel_out else L.BF16X3) if planes_out else _dt(out)), L.PREC_BF16
+    d.out_scale = float(out_scale)
     d.bias, d.act = _ptr(bias), act
     d.residual, d.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
     d.pairs, d.a_plane_stride, d.w_plane_stride = int(pairs), rows * Ka * 2, N * K * 2      # (pairs = 3: the three leading products only)

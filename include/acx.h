@@ -44,6 +44,11 @@ enum { ACX_F32 = 0, ACX_BF16 = 1,                    /* storage dtypes */
                              of all rows are contiguous (element (r, c) at ((c / 32) * rows + r) * 32 + c % 32; ld % 32 == 0,
                              dense).  The plane-reuse kernel then stages a 256-row x 32-column unit from ONE contiguous 16 KB block
                              instead of 256 half cache lines (acx_gemm_desc.panels) */
+enum { ACX_F16 = 5,        /* acx_gemm_desc.a_dtype with pairs = 3: A and W are TWO fp16 planes each (acx_split_f16x2: x = hi + lo,
+                              hi = fp16(x), lo = fp16(x - hi)) -- the ACX_PREC_F16X3 arithmetic: products (lo,hi) (hi,lo) (hi,hi) on
+                              v_mfma_f32_32x32x16_f16, an error of ~2^-22 of sum |a||w| for operands inside fp16's range */
+       ACX_F16X2P = 6 };   /* the two fp16 planes in K-panel layout (plane = [ld / 32][rows][32], plane p at base + p * rows * ld
+                              elements): output of acx_layernorm / acx_vit_patches / an ACX_F16 product, input of the next one */
 enum { ACX_BF16X2P = 4 };  /* acx_layernorm y_dtype / acx_vit_patches out_dtype: the ACX_BF16X3P image with the hi and mid planes written
                               only (the lo plane's bytes are left as they are): the A operand of a pairs = 3 product, which never reads
                               the lo plane.  A producer that does not special-case it writes all three planes. */
@@ -52,9 +57,15 @@ enum { ACX_PREC_F32 = 0, ACX_PREC_BF16 = 1,          /* MFMA arithmetic: exact f
                                  (mid, hi) (hi, mid) (hi, hi)): sixteen significant bits per operand -- an error of ~1e-5 of sum |a||w| per
                                  product, between TF32 and f32 -- at about twice the GEMM rate of ACX_PREC_F32X6.  NOT an f32-accurate
                                  path: opt-in (precision "bf16x3"); the attention keeps its six-product form */
+       ACX_PREC_F16X3 = 4,    /* the same drivers with TWO fp16 planes per operand and the three products (lo,hi) (hi,lo) (hi,hi):
+                                 the fp16 pair holds the f32 value to 2^-24 (lo normal), every product is exact in f32, the dropped
+                                 (lo,lo) term is <= 2^-22: f32-MFMA-level results at the three-product rate, for operands inside fp16's
+                                 range (|x| < 65504; weights are pre-scaled by a power of two per matrix).  Opt-in (precision "f16x3") */
        ACX_PREC_F32X6 = 2 };  /* acx_vit_encode / acx_transformer_forward only: f32 everywhere, the four large GEMMs of a layer as
                                  f32-accurate bf16 x 6 products (acx_gemm_desc.pairs); the *_w_bf16 weight fields then hold THREE
                                  planes each (acx_split_bf16x3 of the f32 weight) */
+#define ACX_F16X3_WSCALE 1024.0f   /* ACX_PREC_F16X3: the weights' fp16 planes hold 2^10 * w (acx_split_f16x2: lifts CLIP-sized weights into
+                                      fp16's normal range so that the lo plane keeps its 11 bits; |w| < 63.9); the drivers' products undo it */
 enum { ACX_ACT_NONE = 0, ACX_ACT_QUICKGELU = 1, ACX_ACT_LEAKYRELU = 2 };
 enum { ACX_AMAP_IDENTITY = 0, ACX_AMAP_CONV3X3 = 1, ACX_AMAP_TESTTILE = 2, ACX_AMAP_TILETABLE = 3 };
 enum { ACX_NORM_LAYER = 0, ACX_NORM_CHAN = 1 };     /* nn.LayerNorm vs axial_attention ChanLayerNorm (eps added to std) */
@@ -172,6 +183,8 @@ typedef struct acx_gemm_desc {
   int64_t c_plane_rows;   /* plane outputs (ACX_BF16X3 / ACX_BF16X3P): rows of the WHOLE plane image when C addresses a row sub-range of
                              it (plane p of the output at C + p * c_plane_rows * ldc elements; K-panel rows counted over c_plane_rows);
                              0: M.  acx_gemm uses it itself when it splits a launch into full rounds of tiles + a K-split tail. */
+  float out_scale;        /* pairs = 3 with fp16 planes (a_dtype = ACX_F16): the accumulator is multiplied by this power of two before bias
+                             / activation / residual (operand planes that were scaled by acx_split_f16x2); 0 = 1 */
 } acx_gemm_desc;
 int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream);
 
@@ -369,6 +382,11 @@ int acx_split_bf16x3(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int6
                      int64_t cols, void* stream);
 /* the same into K-panel layout (ACX_BF16X3P: plane = [cols / 32][rows][32]; cols % 32 == 0) */
 int acx_split_bf16x3_panel(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_bytes, int64_t rows, int64_t cols, void* stream);
+/* TWO fp16 planes hi | lo of scale * src (hi = fp16(.), lo = fp16(. - hi); scale a power of two: exact), row-major or K-panel
+ * layout: operands of a pairs = 3 product with a_dtype = ACX_F16 (the ACX_PREC_F16X3 arithmetic); the product's acx_gemm_desc.out_scale
+ * takes the scales out again */
+int acx_split_f16x2(acx_ctx* ctx, const float* src, int64_t ld, void* dst, int64_t plane_stride_bytes, int64_t rows, int64_t cols,
+                    float scale, int32_t panel, void* stream);
 /* n dense f32 tensors (numel[i] elements each, multiples of 8, 16-byte aligned) -> three row-major bf16 planes each
  * (dst[i]: 3 * numel[i] bf16, plane stride numel[i]) in ONE launch: a training step re-splits every convolution weight of the
  * temporal model after the optimizer has stepped. */

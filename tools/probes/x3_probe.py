@@ -24,28 +24,35 @@ for (M, N, K, act, res) in ((4096, 768, 768, L.ACT_NONE, False), (100864, 2304, 
         outs[pairs] = fn()
         t = _event_time(fn, 6)
         print(f"M {M} N {N} K {K} act {act} res {res} pairs {pairs}: {t * 1e3:.3f} ms  {2 * M * N * K / t / 1e12:.1f} TFLOP/s f32-equivalent", flush=True)
+    # two fp16 planes per operand, three products (precision "f16x3"); the weights' planes hold 2^10 w
+    af, wf = ops.split_f16x2(a, panel=True), ops.split_f16x2(w, panel=True, scale=1024.0)
+    fnf = lambda: ops.gemm_x6(af, wf, act=act, residual=r, panels=3, pairs=3, out_scale=1.0 / 1024.0)
+    outs["f16"] = fnf()
+    t = _event_time(fnf, 6)
+    print(f"M {M} N {N} K {K} act {act} res {res} fp16 x 2 planes, 3 products: {t * 1e3:.3f} ms  {2 * M * N * K / t / 1e12:.1f} TFLOP/s f32-equivalent", flush=True)
     if M <= 8192:
         ref = a.double() @ w.double().t()
         den = (a.double().abs() @ w.double().abs().t())
-        for pairs in (6, 3):
+        for pairs in (6, 3, "f16"):
             e = (outs[pairs].double() - ref).abs()
             print(f"   pairs {pairs}: max err / max|ref| {float(e.max() / ref.abs().max()):.3e}   max err / sum|a||w| {float((e / den).max()):.3e}")
     else:
         e = (outs[3] - outs[6]).abs().max() / outs[6].abs().max()
-        print(f"   pairs 3 vs 6: max |diff| / max|out| {float(e):.3e}")
+        ef = (outs["f16"] - outs[6]).abs().max() / outs[6].abs().max()
+        print(f"   pairs 3 vs 6: max |diff| / max|out| {float(e):.3e}   fp16 planes vs 6: {float(ef):.3e}")
     del a, w, a3, w3, r, outs
 
 net, sd, eot, hc = B.build_net("auto", dev, 512)
 vit = net.image_encoder
 frames = torch.randn(512, 3, 224, 224, generator=g, device=dev)
 feats = {}
-for prec in ("auto", "bf16x3", "f32"):
+for prec in ("auto", "bf16x3", "f16x3", "f32"):
     vit.precision = prec
     feats[prec] = vit(frames).clone()
     t = _event_time(lambda: vit(frames), 4)
     print(f"ViT-B/16 encode, 512 frames, precision {prec}: {512 / t:.0f} frames/s ({t * 1e3:.2f} ms)", flush=True)
 ref = feats["f32"]
-for prec in ("auto", "bf16x3"):
+for prec in ("auto", "bf16x3", "f16x3"):
     d = (feats[prec] - ref).abs()
     print(f"features {prec} vs f32 MFMA path: max |diff| / max|ref| {float(d.max() / ref.abs().max()):.3e}, max elementwise rel (|ref| > 1e-2 max) "
           f"{float((d / ref.abs().clamp_min(1e-2 * float(ref.abs().max()))).max()):.3e}")
