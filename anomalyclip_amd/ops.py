@@ -380,6 +380,12 @@ def attention_p3(qkv3: torch.Tensor, batch: int, L_: int, heads: int, products: 
     three bf16 planes of q | k | v in K-panel memory order (split_bf16x3(panel=True)); returns the three planes of the output
     [3, batch * L, heads * 64], K-panel memory order as well (unpanel() for row-major)."""
     W = heads * 64
+    if products == 103:                                   # two fp16 planes (split_f16x2(panel=True)), three products: the "f16x3" arithmetic
+        assert qkv3.dtype == torch.float16 and qkv3.is_contiguous() and qkv3.shape == (2, batch * L_, 3 * W)
+        out = torch.empty(2, batch * L_, W, dtype=torch.float16, device=qkv3.device)
+        h = _h(qkv3)
+        L.check(L.lib().acx_attention_p3n(h, qkv3.data_ptr(), out.data_ptr(), batch, L_, heads, 103, _stream()), h)
+        return out
     assert qkv3.dtype == _BF16 and qkv3.is_contiguous() and qkv3.shape == (3, batch * L_, 3 * W)
     out = (torch.zeros if products == 3 else torch.empty)(3, batch * L_, W, dtype=_BF16, device=qkv3.device)   # (3 products: lo plane unwritten)
     h = _h(qkv3)

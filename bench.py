@@ -600,8 +600,9 @@ def gemm_error_vs_fp64(dev):
     a3_, w3_ = ops.split_bf16x3(a), ops.split_bf16x3(w)
     y6 = ops.gemm_x6(a3_, w3_, bias=b)
     y3 = ops.gemm_x6(a3_, w3_, bias=b, pairs=3)        # the opt-in three-product mode (precision "bf16x3"): not f32-accurate
+    yf = ops.gemm_x6(ops.split_f16x2(a), ops.split_f16x2(w, scale=1024.0), bias=b, pairs=3, out_scale=1.0 / 1024.0)   # opt-in "f16x3"
     out = {"shape": [M, N, K]}
-    for name, y in (("f32_mfma", y32), ("bf16x6", y6), ("bf16x3_opt_in", y3)):
+    for name, y in (("f32_mfma", y32), ("bf16x6", y6), ("f16x3_opt_in", yf), ("bf16x3_opt_in", y3)):
         e = (y.double() - ref).abs()
         out[name] = {"max_err_over_max_ref": float(e.max() / ref.abs().max()), "max_err_over_sum_abs_products": float((e / scale).max())}
     return out
@@ -901,34 +902,43 @@ def main():
             finally:
                 net.image_encoder.precision = args.precision
             if args.precision == "auto":
-                # opt-in precision "bf16x3": the plane kernels with the THREE leading cross products only (sixteen significant bits per
-                # operand: between TF32 and f32; NOT the f32-accurate default and never the headline) -- frames/s and its distance from
-                # the headline path's outputs
-                try:
-                    ref_probs, ref_sc = (t.clone() for t in out_holder["o"])
-                    net.image_encoder.precision = "bf16x3"
-                    timer.run(step_keep, 1, 0)
-                    p3, s3 = out_holder["o"]
-                    dt3 = timer.run(step_keep, k, 1)
-                    prof.start_gemm_only(); timer.run(step_keep, 1, 0); prof.stop()
-                    gf3, c3, t3 = prof.collect()
-                    extra["bf16x3_mode_opt_in"] = {
-                        "frames_per_s": round(FRAMES_PER_CLIP * k * world / dt3, 2), "ms_per_step": round(dt3 / k * 1e3, 3),
-                        "max_abs_diff_vs_headline_path": {"class_probs": float((p3 - ref_probs).abs().max()), "scores": float((s3 - ref_sc).abs().max()),
-                                                          "relative_to_max": [float((p3 - ref_probs).abs().max()) / max(float(ref_probs.abs().max()), 1e-30),
-                                                                              float((s3 - ref_sc).abs().max()) / max(float(ref_sc.abs().max()), 1e-30)]},
-                        "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_x6_p4_kernel<.., X3>: three v_mfma_f32_32x32x16_bf16 products per f32 product)",
-                                     "launches": c3[0], "gemm_ms_per_step": round(t3[0], 3),
-                                     "achieved": round(gf3 / 1e9 / t3[0], 2) if t3[0] else None, "peak": round(PEAK_TFLOPS["bf16"] / 3, 2),
-                                     "unit": "TFLOP/s (f32-equivalent: 2 M N K per launch; x 3 = executed bf16 TFLOP/s)",
-                                     "frac": round(3 * gf3 / 1e9 / t3[0] / PEAK_TFLOPS["bf16"], 4) if t3[0] else None},
-                        "note": "VisionTransformer(precision = 'bf16x3') / ACX_PREC_F32X3: products (mid,hi) (hi,mid) (hi,hi) of the exact 24-bit plane "
-                                "split, the lo planes neither written nor read, the attention with three products too; ViT-B/16 features within "
-                                "5e-5 of the reference's (tests/test_gpu_model.py::test_vit_b16_three_product_mode), inside BASELINE.json's 1e-3"}
-                except Exception as e:  # noqa: BLE001
-                    extra["bf16x3_mode_opt_in"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                finally:
-                    net.image_encoder.precision = args.precision
+                # the two opt-in three-product arithmetics of the plane kernels, never the headline:
+                #   "f16x3"  TWO fp16 planes per operand (the f32 value to 2^-24), products (lo,hi) (hi,lo) (hi,hi) exact on the fp16 matrix
+                #            cores: f32-MFMA-level results (the default's test bounds) for operands inside fp16's range
+                #   "bf16x3" the three LEADING products of the default's bf16 split: sixteen significant bits per operand (~1e-5 per product)
+                # -- frames/s and the distance from the headline path's outputs
+                for mode, leg, desc in (("f16x3", "f16x3_mode_opt_in",
+                                         "VisionTransformer(precision = 'f16x3') / ACX_PREC_F16X3: two fp16 planes per operand (hi = fp16(x), lo = fp16(x - hi)), "
+                                         "products (lo,hi) (hi,lo) (hi,hi) on v_mfma_f32_32x32x16_f16, f32 accumulation; holds the default's golden bounds "
+                                         "(tests/test_gpu_model.py::test_vit_b16_f16x3_mode, test_gpu_kernels.py::test_gemm_f16x3_is_f32_accurate); operands must "
+                                         "lie inside fp16's range (|x| < 65504, weights' planes scaled by 2^10): not f32's range, hence opt-in"),
+                                        ("bf16x3", "bf16x3_mode_opt_in",
+                                         "VisionTransformer(precision = 'bf16x3') / ACX_PREC_F32X3: products (mid,hi) (hi,mid) (hi,hi) of the exact 24-bit bf16 plane "
+                                         "split, the lo planes neither written nor read; ViT-B/16 features within 5e-5 of the reference's "
+                                         "(tests/test_gpu_model.py::test_vit_b16_three_product_mode), inside BASELINE.json's 1e-3; not f32-accurate")):
+                    try:
+                        ref_probs, ref_sc = (t.clone() for t in out_holder["o"])
+                        net.image_encoder.precision = mode
+                        timer.run(step_keep, 1, 0)
+                        p3, s3 = out_holder["o"]
+                        dt3 = timer.run(step_keep, k, 1)
+                        prof.start_gemm_only(); timer.run(step_keep, 1, 0); prof.stop()
+                        gf3, c3, t3 = prof.collect()
+                        extra[leg] = {
+                            "frames_per_s": round(FRAMES_PER_CLIP * k * world / dt3, 2), "ms_per_step": round(dt3 / k * 1e3, 3),
+                            "max_abs_diff_vs_headline_path": {"class_probs": float((p3 - ref_probs).abs().max()), "scores": float((s3 - ref_sc).abs().max()),
+                                                              "relative_to_max": [float((p3 - ref_probs).abs().max()) / max(float(ref_probs.abs().max()), 1e-30),
+                                                                                  float((s3 - ref_sc).abs().max()) / max(float(ref_sc.abs().max()), 1e-30)]},
+                            "roofline": {"bound": "mfma", "kernel": "acx_gemm (gemm_x6_p4_kernel<.., X3>: three 16-bit MFMA products per f32 product)",
+                                         "launches": c3[0], "gemm_ms_per_step": round(t3[0], 3),
+                                         "achieved": round(gf3 / 1e9 / t3[0], 2) if t3[0] else None, "peak": round(PEAK_TFLOPS["bf16"] / 3, 2),
+                                         "unit": "TFLOP/s (f32-equivalent: 2 M N K per launch; x 3 = executed 16-bit TFLOP/s)",
+                                         "frac": round(3 * gf3 / 1e9 / t3[0] / PEAK_TFLOPS["bf16"], 4) if t3[0] else None},
+                            "note": desc}
+                    except Exception as e:  # noqa: BLE001
+                        extra[leg] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    finally:
+                        net.image_encoder.precision = args.precision
             try:
                 extra["gemm_error_vs_fp64"] = gemm_error_vs_fp64(dev)
             except Exception as e:  # noqa: BLE001
@@ -1053,6 +1063,7 @@ def main():
         out["value_vit_chunk_256"] = extra.get("vit_chunk_256", {}).get("frames_per_s")
         out["value_f32_mfma_path"] = extra.get("f32_mfma_path", {}).get("frames_per_s")
         out["value_vit_two_streams_opt_in"] = extra.get("vit_two_streams", {}).get("frames_per_s")
+        out["value_f16x3_mode_opt_in"] = extra.get("f16x3_mode_opt_in", {}).get("frames_per_s")
         out["value_bf16x3_mode_opt_in"] = extra.get("bf16x3_mode_opt_in", {}).get("frames_per_s")
         out["value_text_recomputed_every_step"] = extra.get("text_recomputed_every_step", {}).get("frames_per_s")
         if world == 1 and not args.no_cpu_baseline:

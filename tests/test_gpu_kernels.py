@@ -675,6 +675,73 @@ def test_gemm_three_products_error_and_bits(M, N, K, act, res, panels):
         assert bool(((two - yb).abs() <= 2.0 ** -15 * yb.abs() + 1e-30).all())
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(2048, 768, 768, 0, 1), (1536, 2304, 768, 0, 0), (1024, 3072, 768, 1, 0), (1000, 772, 3072, 0, 1),
+                                           (70144, 768, 768, 0, 1), (64, 768, 3072, 0, 0)])
+def test_gemm_f16x3_is_f32_accurate(M, N, K, act, res):
+    """The ACX_PREC_F16X3 product (opt-in precision "f16x3"): A and W as TWO fp16 planes each (acx_split_f16x2: hi = fp16(x),
+    lo = fp16(x - hi); the weights' planes hold 2^10 w, undone by out_scale), the three products (lo,hi) (hi,lo) (hi,hi) on
+    v_mfma_f32_32x32x16_f16 with f32 accumulation.  Inside fp16's range -- rows spanning 8 binades around 1, a x60 massive-activation
+    column -- against fp64: element-wise within 2e-6 * sum_k |a||w| (THE bound of the f32 MFMA kernels and of the six-product default)
+    and no worse than 1.5 x the f32 MFMA kernel's own maximum error; the split reproduces the operands to 2^-23; whole tiles, column
+    strips (70144 rows), a K-split single row tile; run-to-run identical."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 5, (M, 1), generator=g).float())
+    a[:, 3] *= 60.0
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    x = torch.randn(M, N, generator=g) if res else None
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    xd = x.to(DEV) if res else None
+    a2, w2 = ops.split_f16x2(ad, panel=True), ops.split_f16x2(wd, panel=True, scale=1024.0)
+    ra, rw = ops.unpanel(a2).float().sum(0), ops.unpanel(w2).float().sum(0) / 1024.0
+    assert bool(((ra - ad).abs() <= 2.0 ** -23 * ad.abs() + 2.0 ** -24).all()) and bool(((rw - wd).abs() <= 2.0 ** -23 * wd.abs() + 2.0 ** -24 / 1024.0).all())
+    kw = dict(bias=bd, act=L.ACT_QUICKGELU if act else L.ACT_NONE, residual=xd, panels=3, pairs=3, out_scale=1.0 / 1024.0)
+    y = ops.gemm_x6(a2, w2, **kw)
+    assert torch.isfinite(y).all() and torch.equal(y, ops.gemm_x6(a2, w2, **kw))
+    y32 = ops.gemm(ad, wd, bias=bd, act=L.ACT_QUICKGELU if act else L.ACT_NONE, residual=xd)
+    pre = ad.double() @ wd.double().t() + bd.double()
+    mag = ad.double().abs() @ wd.double().abs().t() + bd.double().abs()
+    ref = pre * torch.sigmoid(1.702 * pre) if act else pre
+    if res:
+        ref = ref + xd.double()
+    e, e32 = (y.double() - ref).abs(), (y32.double() - ref).abs()
+    print("f16x3: max err / sum|a||w|", float((e / mag).max()), " f32 MFMA kernel:", float((e32 / mag).max()))
+    assert bool((e <= 2e-6 * mag + 1e-30).all()), float((e / mag).max())
+    assert float(e.max()) <= 1.5 * float(e32.max()) + 1e-12
+    if not act and N % 8 == 0 and M >= 256:
+        # fp16 plane output (K-panel layout): hi + lo reproduces the f32 result of the same product to 2^-22
+        o2 = ops.gemm_x6(a2, w2, bias=bd, panels=3, pairs=3, out_scale=1.0 / 1024.0, planes_out=True, panel_out=True)
+        yb = ops.gemm_x6(a2, w2, bias=bd, panels=3, pairs=3, out_scale=1.0 / 1024.0)
+        two = ops.unpanel(o2).float().sum(0)
+        assert bool(((two - yb).abs() <= 2.0 ** -22 * yb.abs() + 2.0 ** -24).all())
+
+
+@pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (40, 197, 12)])
+def test_attention_f16x3_vs_fp64(batch, L_, heads):
+    """acx_attention_p3n(products = 103): the planes attention on TWO fp16 planes, three exact products per contraction (precision
+    "f16x3"): against fp64 no worse than 1.5 x the f32 MFMA attention kernel's maximum error and within 2e-6 of the largest output
+    (the six-product default's bounds); identical sequences bit-identical wherever they sit."""
+    W = heads * 64
+    g = torch.Generator().manual_seed(batch * 1000 + L_)
+    qkv = torch.randn(batch * L_, 3 * W, generator=g) * 1.7
+    qkv[:, :W] *= 1.5
+    if batch > 2:
+        qkv[(batch - 1) * L_:] = qkv[:L_]
+    qd = qkv.to(DEV)
+    q2 = ops.split_f16x2(qd, panel=True)
+    o2 = ops.attention_p3(q2, batch, L_, heads, products=103)
+    out = ops.unpanel(o2).float().sum(0)
+    ref32 = ops.attention(qd, batch, L_, heads, False)
+    x = qd.double().view(batch, L_, 3, heads, 64)
+    q_, k_, v_ = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q_ @ k_.transpose(-1, -2) / 8.0, dim=-1) @ v_).transpose(1, 2).reshape(batch * L_, W)
+    e, e32 = (out.double() - ref).abs().max().item(), (ref32.double() - ref).abs().max().item()
+    print("f16x3 attention: max |err| vs fp64", e, " f32 MFMA", e32)
+    assert torch.isfinite(out).all() and e <= 1.5 * e32 + 1e-9 and e <= 2e-6 * ref.abs().max().item()
+    if batch > 2:
+        assert torch.equal(out[(batch - 1) * L_:], out[:L_])
+
+
 @pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (40, 197, 12)])
 def test_attention_three_products_vs_fp64(batch, L_, heads):
     """acx_attention_p3n(products = 3): the three leading products of QK^T and PV (precision "bf16x3"); against fp64 within 1e-4 of the

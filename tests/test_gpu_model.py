@@ -189,6 +189,33 @@ def test_vit_b16_three_product_mode(golden, chunk):
     assert relerr(out, vit32(eight[idx].to(DEV))) < 5e-5
 
 
+@pytest.mark.parametrize("chunk", [64, 256])
+def test_vit_b16_f16x3_mode(golden, chunk):
+    """precision "f16x3" (opt-in; ACX_PREC_F16X3: two fp16 planes per operand, three exact products) holds the DEFAULT's bounds: the
+    golden bounds against the REFERENCE's output (relerr < TOL, element-wise elem_ok), round-off distance to the f32 MFMA path on every
+    frame, identical frames -> bit-identical rows wherever they sit in the launch."""
+    g = golden("vit_b16")
+    vit, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="f16x3")
+    vit.chunk = chunk
+    base = R.vit_frames(int(g["seed"]), 2, 224)
+    extra = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    eight = torch.cat([base, extra], 0)
+    idx = torch.arange(chunk) % 8
+    idx[chunk - 12:] = torch.tensor([7, 3, 0, 1, 5, 5, 2, 6, 4, 0, 1, 7])
+    out = vit(eight[idx].to(DEV))
+    assert out.shape == (chunk, 512) and torch.isfinite(out).all()
+    for k in range(8):
+        rows = out[idx == k]
+        assert torch.equal(rows, rows[:1].expand_as(rows)), k
+    first = [int((idx == k).nonzero()[0]) for k in (0, 1)]
+    print("f16x3 ViT-B/16 rel err vs reference:", relerr(out[first], g["out"]))
+    assert relerr(out[first], g["out"]) < TOL and elem_ok(out[first], g["out"])
+    vit32, _ = make_vit(IW.VIT_B16, int(g["seed"]), precision="f32")
+    vit32.chunk = chunk
+    o32 = vit32(eight[idx].to(DEV))
+    assert relerr(out, o32) < 5e-6 and elem_ok(out, o32)
+
+
 def test_model_precision_bf16x3_end_to_end(prompts_table):
     """AnomalyCLIP(precision = "bf16x3") from FRAMES at the ViT-B/16 geometry (512 frames = one test tile, UCF head): the ViT runs the
     three-product plane kernels, the head the default's arithmetic; similarity logits and scores stay within 1e-4 (relative to the
@@ -197,7 +224,7 @@ def test_model_precision_bf16x3_end_to_end(prompts_table):
     frames = torch.randn(1, 512, 3, 224, 224, generator=torch.Generator().manual_seed(21)) * 0.7
     nc = torch.randn(512, generator=torch.Generator().manual_seed(22)) * 0.05
     out = {}
-    for precision in ("auto", "bf16x3"):
+    for precision in ("auto", "bf16x3", "f16x3"):
         net, sd, eot = build_net("ViT-B/16", hc, "ucf", 31, prompts_table, precision=precision)
         net.load_from_features = False
         net.eval()
@@ -205,11 +232,12 @@ def test_model_precision_bf16x3_end_to_end(prompts_table):
         with torch.no_grad():
             out[precision] = tuple(t.clone() for t in net(frames.to(DEV), None, nc.to(DEV), 1, True))
         del net
-    (s6, c6), (s3, c3) = out["auto"], out["bf16x3"]
-    assert torch.isfinite(s3).all() and torch.isfinite(c3).all()
-    print("bf16x3 vs auto: similarity", relerr(s3, s6), "scores", relerr(c3, c6))
+    (s6, c6), (s3, c3), (sf, cf) = out["auto"], out["bf16x3"], out["f16x3"]
+    assert torch.isfinite(s3).all() and torch.isfinite(c3).all() and torch.isfinite(sf).all() and torch.isfinite(cf).all()
+    print("bf16x3 vs auto: similarity", relerr(s3, s6), "scores", relerr(c3, c6), "| f16x3 vs auto:", relerr(sf, s6), relerr(cf, c6))
     assert relerr(s3, s6) < 1e-4 and relerr(c3, c6) < 1e-4
-    assert not torch.equal(s3, s6)                      # (the mode is really in use)
+    assert relerr(sf, s6) < 5e-6 and relerr(cf, c6) < 5e-6              # f16x3: round-off away from the default
+    assert not torch.equal(s3, s6) and not torch.equal(sf, s6)            # (the modes are really in use)
 
 
 def test_vit_two_streams_equals_sequential_half_launches(golden):
