@@ -173,6 +173,33 @@ class VisionTransformer(nn.Module):
         self._ws2: Optional[torch.Tensor] = None
         self._side = None
 
+    @torch.no_grad()
+    def f16x3_range_report(self) -> dict:
+        """Worst-case magnitudes of every operand the opt-in precision "f16x3" stores as fp16 planes, PROVEN from the weights alone
+        (whatever the frames are, the patch embedding excepted: its A operand is the pixels themselves):
+          LayerNorm outputs   |y_i| <= |gamma_i| sqrt(D - 1) + |beta_i|          (a unit-variance row has no element above sqrt(D - 1))
+          attention outputs   convex combinations of V rows: |v_j| <= ln1_bound * ||W_v,j||_1 + |b_v,j|
+          QuickGELU hiddens   |x sigmoid(1.702 x)| <= |x| <= ln2_bound * ||W_fc,j||_1 + |b_fc,j|
+          weight planes       2^10 |w|
+        against fp16's largest finite number 65504.  `safe` says every bound is below it; `margin` is the smallest ratio 65504 / bound."""
+        D = self.width
+        lim = 65504.0
+        worst = {"weight_planes": 0.0, "layernorm_out": 0.0, "attention_out": 0.0, "mlp_hidden": 0.0}
+
+        def ln_bound(ln):
+            return float((ln.weight.abs() * (D - 1) ** 0.5 + ln.bias.abs()).max())
+        mats = [self.conv1.weight.reshape(D, -1)]
+        for b in self.transformer.resblocks:
+            l1, l2 = ln_bound(b.ln_1), ln_bound(b.ln_2)
+            wv, bv = b.attn.in_proj_weight[2 * D:], b.attn.in_proj_bias[2 * D:]
+            worst["layernorm_out"] = max(worst["layernorm_out"], l1, l2)
+            worst["attention_out"] = max(worst["attention_out"], float((wv.abs().sum(1) * l1 + bv.abs()).max()))
+            worst["mlp_hidden"] = max(worst["mlp_hidden"], float((b.mlp.c_fc.weight.abs().sum(1) * l2 + b.mlp.c_fc.bias.abs()).max()))
+            mats += [b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight, b.mlp.c_proj.weight]
+        worst["weight_planes"] = F16X3_WSCALE * max(float(m.abs().max()) for m in mats)
+        margin = min(lim / max(v, 1e-30) for v in worst.values())
+        return {"bounds": worst, "fp16_max": lim, "margin": margin, "safe": margin > 1.0}
+
     def _weights(self, prec: int):
         key = (prec, ops.WEIGHT_EPOCH[0]) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._wcache is not None and self._wcache[0] == key:

@@ -527,3 +527,20 @@ def test_phase_interleaved_dma_schedule_model():
     for kt in (s + 1, s + 2):
         for h in ("AH0", "BH0", "BH1", "AH1"):
             assert (h, kt) in landed, (h, kt)
+
+
+def test_f16x3_range_report_on_vit_b16():
+    """VisionTransformer.f16x3_range_report: the operand magnitudes the opt-in precision "f16x3" must keep inside fp16's range, proven
+    from the weights -- a randomly initialised ViT-B/16 (the benchmark's weights) has a margin of more than an order of magnitude; a
+    weight of 100 (2^10 x 100 > 65504) is reported as unsafe."""
+    import torch
+    from anomalyclip_amd.components.clip_vit import VisionTransformer
+    torch.manual_seed(0)
+    vit = VisionTransformer(224, 16, 768, 2, 12, 512, precision="f16x3")
+    rep = vit.f16x3_range_report()
+    assert rep["safe"] and rep["margin"] > 10.0, rep
+    assert set(rep["bounds"]) == {"weight_planes", "layernorm_out", "attention_out", "mlp_hidden"}
+    with torch.no_grad():
+        vit.transformer.resblocks[1].mlp.c_proj.weight[3, 5] = 100.0
+    rep2 = vit.f16x3_range_report()
+    assert not rep2["safe"] and rep2["bounds"]["weight_planes"] > 65504.0
