@@ -13,7 +13,7 @@ cp $G/refresh/bench_bf16.json $P/${TAG}_bench_bf16.json
 grep -v amdgpu.ids $G/refresh/x6_probe.txt > $P/${TAG}_gemm_bf16x6_vs_f32.txt
 { echo "# tools/probes/x6_time.py all (the plane-reuse kernel: ViT shapes at 512 frames, the head's convolutions and weight gradients)"; grep -v amdgpu.ids $G/refresh/x6_time.txt;
   echo "# tools/probes/attn_p3_time.py"; grep -v amdgpu.ids $G/refresh/attn_p3_time.txt; } > $P/${TAG}_x6_kernels.txt
-[ -f $G/refresh/x3_probe.txt ] && { echo "# tools/probes/x3_probe.py: the three-product mode (acx_gemm_desc.pairs = 3, precision bf16x3, opt-in) against the six-product default: GEMM shapes of the ViT, the encode in both modes and on the f32 MFMA kernels, the attention with six / three products"; grep -v amdgpu.ids $G/refresh/x3_probe.txt; } > $P/${TAG}_bf16x3_mode.txt
+[ -f $G/refresh/x3_probe.txt ] && { echo "# tools/probes/x3_probe.py: the three-product modes (acx_gemm_desc.pairs = 3: precision bf16x3 on the bf16 planes, precision f16x3 on two fp16 planes; both opt-in) against the six-product default: GEMM shapes of the ViT, the encode in every mode and on the f32 MFMA kernels, the attention with six / three products"; grep -v amdgpu.ids $G/refresh/x3_probe.txt; } > $P/${TAG}_bf16x3_mode.txt
 [ -f $G/refresh/vit_two_streams.txt ] && { echo "# tools/probes/vit_two_streams.py: the 512-frame encode as n half / third / ... batches on n HIP streams (VisionTransformer.streams = 2 is the product's opt-in form)"; grep -v amdgpu.ids $G/refresh/vit_two_streams.txt; } > $P/${TAG}_vit_two_streams.txt
 cp $G/refresh/bench_head_f32.json $P/${TAG}_bench_head_f32.json
 cp $G/refresh/bench_head_f32_emulated_world8.json $P/${TAG}_bench_head_f32_emulated_world8.json
