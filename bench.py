@@ -935,6 +935,11 @@ def main():
                                          "unit": "TFLOP/s (f32-equivalent: 2 M N K per launch; x 3 = executed 16-bit TFLOP/s)",
                                          "frac": round(3 * gf3 / 1e9 / t3[0] / PEAK_TFLOPS["bf16"], 4) if t3[0] else None},
                             "note": desc}
+                        if mode == "f16x3":              # worst-case operand magnitudes PROVEN from the weights against fp16's 65504
+                            rep = net.image_encoder.f16x3_range_report()
+                            extra[leg]["operand_range_proven_from_weights"] = {
+                                "bounds": {k_: round(v_, 2) for k_, v_ in rep["bounds"].items()}, "fp16_max": rep["fp16_max"],
+                                "margin": round(rep["margin"], 1), "safe": rep["safe"]}
                     except Exception as e:  # noqa: BLE001
                         extra[leg] = {"error": f"{type(e).__name__}: {e}"[:300]}
                     finally:
