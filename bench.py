@@ -838,16 +838,6 @@ def main():
             extra["vit_chunk_256"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt256, 2),
                                       "ms_per_step": round(dt256 / k * 1e3, 3),
                                       "note": "config[2]'s literal batch: two 256-frame ViT launches per clip"}
-            # opt-in: the clip as two 256-frame half batches on two streams (VisionTransformer.streams = 2): one half's LayerNorm /
-            # attention launches run beside the other half's GEMMs.  Not the headline: overlapping launches have no per-launch time
-            try:
-                net.image_encoder.streams = 2
-                dt2s = timer.run(step_keep, k, 1)
-                extra["vit_two_streams"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt2s, 2), "ms_per_step": round(dt2s / k * 1e3, 3),
-                                            "note": "VisionTransformer(streams = 2), opt-in: two 256-frame halves of the clip on two HIP streams with "
-                                                    "their own workspaces; same kernels and bits as two 256-frame launches"}
-            finally:
-                net.image_encoder.streams = 1
             if args.precision == "auto":
                 # the opt-in K split of the partly filled last round of tiles (ACX_OPT_X6_TAIL_SPLIT; off by default: it gives the
                 # tail rows of a launch another summation order than the rows before them)
@@ -965,6 +955,23 @@ def main():
                 extra["config4_xd_bf16"] = config4_leg(dev, timer, prof, world, max(4, min(args.steps, 10)))
             except Exception as e:  # noqa: BLE001
                 extra["config4_xd_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # LAST of the legs: it creates two more HIP streams, and the streams of a process share four hardware queues -- created before
+        # the training legs, they put the step graph's text stream onto the main stream's queue (head step 10.8 -> 15.8 ms in one refresh run)
+        if args.vit_chunk != 256:
+            # opt-in: the clip as two 256-frame half batches on two streams (VisionTransformer.streams = 2): one half's LayerNorm /
+            # attention launches run beside the other half's GEMMs.  Not the headline: overlapping launches have no per-launch time
+            try:
+                net.load_from_features = False          # (the training legs switched the net to feature input and stepped its head)
+                net.eval()
+                net.image_encoder.streams = 2
+                dt2s = timer.run(step_keep, k, 1)
+                extra["vit_two_streams"] = {"frames_per_s": round(FRAMES_PER_CLIP * k * world / dt2s, 2), "ms_per_step": round(dt2s / k * 1e3, 3),
+                                            "note": "VisionTransformer(streams = 2), opt-in: two 256-frame halves of the clip on two HIP streams with "
+                                                    "their own workspaces; same kernels and bits as two 256-frame launches"}
+            except Exception as e:  # noqa: BLE001
+                extra["vit_two_streams"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                net.image_encoder.streams = 1
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
