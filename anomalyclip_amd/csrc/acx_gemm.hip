@@ -586,7 +586,7 @@ extern "C" int acx_gemm(acx_ctx* ctx, const acx_gemm_desc* d, void* stream) {
   // ACX_F16: fp16 planes of the two-plane split (pairs = 3 only: the X3 = 2 instantiation of the plane-reuse kernel); handled with the
   // bf16 planes' checks below (16-bit elements)
   const int a_f16 = d->a_dtype == ACX_F16;
-  if (a_f16 != (d->c_dtype == ACX_F16X2P ? 1 : a_f16) || (a_f16 && d->pairs != 3) || (d->c_dtype == ACX_F16X2P && !a_f16))
+  if ((a_f16 && d->pairs != 3) || (d->c_dtype == ACX_F16X2P && !a_f16))
     return acx_fail(ctx, ACX_E_UNSUPPORTED, "acx_gemm: fp16 planes (ACX_F16 / ACX_F16X2P) come with pairs = 3%s");
   const int a_bf16 = d->a_dtype == ACX_BF16 || a_f16, c_bf16 = d->c_dtype == ACX_BF16;
   if (prec == ACX_PREC_F32 && (a_bf16))

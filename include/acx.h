@@ -213,8 +213,9 @@ int acx_attention_x3(acx_ctx* ctx, const float* qkv, int64_t ldqkv, void* out_pl
  * accumulation, softmax in f32; output = three bf16 planes of [batch * L, heads * 64] in K-panel layout (the out-projection's
  * A operand).  Non-causal, 192 < L <= 208 (seven 32-query tiles: the ViT-B/16 sequence of 197). */
 int acx_attention_p3(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads, void* stream);
-/* ... with the number of cross products per contraction: 6 (= acx_attention_p3) or 3 (the three leading ones: the operands' lo planes
- * are not read, the output's lo plane is not written -- the ACX_PREC_F32X3 mode, not f32-accurate) */
+/* ... with the number of cross products per contraction: 6 (= acx_attention_p3), 3 (the three leading ones: the operands' lo planes
+ * are not read, the output's lo plane is not written -- the ACX_PREC_F32X3 mode, not f32-accurate), or 103 = three products on TWO
+ * fp16 planes per operand (ACX_F16X2P images of q | k | v in, of the output out: the ACX_PREC_F16X3 mode) */
 int acx_attention_p3n(acx_ctx* ctx, const void* qkv_planes, void* out_planes, int32_t batch, int32_t L, int32_t heads, int32_t products,
                       void* stream);
 /* ... with the planes in K-panel layout (ACX_BF16X3P: [ldo / 32][batch * L][32] each; ldo == heads * 64) */
