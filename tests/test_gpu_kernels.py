@@ -716,6 +716,34 @@ def test_gemm_f16x3_is_f32_accurate(M, N, K, act, res):
         assert bool(((two - yb).abs() <= 2.0 ** -22 * yb.abs() + 2.0 ** -24).all())
 
 
+def test_gemm_f16x3_outside_its_operand_range():
+    """What precision "f16x3" does OUTSIDE the range it is documented for (the reason it is opt-in):
+    (a) rows whose elements are all far below 2^-3 (here ~2^-12): the lo plane is a subnormal fp16 number or zero, every element keeps an
+        ABSOLUTE accuracy of 2^-25 only -- the error is bounded by 2e-6 sum|a||w| + 2^-25 sum|w|, i.e. no longer small relative to such
+        a row's own result;
+    (b) a weight whose 2^10-scaled plane exceeds fp16's largest finite number (|w| >= 63.97): the product is non-finite, loudly --
+        VisionTransformer.f16x3_range_report() flags such weights before any launch (tests/test_cpu_host.py)."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 512, 768, 768
+    a = (torch.randn(M, K, generator=g) * 2.0 ** -12).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.04).to(DEV)
+    a2, w2 = ops.split_f16x2(a, panel=True), ops.split_f16x2(w, panel=True, scale=1024.0)
+    y = ops.gemm_x6(a2, w2, panels=3, pairs=3, out_scale=1.0 / 1024.0)
+    ref = a.double() @ w.double().t()
+    mag = a.double().abs() @ w.double().abs().t()
+    floor = 2.0 ** -25 * w.double().abs().sum(1)[None, :]
+    e = (y.double() - ref).abs()
+    assert torch.isfinite(y).all() and bool((e <= 2e-6 * mag + floor).all())
+    print("tiny rows: max err / max|ref|", float(e.max() / ref.abs().max()), "(six bf16 products on the same operands:",
+          float(((ops.gemm_x6(ops.split_bf16x3(a, panel=True), ops.split_bf16x3(w, panel=True), panels=3).double() - ref).abs().max() / ref.abs().max())), ")")
+    wbig = w.clone()
+    wbig[5, 7] = 100.0
+    yb = ops.gemm_x6(ops.split_f16x2((a * 2.0 ** 12).contiguous(), panel=True), ops.split_f16x2(wbig, panel=True, scale=1024.0), panels=3, pairs=3,
+                     out_scale=1.0 / 1024.0)
+    assert not torch.isfinite(yb[:, 5]).all()            # the overflowing weight's output column is non-finite ...
+    assert torch.isfinite(yb[:, :5]).all() and torch.isfinite(yb[:, 6:]).all()     # ... and only that column
+
+
 @pytest.mark.parametrize("batch,L_,heads", [(3, 197, 12), (2, 208, 2), (40, 197, 12)])
 def test_attention_f16x3_vs_fp64(batch, L_, heads):
     """acx_attention_p3n(products = 103): the planes attention on TWO fp16 planes, three exact products per contraction (precision
