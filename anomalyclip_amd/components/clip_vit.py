@@ -166,7 +166,9 @@ class VisionTransformer(nn.Module):
         # streams = 2 (opt-in): every chunk runs as TWO half chunks on two side streams with their own workspaces -- one half's
         # memory-bound launches (LayerNorm, attention) then run beside the other half's matrix-bound GEMMs (+1-2 % frames/s at 512
         # frames, tools/probes/vit_two_streams.py).  Same kernels, same per-row arithmetic: the features are those of two launches of
-        # chunk / 2 frames.  Not the default: per-launch timings of overlapping kernels (bench.py's roofline) stop meaning anything.
+        # chunk / 2 frames.  Not the default: per-launch timings of overlapping kernels (bench.py's roofline) stop meaning anything, and
+        # the two extra HIP streams share the process's four hardware queues with every other stream -- created BEFORE a training step
+        # graph they put its text stream onto the main stream's queue (configs[1] step 10.8 -> 15.8 ms, measured in bench.py).
         self.streams = streams
         self._wcache = None
         self._ws: Optional[torch.Tensor] = None
