@@ -262,7 +262,8 @@ class VisionTransformer(nn.Module):
         if self._ws2 is None or self._ws2.numel() < nbytes or self._ws2.device != x.device:
             self._ws2 = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         if self._side is None or self._side[0].device != x.device:
-            self._side = (torch.cuda.Stream(device=x.device), torch.cuda.Stream(device=x.device))
+            s0 = torch.cuda.Stream(device=x.device)
+            self._side = (s0, ops.side_stream_beside(s0, x.device))      # two streams on two hardware queues, or they serialise
         cur = torch.cuda.current_stream()
         wss = (self._ws, self._ws2)
         for st in self._side:

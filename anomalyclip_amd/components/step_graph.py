@@ -215,7 +215,10 @@ class TrainStepGraph:
         self.distributed = par.is_distributed()
         self.cap = torch.cuda.Stream(device=dev)          # capture stream of the main segments
         # the text tower's stream (capture and replay), high priority: its 5-us launches go first whenever a slot is free
-        self.tstream = torch.cuda.Stream(device=dev, priority=-1)
+        # -- on ANOTHER hardware queue than the stream the step replays on (ops.side_stream_beside: with a few more streams alive in
+        # the process -- RCCL's, a loader's -- a fresh stream may share the main stream's queue, and the step's two chains serialise)
+        self.tstream = (torch.cuda.Stream(device=dev, priority=-1) if _os.environ.get("ACX_STEP_PLAIN_TSTREAM") == "1"
+                        else ops.side_stream_beside(torch.cuda.current_stream(), dev, priority=-1))
         self.ev_marks = [torch.cuda.Event() for _ in range(12)]
         self.ev_x = {"text_fwd": torch.cuda.Event(), "text_params": torch.cuda.Event()}
         self._text_state = None

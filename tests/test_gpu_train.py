@@ -1425,3 +1425,26 @@ def test_text_tower_rows_vs_oracle(prompts_table, c_local, truncate):
     assert tf.shape == (c_local, 512) and relerr(tf, ref.detach()) < 2e-5 and R.elem_excess(tf, ref.detach()) <= 1
     assert relerr(d_ctx, sd64["prompt_learner.ctx"].grad) < 1e-4
     assert relerr(d_P, sd64["text_encoder.text_projection"].grad) < 1e-4
+
+
+@pytest.mark.gpu
+def test_side_stream_beside_is_on_another_hardware_queue():
+    """ops.side_stream_beside: whatever other streams the process holds, the stream it returns overtakes a long kernel on the caller's
+    stream (ops.runs_beside), i.e. the step graph's text chain does not serialise behind its main chain
+    (profiles/r06_stream_queues.txt: 10.8 -> 15.6 ms per step when it does)."""
+    from anomalyclip_amd import ops
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream()
+    held = []
+    for n_more in (0, 3, 2):
+        for _ in range(n_more):                      # more live streams, each used once: they take hardware queues
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                torch.zeros(4, device=dev)
+            held.append(st)
+        torch.cuda.synchronize()
+        for prio in (0, -1):
+            side = ops.side_stream_beside(main, dev, priority=prio)
+            assert ops.runs_beside(main, side, dev), (n_more, prio)
+    # a stream does not run beside itself: the test can say no
+    assert not ops.runs_beside(main, main, dev)

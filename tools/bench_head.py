@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--x6-tail", action="store_true", help="ACX_OPT_X6_TAIL_SPLIT on (K-split a partly filled last round of tiles)")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32"], help="auto: the convolutions as bf16 x 6 products (default)")
     ap.add_argument("--config", default="ucf", choices=["ucf", "xd"], help="head configuration (xd: E = 128, 7 classes, one crop)")
+    ap.add_argument("--extra-streams", type=int, default=0,
+                    help="development probe: create (and use once) this many HIP streams BEFORE the step graph exists -- the streams of a "
+                         "process share GPU_MAX_HW_QUEUES (default 4) hardware queues; a text stream that lands on the main stream's queue "
+                         "serialises the step's two chains")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local_rank)
@@ -144,6 +148,13 @@ def main():
     if args.emulate_world > 1:
         stub_collectives(eff_world, net)
 
+    extra_streams = []
+    for _ in range(args.extra_streams):
+        st_ = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st_):
+            torch.zeros(16, device=dev).add_(1.0)
+        extra_streams.append(st_)
+    torch.cuda.synchronize()
     net.train()
     step_i = [0]
     if args.x6_cus >= 0:
