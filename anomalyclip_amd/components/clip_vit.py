@@ -168,7 +168,8 @@ class VisionTransformer(nn.Module):
         # frames, tools/probes/vit_two_streams.py).  Same kernels, same per-row arithmetic: the features are those of two launches of
         # chunk / 2 frames.  Not the default: per-launch timings of overlapping kernels (bench.py's roofline) stop meaning anything, and
         # the two extra HIP streams share the process's four hardware queues with every other stream -- created BEFORE a training step
-        # graph they put its text stream onto the main stream's queue (configs[1] step 10.8 -> 15.8 ms, measured in bench.py).
+        # graph they put its text stream onto the main stream's queue (configs[1] step 10.8 -> 15.8 ms, measured in bench.py; the step
+        # graph now picks a stream that runs beside its caller's -- ops.side_stream_beside, profiles/r06_stream_queues.txt).
         self.streams = streams
         self._wcache = None
         self._ws: Optional[torch.Tensor] = None

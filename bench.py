@@ -956,7 +956,8 @@ def main():
             except Exception as e:  # noqa: BLE001
                 extra["config4_xd_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # LAST of the legs: it creates two more HIP streams, and the streams of a process share four hardware queues -- created before
-        # the training legs, they put the step graph's text stream onto the main stream's queue (head step 10.8 -> 15.8 ms in one refresh run)
+        # the training legs, they put the step graph's text stream onto the main stream's queue (head step 10.8 -> 15.8 ms in one refresh
+        # run; since then the step graph places its text stream by a measured test, ops.side_stream_beside -- the order stays)
         if args.vit_chunk != 256:
             # opt-in: the clip as two 256-frame half batches on two streams (VisionTransformer.streams = 2): one half's LayerNorm /
             # attention launches run beside the other half's GEMMs.  Not the headline: overlapping launches have no per-launch time
