@@ -191,6 +191,8 @@ def side_stream_beside(main: "torch.cuda.Stream", device, priority: int = 0, tri
     """A new stream on another hardware queue than `main` (runs_beside): the first of up to `tries` fresh streams that passes the
     test, else the first one created.  For the side streams whose point is concurrency with the caller's stream (the training step's
     text stream)."""
+    if torch.cuda.is_current_stream_capturing():          # the test synchronises: not inside a capture (placement left to chance)
+        return torch.cuda.Stream(device=device, priority=priority)
     first = None
     try:
         for _ in range(tries):
@@ -200,6 +202,8 @@ def side_stream_beside(main: "torch.cuda.Stream", device, priority: int = 0, tri
             if runs_beside(main, cand, device):
                 return cand
         return first
+    except (RuntimeError, L.AcxError):                     # no room for the test's buffer, ...: a stream all the same
+        return first if first is not None else torch.cuda.Stream(device=device, priority=priority)
     finally:
         _BESIDE_BIG.pop(device.index if device.index is not None else torch.cuda.current_device(), None)
 
