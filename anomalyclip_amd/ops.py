@@ -153,10 +153,7 @@ def _colsum_counters(device) -> torch.Tensor:
     return c
 
 
-_BESIDE_BIG = {}
-
-
-def runs_beside(main: "torch.cuda.Stream", cand: "torch.cuda.Stream", device) -> bool:
+def runs_beside(main: "torch.cuda.Stream", cand: "torch.cuda.Stream", device, _big: Optional[torch.Tensor] = None) -> bool:
     """True when work on `cand` overtakes a long kernel on `main`, i.e. the two streams sit on DIFFERENT hardware queues.  The HIP
     streams of a process share GPU_MAX_HW_QUEUES (default 4) hardware queues per priority, a stream takes its queue at first use,
     and a queue runs its packets in order: two streams on one queue serialise.  Measured here (profiles/r06_stream_queues.txt): with
@@ -164,12 +161,10 @@ def runs_beside(main: "torch.cuda.Stream", cand: "torch.cuda.Stream", device) ->
     10.8 to 15.6 ms.  Test: a 512-MB fill on `main` (~0.1 ms, HBM-bound, few registers: it leaves room on every CU -- a
     register-filling MFMA loop does not, nothing runs beside that on any queue), a 16-byte fill on `cand` that may start once the
     big one has; concurrent streams finish the small fill in ~0.2 of the big one's time, streams on one queue after it.  `cand` is
-    used once before the measurement (its first use creates / attaches the queue, ~0.3-6 ms)."""
+    used once before the measurement (its first use creates / attaches the queue, ~0.3-6 ms).  The 512-MB buffer lives for the call."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     lib, h = L.lib(), L.ctx(idx)
-    big = _BESIDE_BIG.get(idx)
-    if big is None:
-        big = _BESIDE_BIG[idx] = torch.empty(1 << 27, dtype=torch.float32, device=device)
+    big = _big if _big is not None else torch.empty(1 << 27, dtype=torch.float32, device=device)
     tiny = torch.zeros(4, dtype=torch.float32, device=device)
     L.check(lib.acx_fill_f32(h, tiny.data_ptr(), 4, 0.0, cand.cuda_stream), h)
     best = 1.0
@@ -190,22 +185,21 @@ def runs_beside(main: "torch.cuda.Stream", cand: "torch.cuda.Stream", device) ->
 def side_stream_beside(main: "torch.cuda.Stream", device, priority: int = 0, tries: int = 12) -> "torch.cuda.Stream":
     """A new stream on another hardware queue than `main` (runs_beside): the first of up to `tries` fresh streams that passes the
     test, else the first one created.  For the side streams whose point is concurrency with the caller's stream (the training step's
-    text stream)."""
+    text stream, the two-stream ViT's second stream)."""
     if torch.cuda.is_current_stream_capturing():          # the test synchronises: not inside a capture (placement left to chance)
         return torch.cuda.Stream(device=device, priority=priority)
     first = None
     try:
+        big = torch.empty(1 << 27, dtype=torch.float32, device=device)
         for _ in range(tries):
             cand = torch.cuda.Stream(device=device, priority=priority)
             if first is None:
                 first = cand
-            if runs_beside(main, cand, device):
+            if runs_beside(main, cand, device, big):
                 return cand
         return first
     except (RuntimeError, L.AcxError):                     # no room for the test's buffer, ...: a stream all the same
         return first if first is not None else torch.cuda.Stream(device=device, priority=priority)
-    finally:
-        _BESIDE_BIG.pop(device.index if device.index is not None else torch.cuda.current_device(), None)
 
 
 def prime_capture_stream(stream: "torch.cuda.Stream", device) -> None:
