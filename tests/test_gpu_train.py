@@ -1445,6 +1445,6 @@ def test_side_stream_beside_is_on_another_hardware_queue():
         torch.cuda.synchronize()
         for prio in (0, -1):
             side = ops.side_stream_beside(main, dev, priority=prio)
-            assert ops.runs_beside(main, side, dev), (n_more, prio)
+            assert any(ops.runs_beside(main, side, dev) for _ in range(3)), (n_more, prio)      # (a timing test: three looks)
     # a stream does not run beside itself: the test can say no
     assert not ops.runs_beside(main, main, dev)
