@@ -39,6 +39,10 @@ region by libacx's launch timer: event pairs around every acx_gemm launch of the
 -- attention, norms, the rest: `kernel_time_ms_per_step` -- are bracketed in the two untimed initialisation steps instead:
 an event pair costs ~7 us of queue time, and ~150 of them per step in the timed region took 1.1 ms off a 131.5 ms step)
 and `cpu_baseline` (oracle on host cores, bounded sample, rank 0 at N=1 only).
+
+--leg-limit S (default 1200): the headline is measured FIRST; if the secondary legs + CPU baseline have not finished S seconds later
+(a normal run needs ~60 s), rank 0 prints the line from the headline alone (value, ms_per_step, the GEMM roofline of the timed steps;
+`"watchdog"` says so, traffic and cpu_baseline null) and ends the process.
 """
 import argparse
 import ctypes
@@ -748,6 +752,9 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (profiling runs)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 counter passes for roofline.traffic")
     ap.add_argument("--vit-chunk", type=int, default=512, help="frames per ViT launch (default: the whole 512-frame clip)")
+    ap.add_argument("--leg-limit", type=float, default=1200.0,
+                    help="seconds the secondary legs + CPU baseline may take after the headline measurement before rank 0 prints the line "
+                         "from the headline alone and exits (0: no limit); a normal run needs ~60 s")
     args = ap.parse_args()
     if args.precision == "f32x6":
         args.precision = "auto"
@@ -813,6 +820,35 @@ def main():
     assert torch.isfinite(sc).all() and torch.isfinite(probs).all()
 
     extra = {}
+    # ---- the headline is measured: a secondary leg that stops making progress (one unexplained stop of a replayed training step in
+    # round 6's test runs) must not take the line with it.  Rank 0 arms a watchdog: after --leg-limit seconds
+    # without the final line it prints the line from what IS measured (value, ms_per_step, the GEMM roofline from the timed steps'
+    # HIP events; no live traffic pass, no CPU baseline) and ends the process.
+    watchdog = None
+    if rank == 0 and args.leg_limit > 0:
+        import threading
+
+        def _give_up():
+            n_g, ms_g = counts[0], tot[0]
+            ach = (gflops_exec / 1e9 / max(n_g, 1)) / (ms_g / max(n_g, 1)) if ms_g > 0 else 0.0
+            line = {"metric": "frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2",
+                    "value": round(FRAMES_PER_CLIP * args.steps * world / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                    "config": {"workload": "configs[2]: one 512-frame clip per GPU per step (see DESIGN.md)", "vit_chunk": args.vit_chunk,
+                               "precision": args.precision},
+                    "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[args.precision], 2), "unit": "TFLOP/s",
+                                 "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None, "launches": int(n_g)},
+                    "cpu_baseline": None,
+                    "watchdog": f"the secondary legs did not finish within {args.leg_limit} s of the headline measurement: line printed from "
+                                f"the headline alone; legs finished so far: {sorted(extra)}"}
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.leg_limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_extra_legs:
         k = max(2, min(args.steps, 5))
         # encode-only
@@ -1081,6 +1117,8 @@ def main():
         out["value_text_recomputed_every_step"] = extra.get("text_recomputed_every_step", {}).get("frames_per_s")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, eot, hc)
+        if watchdog is not None:
+            watchdog.cancel()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
