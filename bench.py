@@ -5,8 +5,8 @@ Metric (BASELINE.json): frames/sec encoded + anomaly-scored (whole node), ViT-B/
 Workload of `value` (configs[2] of BASELINE.json / SURVEY.md 8d config 3): one STEP = one synthetic clip of
 512 frames (1,512,3,224,224) f32 already resident in HBM -> `AnomalyCLIP.forward(test_mode=True,
 load_from_features=False)`: CLIP ViT-B/16 encode of the clip (one 512-frame launch by default; --vit-chunk 256
-reproduces the config's literal batch 256), text encoder (recomputed every step like the reference,
-anomaly_clip.py:136), selector, axial temporal transformer (one S=1 tile), classifier, then the eval post-processing
+reproduces the config's literal batch 256), text features (frozen prompts under no_grad: cached after the first step by default;
+the leg `text_recomputed_every_step` runs the text encoder in every step like the reference, anomaly_clip.py:136), selector, axial temporal transformer (one S=1 tile), classifier, then the eval post-processing
 softmax(similarity)*score (anomaly_clip_module.py:474-477).  Random-init weights of the UCF-Crime configuration
 (no checkpoints/network in this environment), data synthetic.
 
@@ -42,7 +42,7 @@ and `cpu_baseline` (oracle on host cores, bounded sample, rank 0 at N=1 only).
 
 --leg-limit S (default 1200): the headline is measured FIRST; if the secondary legs + CPU baseline have not finished S seconds later
 (a normal run needs ~60 s), rank 0 prints the line from the headline alone (value, ms_per_step, the GEMM roofline of the timed steps;
-`"watchdog"` says so, traffic and cpu_baseline null) and ends the process.
+`"watchdog"` says so, traffic and cpu_baseline null) and ends the process; at N > 1 the other ranks leave 5 s after it.
 """
 import argparse
 import ctypes
@@ -825,10 +825,14 @@ def main():
     # without the final line it prints the line from what IS measured (value, ms_per_step, the GEMM roofline from the timed steps'
     # HIP events; no live traffic pass, no CPU baseline) and ends the process.
     watchdog = None
-    if rank == 0 and args.leg_limit > 0:
+    if args.leg_limit > 0:
         import threading
 
         def _give_up():
+            if rank != 0:
+                # the other ranks leave with rank 0 (a little later, so that its line is out first): a rank left waiting in a collective
+                # for a peer that is gone would keep the launcher alive until the collective's own timeout
+                os._exit(0)
             n_g, ms_g = counts[0], tot[0]
             ach = (gflops_exec / 1e9 / max(n_g, 1)) / (ms_g / max(n_g, 1)) if ms_g > 0 else 0.0
             line = {"metric": "frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2",
@@ -846,7 +850,7 @@ def main():
             sys.stdout.flush()
             os._exit(0)
 
-        watchdog = threading.Timer(args.leg_limit, _give_up)
+        watchdog = threading.Timer(args.leg_limit + (0.0 if rank == 0 else 5.0), _give_up)
         watchdog.daemon = True
         watchdog.start()
     if not args.no_extra_legs:
@@ -1037,7 +1041,7 @@ def main():
             traffic, pmc_src = live_pmc_traffic(args.vit_chunk, args.precision)
             if traffic is None:
                 pmc_src = None
-        for tag in (("r05", "r04", "r03") if traffic is None else ()):
+        for tag in (("r06", "r05", "r04", "r03") if traffic is None else ()):
             pmc_file = os.path.join(REPO, "profiles", f"{tag}_bench_{args.precision}_pmc.json")
             if args.precision in ("auto", "f32") and args.vit_chunk == 512 and os.path.exists(pmc_file):
                 try:
@@ -1120,6 +1124,8 @@ def main():
         if watchdog is not None:
             watchdog.cancel()
         print(json.dumps(out))
+    if watchdog is not None:
+        watchdog.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
