@@ -42,7 +42,9 @@ and `cpu_baseline` (oracle on host cores, bounded sample, rank 0 at N=1 only).
 
 --leg-limit S (default 1200): the headline is measured FIRST; if the secondary legs + CPU baseline have not finished S seconds later
 (a normal run needs ~60 s), rank 0 prints the line from the headline alone (value, ms_per_step, the GEMM roofline of the timed steps;
-`"watchdog"` says so, traffic and cpu_baseline null) and ends the process; at N > 1 the other ranks leave 5 s after it.
+`"watchdog"` says so, traffic and cpu_baseline null) and ends the process; at N > 1 the limit is at most 420 s and the other ranks leave
+5 s after rank 0.  An exception that escapes a secondary leg (a collective failing because a peer is gone) ends the run the same way: the
+headline-only line from rank 0, exit status 0 on every rank.  Before the headline is measured every failure is loud.
 """
 import argparse
 import ctypes
@@ -56,6 +58,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+_STATE = {}                            # the headline-only line's printer once the headline is measured (main(), __main__)
 FRAMES_PER_CLIP = 512
 VIT_GFLOP_PER_FRAME = 35.127          # 34.895 blocks + 0.231 patch + 0.001 proj
 ATTN_GFLOP_PER_FRAME = 1.43           # QK^T + PV part of the above (runs in acx_attention, not acx_gemm)
@@ -825,14 +828,15 @@ def main():
     # without the final line it prints the line from what IS measured (value, ms_per_step, the GEMM roofline from the timed steps'
     # HIP events; no live traffic pass, no CPU baseline) and ends the process.
     watchdog = None
-    if args.leg_limit > 0:
+    if True:
         import threading
 
-        def _give_up():
-            if rank != 0:
+        def _give_up(why=None):
+            if rank != 0 or _STATE.get("line_printed"):
                 # the other ranks leave with rank 0 (a little later, so that its line is out first): a rank left waiting in a collective
                 # for a peer that is gone would keep the launcher alive until the collective's own timeout
                 os._exit(0)
+            _STATE["line_printed"] = True
             n_g, ms_g = counts[0], tot[0]
             ach = (gflops_exec / 1e9 / max(n_g, 1)) / (ms_g / max(n_g, 1)) if ms_g > 0 else 0.0
             line = {"metric": "frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2",
@@ -844,15 +848,20 @@ def main():
                     "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[args.precision], 2), "unit": "TFLOP/s",
                                  "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None, "launches": int(n_g)},
                     "cpu_baseline": None,
-                    "watchdog": f"the secondary legs did not finish within {args.leg_limit} s of the headline measurement: line printed from "
-                                f"the headline alone; legs finished so far: {sorted(extra)}"}
+                    "watchdog": (why or f"the secondary legs did not finish within {args.leg_limit} s of the headline measurement") +
+                                f": line printed from the headline alone; legs finished so far: {sorted(extra)}"}
             sys.stdout.write(json.dumps(line) + "\n")
             sys.stdout.flush()
             os._exit(0)
 
-        watchdog = threading.Timer(args.leg_limit + (0.0 if rank == 0 else 5.0), _give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        # (an exception that escapes main() after this point -- a collective failing because a peer is gone -- ends the same way: __main__)
+        _STATE["give_up"] = _give_up
+        if args.leg_limit > 0:
+            if world > 1:                    # the N > 1 legs (data-parallel training over RCCL) add ~20 s to a normal run: a shorter leash
+                args.leg_limit = min(args.leg_limit, 420.0)
+            watchdog = threading.Timer(args.leg_limit + (0.0 if rank == 0 else 5.0), _give_up)
+            watchdog.daemon = True
+            watchdog.start()
     if not args.no_extra_legs:
         k = max(2, min(args.steps, 5))
         # encode-only
@@ -1123,7 +1132,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, eot, hc)
         if watchdog is not None:
             watchdog.cancel()
-        print(json.dumps(out))
+        _STATE["line_printed"] = True
+        print(json.dumps(out), flush=True)
     if watchdog is not None:
         watchdog.cancel()
     if dist is not None:
@@ -1132,4 +1142,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        if "give_up" not in _STATE:          # nothing measured yet: fail loudly
+            raise
+        import traceback
+        traceback.print_exc()
+        _STATE["give_up"](f"{type(e).__name__} after the headline measurement ({str(e)[:200]})")
