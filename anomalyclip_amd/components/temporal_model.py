@@ -137,7 +137,7 @@ class TemporalModel(nn.Module):
         divide: E % 256 == 0 (UCF-Crime / ShanghaiTech: 256 x 256 tiles) or E == 128 (XD-Violence: 256 x 128 tiles inside one tap for
         c1's gradient [512, 9 x 128], 128 x 256 tiles for c2's [128, 9 x 512]; acx_gemm_tn_x6's tile geometries)"""
         N, Lg = self.num_segments, self.seg_length
-        return (self.precision == "auto" and self.emb_size % 128 == 0 and N & (N - 1) == 0 and Lg & (Lg - 1) == 0 and
+        return (self.precision == "auto" and (self.emb_size % 256 == 0 or self.emb_size == 128) and N & (N - 1) == 0 and Lg & (Lg - 1) == 0 and
                 (N * Lg) % 256 == 0)
 
     # ---- derived weight layouts for the kernels

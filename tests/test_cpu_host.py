@@ -544,3 +544,16 @@ def test_f16x3_range_report_on_vit_b16():
         vit.transformer.resblocks[1].mlp.c_proj.weight[3, 5] = 100.0
     rep2 = vit.f16x3_range_report()
     assert not rep2["safe"] and rep2["bounds"]["weight_planes"] > 65504.0
+
+
+@pytest.mark.parametrize("E,N,L,want", [(256, 32, 16, True), (512, 32, 16, True), (128, 32, 16, True), (384, 32, 16, False),
+                                         (64, 32, 16, False), (256, 8, 16, False), (256, 24, 16, False)])
+def test_x6_convs_only_for_shapes_the_kernels_take(E, N, L, want):
+    """TemporalModel.x6_convs(): the bf16 x 6 convolutions only where acx_gemm / acx_gemm_tn_x6 have tile geometries -- E % 256 == 0 or
+    E == 128 (the shipped configs: UCF-Crime / ShanghaiTech 256, XD-Violence 128), a power-of-two token grid of whole 256-row tiles;
+    every other head keeps the f32 MFMA convolutions instead of failing with ACX_E_UNSUPPORTED (no fallback inside _ff / TemporalFn)."""
+    from anomalyclip_amd.components.temporal_model import TemporalModel
+    m = TemporalModel(512, E, 1, 8, None, 1, N, L)
+    assert m.x6_convs() is False              # stand-alone default "f32"; AnomalyCLIP(precision="auto") sets it on its head
+    m.precision = "auto"
+    assert m.x6_convs() is want
