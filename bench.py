@@ -58,6 +58,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+DTYPE_TEXT = {"auto": "f32 (bf16x6 operands, exact 24-bit split, f32 accumulate)", "f32": "f32", "bf16": "bf16(mfma)/f32(acc,attention)"}
 _STATE = {}                            # the headline-only line's printer once the headline is measured (main(), __main__)
 FRAMES_PER_CLIP = 512
 VIT_GFLOP_PER_FRAME = 35.127          # 34.895 blocks + 0.231 patch + 0.001 proj
@@ -842,7 +843,7 @@ def main():
             line = {"metric": "frames/sec encoded + anomaly-scored (whole node), ViT-B/16 224^2",
                     "value": round(FRAMES_PER_CLIP * args.steps * world / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                     "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                    "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                    "vs_baseline": None, "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
                     "config": {"workload": "configs[2]: one 512-frame clip per GPU per step (see DESIGN.md)", "vit_chunk": args.vit_chunk,
                                "precision": args.precision},
                     "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[args.precision], 2), "unit": "TFLOP/s",
@@ -1079,8 +1080,7 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "world": {"size": world, "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"auto": "f32 (bf16x6 operands, exact 24-bit split, f32 accumulate)", "f32": "f32",
-                      "bf16": "bf16(mfma)/f32(acc,attention)"}[args.precision],
+            "dtype": DTYPE_TEXT[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[2]: synthetic 224x224 RGB frames, ViT-B/16 encode + selector + axial temporal head + eval "
                                    "post-processing; step = one 512-frame clip per GPU in ONE ViT launch, UCF-Crime head config, "
